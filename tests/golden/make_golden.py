@@ -1,0 +1,405 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz|json by running the REFERENCE (/root/reference) on CPU.
+
+Runs only in the build container (the reference is absent on the GPU box).  Nothing from the reference is
+copied: this script imports its modules (with import-only stand-ins for the absent, unused packages
+torchvision / imageio / bcolz / wandb -- SURVEY.md App. C), feeds them inputs and weights from the
+repo's own counter-based generator (stylegan-for-facerec_amd/frhip/synth.py) and stores the outputs.
+
+    python tests/golden/make_golden.py            # writes next to this file
+
+Fixtures: g1_head, g2_focal, g3_blocks, g4_se, g5_ir50, g6_psp, g7_sgd, g8_structure.json,
+g9_stage2.
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+sys.dont_write_bytecode = True
+
+
+def _load_synth():
+    spec = importlib.util.spec_from_file_location(
+        "frhip_synth", os.path.join(REPO, "stylegan-for-facerec_amd", "frhip", "synth.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+synth = _load_synth()
+
+
+def _install_stubs():
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return None
+
+        def __getattr__(self, name):
+            return _Any()
+
+    def mk(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    tv = mk("torchvision")
+    tv.models = mk("torchvision.models")
+    tv.models.resnet = mk("torchvision.models.resnet", resnet34=_Any)
+    tv.transforms = mk("torchvision.transforms", Compose=_Any, ToPILImage=_Any, ToTensor=_Any, Normalize=_Any,
+                       Resize=_Any, CenterCrop=_Any, functional=_Any())
+    mk("imageio")
+    mk("bcolz")
+    mk("wandb")
+
+
+_install_stubs()
+sys.path.insert(0, REF)
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+from backbone import model_irse as ref_irse  # noqa: E402
+from backbone import restyle_psp as ref_psp  # noqa: E402
+from backbone import restyle_psp_helpers as ref_helpers  # noqa: E402
+from head import metrics as ref_heads  # noqa: E402
+from loss.focal import FocalLoss as RefFocal  # noqa: E402
+from util import utils as ref_utils  # noqa: E402
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()  # copy: live buffers are mutated later
+
+
+def onehot(label, n):
+    return torch.zeros(label.shape[0], n).scatter_(1, label.view(-1, 1), 1)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------------------------------------ G1
+
+
+def head_inputs():
+    """x [8,512], W [100,512], labels with edge cases; rows 4..7 force cos(label) to +1, -1, th, just above th."""
+    n, d = 100, 512
+    x = synth.normal(11, "g1.x", (8, d))
+    w = synth.uniform(11, "g1.w", (n, d), -0.1, 0.1)
+    label = torch.tensor([0, n - 1, 7, 7, 13, 21, 34, 55], dtype=torch.int64)
+    wn = torch.nn.functional.normalize(w)
+    x[4] = 3.0 * wn[13]  # cos = +1
+    x[5] = -2.0 * wn[21]  # cos = -1  (< th)
+    th = np.cos(np.pi - 0.5)
+    for row, cls, c in ((6, 34, th), (7, 55, th + 1e-4)):
+        u = wn[cls]
+        v = synth.normal(11, "g1.v%d" % row, (d,))
+        v = v - (v @ u) * u
+        v = v / v.norm()
+        x[row] = 1.7 * (float(c) * u + float(np.sqrt(1 - c * c)) * v)
+    return x, w, label
+
+
+def g1_head():
+    x0, w0, label = head_inputs()
+    out = {"x": npy(x0), "w": npy(w0), "label": npy(label)}
+    gout = synth.normal(11, "g1.gout", (8, 100))
+    out["gout"] = npy(gout)
+    for kind in ("ArcFace", "CosFace"):
+        x = x0.clone().requires_grad_(True)
+        head = getattr(ref_heads, kind)(512, 100, None)
+        with torch.no_grad():
+            head.weight.copy_(w0)
+        if kind == "ArcFace":
+            y = head(x, label, onehot_vec=onehot(label, 100))
+        else:
+            y = head(x, label)
+        gx, gw = torch.autograd.grad(y, [x, head.weight], gout)
+        out[kind + ".logits"] = npy(y)
+        out[kind + ".gx"] = npy(gx)
+        out[kind + ".gw"] = npy(gw)
+    # easy-margin + non-default s/m variant
+    head = ref_heads.ArcFace(512, 100, None, s=30.0, m=0.35, easy_margin=True)
+    with torch.no_grad():
+        head.weight.copy_(w0)
+    out["ArcFace.easy.logits"] = npy(head(x0, label, onehot_vec=onehot(label, 100)))
+    save("g1_head", **out)
+
+
+# ------------------------------------------------------------------------------------------------ G2
+
+
+def g2_focal():
+    logits = synth.normal(12, "g2.logits", (8, 100), std=8.0).requires_grad_(True)
+    label = synth.labels(12, "g2.label", 8, 100)
+    loss, aux = RefFocal()(logits, label)
+    assert aux is None
+    (g,) = torch.autograd.grad(loss, [logits])
+    p1, p5 = ref_utils.accuracy(logits.data, label, topk=(1, 5))
+    save("g2_focal", logits=npy(logits), label=npy(label), loss=npy(loss), grad=npy(g), prec1=npy(p1),
+         prec5=npy(p5))
+
+
+# ------------------------------------------------------------------------------------------------ G3/G4
+
+BLOCKS = [
+    ("ir_64_64_1", False, 64, 64, 1, 16),
+    ("ir_64_128_2", False, 64, 128, 2, 16),
+    ("irse_128_128_1", True, 128, 128, 1, 8),
+    ("irse_256_512_2", True, 256, 512, 2, 8),
+]
+
+
+def g3_blocks():
+    out = {}
+    for tag, se, cin, depth, stride, hw in BLOCKS:
+        cls = ref_irse.bottleneck_IR_SE if se else ref_irse.bottleneck_IR
+        blk = cls(cin, depth, stride)
+        sd = {k: v.clone() for k, v in blk.state_dict().items()}  # clone: train pass mutates live buffers
+        synth.fill_state_dict(sd, 13)
+        blk.load_state_dict(sd)
+        x = synth.normal(13, "g3.x." + tag, (4, cin, hw, hw)).requires_grad_(True)
+        ho = hw // stride
+        gout = synth.normal(13, "g3.g." + tag, (4, depth, ho, ho))
+        for mode in ("train", "eval"):
+            blk.load_state_dict(sd)
+            blk.train(mode == "train")
+            y = blk(x)
+            names = [n for n, _ in blk.named_parameters()]
+            gs = torch.autograd.grad(y, [x] + [p for _, p in blk.named_parameters()], gout)
+            out["%s.%s.y" % (tag, mode)] = npy(y)
+            out["%s.%s.gx" % (tag, mode)] = npy(gs[0])
+            for n, g in zip(names, gs[1:]):
+                # big conv-weight grads are pinned by their L2 norm + the first 2048 elements (fixture size)
+                out["%s.%s.gnorm.%s" % (tag, mode, n)] = np.array(float(g.double().norm()))
+                out["%s.%s.g.%s" % (tag, mode, n)] = npy(g.reshape(-1)[:2048])
+            if mode == "train":
+                for n, b in blk.named_buffers():
+                    out["%s.train.buf.%s" % (tag, n)] = npy(b)
+    save("g3_blocks", **out)
+
+
+def g4_se():
+    se = ref_irse.SEModule(128, 16)
+    sd = se.state_dict()
+    synth.fill_state_dict(sd, 14)
+    se.load_state_dict(sd)
+    x = synth.normal(14, "g4.x", (4, 128, 14, 14)).requires_grad_(True)
+    gout = synth.normal(14, "g4.g", (4, 128, 14, 14))
+    y = se(x)
+    gx, g1, g2 = torch.autograd.grad(y, [x, se.fc1.weight, se.fc2.weight], gout)
+    save("g4_se", y=npy(y), gx=npy(gx), gfc1=npy(g1), gfc2=npy(g2))
+
+
+# ------------------------------------------------------------------------------------------------ G5/G6/G7
+
+
+def _disable_dropout(model):
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+
+
+def full_model(kind):
+    """Returns (model, prefix, avg_image|None).  Weights from synth.fill_state_dict(seed 15)."""
+    if kind == "ir50":
+        model = ref_irse.IR_50([112, 112])
+        prefix = ""
+        avg = None
+    elif kind == "irse101":
+        model = ref_irse.IR_SE_101([112, 112])
+        prefix = ""
+        avg = None
+    else:
+        model = ref_psp.pSp(size=112, checkpoint_path=None, avg_image=None, include_dropout=False)
+        prefix = "encoder."
+        avg = synth.uniform(15, "avg_image", (3, 112, 112))
+        model.avg_image = avg
+    sd = model.state_dict()
+    synth.fill_state_dict(sd, 15)
+    model.load_state_dict(sd)
+    _disable_dropout(model)
+    return model, prefix, avg
+
+
+def run_full(kind, tag, batch=8, nclass=100):
+    model, prefix, avg = full_model(kind)
+    model.train()
+    x = synth.uniform(16, "full.x", (batch, 3, 112, 112))
+    label = synth.labels(16, "full.label", batch, nclass)
+    head = ref_heads.ArcFace(512, nclass, None, s=64.0)
+    with torch.no_grad():
+        head.weight.copy_(synth.uniform(16, "full.head", (nclass, 512), -0.1, 0.1))
+    feats = model(x)
+    logits = head(feats, label, onehot_vec=onehot(label, nclass))
+    loss, _ = RefFocal()(logits, label)
+    named = list(model.named_parameters())
+    gs = torch.autograd.grad(loss, [p for _, p in named] + [head.weight])
+    out = {"features": npy(feats), "logits": npy(logits), "loss": npy(loss)}
+    out["grad_names"] = np.array([n for n, _ in named] + ["head.weight"])
+    out["grad_norms"] = np.array([float(g.double().norm()) for g in gs])
+    gd = dict(zip([n for n, _ in named], gs))
+    for n in (prefix + "input_layer.0.weight", prefix + "output_layer.4.weight", prefix + "output_layer.4.bias",
+              prefix + "body.0.res_layer.2.weight", prefix + "body.3.shortcut_layer.0.weight"):
+        out["g." + n] = npy(gd[n])
+    out["g.head.weight"] = npy(gs[-1])
+    bufs = dict(model.named_buffers())
+    for n in (prefix + "input_layer.1", prefix + "body.7.res_layer.4", prefix + "output_layer.4"):
+        out["buf." + n + ".running_mean"] = npy(bufs[n + ".running_mean"])
+        out["buf." + n + ".running_var"] = npy(bufs[n + ".running_var"])
+        out["buf." + n + ".num_batches_tracked"] = npy(bufs[n + ".num_batches_tracked"])
+    save(tag, **out)
+
+
+def g7_sgd():
+    """Two SGD steps, lr 0.03 / momentum 0.9 / wd 2e-3 on the non-BN group (train.py:188-196, 296-316)."""
+    model, prefix, _ = full_model("ir50")
+    model.train()
+    nclass, batch = 100, 8
+    head = ref_heads.ArcFace(512, nclass, None, s=64.0)
+    with torch.no_grad():
+        head.weight.copy_(synth.uniform(16, "full.head", (nclass, 512), -0.1, 0.1))
+    bn, wo = ref_utils.separate_irse_bn_paras(model)
+    _, hwo = ref_utils.separate_irse_bn_paras(head)
+    opt = torch.optim.SGD([{"params": wo + hwo, "weight_decay": 2e-3}, {"params": bn}], lr=0.03, momentum=0.9)
+    out = {"loss": [], "prec1": [], "prec5": []}
+    for step in range(2):
+        x = synth.uniform(17, "sgd.x%d" % step, (batch, 3, 112, 112))
+        label = synth.labels(17, "sgd.label%d" % step, batch, nclass)
+        feats = model(x)
+        logits = head(feats, label, onehot_vec=onehot(label, nclass))
+        loss, _ = RefFocal()(logits, label)
+        p1, p5 = ref_utils.accuracy(logits.data, label, topk=(1, 5))
+        out["loss"].append(float(loss))
+        out["prec1"].append(float(p1))
+        out["prec5"].append(float(p5))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    res = {k: np.array(v) for k, v in out.items()}
+    names = [n for n, _ in model.named_parameters()]
+    res["param_names"] = np.array(names + ["head.weight"])
+    ps = [p for _, p in model.named_parameters()] + [head.weight]
+    res["param_sums"] = np.array([float(p.double().sum()) for p in ps])
+    res["param_norms"] = np.array([float(p.double().norm()) for p in ps])
+    res["buf_norms"] = np.array([float(opt.state[p]["momentum_buffer"].double().norm()) for p in ps])
+    res["w.input_layer.0.weight"] = npy(model.input_layer[0].weight)
+    res["w.output_layer.4.weight"] = npy(model.output_layer[4].weight)
+    res["w.head.weight.rows0_3"] = npy(head.weight[:4])
+    save("g7_sgd", **res)
+
+
+# ------------------------------------------------------------------------------------------------ G8/G9
+
+
+def g8_structure():
+    info = {}
+    specs = {
+        "IR_50": lambda: ref_irse.IR_50([112, 112]),
+        "IR_SE_50": lambda: ref_irse.IR_SE_50([112, 112]),
+        "IR_SE_101": lambda: ref_irse.IR_SE_101([112, 112]),
+        "IR_101": lambda: ref_irse.IR_101([112, 112]),
+        "pSp": lambda: ref_psp.pSp(size=112),
+        "pSp34": lambda: ref_psp.pSp(size=112, encoder_type="BackboneEncoder34"),
+    }
+    for name, ctor in specs.items():
+        m = ctor()
+        bn, wo = ref_utils.separate_irse_bn_paras(m)
+        info[name] = {
+            "keys": [[k, list(v.shape)] for k, v in m.state_dict().items()],
+            "param_names": [n for n, _ in m.named_parameters()],
+            "n_bn": len(bn), "n_wo": len(wo),
+            "bn_numel": int(sum(p.numel() for p in bn)), "wo_numel": int(sum(p.numel() for p in wo)),
+        }
+    for name in ("ArcFace", "CosFace", "SphereFace", "Am_softmax"):
+        h = getattr(ref_heads, name)(512, 100, None)
+        bn, wo = ref_utils.separate_irse_bn_paras(h)
+        info[name] = {"keys": [[k, list(v.shape)] for k, v in h.state_dict().items()], "n_bn": len(bn),
+                      "n_wo": len(wo)}
+    # pSp with additional dropouts (restyle_psp.py:401-405, helpers :201-209): child order after insertion
+    m = ref_psp.pSp(size=112, include_dropout=0.15)
+    blk = m.encoder.body[0]
+    info["pSp.dropout.body0.res_layer"] = [type(c).__name__ for c in blk.res_layer]
+    blk = m.encoder.body[3]
+    info["pSp.dropout.body3.shortcut_layer"] = [type(c).__name__ for c in blk.shortcut_layer]
+    try:
+        ref_psp.pSp(size=112, encoder_type="nope")
+    except Exception as e:  # noqa: BLE001
+        info["pSp.bad_encoder_error"] = str(e)
+    # LR helpers (util/utils.py:184-196)
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.03)
+    ref_utils.warm_up_lr(3, 10, 0.03, opt)
+    info["warm_up_lr_3_10_0.03"] = opt.param_groups[0]["lr"]
+    opt.param_groups[0]["lr"] = 0.03
+    ref_utils.schedule_lr(opt)
+    info["schedule_lr_0.03"] = opt.param_groups[0]["lr"]
+    with open(os.path.join(HERE, "g8_structure.json"), "w") as f:
+        json.dump(info, f)
+    print("wrote g8_structure.json")
+
+
+def g9_stage2():
+    """Stage-2 checkpoint import (restyle_psp.py:419-437): only encoder.input_layer/body load."""
+    src = ref_psp.pSp(size=112)
+    sd = {"encoder." + k[len("encoder."):]: v.clone() for k, v in src.state_dict().items()
+          if k.startswith("encoder.input_layer") or k.startswith("encoder.body")}
+    synth.fill_state_dict(sd, 19)
+    ckpt_sd = dict(sd)
+    ckpt_sd["encoder.styles.0.convs.0.weight"] = torch.ones(2, 2)
+    ckpt_sd["decoder.style.1.weight"] = torch.ones(3)
+    path = os.path.join("/tmp", "g9_stage2_ckpt.pt")
+    torch.save({"state_dict": ckpt_sd, "latent_avg": torch.zeros(18, 512), "opts": {"x": 1}}, path)
+    torch.manual_seed(5)
+    m = ref_psp.pSp(size=112, checkpoint_path=path)
+    got = m.state_dict()
+    loaded = [k for k in sd if torch.equal(got[k], sd[k])]
+    out_keys = [k for k in got if k.startswith("encoder.output_layer")]
+    res = {
+        "n_ckpt_encoder_keys": len(sd), "n_loaded_equal": len(loaded),
+        "output_layer_keys": out_keys,
+        "ignored": ["encoder.styles.0.convs.0.weight", "decoder.style.1.weight"],
+        "sum.encoder.input_layer.0.weight": float(got["encoder.input_layer.0.weight"].double().sum()),
+        "sum.encoder.body.23.res_layer.3.weight": float(got["encoder.body.23.res_layer.3.weight"].double().sum()),
+    }
+    with open(os.path.join(HERE, "g9_stage2.json"), "w") as f:
+        json.dump(res, f)
+    os.remove(path)
+    print("wrote g9_stage2.json")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g9"]
+    if "g1" in which:
+        g1_head()
+    if "g2" in which:
+        g2_focal()
+    if "g3" in which:
+        g3_blocks()
+    if "g4" in which:
+        g4_se()
+    if "g5" in which:
+        run_full("ir50", "g5_ir50")
+    if "g6" in which:
+        run_full("psp", "g6_psp")
+    if "g6b" in which:
+        run_full("irse101", "g6b_irse101", batch=4)
+    if "g7" in which:
+        g7_sgd()
+    if "g8" in which:
+        g8_structure()
+    if "g9" in which:
+        g9_stage2()
