@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Stage-3 training step throughput (BASELINE.json metric) on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): IR-50 + ArcFace(512 -> 7000 ids, s=64, m=0.5) + FocalLoss(gamma=2) +
+SGD(lr 0.03, momentum 0.9, wd 2e-3 on the non-BN group), synthetic 112x112x3 batches resident in HBM, 256 images per
+GPU, bf16 storage / fp32 accumulate.  A step = forward, margin head, loss, top-1/5 rank pass, backward, gradient
+all-reduce (N > 1), optimizer step -- everything the reference loop does per iteration (train.py:287-316) except
+its three host syncs.  Rank 0 prints ONE JSON line.
+
+Besides the contract fields the line carries
+  roofline      dominant kernel (by time) of one event-instrumented step after the timed region: algorithmic
+                FLOPs of its launches / their summed duration, against the dense bf16 MFMA peak (2.5 PFLOP/s,
+                MI355X_MICROARCH.md); plus the whole-step fraction
+  cpu_baseline  the CPU oracle (oracle/irse_ref.py, a port of the reference's PyTorch path) timed on the host
+                cores of this box on a bounded sample of the same workload (N = 1, rank 0 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(REPO, "stylegan-for-facerec_amd"), REPO):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_F32_TFLOPS = 157.3     # f32-input MFMA == vector peak
+IR50_FLOPS_PER_IMG = 37.7356e9   # conv + Linear, fwd+bwd, 2 flop/MAC (measured on the reference)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--classes", type=int, default=7000)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--kernel-table", default="", help="write the per-launch timing table of the instrumented step")
+    return ap.parse_args()
+
+
+def build_job(args, device, rank):
+    from backbone.model_irse import IR_50
+    from frhip import synth
+    from frhip.optim import SGD
+    from head.metrics import ArcFace
+    from loss.focal import FocalLoss
+    from util.utils import separate_irse_bn_paras
+    torch.manual_seed(900)
+    model = IR_50([112, 112])
+    synth.fill_state_dict(model.state_dict(), 15)   # identical "trained-looking" weights on every rank
+    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = model.to(device).train()
+    head = ArcFace(512, args.classes, None, s=64.0)
+    with torch.no_grad():
+        head.weight.copy_(synth.uniform(16, "bench.head", (args.classes, 512), -0.05, 0.05))
+    head = head.to(device).train()
+    bn, wo = separate_irse_bn_paras(model)
+    _, hwo = separate_irse_bn_paras(head)
+    opt = SGD([{"params": wo + hwo, "weight_decay": 2e-3}, {"params": bn}], lr=0.03, momentum=0.9)
+    x = synth.uniform(1000 + rank, "bench.x", (args.batch, 3, 112, 112)).to(device)
+    y = synth.labels(1000 + rank, "bench.y", args.batch, args.classes).to(device)
+    return model, head, FocalLoss(), opt, x, y
+
+
+def make_step(model, head, loss_fn, opt, dp):
+    from frhip import functional as FRF
+    from util.utils import accuracy
+    FRF.CHECK_LABELS = False  # synthetic labels are in range by construction; the check is a host sync
+
+    def step(x, y):
+        feats = model(x)
+        logits = head(feats, y)
+        loss, _ = loss_fn(logits, y)
+        prec = accuracy(logits.data, y, topk=(1, 5))
+        opt.zero_grad(set_to_none=False)
+        loss.backward()
+        if dp is not None:
+            dp.synchronize()
+        opt.step()
+        return loss, prec
+    return step
+
+
+def conv_flops(launch):
+    a = launch.keep[0]
+    M = a.B * a.RH * a.RW
+    return 2.0 * M * a.N * a.KH * a.KW * a.SC
+
+
+def wgrad_flops(launch):
+    a = launch.keep[0]
+    return 2.0 * a.B * a.GH * a.GW * a.Cout * a.SC * a.KH * a.KW
+
+
+def instrumented_step(step, x, y, dtype_name):
+    """One extra step with a HIP event pair around every launch of the C ABI (same stream as the launches)."""
+    from frhip import ops
+    records = []
+    orig_call = ops.Launch.__call__
+
+    def timed_call(self):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_call(self)
+        e1.record()
+        records.append((self, e0, e1))
+
+    ops.Launch.__call__ = timed_call
+    try:
+        step(x, y)
+        torch.cuda.synchronize()
+    finally:
+        ops.Launch.__call__ = orig_call
+    fams = {}
+    for launch, e0, e1 in records:
+        ms = e0.elapsed_time(e1)
+        name, flops = launch.name, 0.0
+        if launch.name == "fr_conv_igemm":
+            a = launch.keep[0]
+            name = "conv_igemm<%s,BN=%d,PRO=%d>" % (dtype_name if launch.args[1] == 1 else "f32",
+                                                    64 if a.N <= 64 else 128, a.pro)
+            flops = conv_flops(launch)
+        elif launch.name == "fr_conv_wgrad":
+            a = launch.keep[0]
+            name = "conv_wgrad<%s,%d,%d,PRO=%d>" % (dtype_name if launch.args[1] == 1 else "f32",
+                                                    128 if a.Cout >= 128 else 64,
+                                                    128 if a.SC >= 128 else (64 if a.SC >= 64 else 32), a.pro)
+            flops = wgrad_flops(launch)
+        f = fams.setdefault(name, [0, 0.0, 0.0])
+        f[0] += 1
+        f[1] += ms
+        f[2] += flops
+    return fams
+
+
+def host_cores():
+    """Cores this process may actually run on (cgroup/affinity aware), not the machine total."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:  # cgroup v2 CPU quota
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
+
+
+def cpu_baseline(classes, seconds_budget=20.0):
+    """The oracle (CPU port of the reference path) on this box's host cores: IR-50 + ArcFace + focal + SGD, fp32,
+    batch 16: one warm-up step, then as many timed steps as fit the budget (at least 1)."""
+    from frhip import synth
+    from oracle import irse_ref as O
+    from backbone.model_irse import IR_50
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    B = 16
+    sd = {k: v.detach().clone() for k, v in IR_50([112, 112]).state_dict().items()}
+    synth.fill_state_dict(sd, 15)
+    names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    for k in names:
+        sd[k].requires_grad_(True)
+    hw = synth.uniform(16, "bench.head", (classes, 512), -0.05, 0.05).requires_grad_(True)
+    x = synth.uniform(7, "cpu.x", (B, 3, 112, 112))
+    y = synth.labels(7, "cpu.y", B, classes)
+    bufs = {n: None for n in names + ["head"]}
+
+    def one():
+        _f, logits, _loss, grads = O.train_step(sd, x, y, hw)
+        O.topk_accuracy(logits.detach(), y)
+        with torch.no_grad():
+            for n in names:
+                bufs[n] = O.sgd_step([sd[n]], [grads[n]], [bufs[n]], 0.03, 0.9, 0.0 if O.is_bn_key(n) else 2e-3)[0]
+            bufs["head"] = O.sgd_step([hw], [grads["head.weight"]], [bufs["head"]], 0.03, 0.9, 2e-3)[0]
+
+    one()
+    t0 = time.time()
+    n = 0
+    while n < 1 or (time.time() - t0 < seconds_budget and n < 10):
+        one()
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(B * n / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "oracle/irse_ref.py train_step+sgd, IR-50+ArcFace(%d)+Focal, fp32, batch %d, %d steps in %.1fs"
+                      % (classes, B, n, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback for the product path)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    model, head, loss_fn, opt, x, y = build_job(args, device, rank)
+    dp = None
+    if world > 1:
+        from frhip.parallel import DataParallel
+        dp = DataParallel(model, head)
+    step = make_step(model, head, loss_fn, opt, dp)
+
+    for _ in range(args.warmup):
+        step(x, y)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _prec = step(x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss_val = float(loss)
+    assert loss_val == loss_val, "loss is NaN"
+
+    ms = dt / args.steps * 1e3
+    ips = args.batch * world * args.steps / dt
+    out = {
+        "metric": "images/sec/GPU IR-50+ArcFace 112x112 bs=256; 1->8 GPU scaling eff.",
+        "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "IR-50 + ArcFace(%d ids) + Focal + SGD train step, synthetic 112x112x3, bs=%d/GPU"
+                               % (args.classes, args.batch),
+                   "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                   "images_per_sec_per_gpu": round(ips / world, 1), "final_loss": round(loss_val, 4)},
+    }
+    if rank == 0:
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        flops_img = IR50_FLOPS_PER_IMG + 6.0 * 512 * args.classes
+        step_tflops = flops_img * ips / world / 1e12
+        if not args.no_roofline:
+            fams = instrumented_step(step, x, y, args.dtype)
+            table = sorted(fams.items(), key=lambda kv: -kv[1][1])
+            dom = next(((k, v) for k, v in table if v[2] > 0), None)
+            total_ms = sum(v[1] for v in fams.values())
+            if args.kernel_table:
+                with open(args.kernel_table, "w") as f:
+                    json.dump({k: {"launches": v[0], "ms": round(v[1], 4), "tflops": round(v[2] / 1e12, 4)}
+                               for k, v in table}, f, indent=1)
+            if dom is not None:
+                name, (cnt, kms, flops) = dom
+                ach = flops / (kms * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                                   "frac": round(ach / peak, 4), "traffic": None, "kernel": name, "launches": cnt,
+                                   "avg_launch_ms": round(kms / cnt, 4),
+                                   "share_of_step": round(kms / total_ms, 3),
+                                   "step_achieved": round(step_tflops, 2), "step_frac": round(step_tflops / peak, 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.classes)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

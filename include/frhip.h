@@ -1,0 +1,267 @@
+/* frhip -- C ABI of the MI355X (gfx950) kernels behind the Stage-3 face-recognition training step.
+ *
+ * Drop-in boundary.  The reference has no FFI for this path: it reaches its arithmetic
+ * through torch.nn modules (cuDNN/cuBLAS underneath).  Every entry point below therefore cites the
+ * reference call site (file:line under /root/reference) whose arithmetic it replaces.  The only native
+ * boundary the reference does have (backbone/stylegan2/op/fused_bias_act.cpp:11-21, upfirdn2d.cpp:12-22)
+ * sets the conventions copied here: contiguous device buffers, work enqueued on the caller's stream, no
+ * host synchronisation, autograd kept on the Python side.
+ *
+ * Conventions
+ *   - every function returns int: 0 ok, <0 unsupported argument (see fr_last_error_string), >0 hipError_t
+ *   - pointers are device pointers borrowed for the duration of the enqueue; `stream` is a hipStream_t
+ *   - no allocation, no synchronisation, no global mutable state besides the per-thread error string
+ *   - activations are NHWC ("pixels x channels") in the compute dtype (FR_F32 or FR_BF16); statistics,
+ *     gradients of parameters and optimizer state are always fp32; labels are int64
+ */
+#ifndef FRHIP_H
+#define FRHIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FR_ABI_VERSION 1
+
+enum { FR_F32 = 0, FR_BF16 = 1 };
+
+/* prologue applied to the gathered A operand */
+enum { FR_PRO_NONE = 0, FR_PRO_BN = 1 /* x*a[c]+b[c] */, FR_PRO_PRELU = 2 /* x>0?x:a[c]*x */ };
+
+/* epilogue of fr_conv_igemm */
+enum {
+  FR_EPI_STORE = 0,     /* out = acc (+bias) */
+  FR_EPI_STATS = 1,     /* + part[mtile][0][n] = sum_rows out, part[mtile][1][n] = sum_rows out^2 */
+  FR_EPI_PRELU_BWD = 2, /* out = acc * (aux>0 ? 1 : epi_a[n]); part[mtile][0][n] = sum acc*aux*[aux<=0] */
+  FR_EPI_BNBWD = 3,     /* out = acc; part[.][0] = sum acc; part[.][1] = sum acc*(aux-epi_a[n])*epi_b[n] */
+  FR_EPI_MARGIN = 4,    /* out = scale*(n==label[m] ? phi(acc) : acc); cos_t[m] = acc[label] */
+  FR_EPI_ATOMIC = 5     /* atomicAdd(out, acc) fp32; used with splitk > 1 */
+};
+
+typedef struct FrConvArgs {
+  const void* src; /* A operand: NHWC [B,SH,SW,SC], pixel stride lda (elements) */
+  const void* w;   /* B operand: [N][KH*KW][SC] in the compute dtype */
+  void* out;       /* [B*RH*RW][ldc], compute dtype or fp32 (out_f32) */
+  int32_t B, RH, RW;   /* row space: one GEMM row per (b, rh, rw) */
+  int32_t SH, SW, SC;  /* source tensor geometry; SC % 32 == 0 */
+  int32_t N;           /* output columns */
+  int32_t KH, KW, stride, pad;
+  int32_t mode;        /* 0: sh = rh*stride+kh-pad (forward); 1: sh = (rh+pad-kh)/stride (data gradient) */
+  int32_t lda, ldc, ldaux;
+  int32_t pro;         /* FR_PRO_* */
+  int32_t epi;         /* FR_EPI_* */
+  int32_t out_f32;
+  int32_t splitk;      /* >1: K loop split over gridDim.z, requires FR_EPI_ATOMIC + out_f32 */
+  int32_t stride_log2; /* filled in by the library */
+  int32_t margin_kind; /* 0 ArcFace, 1 CosFace */
+  int32_t easy_margin;
+  float cos_m, sin_m, th, mm, scale;
+  const float* pro_a; /* [SC] */
+  const float* pro_b; /* [SC] */
+  const float* bias;  /* [N] or NULL */
+  const float* epi_a; /* [N] */
+  const float* epi_b; /* [N] */
+  const void* aux;    /* [rows][ldaux] compute dtype */
+  float* part;        /* [ceil(rows/128)][2][N] partial column sums */
+  const int64_t* label; /* [rows] */
+  float* cos_t;         /* [rows] */
+} FrConvArgs;
+
+/* Convolution forward / data gradient / dense GEMM on MFMA.
+ * Replaces: Conv2d 3x3 s1/s2 + neighbours in bottleneck_IR (backbone/model_irse.py:56-60), stem conv
+ * (:140, through fr_stem_im2col), shortcut conv1x1 (:55), Linear(25088,512) (:147), and
+ * F.linear(F.normalize(x), F.normalize(W)) + margin blend of ArcFace/CosFace (head/metrics.py:103,115-138,
+ * :167,181-189); their autograd data-gradients with mode = 1. */
+int fr_conv_igemm(const FrConvArgs* args, int dtype, void* stream);
+
+typedef struct FrWgradArgs {
+  const void* g;   /* gradient of the conv output: [B*GH*GW][ldg], columns = Cout */
+  const void* src; /* conv input, NHWC [B,SH,SW,SC], pixel stride lda */
+  float* dw;       /* [Cout][KH*KW][SC] fp32, accumulated with atomicAdd: caller zeroes it first */
+  int32_t B, GH, GW, Cout;
+  int32_t SH, SW, SC;
+  int32_t KH, KW, stride, pad;
+  int32_t ldg, lda;
+  int32_t pro; /* FR_PRO_* applied to src */
+  int32_t nsplit; /* pixel slices (gridDim.y) */
+  const float* pro_a;
+  const float* pro_b;
+} FrWgradArgs;
+
+/* Weight gradient  dw[co][tap][ci] += sum_p g[p][co] * pro(src[pixel(p,tap)][ci]).
+ * Replaces the autograd weight-gradient of every Conv2d / Linear above. */
+int fr_conv_wgrad(const FrWgradArgs* args, int dtype, void* stream);
+
+/* ---- stem: NCHW fp32 images (+ optional constant avg image, restyle_psp.py:445-447) -> im2col rows
+ * out[(b,h,w)][(kh*3+kw)*C + c] in the compute dtype, K padded with zeros to ldk (32 or 64).
+ * Replaces the unfold half of input_layer Conv2d(3|6,64,3,1,1) (model_irse.py:140, restyle_psp.py:137). */
+int fr_stem_im2col(const float* x, const float* avg, void* out, int B, int H, int W, int C, int Cavg, int ldk,
+                   int dtype, void* stream);
+
+/* ---- BatchNorm statistics (train mode; torch defaults eps 1e-5, momentum 0.1 -- SURVEY App. B 13)
+ * part: [nparts][2][C] partial (sum, sum of squares) rows; count = elements per channel.
+ * Writes mean, invstd, scale = gamma*invstd, shift = beta - mean*scale; updates running stats (unbiased var)
+ * and num_batches_tracked when those pointers are non-NULL.  Replaces nn.BatchNorm2d/1d statistics
+ * (model_irse.py:57,60,141,144,148). */
+int fr_bn_finalize(const float* part, int nparts, int C, double count, const float* gamma, const float* beta,
+                   float eps, float momentum, float* running_mean, float* running_var, int64_t* nbt,
+                   float* mean, float* invstd, float* scale, float* shift, void* stream);
+
+/* per-channel (sum, sumsq) partials of an NHWC tensor: part[blk][2][C], blk < nblocks (= grid size) */
+int fr_channel_stats(const void* x, long long rows, int C, float* part, int nblocks, int dtype, void* stream);
+
+/* out = [prelu]( x*scale+shift [* se[b][c]] ) [+ res]  with (sum,sumsq) partials of `out` for the next BN.
+ *   res_kind 0 none | 1 identity shortcut x_in[b, h*stride, w*stride, c] (MaxPool2d(1,s), model_irse.py:53)
+ *            | 2 BN'd conv shortcut: res*rscale+rshift (model_irse.py:55-56)
+ * Replaces BN apply + PReLU of the stem (:141-142) and BN + SE excite + residual add of a unit (:60-66). */
+typedef struct FrApplyArgs {
+  const void* x;       /* [B*H*W][C] */
+  void* out;           /* [B*H*W][C] */
+  const float* scale;  /* [C] */
+  const float* shift;  /* [C] */
+  const float* slope;  /* PReLU [C] or NULL */
+  const float* se;     /* [B][C] or NULL */
+  const void* res;     /* residual source or NULL */
+  const float* rscale; /* [C] for res_kind 2 */
+  const float* rshift;
+  float* part;         /* [nblocks][2][C] or NULL */
+  int32_t B, H, W, C;
+  int32_t res_kind, res_stride; /* identity: res has geometry [B, H*res_stride, W*res_stride, C] */
+  int32_t nblocks;     /* grid size == number of partial rows */
+} FrApplyArgs;
+int fr_bn_apply(const FrApplyArgs* args, int dtype, void* stream);
+
+/* ---- BatchNorm backward.  g' is the gradient at the BN output:
+ *   g' = g                                    plain
+ *      = g * prelu'(u),  u = x*scale+shift    slope != NULL  (stem: BN -> PReLU, model_irse.py:141-142)
+ *      = g * se[b][c] + gse[b][c]             se != NULL     (IR-SE: BN -> SE excite, model_irse.py:86-87)
+ * fr_bn_bwd_reduce: part[blk][3][C]: k=0 sum g', k=1 sum g'*xhat, k=2 sum g*u*[u<=0] (PReLU slope gradient)
+ * fr_bn_bwd_apply : gx = gamma*invstd*(g' - s0/n - xhat*s1/n) [+ add]
+ *   add_kind 0 none | 1 tensor of the same geometry (conv-shortcut data gradient)
+ *            | 2 identity shortcut MaxPool2d(1,s): add[b, h/s, w/s, c] where h%s==0 and w%s==0 */
+typedef struct FrBnBwdArgs {
+  const void* g;       /* upstream gradient [rows][C] */
+  const void* x;       /* BN input [rows][C] */
+  void* gx;            /* apply: output gradient [rows][C] */
+  const float* mean;
+  const float* invstd;
+  const float* scale;  /* gamma*invstd, shift: only read when slope != NULL */
+  const float* shift;
+  const float* slope;
+  const float* se;     /* [B][C] */
+  const float* gse;    /* [B][C] gradient wrt the pooled BN output, already divided by H*W */
+  const float* gamma;  /* apply */
+  const float* s0;     /* apply: reduced sums [C] */
+  const float* s1;
+  const void* add;     /* apply */
+  float* part;         /* reduce: [nblocks][3][C] */
+  long long rows;
+  float inv_count;     /* 1 / rows */
+  int32_t C;
+  int32_t rows_per_image; /* H*W (se indexing, identity scatter) */
+  int32_t add_kind;
+  int32_t H, W, add_stride; /* geometry of gx for add_kind 2 */
+  int32_t nblocks;
+} FrBnBwdArgs;
+int fr_bn_bwd_reduce(const FrBnBwdArgs* args, int dtype, void* stream);
+int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream);
+
+/* add partial rows in double: o_k[c] = sum_blk part[blk][k][c], k < K <= 3; NULL outputs are skipped.
+ * Used for d gamma (k=1), d beta (k=0), d PReLU slope (k=2) and for the conv-epilogue partials. */
+int fr_reduce_parts(const float* part, int nparts, int K, int C, float* o0, float* o1, float* o2, void* stream);
+
+/* eval-mode BatchNorm coefficients from the running statistics */
+int fr_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                      float eps, int C, float* mean, float* invstd, float* scale, float* shift, void* stream);
+
+/* ---- SE block (model_irse.py:23-46 / restyle_psp_helpers.py:67-83) */
+/* pooled[b][c] = mean_hw (x*scale+shift)  */
+int fr_se_pool(const void* x, const float* scale, const float* shift, float* pooled, int B, int HW, int C,
+               int dtype, void* stream);
+/* s = sigmoid(W2 relu(W1 pooled)); W1 [R][C], W2 [C][R]; saves hidden [B][R] */
+int fr_se_mlp_fwd(const float* pooled, const float* w1, const float* w2, float* hidden, float* s, int B, int C,
+                  int R, void* stream);
+/* gs[b][c] = sum_hw g * (x*scale+shift)  (gradient wrt the excite scale) */
+int fr_se_gscale(const void* g, const void* x, const float* scale, const float* shift, float* gs, int B, int HW,
+                 int C, int dtype, void* stream);
+/* backward of the MLP: gpooled [B][C] (already divided by HW), dW1, dW2 accumulated (+=) */
+int fr_se_mlp_bwd(const float* gs, const float* s, const float* hidden, const float* pooled, const float* w1,
+                  const float* w2, float* gpooled, float* dw1, float* dw2, int B, int C, int R, int HW,
+                  void* stream);
+
+/* ---- output layer pieces (model_irse.py:144-148) */
+/* a[b][(h*7+w)*C + c] = dropout(x*scale+shift): mask from a counter hash of (seed, element index in the
+ * reference's C-major flatten order), keep prob 1-p, scaled 1/(1-p); p = 0 disables. */
+int fr_bn_dropout(const void* x, void* out, const float* scale, const float* shift, long long rows, int C, int HW,
+                  float p, uint64_t seed, int dtype, void* stream);
+int fr_dropout_bwd(void* g, long long rows, int C, int HW, float p, uint64_t seed, int dtype, void* stream);
+
+/* ---- weight packing: fp32 master [Cout][taps][Cin] (channels-last storage of the OIHW Parameter)
+ *   wp [Cout][taps][Cin] compute dtype (NULL to skip), wt [Cin][taps][Cout] compute dtype (NULL to skip) */
+int fr_pack_weight(const float* w, void* wp, void* wt, int Cout, int taps, int Cin, int dtype, void* stream);
+/* Linear(25088,512): torch layout [O][C*HW] (c-major) <-> NHWC-flatten [O][HW*C]; dir 0: torch->packed
+ * (dtype out, optional transposed copy wt [HW*C][O]), dir 1: packed fp32 grad -> torch fp32 grad */
+int fr_permute_linear(const float* in, void* out, void* wt, int O, int C, int HW, int dir, int dtype,
+                      void* stream);
+/* stem weight: torch [64][C][3][3] fp32 (any strides given) <-> packed [64][ldk] with k=(kh*3+kw)*C+c */
+int fr_pack_stem(const float* w, long long s_o, long long s_c, long long s_h, long long s_w, void* wp, int Cout,
+                 int C, int ldk, int dtype, void* stream);
+int fr_unpack_stem_grad(const float* gp, float* gw, long long s_o, long long s_c, long long s_h, long long s_w,
+                        int Cout, int C, int ldk, void* stream);
+/* generic cast fp32 -> compute dtype (n elements) and back */
+int fr_cast(const void* in, void* out, long long n, int dtype_in, int dtype_out, void* stream);
+
+/* ---- margin head (head/metrics.py:97-140 ArcFace, :164-191 CosFace) */
+/* row L2 normalise (F.normalize, eps 1e-12): xn [rows][ldn] compute dtype (rows..rows_pad zero filled),
+ * optional transposed copy xt [D][ldt], inv [rows] = 1/max(||x||,eps) */
+int fr_row_normalize(const float* x, void* xn, void* xt, float* inv, int rows, int rows_pad, int D, int ldt,
+                     int dtype, void* stream);
+/* gcos[m][n] = scale * g[m][n] * (n==label[m] ? dphi(cos_t[m]) : 1), zero padded to ldg columns */
+int fr_margin_bwd(const float* g, const int64_t* label, const float* cos_t, void* gcos, int rows, int N, int ldg,
+                  int kind, int easy, float cos_m, float sin_m, float th, float scale, int dtype, void* stream);
+/* backward through F.normalize: gx = (G - xhat*(xhat.G)) * inv, xhat = x*inv, rows of D */
+int fr_normalize_bwd(const float* G, const float* x, const float* inv, float* gx, int rows, int D, void* stream);
+
+/* ---- focal loss on the batch-mean cross entropy (loss/focal.py:17-21) + top-k (util/utils.py:343-358) */
+/* per row: lse[m], ce[m] = lse - z[label], rank[m] = #{n: z[n] > z[label]} */
+int fr_ce_rows(const float* logits, const int64_t* label, float* lse, float* ce, int32_t* rank, int rows, int N,
+               int ld, void* stream);
+/* rank[m] only (accuracy on arbitrary logits, util/utils.py:343-358) */
+int fr_rank_rows(const float* logits, const int64_t* label, int32_t* rank, int rows, int N, int ld, void* stream);
+/* scalars[0]=loss, [1]=dloss/dmeanCE, [2]=prec@1, [3]=prec@5, [4]=mean CE */
+int fr_focal_finalize(const float* ce, const int32_t* rank, int rows, float gamma, float* scalars, void* stream);
+/* grad[m][n] = gup[0]*scalars[1]/rows * (exp(z-lse[m]) - [n==label[m]]) */
+int fr_focal_bwd(const float* logits, const int64_t* label, const float* lse, const float* scalars,
+                 const float* gup, float* grad, int rows, int N, int ld, void* stream);
+
+/* ---- multi-tensor SGD with momentum (torch.optim.SGD defaults; train.py:196)
+ *   d = g + wd*p ; buf = momentum*buf + d ; p -= lr*buf      (buf starts at 0, so the first step gives buf = d)
+ * table_dev: device array of tensor records; chunks_dev: device array of (tensor index, chunk index) pairs,
+ * one thread block per chunk of fr_sgd_chunk_elems() elements. */
+typedef struct FrSgdTensor {
+  float* p;
+  const float* g;
+  float* buf;
+  long long n;
+  float wd;
+  int32_t pad_;
+} FrSgdTensor;
+int fr_sgd_chunk_elems(void);
+int fr_sgd_step(const FrSgdTensor* table_dev, const int32_t* chunks_dev, int nchunks, float lr, float momentum,
+                void* stream);
+
+/* out[r][c] = bias ? bias[c] : 0  (fp32 [rows][C]); seeds the split-K accumulation of Linear(25088,512) */
+int fr_fill_rows(float* out, const float* bias, long long rows, int C, void* stream);
+
+/* ---- misc */
+int fr_abi_version(void);
+/* sizeof() of the argument structs as compiled, for binding self-checks: 0 FrConvArgs, 1 FrWgradArgs,
+ * 2 FrApplyArgs, 3 FrBnBwdArgs, 4 FrSgdTensor */
+int fr_struct_size(int which);
+const char* fr_last_error_string(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,457 @@
+// frhip -- implicit-GEMM convolution / dense GEMM on MFMA for gfx950.
+//
+//   out[m][n] = sum_{tap, c}  pro( src[pixel(m, tap)][c] ) * w[n][tap][c]
+//
+// m enumerates the pixels (b, h, w) of the "row space" [B, RH, RW]; the A operand is gathered on the fly
+// from an NHWC tensor src[B, SH, SW, SC] (implicit im2col, zero padding), the B operand is the packed
+// weight [N][taps][SC].  mode 0 = forward gather (sh = rh*stride + kh - pad); mode 1 = transposed gather
+// for data gradients (sh = (rh + pad - kh)/stride when divisible).  taps = 1, RH = RW = 1 gives a plain
+// row-major GEMM  out[B][N] = src[B][SC] * w[N][SC]^T  (Linear 25088->512, the 512 x N_classes head).
+//
+// Replaces what the reference runs through torch.nn.Conv2d / F.linear (backbone/model_irse.py:56-60,
+// :140-148; head/metrics.py:103), with the neighbouring elementwise ops folded in:
+//   prologue on the A operand: BatchNorm apply (res_layer.0, model_irse.py:57) or PReLU (res_layer.2, :58)
+//   epilogue: bias, per-channel sum / sum-of-squares partials for the next train-mode BatchNorm, PReLU
+//   backward + slope gradient, BatchNorm-backward partial sums, ArcFace/CosFace margin + label select
+//   (head/metrics.py:115-138), split-K atomics.
+//
+// Tiling: 256 threads = 4 waves (2 x 2), block tile 128 x BN (BN = 128 | 64), K step 32, fp32 accumulate in
+// 16x16 MFMA tiles (bf16: v_mfma_f32_16x16x32_bf16, f32: 8 x v_mfma_f32_16x16x4_f32).  Operands are staged
+// global -> registers (prologue applied) -> LDS, double buffered, one barrier per K step; LDS rows are
+// padded by 16 B so the ds_read_b128 fragment reads are (nearly) conflict free.  The accumulator tile goes
+// back through LDS so that global stores and the fused column reductions are row-contiguous 16-B accesses.
+#include "common.h"
+#include "frhip_internal.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int NT = 256;
+
+template <typename T, int BN>
+struct Cfg {
+  static constexpr int VEC = Elt<T>::VEC;          // elements per 16 B
+  static constexpr int CPR = BK / VEC;             // 16-B chunks per tile row
+  static constexpr int LDSROW = BK + VEC;          // padded row, elements
+  static constexpr int NA = BM * CPR / NT;         // A chunks per thread
+  static constexpr int NB = BN * CPR / NT;         // B chunks per thread
+  static constexpr int WM = BM / 2, WN = BN / 2;   // per-wave tile
+  static constexpr int TM = WM / 16, TN = WN / 16;
+  static constexpr int STAGE_BYTES = (BM + BN) * LDSROW * (int)sizeof(T);
+  static constexpr int CROW = BN + 4;              // epilogue tile row (floats)
+  static constexpr int EPI_BYTES = 64 * CROW * 4 + 2 * 16 * BN * 4;
+  static constexpr int LDS_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+};
+
+template <typename T, int BN, int PRO>
+__global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
+  using C = Cfg<T, BN>;
+  constexpr int VEC = C::VEC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* As = reinterpret_cast<T*>(smem);                                  // [2][BM][LDSROW]
+  T* Bs = As + 2 * BM * C::LDSROW;                                     // [2][BN][LDSROW]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- block -> tile (XCD-aware: hardware deals consecutive block ids round-robin over the 8 XCDs; give
+  //      each XCD a contiguous run of tiles so neighbouring M tiles / all N tiles of one M tile share an L2)
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int nb_count = (p.N + BN - 1) / BN;
+  const int mb = bid / nb_count, nb = bid - mb * nb_count;
+  const int m0 = mb * BM, n0 = nb * BN;
+  const int M = p.B * p.RH * p.RW;
+
+  const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
+  const T* __restrict__ wgt = reinterpret_cast<const T*>(p.w);
+
+  // ---- per-thread A rows: decode (b, rh, rw) once
+  int a_pix0[C::NA];   // (b*SH)*SW as pixel base of image b in src
+  int a_h0[C::NA], a_w0[C::NA];
+  const int a_cc = tid % C::CPR;
+#pragma unroll
+  for (int i = 0; i < C::NA; ++i) {
+    const int row = tid / C::CPR + i * (NT / C::CPR);
+    const int m = m0 + row;
+    if (m < M) {
+      const int b = m / (p.RH * p.RW);
+      const int rem = m - b * (p.RH * p.RW);
+      const int rh = rem / p.RW, rw = rem - rh * p.RW;
+      a_pix0[i] = b * p.SH * p.SW;
+      if (p.mode == 0) {
+        a_h0[i] = rh * p.stride - p.pad;
+        a_w0[i] = rw * p.stride - p.pad;
+      } else {
+        a_h0[i] = rh + p.pad;
+        a_w0[i] = rw + p.pad;
+      }
+    } else {
+      a_pix0[i] = -1;
+      a_h0[i] = a_w0[i] = 0;
+    }
+  }
+  // ---- per-thread B rows
+  const int b_cc = tid % C::CPR;
+
+  const int taps = p.KH * p.KW;
+  const int kchunks = p.SC / BK;  // K steps per tap
+  const int nk_total = taps * kchunks;
+  int ks_begin = 0, ks_end = nk_total;
+  if (gridDim.z > 1) {
+    ks_begin = (int)(((long long)nk_total * blockIdx.z) / gridDim.z);
+    ks_end = (int)(((long long)nk_total * (blockIdx.z + 1)) / gridDim.z);
+  }
+
+  U128 ra[C::NA], rb[C::NB];
+  bool va[C::NA];
+  float pa[VEC], pb[VEC];  // prologue coefficients for this thread's channel chunk
+
+  auto gload = [&](int ks) {
+    const int tap = ks / kchunks;
+    const int c0 = (ks - tap * kchunks) * BK;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int ca = c0 + a_cc * VEC;
+#pragma unroll
+    for (int i = 0; i < C::NA; ++i) {
+      int sh, sw;
+      bool ok = a_pix0[i] >= 0;
+      if (p.mode == 0) {
+        sh = a_h0[i] + kh;
+        sw = a_w0[i] + kw;
+      } else {
+        const int nh = a_h0[i] - kh, nw = a_w0[i] - kw;
+        ok = ok && nh >= 0 && nw >= 0 && ((nh | nw) & (p.stride - 1)) == 0;
+        sh = nh >> p.stride_log2;
+        sw = nw >> p.stride_log2;
+      }
+      ok = ok && (unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW;
+      va[i] = ok;
+      if (ok) {
+        const size_t off = (size_t)(a_pix0[i] + sh * p.SW + sw) * (size_t)p.lda + ca;
+        ra[i] = ld16(src + off);
+      } else {
+        ra[i] = zero16();
+      }
+    }
+    if (PRO == FR_PRO_BN) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        pa[j] = p.pro_a[ca + j];
+        pb[j] = p.pro_b[ca + j];
+      }
+    } else if (PRO == FR_PRO_PRELU) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) pa[j] = p.pro_a[ca + j];
+    }
+#pragma unroll
+    for (int i = 0; i < C::NB; ++i) {
+      const int n = n0 + tid / C::CPR + i * (NT / C::CPR);
+      if (n < p.N) {
+        const size_t off = ((size_t)n * taps + tap) * (size_t)p.SC + c0 + b_cc * VEC;
+        rb[i] = ld16(wgt + off);
+      } else {
+        rb[i] = zero16();
+      }
+    }
+  };
+
+  auto lstore = [&](int stage) {
+    T* as = As + stage * BM * C::LDSROW;
+    T* bs = Bs + stage * BN * C::LDSROW;
+#pragma unroll
+    for (int i = 0; i < C::NA; ++i) {
+      const int row = tid / C::CPR + i * (NT / C::CPR);
+      U128 v = ra[i];
+      if (PRO != FR_PRO_NONE) {
+        if (va[i]) {
+          float f[VEC];
+          unpack16<T>(v, f);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            if (PRO == FR_PRO_BN) f[j] = fmaf(f[j], pa[j], pb[j]);
+            else f[j] = f[j] > 0.f ? f[j] : f[j] * pa[j];
+          }
+          v = pack16<T>(f);
+        }
+      }
+      st16(as + row * C::LDSROW + a_cc * VEC, v);
+    }
+#pragma unroll
+    for (int i = 0; i < C::NB; ++i) {
+      const int row = tid / C::CPR + i * (NT / C::CPR);
+      st16(bs + row * C::LDSROW + b_cc * VEC, rb[i]);
+    }
+  };
+
+  f32x4 acc[C::TM][C::TN];
+#pragma unroll
+  for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (ks_begin < ks_end) {
+    gload(ks_begin);
+    lstore(0);
+  }
+  __syncthreads();
+
+  const int frow = lane & 15, fq = lane >> 4;
+  for (int ks = ks_begin; ks < ks_end; ++ks) {
+    const int stage = (ks - ks_begin) & 1;
+    const bool more = ks + 1 < ks_end;
+    if (more) gload(ks + 1);
+    const T* as = As + stage * BM * C::LDSROW + (wm * C::WM + frow) * C::LDSROW + fq * 8;
+    const T* bs = Bs + stage * BN * C::LDSROW + (wn * C::WN + frow) * C::LDSROW + fq * 8;
+    Frag<T> fa[C::TM], fb[C::TN];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i) lds_frag_row(fa[i], as + i * 16 * C::LDSROW);
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) lds_frag_row(fb[j], bs + j * 16 * C::LDSROW);
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) acc[i][j] = mma16(fa[i], fb[j], acc[i][j]);
+    if (more) lstore(stage ^ 1);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------------------------------ epilogue
+  float* Cs = reinterpret_cast<float*>(smem);                // [64][CROW]
+  float* Red = Cs + 64 * C::CROW;                            // [2][16][BN]
+  constexpr int UPR = BN / VEC;                              // units (16-B output chunks) per row
+  constexpr int RPP = NT / UPR;                              // rows covered per pass of all threads
+  const int ucol = (tid % UPR) * VEC;                        // first column of this thread's units
+  const int urow0 = tid / UPR;
+  float s0[VEC], s1[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s0[j] = s1[j] = 0.f;
+  const int epi = p.epi;
+  const bool want_stats = (epi == FR_EPI_STATS || epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD);
+  float ea[VEC], eb[VEC];  // per-column epilogue coefficients
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const int n = n0 + ucol + j;
+    ea[j] = 0.f;
+    eb[j] = 0.f;
+    if (n < p.N) {
+      if (epi == FR_EPI_PRELU_BWD) ea[j] = p.epi_a[n];
+      if (epi == FR_EPI_BNBWD) {
+        ea[j] = p.epi_a[n];
+        eb[j] = p.epi_b[n];
+      }
+      if (p.bias) eb[j] = (epi == FR_EPI_BNBWD) ? eb[j] : p.bias[n];
+    }
+  }
+
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();
+    if (wm == h) {
+#pragma unroll
+      for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            Cs[(i * 16 + fq * 4 + r) * C::CROW + wn * C::WN + j * 16 + frow] = acc[i][j][r];
+    }
+    __syncthreads();
+    for (int rr = urow0; rr < 64; rr += RPP) {
+      const int m = m0 + h * 64 + rr;
+      if (m >= M) continue;
+      const int n = n0 + ucol;
+      if (n >= p.N) continue;
+      float v[VEC];
+      const float* cp = Cs + rr * C::CROW + ucol;
+#pragma unroll
+      for (int j = 0; j < VEC; j += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(cp + j);
+        v[j] = t[0];
+        v[j + 1] = t[1];
+        v[j + 2] = t[2];
+        v[j + 3] = t[3];
+      }
+      const bool full = (n + VEC <= p.N);
+      const size_t ooff = (size_t)m * (size_t)p.ldc + n;
+      if (epi == FR_EPI_ATOMIC) {
+        float* o = reinterpret_cast<float*>(p.out) + ooff;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          if (full || n + j < p.N) atomicAdd(o + j, v[j]);
+        continue;
+      }
+      if (p.bias && epi != FR_EPI_BNBWD) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] += eb[j];
+      }
+      if (epi == FR_EPI_STATS) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          s0[j] += v[j];
+          s1[j] = fmaf(v[j], v[j], s1[j]);
+        }
+      } else if (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD) {
+        float x[VEC];
+        const T* ap = reinterpret_cast<const T*>(p.aux) + (size_t)m * (size_t)p.ldaux + n;
+        if (full) {
+          unpack16<T>(ld16(ap), x);
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) x[j] = (n + j < p.N) ? Elt<T>::ld(ap + j) : 0.f;
+        }
+        if (epi == FR_EPI_PRELU_BWD) {
+          // g_y = g_a * prelu'(y);  d slope += g_a * y  for y <= 0   
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const bool pos = x[j] > 0.f;
+            s0[j] += pos ? 0.f : v[j] * x[j];
+            v[j] = pos ? v[j] : v[j] * ea[j];
+          }
+        } else {
+          // sums for the BatchNorm backward that follows: sum g, sum g * xhat
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const float xh = (x[j] - ea[j]) * eb[j];
+            s0[j] += v[j];
+            s1[j] = fmaf(v[j], xh, s1[j]);
+          }
+        }
+      } else if (epi == FR_EPI_MARGIN) {
+        // out = s * (n == label ? phi(cos) : cos)   -- head/metrics.py:115-138 (ArcFace), :181-189 (CosFace)
+        const long long lab = p.label[m];
+        if (lab >= n && lab < n + VEC) {
+          const int j = (int)(lab - n);
+          const float c = v[j];
+          p.cos_t[m] = c;
+          float phi;
+          if (p.margin_kind == 0) {  // ArcFace
+            float t = 1.0f - c * c;
+            t = fminf(fmaxf(t, 1e-10f), 1.0f - 1e-10f);
+            const float sine = sqrtf(t);
+            phi = c * p.cos_m - sine * p.sin_m;
+            if (p.easy_margin) phi = c > 0.f ? phi : c;
+            else phi = c > p.th ? phi : c - p.mm;
+          } else {  // CosFace
+            phi = c - p.cos_m;  // cos_m carries m
+          }
+#pragma unroll
+          for (int jj = 0; jj < VEC; ++jj)
+            if (jj == j) v[jj] = phi;
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] *= p.scale;
+      }
+      // ---- store
+      if (p.out_f32) {
+        float* o = reinterpret_cast<float*>(p.out) + ooff;
+        if (full) {
+#pragma unroll
+          for (int j = 0; j < VEC; j += 4) {
+            f32x4 t = {v[j], v[j + 1], v[j + 2], v[j + 3]};
+            *reinterpret_cast<f32x4*>(o + j) = t;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j)
+            if (n + j < p.N) o[j] = v[j];
+        }
+      } else {
+        T* o = reinterpret_cast<T*>(p.out) + ooff;
+        if (full) {
+          st16(o, pack16<T>(v));
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j)
+            if (n + j < p.N) Elt<T>::st(o + j, v[j]);
+        }
+      }
+    }
+  }
+
+  if (want_stats) {
+    // reduce the per-thread column partials over the RPP row groups through LDS, then one row of partials
+    // per M tile: part[mb][k][N]
+    __syncthreads();
+    if (urow0 < 16) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        Red[(0 * 16 + urow0) * BN + ucol + j] = s0[j];
+        Red[(1 * 16 + urow0) * BN + ucol + j] = s1[j];
+      }
+    }
+    __syncthreads();
+    if (urow0 >= 16) {  // RPP can be 32 (f32, BN=128: UPR=32 -> RPP=8 .. never >16 rows? keep general)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        atomicAdd(&Red[(0 * 16 + (urow0 & 15)) * BN + ucol + j], s0[j]);
+        atomicAdd(&Red[(1 * 16 + (urow0 & 15)) * BN + ucol + j], s1[j]);
+      }
+    }
+    __syncthreads();
+    const int nred = RPP < 16 ? RPP : 16;
+    for (int c = tid; c < 2 * BN; c += NT) {
+      const int k = c / BN, col = c - k * BN;
+      if (n0 + col < p.N) {
+        float s = 0.f;
+        for (int g = 0; g < nred; ++g) s += Red[(k * 16 + g) * BN + col];
+        p.part[((size_t)mb * 2 + k) * (size_t)p.N + n0 + col] = s;
+      }
+    }
+  }
+}
+
+template <typename T, int BN, int PRO>
+int launch(const FrConvArgs& a, hipStream_t st) {
+  using C = Cfg<T, BN>;
+  const int M = a.B * a.RH * a.RW;
+  const int mbs = (M + BM - 1) / BM, nbs = (a.N + BN - 1) / BN;
+  dim3 grid(mbs * nbs, 1, a.splitk > 1 ? a.splitk : 1);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BN, PRO>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, PRO>), grid, dim3(NT), C::LDS_BYTES, st, a);
+  FR_LAUNCH_CHECK();
+}
+
+template <typename T>
+int dispatch(const FrConvArgs& a, hipStream_t st) {
+  const bool narrow = a.N <= 64;
+  switch (a.pro) {
+    case FR_PRO_NONE:
+      return narrow ? launch<T, 64, FR_PRO_NONE>(a, st) : launch<T, 128, FR_PRO_NONE>(a, st);
+    case FR_PRO_BN:
+      return narrow ? launch<T, 64, FR_PRO_BN>(a, st) : launch<T, 128, FR_PRO_BN>(a, st);
+    case FR_PRO_PRELU:
+      return narrow ? launch<T, 64, FR_PRO_PRELU>(a, st) : launch<T, 128, FR_PRO_PRELU>(a, st);
+  }
+  FR_UNSUPPORTED("fr_conv_igemm: unknown prologue");
+}
+
+}  // namespace
+
+extern "C" int fr_conv_igemm(const FrConvArgs* args, int dtype, void* stream) {
+  FrConvArgs a = *args;
+  if (a.SC % BK != 0) FR_UNSUPPORTED("fr_conv_igemm: source channels must be a multiple of 32");
+  if (a.stride != 1 && a.stride != 2) FR_UNSUPPORTED("fr_conv_igemm: stride must be 1 or 2");
+  if ((long long)a.B * a.RH * a.RW >= (1ll << 31) / 4) FR_UNSUPPORTED("fr_conv_igemm: too many rows");
+  if (a.splitk > 1 && (a.epi != FR_EPI_ATOMIC || !a.out_f32))
+    FR_UNSUPPORTED("fr_conv_igemm: split-K needs the fp32 atomic epilogue");
+  const int esz = dtype == FR_F32 ? 4 : 2;
+  if ((a.lda * esz) % 16 || (a.ldc * (a.out_f32 ? 4 : esz)) % 16 || (a.aux && (a.ldaux * esz) % 16))
+    FR_UNSUPPORTED("fr_conv_igemm: row strides must be 16-byte multiples");
+  a.stride_log2 = a.stride == 2 ? 1 : 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == FR_F32) return dispatch<float>(a, st);
+  if (dtype == FR_BF16) return dispatch<bf16_t>(a, st);
+  FR_UNSUPPORTED("fr_conv_igemm: dtype must be FR_F32 or FR_BF16");
+}

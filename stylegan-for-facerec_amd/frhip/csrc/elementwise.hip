@@ -1,0 +1,813 @@
+// frhip -- HBM-bound channel-wise passes of the IR / IR-SE residual units on gfx950.
+//
+// All tensors are "pixel rows x channels" (NHWC) in the compute dtype; every thread moves 16-byte chunks
+// (8 bf16 / 4 f32 channels), a block's threads are laid out [row-thread][channel-chunk] so global accesses
+// are fully coalesced along the channel axis and per-channel reductions stay in registers until one
+// LDS combine per block.  Partial sums leave the kernel as one row per block (part[blk][k][C]); a tiny
+// second kernel adds them in double precision -- deterministic, no global float atomics.
+//
+// Reference arithmetic replaced (paths under /root/reference):
+//   BatchNorm2d train-mode statistics / apply / backward   backbone/model_irse.py:57,60,141,144
+//   PReLU (stem) fwd / bwd                                 backbone/model_irse.py:142
+//   residual add with MaxPool2d(1,stride) or conv shortcut backbone/model_irse.py:52-66
+//   SEModule squeeze / excite                              backbone/model_irse.py:23-46
+//   Dropout(0.5) + Flatten of the output layer             backbone/model_irse.py:145-146
+#include "common.h"
+#include "frhip_internal.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// combine per-thread column partials acc[K][VEC] across the row-threads of a block; the first row-thread
+// group writes part[blk][k][C].  cpr = chunks per row (C / VEC), must divide NT... or cpr >= NT handled by caller.
+template <int K, int VEC>
+__device__ __forceinline__ void block_col_reduce(float (&acc)[K][VEC], float* red, float* part_blk, int C,
+                                                 int cpr, int tid) {
+  // red: [NT][K*VEC]
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[tid * (K * VEC) + k * VEC + j] = acc[k][j];
+  __syncthreads();
+  const int rt_count = NT / cpr;
+  for (int e = tid; e < cpr * K * VEC; e += NT) {
+    const int cc = e / (K * VEC), kj = e - cc * (K * VEC);
+    float s = 0.f;
+    for (int r = 0; r < rt_count; ++r) s += red[(r * cpr + cc) * (K * VEC) + kj];
+    const int k = kj / VEC, j = kj - k * VEC;
+    part_blk[(size_t)k * C + cc * VEC + j] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ stem im2col
+template <typename T>
+__global__ void stem_im2col_kernel(const float* __restrict__ x, const float* __restrict__ avg, T* __restrict__ out,
+                                   int B, int H, int W, int C, int Cavg, int ldk) {
+  // one thread per (pixel, tap): writes Ct = C + Cavg consecutive k entries; tap 9 = zero tail
+  const int Ct = C + Cavg;
+  const long long total = (long long)B * H * W * 10;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % 10);
+    const long long pix = i / 10;
+    T* o = out + pix * ldk;
+    if (tap == 9) {
+      for (int k = 9 * Ct; k < ldk; ++k) Elt<T>::st(o + k, 0.f);
+      continue;
+    }
+    const int w = (int)(pix % W);
+    const int h = (int)((pix / W) % H);
+    const int b = (int)(pix / ((long long)W * H));
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int sh = h + kh - 1, sw = w + kw - 1;
+    const bool ok = (unsigned)sh < (unsigned)H && (unsigned)sw < (unsigned)W;
+    for (int c = 0; c < Ct; ++c) {
+      float v = 0.f;
+      if (ok) {
+        if (c < C) v = x[(((long long)b * C + c) * H + sh) * W + sw];
+        else v = avg[((long long)(c - C) * H + sh) * W + sw];
+      }
+      Elt<T>::st(o + tap * Ct + c, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ BN finalize
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, long long* nbt,
+                                   float* mean, float* invstd, float* scale, float* shift) {
+  // one wave per channel: lanes stride over the partial rows, double accumulate
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int i = lane; i < nparts; i += 64) {
+    s += (double)part[((size_t)i * 2 + 0) * C + c];
+    q += (double)part[((size_t)i * 2 + 1) * C + c];
+  }
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  if (lane == 0) {
+    const double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    mean[c] = (float)m;
+    invstd[c] = is;
+    scale[c] = g * is;
+    shift[c] = bt - (float)m * g * is;
+    if (running_mean) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+    if (nbt && c == 0) *nbt += 1;
+  }
+}
+
+// eval-mode coefficients from running statistics
+__global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, const float* gamma, const float* beta,
+                                      float eps, int C, float* mean, float* invstd, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.0f / sqrtf(rv[c] + eps);
+  mean[c] = rm[c];
+  invstd[c] = is;
+  scale[c] = gamma[c] * is;
+  shift[c] = beta[c] - rm[c] * gamma[c] * is;
+}
+
+__global__ void reduce_parts_kernel(const float* __restrict__ part, int nparts, int K, int C, float* o0, float* o1,
+                                    float* o2) {
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (idx >= K * C) return;
+  const int k = idx / C, c = idx - k * C;
+  double s = 0.0;
+  for (int i = lane; i < nparts; i += 64) s += (double)part[((size_t)i * K + k) * C + c];
+  s = wave_sum_d(s);
+  if (lane == 0) {
+    float* o = k == 0 ? o0 : (k == 1 ? o1 : o2);
+    if (o) o[c] = (float)s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ channel stats
+template <typename T>
+__global__ __launch_bounds__(NT) void channel_stats_kernel(const T* __restrict__ x, long long rows, int C,
+                                                           float* __restrict__ part) {
+  constexpr int VEC = Elt<T>::VEC;
+  __shared__ float red[NT * 2 * VEC];
+  const int cpr = C / VEC, tid = threadIdx.x;
+  const int cc = tid % cpr, rt = tid / cpr, rtc = NT / cpr;
+  float acc[2][VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = 0.f;
+  for (long long r = (long long)blockIdx.x * rtc + rt; r < rows; r += (long long)gridDim.x * rtc) {
+    float f[VEC];
+    unpack16<T>(ld16(x + r * C + cc * VEC), f);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      acc[0][j] += f[j];
+      acc[1][j] = fmaf(f[j], f[j], acc[1][j]);
+    }
+  }
+  block_col_reduce<2, VEC>(acc, red, part + (size_t)blockIdx.x * 2 * C, C, cpr, tid);
+}
+
+// ------------------------------------------------------------------------------------------ BN apply (+SE, +PReLU, +residual)
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_apply_kernel(const FrApplyArgs p) {
+  constexpr int VEC = Elt<T>::VEC;
+  __shared__ float red[NT * 2 * VEC];
+  const int C = p.C, cpr = C / VEC, tid = threadIdx.x;
+  const int cc = tid % cpr, rt = tid / cpr, rtc = NT / cpr;
+  const int c0 = cc * VEC;
+  const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.res);
+  T* __restrict__ out = reinterpret_cast<T*>(p.out);
+  float sc[VEC], sh[VEC], sl[VEC], rs[VEC], rh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sc[j] = p.scale[c0 + j];
+    sh[j] = p.shift[c0 + j];
+    sl[j] = p.slope ? p.slope[c0 + j] : 1.f;
+    rs[j] = p.res_kind == 2 ? p.rscale[c0 + j] : 1.f;
+    rh[j] = p.res_kind == 2 ? p.rshift[c0 + j] : 0.f;
+  }
+  float acc[2][VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = 0.f;
+  const long long rows = (long long)p.B * p.H * p.W;
+  const int HW = p.H * p.W;
+  for (long long r = (long long)blockIdx.x * rtc + rt; r < rows; r += (long long)gridDim.x * rtc) {
+    float f[VEC];
+    unpack16<T>(ld16(x + r * C + c0), f);
+    const int b = (int)(r / HW);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) f[j] = fmaf(f[j], sc[j], sh[j]);
+    if (p.se) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] *= p.se[(size_t)b * C + c0 + j];
+    }
+    if (p.slope) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] = f[j] > 0.f ? f[j] : f[j] * sl[j];
+    }
+    if (p.res_kind != 0) {
+      long long rr = r;
+      if (p.res_kind == 1 && p.res_stride > 1) {
+        const int rem = (int)(r - (long long)b * HW);
+        const int h = rem / p.W, w = rem - h * p.W;
+        rr = ((long long)b * (p.H * p.res_stride) + (long long)h * p.res_stride) * (p.W * p.res_stride) +
+             (long long)w * p.res_stride;
+      }
+      float g[VEC];
+      unpack16<T>(ld16(res + rr * C + c0), g);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] += fmaf(g[j], rs[j], rh[j]);
+    }
+    const U128 o = pack16<T>(f);
+    st16(out + r * C + c0, o);
+    if (p.part) {
+      float q[VEC];
+      unpack16<T>(o, q);  // statistics of what the next layer will actually read
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        acc[0][j] += q[j];
+        acc[1][j] = fmaf(q[j], q[j], acc[1][j]);
+      }
+    }
+  }
+  if (p.part) block_col_reduce<2, VEC>(acc, red, p.part + (size_t)blockIdx.x * 2 * C, C, cpr, tid);
+}
+
+// ------------------------------------------------------------------------------------------ BN backward
+// g' = g                                  plain
+//    = g * prelu'(u), u = x*scale+shift   when slope != NULL (stem: BN -> PReLU)
+//    = g * se[b][c] + gse[b][c]           when se != NULL (IR-SE: BN -> SE excite)
+template <typename T>
+__device__ __forceinline__ void bn_bwd_gprime(const FrBnBwdArgs& p, const float* g, const float* xv, int b, int c0,
+                                              const float* sc, const float* sh, const float* sl, float* gp,
+                                              float* slope_term) {
+  constexpr int VEC = Elt<T>::VEC;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    float v = g[j];
+    if (p.slope) {
+      const float u = fmaf(xv[j], sc[j], sh[j]);
+      const bool pos = u > 0.f;
+      if (slope_term) slope_term[j] = pos ? 0.f : v * u;
+      v = pos ? v : v * sl[j];
+    }
+    if (p.se) v = fmaf(v, p.se[(size_t)b * p.C + c0 + j], p.gse ? p.gse[(size_t)b * p.C + c0 + j] : 0.f);
+    gp[j] = v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const FrBnBwdArgs p) {
+  constexpr int VEC = Elt<T>::VEC;
+  __shared__ float red[NT * 3 * VEC];
+  const int C = p.C, cpr = C / VEC, tid = threadIdx.x;
+  const int cc = tid % cpr, rt = tid / cpr, rtc = NT / cpr, c0 = cc * VEC;
+  const T* __restrict__ g = reinterpret_cast<const T*>(p.g);
+  const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+  float mu[VEC], is[VEC], sc[VEC], sh[VEC], sl[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    mu[j] = p.mean[c0 + j];
+    is[j] = p.invstd[c0 + j];
+    sc[j] = p.scale ? p.scale[c0 + j] : 1.f;
+    sh[j] = p.shift ? p.shift[c0 + j] : 0.f;
+    sl[j] = p.slope ? p.slope[c0 + j] : 1.f;
+  }
+  float acc[3][VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.f;
+  for (long long r = (long long)blockIdx.x * rtc + rt; r < p.rows; r += (long long)gridDim.x * rtc) {
+    float gv[VEC], xv[VEC], gp[VEC], st[VEC];
+    unpack16<T>(ld16(g + r * C + c0), gv);
+    unpack16<T>(ld16(x + r * C + c0), xv);
+    const int b = (int)(r / p.rows_per_image);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) st[j] = 0.f;
+    bn_bwd_gprime<T>(p, gv, xv, b, c0, sc, sh, sl, gp, st);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      acc[0][j] += gp[j];
+      acc[1][j] = fmaf(gp[j], (xv[j] - mu[j]) * is[j], acc[1][j]);
+      acc[2][j] += st[j];
+    }
+  }
+  block_col_reduce<3, VEC>(acc, red, p.part + (size_t)blockIdx.x * 3 * C, C, cpr, tid);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const FrBnBwdArgs p) {
+  constexpr int VEC = Elt<T>::VEC;
+  const int C = p.C, cpr = C / VEC, tid = threadIdx.x;
+  const int cc = tid % cpr, rt = tid / cpr, rtc = NT / cpr, c0 = cc * VEC;
+  const T* __restrict__ g = reinterpret_cast<const T*>(p.g);
+  const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ add = reinterpret_cast<const T*>(p.add);
+  T* __restrict__ gx = reinterpret_cast<T*>(p.gx);
+  float mu[VEC], is[VEC], sc[VEC], sh[VEC], sl[VEC], coef[VEC], a[VEC], bb[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    mu[j] = p.mean[c0 + j];
+    is[j] = p.invstd[c0 + j];
+    sc[j] = p.scale ? p.scale[c0 + j] : 1.f;
+    sh[j] = p.shift ? p.shift[c0 + j] : 0.f;
+    sl[j] = p.slope ? p.slope[c0 + j] : 1.f;
+    coef[j] = (p.gamma ? p.gamma[c0 + j] : 1.f) * is[j];
+    a[j] = p.s0[c0 + j] * p.inv_count;
+    bb[j] = p.s1[c0 + j] * p.inv_count;
+  }
+  for (long long r = (long long)blockIdx.x * rtc + rt; r < p.rows; r += (long long)gridDim.x * rtc) {
+    float gv[VEC], xv[VEC], gp[VEC];
+    unpack16<T>(ld16(g + r * C + c0), gv);
+    unpack16<T>(ld16(x + r * C + c0), xv);
+    const int b = (int)(r / p.rows_per_image);
+    bn_bwd_gprime<T>(p, gv, xv, b, c0, sc, sh, sl, gp, nullptr);
+    float o[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = coef[j] * (gp[j] - a[j] - (xv[j] - mu[j]) * is[j] * bb[j]);
+    if (p.add_kind == 1) {
+      float e[VEC];
+      unpack16<T>(ld16(add + r * C + c0), e);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] += e[j];
+    } else if (p.add_kind == 2) {
+      // identity shortcut MaxPool2d(1, s): the gradient lands on pixels with h % s == 0 and w % s == 0
+      const int rem = (int)(r - (long long)b * p.rows_per_image);
+      const int h = rem / p.W, w = rem - h * p.W;
+      const int s = p.add_stride;
+      if (h % s == 0 && w % s == 0) {
+        const long long rr = ((long long)b * (p.H / s) + h / s) * (p.W / s) + w / s;
+        float e[VEC];
+        unpack16<T>(ld16(add + rr * C + c0), e);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] += e[j];
+      }
+    }
+    st16(gx + r * C + c0, pack16<T>(o));
+  }
+}
+
+// ------------------------------------------------------------------------------------------ SE
+// pooled[b][c] = mean_hw(x*scale+shift) = scale*mean_hw(x)+shift : one block per (image, 64-channel... ) simple:
+// grid = B blocks, threads [row-thread][chunk] over the image's HW rows.
+template <typename T, bool GS>
+__global__ __launch_bounds__(NT) void se_pool_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                     const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, float* __restrict__ out,
+                                                     int HW, int C) {
+  constexpr int VEC = Elt<T>::VEC;
+  __shared__ float red[NT * VEC];
+  const int cpr = C / VEC, tid = threadIdx.x, b = blockIdx.x;
+  for (int cbase = 0; cbase < cpr; cbase += NT) {  // C/VEC <= 256 always here, loop kept for generality
+    const int cc = (tid % (cpr < NT ? cpr : NT)) + cbase;
+    const int rtc = cpr < NT ? NT / cpr : 1, rt = cpr < NT ? tid / cpr : 0;
+    const int c0 = cc * VEC;
+    float acc[1][VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[0][j] = 0.f;
+    for (int r = rt; r < HW; r += rtc) {
+      float f[VEC];
+      unpack16<T>(ld16(x + ((size_t)b * HW + r) * C + c0), f);
+      if (GS) {
+        float gv[VEC];
+        unpack16<T>(ld16(g + ((size_t)b * HW + r) * C + c0), gv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[0][j] = fmaf(gv[j], fmaf(f[j], scale[c0 + j], shift[c0 + j]), acc[0][j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[0][j] += f[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[tid * VEC + j] = acc[0][j];
+    __syncthreads();
+    if (rt == 0) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float s = 0.f;
+        for (int r = 0; r < rtc; ++r) s += red[(r * cpr + (cc - cbase)) * VEC + j];
+        if (GS) out[(size_t)b * C + c0 + j] = s;
+        else out[(size_t)b * C + c0 + j] = fmaf(s / (float)HW, scale[c0 + j], shift[c0 + j]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// s = sigmoid(W2 relu(W1 pooled)); one block per image
+__global__ void se_mlp_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                  const float* __restrict__ w2, float* __restrict__ hidden, float* __restrict__ s,
+                                  int C, int R) {
+  extern __shared__ float sm[];  // [C] pooled, [R] hidden
+  float* pv = sm;
+  float* hv = sm + C;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < C; c += blockDim.x) pv[c] = pooled[(size_t)b * C + c];
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+  for (int r = wave; r < R; r += nw) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc = fmaf(w1[(size_t)r * C + c], pv[c], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float h = acc > 0.f ? acc : 0.f;
+      hv[r] = h;
+      hidden[(size_t)b * R + r] = h;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += blockDim.x) {
+    float acc = 0.f;
+    for (int r = 0; r < R; ++r) acc = fmaf(w2[(size_t)c * R + r], hv[r], acc);
+    s[(size_t)b * C + c] = 1.0f / (1.0f + __expf(-acc));
+  }
+}
+
+// backward of the MLP for one image per block; dW1/dW2 accumulated with atomics (tiny tensors)
+__global__ void se_mlp_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ s,
+                                  const float* __restrict__ hidden, const float* __restrict__ pooled,
+                                  const float* __restrict__ w1, const float* __restrict__ w2,
+                                  float* __restrict__ gpooled, float* dw1, float* dw2, int C, int R, float inv_hw) {
+  extern __shared__ float sm[];  // [C] gz (grad at fc2 output), [R] gh
+  float* gz = sm;
+  float* gh = sm + C;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < C; c += blockDim.x) {
+    const float sv = s[(size_t)b * C + c];
+    gz[c] = gs[(size_t)b * C + c] * sv * (1.f - sv);
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+  for (int r = wave; r < R; r += nw) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc = fmaf(w2[(size_t)c * R + r], gz[c], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) gh[r] = hidden[(size_t)b * R + r] > 0.f ? acc : 0.f;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += blockDim.x) {
+    float acc = 0.f;
+    const float pc = pooled[(size_t)b * C + c];
+    for (int r = 0; r < R; ++r) {
+      acc = fmaf(w1[(size_t)r * C + c], gh[r], acc);
+      atomicAdd(dw1 + (size_t)r * C + c, gh[r] * pc);
+      atomicAdd(dw2 + (size_t)c * R + r, gz[c] * hidden[(size_t)b * R + r]);
+    }
+    gpooled[(size_t)b * C + c] = acc * inv_hw;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dropout
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f) >= p;
+}
+
+// out[b][(hw)*C + c] = keep ? (x*scale+shift)/(1-p) : 0 ; mask index = reference flatten order b*(C*HW)+c*HW+hw
+template <typename T, bool BWD>
+__global__ void bn_dropout_kernel(const T* __restrict__ x, T* __restrict__ out, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, long long rows, int C, int HW, float p,
+                                  uint64_t seed) {
+  constexpr int VEC = Elt<T>::VEC;
+  const int cpr = C / VEC;
+  const long long total = rows * cpr;
+  const float keep_scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cpr;
+    const int c0 = (int)(i - r * cpr) * VEC;
+    const long long b = r / HW;
+    const int hw = (int)(r - b * HW);
+    float f[VEC];
+    unpack16<T>(ld16(x + r * C + c0), f);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float v = BWD ? f[j] : fmaf(f[j], scale[c0 + j], shift[c0 + j]);
+      if (p > 0.f) {
+        const uint64_t idx = (uint64_t)b * (uint64_t)(C * HW) + (uint64_t)(c0 + j) * HW + hw;
+        v = drop_keep(seed, idx, p) ? v * keep_scale : 0.f;
+      }
+      f[j] = v;
+    }
+    st16(out + r * C + c0, pack16<T>(f));
+  }
+}
+
+// ------------------------------------------------------------------------------------------ weight packing
+// src fp32 [Cout][taps][Cin]; wp [Cout][taps][Cin] (T), wt [Cin][taps][Cout] (T)
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ wp, T* __restrict__ wt, int Cout,
+                                   int taps, int Cin) {
+  __shared__ float tile[32][33];
+  // grid: x over Cin/32, y over Cout/32, z over taps
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, tap = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) {
+      v = w[((size_t)co * taps + tap) * Cin + ci];
+      if (wp) Elt<T>::st(wp + ((size_t)co * taps + tap) * Cin + ci, v);
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  if (wt) {
+    for (int r = ty; r < 32; r += 8) {
+      const int ci = ci0 + r, co = co0 + tx;
+      if (co < Cout && ci < Cin) Elt<T>::st(wt + ((size_t)ci * taps + tap) * Cout + co, tile[tx][r]);
+    }
+  }
+}
+
+// Linear(25088,512): dir 0: torch fp32 [O][C*HW] -> packed T [O][HW*C] (+ transposed T [HW*C][O])
+//                    dir 1: packed fp32 grad [O][HW*C] -> torch fp32 grad [O][C*HW]
+template <typename T>
+__global__ void permute_linear_kernel(const float* __restrict__ in, T* __restrict__ out, T* __restrict__ wt,
+                                      float* __restrict__ gout, int O, int C, int HW, int dir) {
+  const long long total = (long long)O * C * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    // i indexes the packed layout: o, hw, c  (c fastest)
+    const int c = (int)(i % C);
+    const int hw = (int)((i / C) % HW);
+    const int o = (int)(i / ((long long)C * HW));
+    const long long it = (long long)o * C * HW + (long long)c * HW + hw;  // torch layout index
+    if (dir == 0) {
+      const float v = in[it];
+      Elt<T>::st(out + i, v);
+      if (wt) Elt<T>::st(wt + ((long long)hw * C + c) * O + o, v);
+    } else {
+      gout[it] = in[i];
+    }
+  }
+}
+
+template <typename T>
+__global__ void pack_stem_kernel(const float* __restrict__ w, long long s_o, long long s_c, long long s_h,
+                                 long long s_w, T* __restrict__ wp, int Cout, int C, int ldk) {
+  const int total = Cout * ldk;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int o = i / ldk, k = i - o * ldk;
+    float v = 0.f;
+    if (k < 9 * C) {
+      const int tap = k / C, c = k - tap * C;
+      v = w[o * s_o + c * s_c + (tap / 3) * s_h + (tap % 3) * s_w];
+    }
+    Elt<T>::st(wp + i, v);
+  }
+}
+__global__ void unpack_stem_grad_kernel(const float* __restrict__ gp, float* __restrict__ gw, long long s_o,
+                                        long long s_c, long long s_h, long long s_w, int Cout, int C, int ldk) {
+  const int total = Cout * 9 * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int o = i / (9 * C), k = i - o * 9 * C;
+    const int tap = k / C, c = k - tap * C;
+    gw[o * s_o + c * s_c + (tap / 3) * s_h + (tap % 3) * s_w] = gp[(size_t)o * ldk + k];
+  }
+}
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    Elt<TO>::st(out + i, Elt<TI>::ld(in + i));
+}
+
+inline int grid_for(long long work_items, int per_block, int cap = 2048) {
+  long long g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16, name)          \
+  if ((dtype) == FR_F32) {                                    \
+    CALL_F32;                                                 \
+  } else if ((dtype) == FR_BF16) {                            \
+    CALL_BF16;                                                \
+  } else {                                                    \
+    FR_UNSUPPORTED(name ": dtype must be FR_F32 or FR_BF16"); \
+  }
+
+inline bool chan_ok(int C, int dtype) {
+  const int vec = dtype == FR_F32 ? 4 : 8;
+  const int cpr = C / vec;
+  return C % vec == 0 && cpr <= NT && NT % cpr == 0;
+}
+
+}  // namespace
+
+extern "C" int fr_stem_im2col(const float* x, const float* avg, void* out, int B, int H, int W, int C, int Cavg,
+                              int ldk, int dtype, void* stream) {
+  if (9 * (C + Cavg) > ldk) FR_UNSUPPORTED("fr_stem_im2col: ldk too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for((long long)B * H * W * 10, 256, 1 << 16);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(grid), dim3(256), 0, st, x, avg, (float*)out, B, H,
+                                W, C, Cavg, ldk),
+             hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, x, avg, (bf16_t*)out, B,
+                                H, W, C, Cavg, ldk),
+             "fr_stem_im2col");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_bn_finalize(const float* part, int nparts, int C, double count, const float* gamma,
+                              const float* beta, float eps, float momentum, float* running_mean,
+                              float* running_var, int64_t* nbt, float* mean, float* invstd, float* scale,
+                              float* shift, void* stream) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, nparts, C,
+                     count, gamma, beta, eps, momentum, running_mean, running_var, (long long*)nbt, mean, invstd,
+                     scale, shift);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_bn_eval_coeffs(const float* rm, const float* rv, const float* gamma, const float* beta, float eps,
+                                 int C, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, rm, rv, gamma,
+                     beta, eps, C, mean, invstd, scale, shift);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_reduce_parts(const float* part, int nparts, int K, int C, float* o0, float* o1, float* o2,
+                               void* stream) {
+  if (K < 1 || K > 3) FR_UNSUPPORTED("fr_reduce_parts: K must be 1..3");
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((K * C + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, nparts, K,
+                     C, o0, o1, o2);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_channel_stats(const void* x, long long rows, int C, float* part, int nblocks, int dtype,
+                                void* stream) {
+  if (!chan_ok(C, dtype)) FR_UNSUPPORTED("fr_channel_stats: unsupported channel count");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(channel_stats_kernel<float>, dim3(nblocks), dim3(NT), 0, st, (const float*)x, rows,
+                                C, part),
+             hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, dim3(nblocks), dim3(NT), 0, st, (const bf16_t*)x,
+                                rows, C, part),
+             "fr_channel_stats");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_bn_apply(const FrApplyArgs* args, int dtype, void* stream) {
+  if (!chan_ok(args->C, dtype)) FR_UNSUPPORTED("fr_bn_apply: unsupported channel count");
+  if (args->nblocks < 1) FR_UNSUPPORTED("fr_bn_apply: nblocks < 1");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(args->nblocks), dim3(NT), 0, st, *args),
+             hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(args->nblocks), dim3(NT), 0, st, *args),
+             "fr_bn_apply");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_bn_bwd_reduce(const FrBnBwdArgs* args, int dtype, void* stream) {
+  if (!chan_ok(args->C, dtype)) FR_UNSUPPORTED("fr_bn_bwd_reduce: unsupported channel count");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(args->nblocks), dim3(NT), 0, st, *args),
+             hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(args->nblocks), dim3(NT), 0, st, *args),
+             "fr_bn_bwd_reduce");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream) {
+  if (!chan_ok(args->C, dtype)) FR_UNSUPPORTED("fr_bn_bwd_apply: unsupported channel count");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(args->nblocks), dim3(NT), 0, st, *args),
+             hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(args->nblocks), dim3(NT), 0, st, *args),
+             "fr_bn_bwd_apply");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_se_pool(const void* x, const float* scale, const float* shift, float* pooled, int B, int HW, int C,
+                          int dtype, void* stream) {
+  if (!chan_ok(C, dtype)) FR_UNSUPPORTED("fr_se_pool: unsupported channel count");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((se_pool_kernel<float, false>), dim3(B), dim3(NT), 0, st, (const float*)x,
+                                (const float*)nullptr, scale, shift, pooled, HW, C),
+             hipLaunchKernelGGL((se_pool_kernel<bf16_t, false>), dim3(B), dim3(NT), 0, st, (const bf16_t*)x,
+                                (const bf16_t*)nullptr, scale, shift, pooled, HW, C),
+             "fr_se_pool");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_se_gscale(const void* g, const void* x, const float* scale, const float* shift, float* gs, int B,
+                            int HW, int C, int dtype, void* stream) {
+  if (!chan_ok(C, dtype)) FR_UNSUPPORTED("fr_se_gscale: unsupported channel count");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((se_pool_kernel<float, true>), dim3(B), dim3(NT), 0, st, (const float*)x,
+                                (const float*)g, scale, shift, gs, HW, C),
+             hipLaunchKernelGGL((se_pool_kernel<bf16_t, true>), dim3(B), dim3(NT), 0, st, (const bf16_t*)x,
+                                (const bf16_t*)g, scale, shift, gs, HW, C),
+             "fr_se_gscale");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_se_mlp_fwd(const float* pooled, const float* w1, const float* w2, float* hidden, float* s, int B,
+                             int C, int R, void* stream) {
+  hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), (hipStream_t)stream, pooled,
+                     w1, w2, hidden, s, C, R);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_se_mlp_bwd(const float* gs, const float* s, const float* hidden, const float* pooled,
+                             const float* w1, const float* w2, float* gpooled, float* dw1, float* dw2, int B, int C,
+                             int R, int HW, void* stream) {
+  hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), (hipStream_t)stream, gs, s,
+                     hidden, pooled, w1, w2, gpooled, dw1, dw2, C, R, 1.0f / (float)HW);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_bn_dropout(const void* x, void* out, const float* scale, const float* shift, long long rows, int C,
+                             int HW, float p, uint64_t seed, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int vec = dtype == FR_F32 ? 4 : 8;
+  if (C % vec) FR_UNSUPPORTED("fr_bn_dropout: unsupported channel count");
+  const int grid = grid_for(rows * (C / vec), 256, 4096);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((bn_dropout_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)x,
+                                (float*)out, scale, shift, rows, C, HW, p, seed),
+             hipLaunchKernelGGL((bn_dropout_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x,
+                                (bf16_t*)out, scale, shift, rows, C, HW, p, seed),
+             "fr_bn_dropout");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_dropout_bwd(void* g, long long rows, int C, int HW, float p, uint64_t seed, int dtype,
+                              void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int vec = dtype == FR_F32 ? 4 : 8;
+  if (C % vec) FR_UNSUPPORTED("fr_dropout_bwd: unsupported channel count");
+  const int grid = grid_for(rows * (C / vec), 256, 4096);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((bn_dropout_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)g,
+                                (float*)g, (const float*)nullptr, (const float*)nullptr, rows, C, HW, p, seed),
+             hipLaunchKernelGGL((bn_dropout_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)g,
+                                (bf16_t*)g, (const float*)nullptr, (const float*)nullptr, rows, C, HW, p, seed),
+             "fr_dropout_bwd");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_pack_weight(const float* w, void* wp, void* wt, int Cout, int taps, int Cin, int dtype,
+                              void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, taps);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(pack_weight_kernel<float>, grid, dim3(256), 0, st, w, (float*)wp, (float*)wt, Cout,
+                                taps, Cin),
+             hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, grid, dim3(256), 0, st, w, (bf16_t*)wp, (bf16_t*)wt,
+                                Cout, taps, Cin),
+             "fr_pack_weight");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_permute_linear(const float* in, void* out, void* wt, int O, int C, int HW, int dir, int dtype,
+                                 void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for((long long)O * C * HW, 256, 8192);
+  if (dir == 1) {
+    hipLaunchKernelGGL(permute_linear_kernel<float>, dim3(grid), dim3(256), 0, st, in, (float*)nullptr,
+                       (float*)nullptr, (float*)out, O, C, HW, 1);
+    FR_LAUNCH_CHECK();
+  }
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(permute_linear_kernel<float>, dim3(grid), dim3(256), 0, st, in, (float*)out,
+                                (float*)wt, (float*)nullptr, O, C, HW, 0),
+             hipLaunchKernelGGL(permute_linear_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, in, (bf16_t*)out,
+                                (bf16_t*)wt, (float*)nullptr, O, C, HW, 0),
+             "fr_permute_linear");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_pack_stem(const float* w, long long s_o, long long s_c, long long s_h, long long s_w, void* wp,
+                            int Cout, int C, int ldk, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for((long long)Cout * ldk, 256);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(pack_stem_kernel<float>, dim3(grid), dim3(256), 0, st, w, s_o, s_c, s_h, s_w,
+                                (float*)wp, Cout, C, ldk),
+             hipLaunchKernelGGL(pack_stem_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w, s_o, s_c, s_h, s_w,
+                                (bf16_t*)wp, Cout, C, ldk),
+             "fr_pack_stem");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_unpack_stem_grad(const float* gp, float* gw, long long s_o, long long s_c, long long s_h,
+                                   long long s_w, int Cout, int C, int ldk, void* stream) {
+  const int grid = grid_for((long long)Cout * 9 * C, 256);
+  hipLaunchKernelGGL(unpack_stem_grad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gp, gw, s_o, s_c, s_h,
+                     s_w, Cout, C, ldk);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_cast(const void* in, void* out, long long n, int dtype_in, int dtype_out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for(n, 256 * 4, 4096);
+  if (dtype_in == FR_F32 && dtype_out == FR_BF16) {
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)in, (bf16_t*)out,
+                       n);
+  } else if (dtype_in == FR_BF16 && dtype_out == FR_F32) {
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, (float*)out,
+                       n);
+  } else if (dtype_in == FR_F32 && dtype_out == FR_F32) {
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)in, (float*)out, n);
+  } else {
+    FR_UNSUPPORTED("fr_cast: unsupported dtype pair");
+  }
+  FR_LAUNCH_CHECK();
+}

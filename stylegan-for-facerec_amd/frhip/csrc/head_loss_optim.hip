@@ -1,0 +1,282 @@
+// frhip -- margin-head row kernels, focal loss on the batch-mean cross entropy, top-k rank, multi-tensor SGD.
+//
+// Reference arithmetic replaced (paths under /root/reference):
+//   F.normalize(x), F.normalize(W) (eps 1e-12) + their autograd      head/metrics.py:103, :167
+//   d phi / d cos of the ArcFace / CosFace margin, label select       head/metrics.py:115-138, :181-189
+//   FocalLoss on mean CE                                              loss/focal.py:17-21
+//   accuracy top-1/5                                                  util/utils.py:343-358
+//   optim.SGD(momentum, coupled weight decay on group 0)              train.py:196, :313-316
+#include "common.h"
+#include "frhip_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ row normalise
+template <typename T>
+__global__ void row_normalize_kernel(const float* __restrict__ x, T* __restrict__ xn, T* __restrict__ xt,
+                                     float* __restrict__ inv, int rows, int rows_pad, int D, int ldt) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows_pad) return;
+  if (row >= rows) {
+    for (int d = lane; d < D; d += 64) {
+      Elt<T>::st(xn + (size_t)row * D + d, 0.f);
+      if (xt) Elt<T>::st(xt + (size_t)d * ldt + row, 0.f);
+    }
+    return;
+  }
+  float ss = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float v = x[(size_t)row * D + d];
+    ss = fmaf(v, v, ss);
+  }
+  ss = wave_sum(ss);
+  const float nrm = sqrtf(ss);
+  const float iv = 1.0f / fmaxf(nrm, 1e-12f);
+  if (lane == 0) inv[row] = iv;
+  for (int d = lane; d < D; d += 64) {
+    const float v = x[(size_t)row * D + d] * iv;
+    Elt<T>::st(xn + (size_t)row * D + d, v);
+    if (xt) Elt<T>::st(xt + (size_t)d * ldt + row, v);
+  }
+}
+
+__global__ void normalize_bwd_kernel(const float* __restrict__ G, const float* __restrict__ x,
+                                     const float* __restrict__ inv, float* __restrict__ gx, int rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float iv = inv[row];
+  float dot = 0.f;
+  for (int d = lane; d < D; d += 64) dot = fmaf(x[(size_t)row * D + d] * iv, G[(size_t)row * D + d], dot);
+  dot = wave_sum(dot);
+  for (int d = lane; d < D; d += 64) {
+    const float xh = x[(size_t)row * D + d] * iv;
+    gx[(size_t)row * D + d] = (G[(size_t)row * D + d] - xh * dot) * iv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ margin backward
+template <typename T>
+__global__ void margin_bwd_kernel(const float* __restrict__ g, const long long* __restrict__ label,
+                                  const float* __restrict__ cos_t, T* __restrict__ gcos, int rows, int N, int ldg,
+                                  int kind, int easy, float cos_m, float sin_m, float th, float scale) {
+  const int m = blockIdx.y;
+  if (m >= rows) return;
+  const long long lab = label[m];
+  float dphi = 1.f;
+  if (kind == 0) {
+    const float c = cos_t[m];
+    const bool use_phi = easy ? (c > 0.f) : (c > th);
+    if (use_phi) {
+      const float t = 1.0f - c * c;
+      const bool inside = t > 1e-10f && t < 1.0f - 1e-10f;  // clamp passes gradient only strictly inside
+      dphi = cos_m + (inside ? sin_m * c / sqrtf(t) : 0.f);
+    }
+  }
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < ldg; n += gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (n < N) v = scale * g[(size_t)m * N + n] * (n == lab ? dphi : 1.f);
+    Elt<T>::st(gcos + (size_t)m * ldg + n, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ cross entropy rows
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ z, const long long* __restrict__ label,
+                                                      float* __restrict__ lse, float* __restrict__ ce,
+                                                      int* __restrict__ rank, int N, int ld) {
+  __shared__ float sred[4];
+  __shared__ int ired[4];
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = z + (size_t)m * ld;
+  const long long lab = label[m];
+  const float zl = (lab >= 0 && lab < N) ? row[lab] : 0.f;
+  float mx = -INFINITY;
+  int cnt = 0;
+  for (int n = tid; n < N; n += 256) {
+    const float v = row[n];
+    mx = fmaxf(mx, v);
+    cnt += v > zl ? 1 : 0;
+  }
+  mx = wave_max(mx);
+  if (lane == 0) sred[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int n = tid; n < N; n += 256) se += __expf(row[n] - mx);
+  se = wave_sum(se);
+  float fc = wave_sum((float)cnt);
+  if (lane == 0) {
+    sred[wave] = se;
+    ired[wave] = (int)fc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float tot = sred[0] + sred[1] + sred[2] + sred[3];
+    const float l = mx + logf(tot);
+    lse[m] = l;
+    ce[m] = l - zl;
+    rank[m] = ired[0] + ired[1] + ired[2] + ired[3];
+  }
+}
+
+__global__ void focal_finalize_kernel(const float* __restrict__ ce, const int* __restrict__ rank, int rows,
+                                      float gamma, float* __restrict__ scalars) {
+  __shared__ double dred[4];
+  __shared__ int r1[4], r5[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double s = 0.0;
+  int c1 = 0, c5 = 0;
+  for (int i = tid; i < rows; i += 256) {
+    s += (double)ce[i];
+    c1 += rank[i] < 1;
+    c5 += rank[i] < 5;
+  }
+  s = wave_sum_d(s);
+  const float f1 = wave_sum((float)c1), f5 = wave_sum((float)c5);
+  if (lane == 0) {
+    dred[wave] = s;
+    r1[wave] = (int)f1;
+    r5[wave] = (int)f5;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float l = (float)((dred[0] + dred[1] + dred[2] + dred[3]) / rows);
+    const float p = expf(-l);
+    const float omp = 1.0f - p;
+    const float w = powf(omp, gamma);
+    scalars[0] = w * l;
+    // d/dl [(1-p)^g * l] = g (1-p)^(g-1) p l + (1-p)^g          
+    scalars[1] = gamma * powf(omp, gamma - 1.0f) * p * l + w;
+    scalars[2] = 100.0f * (float)(r1[0] + r1[1] + r1[2] + r1[3]) / rows;
+    scalars[3] = 100.0f * (float)(r5[0] + r5[1] + r5[2] + r5[3]) / rows;
+    scalars[4] = l;
+  }
+}
+
+__global__ void focal_bwd_kernel(const float* __restrict__ z, const long long* __restrict__ label,
+                                 const float* __restrict__ lse, const float* __restrict__ scalars,
+                                 const float* __restrict__ gup, float* __restrict__ grad, int rows, int N, int ld) {
+  const int m = blockIdx.y;
+  const float k = gup[0] * scalars[1] / (float)rows;
+  const float l = lse[m];
+  const long long lab = label[m];
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    const float sm = __expf(z[(size_t)m * ld + n] - l);
+    grad[(size_t)m * ld + n] = k * (sm - (n == lab ? 1.f : 0.f));
+  }
+}
+
+// rank-only (accuracy on arbitrary logits)
+__global__ __launch_bounds__(256) void rank_rows_kernel(const float* __restrict__ z, const long long* __restrict__ label,
+                                                        int* __restrict__ rank, int N, int ld) {
+  __shared__ int ired[4];
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = z + (size_t)m * ld;
+  const long long lab = label[m];
+  const float zl = (lab >= 0 && lab < N) ? row[lab] : INFINITY;
+  int cnt = 0;
+  for (int n = tid; n < N; n += 256) cnt += row[n] > zl ? 1 : 0;
+  const float fc = wave_sum((float)cnt);
+  if (lane == 0) ired[wave] = (int)fc;
+  __syncthreads();
+  if (tid == 0) rank[m] = ired[0] + ired[1] + ired[2] + ired[3];
+}
+
+// ------------------------------------------------------------------------------------------ SGD
+constexpr int SGD_CHUNK = 4096;
+__global__ __launch_bounds__(256) void sgd_kernel(const FrSgdTensor* __restrict__ table,
+                                                  const int2* __restrict__ chunks, float lr, float momentum) {
+  const int2 ch = chunks[blockIdx.x];
+  const FrSgdTensor t = table[ch.x];
+  const long long base = (long long)ch.y * SGD_CHUNK;
+  long long end = base + SGD_CHUNK;
+  if (end > t.n) end = t.n;
+  for (long long i = base + threadIdx.x; i < end; i += 256) {
+    const float pv = t.p[i];
+    const float d = fmaf(t.wd, pv, t.g[i]);
+    const float b = fmaf(momentum, t.buf[i], d);
+    t.buf[i] = b;
+    t.p[i] = pv - lr * b;
+  }
+}
+
+}  // namespace
+
+extern "C" int fr_row_normalize(const float* x, void* xn, void* xt, float* inv, int rows, int rows_pad, int D,
+                                int ldt, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (rows_pad + 3) / 4;
+  if (dtype == FR_F32)
+    hipLaunchKernelGGL(row_normalize_kernel<float>, dim3(grid), dim3(256), 0, st, x, (float*)xn, (float*)xt, inv,
+                       rows, rows_pad, D, ldt);
+  else if (dtype == FR_BF16)
+    hipLaunchKernelGGL(row_normalize_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, x, (bf16_t*)xn, (bf16_t*)xt, inv,
+                       rows, rows_pad, D, ldt);
+  else
+    FR_UNSUPPORTED("fr_row_normalize: dtype");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_normalize_bwd(const float* G, const float* x, const float* inv, float* gx, int rows, int D,
+                                void* stream) {
+  hipLaunchKernelGGL(normalize_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, G, x, inv, gx,
+                     rows, D);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_margin_bwd(const float* g, const int64_t* label, const float* cos_t, void* gcos, int rows, int N,
+                             int ldg, int kind, int easy, float cos_m, float sin_m, float th, float scale, int dtype,
+                             void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((ldg + 1023) / 1024, rows);
+  if (dtype == FR_F32)
+    hipLaunchKernelGGL(margin_bwd_kernel<float>, grid, dim3(256), 0, st, g, (const long long*)label, cos_t,
+                       (float*)gcos, rows, N, ldg, kind, easy, cos_m, sin_m, th, scale);
+  else if (dtype == FR_BF16)
+    hipLaunchKernelGGL(margin_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, g, (const long long*)label, cos_t,
+                       (bf16_t*)gcos, rows, N, ldg, kind, easy, cos_m, sin_m, th, scale);
+  else
+    FR_UNSUPPORTED("fr_margin_bwd: dtype");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_ce_rows(const float* logits, const int64_t* label, float* lse, float* ce, int32_t* rank, int rows,
+                          int N, int ld, void* stream) {
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, (const long long*)label,
+                     lse, ce, rank, N, ld);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_rank_rows(const float* logits, const int64_t* label, int32_t* rank, int rows, int N, int ld,
+                            void* stream) {
+  hipLaunchKernelGGL(rank_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
+                     (const long long*)label, rank, N, ld);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_focal_finalize(const float* ce, const int32_t* rank, int rows, float gamma, float* scalars,
+                                 void* stream) {
+  hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ce, rank, rows, gamma,
+                     scalars);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_focal_bwd(const float* logits, const int64_t* label, const float* lse, const float* scalars,
+                            const float* gup, float* grad, int rows, int N, int ld, void* stream) {
+  dim3 grid((N + 1023) / 1024, rows);
+  hipLaunchKernelGGL(focal_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, logits, (const long long*)label,
+                     lse, scalars, gup, grad, rows, N, ld);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_sgd_chunk_elems(void) { return SGD_CHUNK; }
+
+extern "C" int fr_sgd_step(const FrSgdTensor* table_dev, const int32_t* chunks_dev, int nchunks, float lr,
+                           float momentum, void* stream) {
+  if (nchunks <= 0) return 0;
+  hipLaunchKernelGGL(sgd_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table_dev,
+                     (const int2*)chunks_dev, lr, momentum);
+  FR_LAUNCH_CHECK();
+}

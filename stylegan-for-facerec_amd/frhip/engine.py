@@ -1,0 +1,721 @@
+"""Static execution plan of the IR / IR-SE backbone training step on one MI355X.
+
+The reference runs ``Backbone.forward`` (backbone/model_irse.py:167-172) / ``BackboneEncoderDiffHead.forward``
+(backbone/restyle_psp.py:193-216) as ~300 separate torch.nn calls and lets autograd replay them.  Here the
+module tree only *holds* the parameters (same names, same state-dict keys); the arithmetic is a fixed list of
+HIP launches over buffers that are laid out once per (batch, dtype):
+
+  forward, per residual unit (x = unit input, NHWC, statistics of x already reduced by its producer)
+    conv1  : y1  = conv3x3( BN1(x) )            BN apply fused into the A-operand gather      (model_irse.py:57)
+    conv2  : y2  = conv3x3_s( PReLU(y1) )       PReLU fused into the gather; epilogue emits sum / sumsq of y2
+    [convS : yS  = conv1x1_s(x)                 + statistics]                                  (model_irse.py:55)
+    [SE    : pooled = mean_hw BN2(y2); s = sigmoid(W2 relu(W1 pooled))]                        (model_irse.py:23-46)
+    apply  : out = BN2(y2) [* s] + (x[::s, ::s] | BNS(yS))   + statistics of out for the next BN1
+  backward walks the same units in reverse with: BN-backward reduce/apply, conv2 data-gradient with the
+  PReLU-backward + slope-gradient epilogue, conv1 data-gradient with the BN-backward-sums epilogue, the two
+  weight gradients (split over pixel slices, fp32 atomics), and one pass that forms the unit's input gradient.
+
+Activations are stored once (y1, y2, [yS], out per unit); nothing is recomputed and no BN/PReLU output is ever
+materialised.  Parameter gradients are written straight into one flat fp32 arena whose order is the order in
+which they become ready (output layer first, stem last) so that data-parallel buckets are contiguous slices.
+"""
+import ctypes
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from ._lib import FR_BF16, FR_F32
+
+_EPS, _MOM = 1e-5, 0.1
+
+
+def compute_dtype_default():
+    v = os.environ.get("FRHIP_COMPUTE_DTYPE", "fp32").lower()
+    return torch.bfloat16 if v in ("bf16", "bfloat16") else torch.float32
+
+
+# ------------------------------------------------------------------------------------------------ structure
+
+
+class _Unit(object):
+    __slots__ = ("idx", "cin", "depth", "stride", "H", "Ho", "bn1", "conv1", "prelu", "conv2", "bn2", "se",
+                 "sc_conv", "sc_bn")
+
+
+def _children_of(container):
+    return list(container.children()) if not isinstance(container, (list, tuple)) else list(container)
+
+
+def describe(module):
+    """Walk the parameter-holding module tree (either Backbone of model_irse.py or BackboneEncoderDiffHead of
+    restyle_psp.py -- Sequential or ModuleList children) and return (stem, units, out) layer handles."""
+    stem_conv, stem_bn, stem_prelu = _children_of(module.input_layer)[:3]
+    units = []
+    H = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
+    for i, blk in enumerate(module.body):
+        u = _Unit()
+        u.idx = i
+        res = _children_of(blk.res_layer)
+        for c in res:
+            if isinstance(c, nn.Dropout) and c.p > 0 and c.training:
+                raise NotImplementedError("frhip: Dropout inside residual units (pSp include_dropout) is not "
+                                          "on the accelerated path")
+        bns = [c for c in res if isinstance(c, nn.BatchNorm2d)]
+        convs = [c for c in res if isinstance(c, nn.Conv2d)]
+        prelus = [c for c in res if isinstance(c, nn.PReLU)]
+        ses = [c for c in res if hasattr(c, "fc1") and hasattr(c, "fc2")]
+        u.bn1, u.bn2 = bns
+        u.conv1, u.conv2 = convs
+        (u.prelu,) = prelus
+        u.se = ses[0] if ses else None
+        u.cin, u.depth = u.conv1.in_channels, u.conv1.out_channels
+        u.stride = u.conv2.stride[0]
+        u.H, u.Ho = H, H // u.stride
+        sc = blk.shortcut_layer
+        if isinstance(sc, nn.MaxPool2d):
+            u.sc_conv = u.sc_bn = None
+        else:
+            ch = _children_of(sc)
+            u.sc_conv = [c for c in ch if isinstance(c, nn.Conv2d)][0]
+            u.sc_bn = [c for c in ch if isinstance(c, nn.BatchNorm2d)][0]
+        units.append(u)
+        H = u.Ho
+    out = _children_of(module.output_layer)
+    out_bn = [c for c in out if isinstance(c, nn.BatchNorm2d)][0]
+    out_drop = [c for c in out if isinstance(c, nn.Dropout)][0]
+    out_lin = [c for c in out if isinstance(c, nn.Linear)][0]
+    out_bn1d = [c for c in out if isinstance(c, nn.BatchNorm1d)][0]
+    return (stem_conv, stem_bn, stem_prelu), units, (out_bn, out_drop, out_lin, out_bn1d)
+
+
+def ready_order_params(module):
+    """Parameters in the order their gradients complete during backward (for bucketing)."""
+    (sc, sb, sp), units, (ob, _od, ol, ob1) = describe(module)
+    order = [ob1.weight, ob1.bias, ol.weight, ol.bias, ob.weight, ob.bias]
+    for u in reversed(units):
+        order += [u.bn2.weight, u.bn2.bias]
+        if u.se is not None:
+            order += [u.se.fc1.weight, u.se.fc2.weight]
+        if u.sc_conv is not None:
+            order += [u.sc_bn.weight, u.sc_bn.bias, u.sc_conv.weight]
+        order += [u.prelu.weight, u.conv2.weight, u.bn1.weight, u.bn1.bias, u.conv1.weight]
+    order += [sb.weight, sb.bias, sp.weight, sc.weight]
+    return order
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+
+
+class _BN(object):
+    """Device-side coefficients of one BatchNorm: mean, invstd, scale (= gamma*invstd), shift."""
+    __slots__ = ("mod", "C", "mean", "invstd", "scale", "shift")
+
+    def __init__(self, mod, pool):
+        self.mod, self.C = mod, mod.num_features
+        self.mean, self.invstd, self.scale, self.shift = (pool.take(self.C) for _ in range(4))
+
+
+class _Pool(object):
+    """Bump allocator over one fp32 device tensor (small per-channel vectors)."""
+
+    def __init__(self, n, device):
+        self.buf = torch.zeros(n, device=device)
+        self.off = 0
+
+    def take(self, n):
+        n_pad = (n + 63) // 64 * 64
+        if self.off + n_pad > self.buf.numel():
+            raise _lib.FrhipError("frhip: coefficient pool exhausted")
+        t = self.buf[self.off:self.off + n]
+        self.off += n_pad
+        return t
+
+
+def _cl_weight_ok(w):
+    """Conv weight stored as [Cout][kh][kw][Cin] (channels-last memory of the OIHW Parameter)?"""
+    return w.permute(0, 2, 3, 1).is_contiguous()
+
+
+def _dense(t):
+    dims = sorted((s, n) for s, n in zip(t.stride(), t.shape) if n > 1)
+    expect = 1
+    for s, n in dims:
+        if s != expect:
+            return False
+        expect *= n
+    return True
+
+
+def _wgrad_slices(pixels, tiles):
+    """Pixel slices for the weight-gradient kernel: aim at >= 512 blocks, slices >= 256 pixels, <= 256 slices."""
+    want = max(1, (768 + tiles - 1) // tiles)
+    return int(max(1, min(want, 256, pixels // 256 if pixels >= 256 else 1)))
+
+
+# ------------------------------------------------------------------------------------------------ the plan
+
+
+class BackbonePlan(object):
+    def __init__(self, module, B, dtype, device, in_channels, avg_channels):
+        self.module, self.B, self.device = module, B, device
+        self.tdtype = dtype
+        self.fr = FR_F32 if dtype == torch.float32 else FR_BF16
+        self.esz = 4 if dtype == torch.float32 else 2
+        self.stem, self.units, self.out = describe(module)
+        self.in_channels, self.avg_channels = in_channels, avg_channels
+        self.stream = ops.current_stream_ptr()
+        self.stream_id = torch.cuda.current_stream().cuda_stream
+        self.S = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
+        self.generation = 0
+        self.seed_launches = []
+        self._normalize_params()
+        self._alloc()
+        self._bind_params()
+        self._build_forward()
+        self._build_backward()
+
+    # ---- buffers -----------------------------------------------------------------------------------
+    def _act(self, rows, C):
+        return torch.empty(rows, C, device=self.device, dtype=self.tdtype)
+
+    def _alloc(self):
+        B, S, dev = self.B, self.S, self.device
+        self.pool = _Pool(64 * 1024 + 16 * 512 * (len(self.units) * 4 + 8), dev)
+        ct = self.in_channels + self.avg_channels
+        self.K0 = 32 if 9 * ct <= 32 else 64
+        M0 = B * S * S
+        self.M0 = M0
+        self.X0 = self._act(M0, self.K0)
+        self.y0 = self._act(M0, 64)
+        self.z0 = self._act(M0, 64)
+        self.W0p = torch.empty(64, self.K0, device=dev, dtype=self.tdtype)
+        self.gW0p = torch.zeros(64, self.K0, device=dev)
+        self.bn0 = _BN(self.stem[1], self.pool)
+        self.ubuf = []
+        max_in = M0 * 64
+        max_mid = 0
+        max_out = 0
+        max_xs = 0
+        for u in self.units:
+            rin, rout = B * u.H * u.H, B * u.Ho * u.Ho
+            d = {
+                "y1": self._act(rin, u.depth), "y2": self._act(rout, u.depth), "out": self._act(rout, u.depth),
+                "bn1": _BN(u.bn1, self.pool), "bn2": _BN(u.bn2, self.pool),
+                "wt1": torch.empty(u.cin, 9, u.depth, device=dev, dtype=self.tdtype),
+                "wt2": torch.empty(u.depth, 9, u.depth, device=dev, dtype=self.tdtype),
+            }
+            if self.fr == FR_BF16:
+                d["wp1"] = torch.empty(u.depth, 9, u.cin, device=dev, dtype=self.tdtype)
+                d["wp2"] = torch.empty(u.depth, 9, u.depth, device=dev, dtype=self.tdtype)
+            if u.sc_conv is not None:
+                d["yS"] = self._act(rout, u.depth)
+                d["bnS"] = _BN(u.sc_bn, self.pool)
+                d["wtS"] = torch.empty(u.cin, 1, u.depth, device=dev, dtype=self.tdtype)
+                if self.fr == FR_BF16:
+                    d["wpS"] = torch.empty(u.depth, 1, u.cin, device=dev, dtype=self.tdtype)
+                max_xs = max(max_xs, rin * u.cin)
+            if u.se is not None:
+                R = u.se.fc1.out_channels
+                for k, n in (("pooled", u.depth), ("s", u.depth), ("gs", u.depth), ("gpooled", u.depth), ("hidden", R)):
+                    d[k] = torch.zeros(B, n, device=dev)
+            self.ubuf.append(d)
+            max_in = max(max_in, rin * u.cin)
+            max_mid = max(max_mid, rin * u.depth)
+            max_out = max(max_out, rout * u.depth)
+        last = self.units[-1]
+        self.HWo = last.Ho * last.Ho
+        self.feat_in = last.depth * self.HWo
+        self.bn_out = _BN(self.out[0], self.pool)
+        self.bn1d = _BN(self.out[3], self.pool)
+        self.a = self._act(B, self.feat_in)
+        self.f = torch.empty(B, 512, device=dev)
+        self.feat = torch.empty(B, 512, device=dev)
+        self.Wlin = torch.empty(512, self.feat_in, device=dev, dtype=self.tdtype)
+        self.WlinT = torch.empty(self.feat_in, 512, device=dev, dtype=self.tdtype)
+        self.gWlin = torch.zeros(512, self.feat_in, device=dev)
+        # backward scratch (sized for the largest unit)
+        self.g_pp = [self._act(max_in, 1).view(-1), self._act(max_in, 1).view(-1)]   # unit input/output gradients
+        self.g_y2 = self._act(max_out, 1).view(-1)
+        self.g_yS = self._act(max_out, 1).view(-1) if max_xs else None
+        self.g_y1 = self._act(max(max_mid, M0 * 64), 1).view(-1)
+        self.g_xh = self._act(max_in, 1).view(-1)
+        self.g_xS = self._act(max_xs, 1).view(-1) if max_xs else None
+        self.g_f32 = torch.empty(B, 512, device=dev)     # BN1d backward output (fp32)
+        self.g_fT = self._act(B, 512)
+        self.part = torch.zeros(max(4 * 1024 * 1024, ((M0 + 127) // 128) * 2 * 64 + 4096), device=dev)
+        self.se_scratch = torch.zeros(2, 512 * 64, device=dev)  # dW1/dW2 sink while the SE weights are frozen
+        self.zeros_c = torch.zeros(512, device=dev)
+        self.sums = torch.zeros(3, 512, device=dev)      # scratch reduce target for frozen parameters
+        self.nbt_dummy = None
+
+    # ---- parameters --------------------------------------------------------------------------------
+    def _normalize_params(self):
+        """Conv weights of the residual units live as [Cout][kh][kw][Cin] (channels-last memory behind the OIHW
+        Parameter) so the fp32 master is already the packed GEMM operand; convert once if a caller replaced them."""
+        for u in self.units:
+            for conv in (u.conv1, u.conv2, u.sc_conv):
+                if conv is None:
+                    continue
+                w = conv.weight
+                if w.dtype != torch.float32:
+                    raise _lib.FrhipError("frhip: parameters must be fp32 master weights")
+                if not _cl_weight_ok(w):
+                    with torch.no_grad():
+                        w.data = w.data.contiguous(memory_format=torch.channels_last)
+                    if w.grad is not None:
+                        w.grad = None
+
+    def _param_list(self):
+        return ready_order_params(self.module)
+
+    def _bind_params(self):
+        """(Re)create the flat gradient arena and remember parameter storage addresses."""
+        params = self._param_list()
+        total = sum((p.numel() + 63) // 64 * 64 for p in params)
+        self.arena = torch.zeros(total, device=self.device)
+        self.gviews = {}
+        self.arena_slices = []
+        off = 0
+        for p in params:
+            n = p.numel()
+            flat = self.arena[off:off + n]
+            if not p.is_contiguous() and not _dense(p):
+                raise _lib.FrhipError("frhip: parameter storage must be dense")
+            v = flat.as_strided(tuple(p.shape), tuple(p.stride()))  # gradient shares the parameter's layout
+            self.gviews[id(p)] = v
+            self.arena_slices.append((p, off, n))
+            off += (n + 63) // 64 * 64
+        self.param_sig = self._signature()
+
+    def _signature(self):
+        return (tuple((p.data_ptr(), p.requires_grad) for p in self._param_list()),
+                tuple(b.data_ptr() for b in self.module.buffers()),
+                tuple(m.training for m in self.module.modules()))
+
+    def grad_of(self, p):
+        """Gradient target of a parameter: its arena view when it trains, else None."""
+        return self.gviews[id(p)] if p.requires_grad else None
+
+    def _conv_master(self, conv):
+        return conv.weight
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def _bn_train_launches(self, L, bn, part, nparts, count):
+        m = bn.mod
+        st = self.stream
+        if m.training:
+            L.append(ops.call("fr_bn_finalize", part, nparts, bn.C, float(count), m.weight, m.bias, float(m.eps),
+                              float(m.momentum if m.momentum is not None else 0.1),
+                              m.running_mean if m.track_running_stats else None,
+                              m.running_var if m.track_running_stats else None,
+                              m.num_batches_tracked if m.track_running_stats else None, bn.mean, bn.invstd, bn.scale,
+                              bn.shift, st))
+        else:
+            L.append(ops.call("fr_bn_eval_coeffs", m.running_mean, m.running_var, m.weight, m.bias, float(m.eps),
+                              bn.C, bn.mean, bn.invstd, bn.scale, bn.shift, st))
+
+    def _build_forward(self):
+        B, S, st, fr = self.B, self.S, self.stream, self.fr
+        P = []  # weight packing (runs every step: master weights change)
+        L = []
+        sc, sb, sp = self.stem
+        # ---- stem: im2col -> GEMM(+stats) -> BN+PReLU apply (+stats for unit 0's BN1)
+        w0 = sc.weight
+        P.append(ops.call("fr_pack_stem", w0, w0.stride(0), w0.stride(1), w0.stride(2), w0.stride(3), self.W0p, 64,
+                          w0.shape[1], self.K0, fr, st))
+        self.l_im2col = None  # bound per call (input pointer changes)
+        mt0 = (self.M0 + 127) // 128
+        L.append(ops.conv(st, fr, src=self.X0, w=self.W0p, out=self.y0, B=self.M0, RH=1, RW=1, SH=1, SW=1, SC=self.K0,
+                          N=64, KH=1, KW=1, stride=1, pad=0, mode=0, lda=self.K0, ldc=64, pro=0, epi=ops.EPI_STATS,
+                          part=self.part))
+        self._bn_train_launches(L, self.bn0, self.part, mt0, self.M0)
+        nb = ops.grid_blocks(self.M0, 64, fr)
+        first_bn = self.ubuf[0]["bn1"]
+        L.append(ops.bn_apply(st, fr, x=self.y0, out=self.z0, scale=self.bn0.scale, shift=self.bn0.shift,
+                              slope=sp.weight, part=self.part, B=B, H=S, W=S, C=64, res_kind=0, res_stride=1,
+                              nblocks=nb))
+        self._bn_train_launches(L, first_bn, self.part, nb, self.M0)
+        x = self.z0
+        for i, u in enumerate(self.units):
+            d = self.ubuf[i]
+            rin, rout = B * u.H * u.H, B * u.Ho * u.Ho
+            w1, w2 = self._conv_master(u.conv1), self._conv_master(u.conv2)
+            if fr == FR_BF16:
+                P.append(ops.call("fr_pack_weight", w1, d["wp1"], d["wt1"], u.depth, 9, u.cin, fr, st))
+                P.append(ops.call("fr_pack_weight", w2, d["wp2"], d["wt2"], u.depth, 9, u.depth, fr, st))
+                wp1, wp2 = d["wp1"], d["wp2"]
+            else:
+                P.append(ops.call("fr_pack_weight", w1, None, d["wt1"], u.depth, 9, u.cin, fr, st))
+                P.append(ops.call("fr_pack_weight", w2, None, d["wt2"], u.depth, 9, u.depth, fr, st))
+                wp1, wp2 = w1, w2
+            bn1, bn2 = d["bn1"], d["bn2"]
+            L.append(ops.conv(st, fr, src=x, w=wp1, out=d["y1"], B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H, SC=u.cin,
+                              N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.cin, ldc=u.depth,
+                              pro=ops.PRO_BN, pro_a=bn1.scale, pro_b=bn1.shift, epi=ops.EPI_STORE))
+            L.append(ops.conv(st, fr, src=d["y1"], w=wp2, out=d["y2"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H,
+                              SC=u.depth, N=u.depth, KH=3, KW=3, stride=u.stride, pad=1, mode=0, lda=u.depth,
+                              ldc=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight, epi=ops.EPI_STATS,
+                              part=self.part))
+            self._bn_train_launches(L, bn2, self.part, (rout + 127) // 128, rout)
+            if u.sc_conv is not None:
+                ws = self._conv_master(u.sc_conv)
+                if fr == FR_BF16:
+                    P.append(ops.call("fr_pack_weight", ws, d["wpS"], d["wtS"], u.depth, 1, u.cin, fr, st))
+                    wps = d["wpS"]
+                else:
+                    P.append(ops.call("fr_pack_weight", ws, None, d["wtS"], u.depth, 1, u.cin, fr, st))
+                    wps = ws
+                L.append(ops.conv(st, fr, src=x, w=wps, out=d["yS"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H, SC=u.cin,
+                                  N=u.depth, KH=1, KW=1, stride=u.stride, pad=0, mode=0, lda=u.cin, ldc=u.depth,
+                                  pro=0, epi=ops.EPI_STATS, part=self.part))
+                self._bn_train_launches(L, d["bnS"], self.part, (rout + 127) // 128, rout)
+            if u.se is not None:
+                R = u.se.fc1.out_channels
+                L.append(ops.call("fr_se_pool", d["y2"], bn2.scale, bn2.shift, d["pooled"], B, u.Ho * u.Ho, u.depth,
+                                  fr, st))
+                L.append(ops.call("fr_se_mlp_fwd", d["pooled"], u.se.fc1.weight, u.se.fc2.weight, d["hidden"],
+                                  d["s"], B, u.depth, R, st))
+            nb = ops.grid_blocks(rout, u.depth, fr)
+            kw = dict(x=d["y2"], out=d["out"], scale=bn2.scale, shift=bn2.shift, part=self.part, B=B, H=u.Ho, W=u.Ho,
+                      C=u.depth, nblocks=nb)
+            if u.se is not None:
+                kw["se"] = d["s"]
+            if u.sc_conv is None:
+                kw.update(res=x, res_kind=1, res_stride=u.stride)
+            else:
+                kw.update(res=d["yS"], res_kind=2, res_stride=1, rscale=d["bnS"].scale, rshift=d["bnS"].shift)
+            L.append(ops.bn_apply(st, fr, **kw))
+            nxt = self.ubuf[i + 1]["bn1"] if i + 1 < len(self.units) else self.bn_out
+            self._bn_train_launches(L, nxt, self.part, nb, rout)
+            x = d["out"]
+        # ---- output layer: BN -> Dropout -> Flatten -> Linear(+bias) -> BN1d
+        ob, od, ol, ob1 = self.out
+        last = self.units[-1]
+        C = last.depth
+        P.append(ops.call("fr_permute_linear", ol.weight, self.Wlin, self.WlinT, 512, C, self.HWo, 0, fr, st))
+        drop = ops.call("fr_bn_dropout", x, self.a, self.bn_out.scale, self.bn_out.shift, B * self.HWo, C, self.HWo,
+                        0.0, 0, fr, st)
+        L.append(drop)
+        self.l_drop_fwd = drop
+        L.append(ops.call("fr_fill_rows", self.f, ol.bias, B, 512, st))
+        nk = self.feat_in // 32
+        self.lin_splitk = max(1, min(64, nk // 16))
+        L.append(ops.conv(st, fr, src=self.a, w=self.Wlin, out=self.f, B=B, RH=1, RW=1, SH=1, SW=1, SC=self.feat_in,
+                          N=512, KH=1, KW=1, stride=1, pad=0, mode=0, lda=self.feat_in, ldc=512, pro=0,
+                          epi=ops.EPI_ATOMIC, out_f32=1, splitk=self.lin_splitk))
+        nbf = ops.grid_blocks(B, 512, FR_F32)
+        L.append(ops.call("fr_channel_stats", self.f, B, 512, self.part, nbf, FR_F32, st))
+        self._bn_train_launches(L, self.bn1d, self.part, nbf, B)
+        L.append(ops.bn_apply(st, FR_F32, x=self.f, out=self.feat, scale=self.bn1d.scale, shift=self.bn1d.shift, B=B,
+                              H=1, W=1, C=512, res_kind=0, res_stride=1, nblocks=nbf))
+        self.pack_list, self.fwd_list = P, L
+
+    # ---- backward ----------------------------------------------------------------------------------
+    def _reduce(self, L, nparts, K, C, o0, o1, o2=None):
+        L.append(ops.call("fr_reduce_parts", self.part, nparts, K, C, o0, o1, o2, self.stream))
+
+    def _bn_grads(self, bn):
+        """(dbeta target, dgamma target): the parameter gradients when they train, scratch otherwise."""
+        m = bn.mod
+        gb = self.grad_of(m.bias)
+        gg = self.grad_of(m.weight)
+        return (gb if gb is not None else self.sums[0, :bn.C]), (gg if gg is not None else self.sums[1, :bn.C])
+
+    def _s01(self, bn, s0, s1):
+        """BN in eval mode has no batch-statistics terms in its backward."""
+        if bn.mod.training:
+            return s0, s1
+        return self.zeros_c[:bn.C], self.zeros_c[:bn.C]
+
+    def _build_backward(self):
+        B, st, fr = self.B, self.stream, self.fr
+        L = []
+        self.ready_marks = []  # (index into L after which a group of params is complete, [params])
+        ob, od, ol, ob1 = self.out
+        last = self.units[-1]
+        C = last.depth
+        rows_o = B * self.HWo
+        # ---- BN1d backward (fp32 tensors): g_in arrives in self.g_feat_in (bound per call)
+        self.g_feat_in = torch.empty(B, 512, device=self.device)
+        nbf = ops.grid_blocks(B, 512, FR_F32)
+        db, dg = self._bn_grads(self.bn1d)
+        common = dict(g=self.g_feat_in, x=self.f, mean=self.bn1d.mean, invstd=self.bn1d.invstd, rows=B, C=512,
+                      rows_per_image=1, nblocks=nbf)
+        L.append(ops.bn_bwd_reduce(st, FR_F32, part=self.part, **common))
+        self._reduce(L, nbf, 3, 512, db, dg)
+        s0, s1 = self._s01(self.bn1d, db, dg)
+        L.append(ops.bn_bwd_apply(st, FR_F32, gx=self.g_f32, gamma=ob1.weight, s0=s0, s1=s1, inv_count=1.0 / B,
+                                  **common))
+        # Linear bias gradient = column sums of g_f
+        gbias = self.grad_of(ol.bias)
+        if gbias is not None:
+            L.append(ops.call("fr_channel_stats", self.g_f32, B, 512, self.part, nbf, FR_F32, st))
+            self._reduce(L, nbf, 2, 512, gbias, None)
+        if fr == FR_BF16:
+            L.append(ops.call("fr_cast", self.g_f32, self.g_fT, B * 512, FR_F32, FR_BF16, st))
+            gfT = self.g_fT
+        else:
+            gfT = self.g_f32
+        # Linear weight gradient (packed layout) -> torch layout
+        glw = self.grad_of(ol.weight)
+        if glw is not None:
+            L.append(ops.call("fr_fill_rows", self.gWlin, None, 512, self.feat_in, st))
+            L.append(ops.wgrad(st, fr, g=gfT, src=self.a, dw=self.gWlin, B=B, GH=1, GW=1, Cout=512, SH=1, SW=1,
+                               SC=self.feat_in, KH=1, KW=1, stride=1, pad=0, ldg=512, lda=self.feat_in, pro=0,
+                               nsplit=1))
+            L.append(ops.call("fr_permute_linear", self.gWlin, glw, None, 512, C, self.HWo, 1, FR_F32, st))
+        # Linear data gradient -> dropout backward -> BN(out) backward
+        g_a = self.g_xh[:B * self.feat_in].view(B, self.feat_in)
+        L.append(ops.conv(st, fr, src=gfT, w=self.WlinT, out=g_a, B=B, RH=1, RW=1, SH=1, SW=1, SC=512, N=self.feat_in,
+                          KH=1, KW=1, stride=1, pad=0, mode=0, lda=512, ldc=self.feat_in, pro=0, epi=ops.EPI_STORE))
+        dropb = ops.call("fr_dropout_bwd", g_a, rows_o, C, self.HWo, 0.0, 0, fr, st)
+        L.append(dropb)
+        self.l_drop_bwd = dropb
+        x_last = self.ubuf[-1]["out"]
+        nb = ops.grid_blocks(rows_o, C, fr)
+        db, dg = self._bn_grads(self.bn_out)
+        common = dict(g=g_a, x=x_last, mean=self.bn_out.mean, invstd=self.bn_out.invstd, rows=rows_o, C=C,
+                      rows_per_image=self.HWo, nblocks=nb)
+        L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
+        self._reduce(L, nb, 3, C, db, dg)
+        s0, s1 = self._s01(self.bn_out, db, dg)
+        cur = 0
+        g_out = self.g_pp[cur][:rows_o * C]
+        L.append(ops.bn_bwd_apply(st, fr, gx=g_out, gamma=ob.weight, s0=s0, s1=s1, inv_count=1.0 / rows_o, **common))
+        self.ready_marks.append((len(L), [ob1.weight, ob1.bias, ol.weight, ol.bias, ob.weight, ob.bias]))
+        # ---- residual units in reverse
+        for i in range(len(self.units) - 1, -1, -1):
+            u, d = self.units[i], self.ubuf[i]
+            x = self.ubuf[i - 1]["out"] if i > 0 else self.z0
+            rin, rout = B * u.H * u.H, B * u.Ho * u.Ho
+            HWo = u.Ho * u.Ho
+            bn1, bn2 = d["bn1"], d["bn2"]
+            g_y2 = self.g_y2[:rout * u.depth]
+            nb = ops.grid_blocks(rout, u.depth, fr)
+            ready = [u.bn2.weight, u.bn2.bias]
+            se_kw = {}
+            if u.se is not None:
+                R = u.se.fc1.out_channels
+                L.append(ops.call("fr_se_gscale", g_out, d["y2"], bn2.scale, bn2.shift, d["gs"], B, HWo, u.depth, fr,
+                                  st))
+                g1, g2 = self.grad_of(u.se.fc1.weight), self.grad_of(u.se.fc2.weight)
+                if g1 is None:
+                    g1 = self.se_scratch[0, :R * u.depth]
+                if g2 is None:
+                    g2 = self.se_scratch[1, :R * u.depth]
+                L.append(ops.call("fr_se_mlp_bwd", d["gs"], d["s"], d["hidden"], d["pooled"], u.se.fc1.weight,
+                                  u.se.fc2.weight, d["gpooled"], g1, g2, B, u.depth, R, HWo, st))
+                se_kw = dict(se=d["s"], gse=d["gpooled"])
+                ready += [u.se.fc1.weight, u.se.fc2.weight]
+            db, dg = self._bn_grads(bn2)
+            common = dict(g=g_out, x=d["y2"], mean=bn2.mean, invstd=bn2.invstd, rows=rout, C=u.depth,
+                          rows_per_image=HWo, nblocks=nb, **se_kw)
+            L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
+            self._reduce(L, nb, 3, u.depth, db, dg)
+            s0, s1 = self._s01(bn2, db, dg)
+            L.append(ops.bn_bwd_apply(st, fr, gx=g_y2, gamma=u.bn2.weight, s0=s0, s1=s1, inv_count=1.0 / rout,
+                                      **common))
+            g_xS = None
+            if u.sc_conv is not None:
+                bnS = d["bnS"]
+                g_yS = self.g_yS[:rout * u.depth]
+                db, dg = self._bn_grads(bnS)
+                common = dict(g=g_out, x=d["yS"], mean=bnS.mean, invstd=bnS.invstd, rows=rout, C=u.depth,
+                              rows_per_image=HWo, nblocks=nb)
+                L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
+                self._reduce(L, nb, 3, u.depth, db, dg)
+                s0, s1 = self._s01(bnS, db, dg)
+                L.append(ops.bn_bwd_apply(st, fr, gx=g_yS, gamma=u.sc_bn.weight, s0=s0, s1=s1,
+                                          inv_count=1.0 / rout, **common))
+                g_xS = self.g_xS[:rin * u.cin]
+                L.append(ops.conv(st, fr, src=g_yS, w=d["wtS"], out=g_xS, B=B, RH=u.H, RW=u.H, SH=u.Ho, SW=u.Ho,
+                                  SC=u.depth, N=u.cin, KH=1, KW=1, stride=u.stride, pad=0, mode=1, lda=u.depth,
+                                  ldc=u.cin, pro=0, epi=ops.EPI_STORE))
+                gws = self.grad_of(u.sc_conv.weight)
+                if gws is not None:
+                    tiles = ((u.depth + 127) // 128) * ((u.cin + 127) // 128)
+                    L.append(ops.wgrad(st, fr, g=g_yS, src=x, dw=gws, B=B, GH=u.Ho, GW=u.Ho, Cout=u.depth, SH=u.H,
+                                       SW=u.H, SC=u.cin, KH=1, KW=1, stride=u.stride, pad=0, ldg=u.depth, lda=u.cin,
+                                       pro=0, nsplit=_wgrad_slices(rout, tiles)))
+                ready += [u.sc_bn.weight, u.sc_bn.bias, u.sc_conv.weight]
+            # conv2: data gradient with the PReLU backward epilogue, then the weight gradient
+            g_y1 = self.g_y1[:rin * u.depth]
+            mt = (rin + 127) // 128
+            L.append(ops.conv(st, fr, src=g_y2, w=d["wt2"], out=g_y1, B=B, RH=u.H, RW=u.H, SH=u.Ho, SW=u.Ho,
+                              SC=u.depth, N=u.depth, KH=3, KW=3, stride=u.stride, pad=1, mode=1, lda=u.depth,
+                              ldc=u.depth, ldaux=u.depth, pro=0, epi=ops.EPI_PRELU_BWD, aux=d["y1"],
+                              epi_a=u.prelu.weight, part=self.part))
+            gsl = self.grad_of(u.prelu.weight)
+            self._reduce(L, mt, 2, u.depth, gsl if gsl is not None else self.sums[2, :u.depth], None)
+            gw2 = self.grad_of(u.conv2.weight)
+            if gw2 is not None:
+                tiles = ((u.depth + 127) // 128) ** 2 * 9
+                L.append(ops.wgrad(st, fr, g=g_y2, src=d["y1"], dw=gw2, B=B, GH=u.Ho, GW=u.Ho, Cout=u.depth, SH=u.H,
+                                   SW=u.H, SC=u.depth, KH=3, KW=3, stride=u.stride, pad=1, ldg=u.depth, lda=u.depth,
+                                   pro=ops.PRO_PRELU, pro_a=u.prelu.weight, nsplit=_wgrad_slices(rout, tiles)))
+            # conv1: data gradient with the BN1-backward sums epilogue, then the weight gradient
+            g_xh = self.g_xh[:rin * u.cin]
+            L.append(ops.conv(st, fr, src=g_y1, w=d["wt1"], out=g_xh, B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H,
+                              SC=u.depth, N=u.cin, KH=3, KW=3, stride=1, pad=1, mode=1, lda=u.depth, ldc=u.cin,
+                              ldaux=u.cin, pro=0, epi=ops.EPI_BNBWD, aux=x, epi_a=bn1.mean, epi_b=bn1.invstd,
+                              part=self.part))
+            db, dg = self._bn_grads(bn1)
+            self._reduce(L, mt, 2, u.cin, db, dg)
+            gw1 = self.grad_of(u.conv1.weight)
+            if gw1 is not None:
+                tiles = ((u.depth + 127) // 128) * ((u.cin + 127) // 128) * 9
+                L.append(ops.wgrad(st, fr, g=g_y1, src=x, dw=gw1, B=B, GH=u.H, GW=u.H, Cout=u.depth, SH=u.H, SW=u.H,
+                                   SC=u.cin, KH=3, KW=3, stride=1, pad=1, ldg=u.depth, lda=u.cin, pro=ops.PRO_BN,
+                                   pro_a=bn1.scale, pro_b=bn1.shift, nsplit=_wgrad_slices(rin, tiles)))
+            ready += [u.prelu.weight, u.conv2.weight, u.bn1.weight, u.bn1.bias, u.conv1.weight]
+            # unit input gradient = BN1 backward of g_xh + shortcut gradient
+            nxt = 1 - cur
+            g_x = self.g_pp[nxt][:rin * u.cin]
+            s0, s1 = self._s01(bn1, db, dg)
+            kw = dict(g=g_xh, x=x, gx=g_x, mean=bn1.mean, invstd=bn1.invstd, gamma=u.bn1.weight, s0=s0, s1=s1,
+                      rows=rin, inv_count=1.0 / rin, C=u.cin, rows_per_image=u.H * u.H,
+                      nblocks=ops.grid_blocks(rin, u.cin, fr))
+            if u.sc_conv is not None:
+                kw.update(add=g_xS, add_kind=1)
+            elif u.stride == 1:
+                kw.update(add=g_out, add_kind=1)
+            else:
+                kw.update(add=g_out, add_kind=2, H=u.H, W=u.H, add_stride=u.stride)
+            L.append(ops.bn_bwd_apply(st, fr, **kw))
+            self.ready_marks.append((len(L), ready))
+            g_out, cur = g_x, nxt
+        # ---- stem: z0 = PReLU(BN0(y0)); y0 = X0 * W0p^T
+        sc, sb, sp = self.stem
+        nb = ops.grid_blocks(self.M0, 64, fr)
+        db, dg = self._bn_grads(self.bn0)
+        gsl = self.grad_of(sp.weight)
+        common = dict(g=g_out, x=self.y0, mean=self.bn0.mean, invstd=self.bn0.invstd, scale=self.bn0.scale,
+                      shift=self.bn0.shift, slope=sp.weight, rows=self.M0, C=64, rows_per_image=self.S * self.S,
+                      nblocks=nb)
+        L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
+        self._reduce(L, nb, 3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64])
+        s0, s1 = self._s01(self.bn0, db, dg)
+        g_y0 = self.g_y1[:self.M0 * 64]
+        L.append(ops.bn_bwd_apply(st, fr, gx=g_y0, gamma=sb.weight, s0=s0, s1=s1, inv_count=1.0 / self.M0, **common))
+        gw0 = self.grad_of(sc.weight)
+        if gw0 is not None:
+            L.append(ops.call("fr_fill_rows", self.gW0p, None, 64, self.K0, st))
+            L.append(ops.wgrad(st, fr, g=g_y0, src=self.X0, dw=self.gW0p, B=self.M0, GH=1, GW=1, Cout=64, SH=1, SW=1,
+                               SC=self.K0, KH=1, KW=1, stride=1, pad=0, ldg=64, lda=self.K0, pro=0,
+                               nsplit=_wgrad_slices(self.M0, 1)))
+            L.append(ops.call("fr_unpack_stem_grad", self.gW0p, gw0, gw0.stride(0), gw0.stride(1), gw0.stride(2),
+                              gw0.stride(3), 64, sc.weight.shape[1], self.K0, st))
+        self.ready_marks.append((len(L), [sb.weight, sb.bias, sp.weight, sc.weight]))
+        self.bwd_list = L
+
+    # ---- execution ---------------------------------------------------------------------------------
+    def check_current(self):
+        if torch.cuda.current_stream().cuda_stream != self.stream_id:
+            return False
+        return self._signature() == self.param_sig
+
+    def run_forward(self, x, avg_image, seed):
+        B, S = self.B, self.S
+        st = self.stream
+        avg = avg_image
+        rc = _lib.lib.fr_stem_im2col(ops.ptr(x), ops.ptr(avg), ops.ptr(self.X0), B, S, S, self.in_channels,
+                                     self.avg_channels, self.K0, self.fr, st)
+        _lib.check(rc, "fr_stem_im2col")
+        od = self.out[1]
+        p = float(od.p) if od.training else 0.0
+        self.l_drop_fwd.args[7] = p
+        self.l_drop_fwd.args[8] = seed
+        self.l_drop_bwd.args[4] = p
+        self.l_drop_bwd.args[5] = seed
+        ops.run(self.pack_list)
+        ops.run(self.fwd_list)
+        self.generation += 1
+        return self.feat
+
+    def run_backward(self, g_feat, on_ready=None):
+        self.g_feat_in.copy_(g_feat)
+        self.arena.zero_()
+        for p, _off, _n in self.arena_slices:
+            if p.requires_grad:
+                if p.grad is None or p.grad.data_ptr() != self.gviews[id(p)].data_ptr():
+                    p.grad = self.gviews[id(p)]
+        if on_ready is None:
+            ops.run(self.bwd_list)
+            return
+        pos = 0
+        for end, params in self.ready_marks:
+            ops.run(self.bwd_list[pos:end])
+            pos = end
+            on_ready([p for p in params if p.requires_grad])
+        ops.run(self.bwd_list[pos:])
+
+
+# ------------------------------------------------------------------------------------------------ autograd glue
+
+
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, runner, x, *params):
+        feats = runner._forward_impl(x)
+        ctx.runner = runner
+        ctx.plan = runner.plan
+        ctx.generation = runner.plan.generation
+        return feats.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        if plan.generation != ctx.generation:
+            raise RuntimeError("frhip: the backbone ran another forward before this backward; the activation "
+                               "buffers of the static plan hold one step at a time")
+        plan.run_backward(g.contiguous().float(), ctx.runner.on_grads_ready)
+        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class BackboneRunner(object):
+    """Owns the plan cache of one backbone module and exposes ``__call__(x) -> features [B,512]``."""
+
+    def __init__(self, module, in_channels=3):
+        self.module = module
+        self.in_channels = in_channels
+        self.plan = None
+        self.plans = {}
+        self.compute_dtype = None
+        self.on_grads_ready = None
+        self.step_seed = 0x5EED
+
+    def _get_plan(self, x, avg_channels):
+        dtype = self.compute_dtype or getattr(self.module, "compute_dtype", None) or compute_dtype_default()
+        key = (x.shape[0], dtype, x.device, avg_channels)
+        plan = self.plans.get(key)
+        if plan is None or not plan.check_current():
+            plan = BackbonePlan(self.module, x.shape[0], dtype, x.device, self.in_channels - avg_channels,
+                                avg_channels)
+            self.plans = {key: plan}  # one live plan: activations of a 256-batch are several GB
+        return plan
+
+    def _forward_impl(self, x):
+        avg = self._avg
+        self.plan = self._get_plan(x, 0 if avg is None else avg.shape[0])
+        self.step_seed = (self.step_seed * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        return self.plan.run_forward(x, avg, self.step_seed)
+
+    def __call__(self, x, avg_image=None):
+        if not x.is_cuda:
+            raise _lib.FrhipError("frhip: the backbone runs on the HIP path only -- got a %s tensor. Move the "
+                                  "model and batch to a ROCm device (the CPU restatement is oracle/, for tests)."
+                                  % x.device)
+        if x.requires_grad:
+            raise NotImplementedError("frhip: gradients with respect to the input images are not implemented")
+        x = x.contiguous().float()
+        S = self.module.input_size if isinstance(self.module.input_size, int) else self.module.input_size[0]
+        if x.shape[2] != S or x.shape[3] != S:
+            raise _lib.FrhipError("frhip: expected %dx%d inputs, got %s" % (S, S, tuple(x.shape)))
+        self._avg = None if avg_image is None else avg_image.to(x.device).contiguous().float()
+        params = [p for p in self.module.parameters()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _BackboneFn.apply(self, x, *params)
+        return self._forward_impl(x).clone()

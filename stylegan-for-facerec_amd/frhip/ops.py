@@ -1,0 +1,107 @@
+"""Launch records for the C-ABI entry points of libfrhip.so.
+
+Every builder returns a ``Launch``: the C function plus a fully marshalled argument list (device pointers,
+geometry, stream).  The training step is static -- same shapes, same buffers every iteration -- so the
+engine marshals once and replays lists of launches; nothing here touches tensors element-wise and nothing
+synchronises.  All tensors must live on a ROCm device: there is no CPU path behind these calls.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_ATOMIC, EPI_BNBWD, EPI_MARGIN, EPI_PRELU_BWD, EPI_STATS, EPI_STORE, FR_BF16, FR_F32,  # noqa: F401
+                   PRO_BN, PRO_NONE, PRO_PRELU, lib)
+
+TORCH_DTYPE = {FR_F32: torch.float32, FR_BF16: torch.bfloat16}
+
+
+def fr_dtype(t):
+    if t.dtype == torch.float32:
+        return FR_F32
+    if t.dtype == torch.bfloat16:
+        return FR_BF16
+    raise _lib.FrhipError("frhip: unsupported tensor dtype %s" % t.dtype)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: the product path has no CPU fallback."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.FrhipError("frhip: expected a ROCm device tensor, got a %s tensor -- the HIP path has no CPU "
+                              "fallback (the CPU restatement lives in oracle/ for tests only)" % t.device)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Launch(object):
+    __slots__ = ("fn", "args", "name", "keep")
+
+    def __init__(self, name, args, keep=None):
+        self.fn = getattr(lib, name)
+        self.args = list(args)
+        self.name = name
+        self.keep = keep
+
+    def __call__(self):
+        rc = self.fn(*self.args)
+        if rc:
+            _lib.check(rc, self.name)
+
+
+def run(launches):
+    for l in launches:
+        l()
+
+
+def _fill(struct, **kw):
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = ptr(v)
+        setattr(struct, k, v)
+    return struct
+
+
+def conv(stream, dtype, **kw):
+    """fr_conv_igemm.  kw = FrConvArgs fields (tensors allowed for pointer fields)."""
+    a = _fill(_lib.FrConvArgs(), **kw)
+    return Launch("fr_conv_igemm", [ctypes.byref(a), dtype, stream], keep=(a, kw))
+
+
+def wgrad(stream, dtype, **kw):
+    a = _fill(_lib.FrWgradArgs(), **kw)
+    return Launch("fr_conv_wgrad", [ctypes.byref(a), dtype, stream], keep=(a, kw))
+
+
+def bn_apply(stream, dtype, **kw):
+    a = _fill(_lib.FrApplyArgs(), **kw)
+    return Launch("fr_bn_apply", [ctypes.byref(a), dtype, stream], keep=(a, kw))
+
+
+def bn_bwd_reduce(stream, dtype, **kw):
+    a = _fill(_lib.FrBnBwdArgs(), **kw)
+    return Launch("fr_bn_bwd_reduce", [ctypes.byref(a), dtype, stream], keep=(a, kw))
+
+
+def bn_bwd_apply(stream, dtype, **kw):
+    a = _fill(_lib.FrBnBwdArgs(), **kw)
+    return Launch("fr_bn_bwd_apply", [ctypes.byref(a), dtype, stream], keep=(a, kw))
+
+
+def call(name, *args):
+    """Generic positional launch: tensors -> pointers, everything else passed through."""
+    keep = args
+    conv_args = [ptr(a) if isinstance(a, torch.Tensor) else a for a in args]
+    return Launch(name, conv_args, keep=keep)
+
+
+def grid_blocks(rows, C, dtype, cap=1024):
+    """Grid size for the [row-thread][channel-chunk] kernels: enough blocks to fill 256 CUs a few times."""
+    vec = 4 if dtype == FR_F32 else 8
+    rows_per_block = max(1, 256 // (C // vec))
+    need = (rows + rows_per_block - 1) // rows_per_block
+    return int(max(1, min(cap, need)))

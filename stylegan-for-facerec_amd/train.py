@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Stage-3 face-recognition training driver -- counterpart of the reference's train.py on the frhip HIP engine.
+
+    python train.py --config configs/config_BUPT_IR_50_baseline.py
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py --config configs/...
+    python train.py --config configs/config_synthetic_smoke.py --synthetic 100x12 --max-steps 20
+
+Kept from the reference (train.py:41-421): every config key, module construction order (all four heads are built
+eagerly), the BN / non-BN parameter groups, LR stages (/1.5), optional warm-up, the freeze -> unfreeze schedule on
+``.module.encoder.body``, per-step top-1/5, per-epoch checkpoint file names.  Changed on purpose (SURVEY.md section 7,
+hard parts): one process per GPU with RCCL gradient all-reduce instead of nn.DataParallel (BATCH_SIZE is per GPU),
+the head lives on the GPU, metrics are read back every DISP_FREQ steps instead of three ``.item()`` syncs per step,
+wandb / bcolz validation are optional.
+"""
+import argparse
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from backbone.model_irse import IR_50, IR_101, IR_152, IR_SE_50, IR_SE_101, IR_SE_152
+from backbone.model_resnet import ResNet_50, ResNet_101, ResNet_152  # noqa: F401  (import parity with the reference)
+from backbone.restyle_psp import pSp
+from dataset import FacesDataset, SyntheticFaces, TrainTransform
+from frhip import functional as FRF
+from frhip.optim import SGD
+from frhip.parallel import DataParallel
+from head.metrics import Am_softmax, ArcFace, CosFace, SphereFace
+from loss.focal import FocalLoss
+from util.utils import (AverageMeter, accuracy, collate_fn_ignore_none, get_time, get_val_data, schedule_lr,
+                        separate_irse_bn_paras, warm_up_lr)
+
+IRSE = {"IR_50": IR_50, "IR_101": IR_101, "IR_152": IR_152, "IR_SE_50": IR_SE_50, "IR_SE_101": IR_SE_101,
+        "IR_SE_152": IR_SE_152}
+RESTYLE = {"IR_34_ReStyle": "BackboneEncoder34", "IR_50_ReStyle": "BackboneEncoder", "IR_100_ReStyle": "BackboneEncoder100"}
+
+
+class _ConsoleLog(object):
+    def log(self, stats):
+        print("[log]", {k: (round(v, 5) if isinstance(v, float) else v) for k, v in stats.items()})
+
+
+def make_logger(cfg, rank):
+    if rank != 0:
+        return None
+    try:
+        import wandb
+        wandb.init(project=cfg.get("PROJECT_NAME", "face-evolve"), config=cfg)
+        wandb.run.name = cfg["EXP_NAME"]
+        return wandb
+    except Exception:  # noqa: BLE001 -- wandb is optional here
+        return _ConsoleLog()
+
+
+def build_backbone(cfg):
+    name = cfg["BACKBONE_NAME"]
+    if name in IRSE:
+        return IRSE[name](cfg["INPUT_SIZE"])
+    if name in RESTYLE:
+        return pSp(encoder_type=RESTYLE[name], size=cfg.get("ENCODER_INPUT_SIZE", 112),
+                   checkpoint_path=cfg.get("ENCODER_CHECKPOINT"), avg_image=cfg.get("ENCODER_AVG_IMAGE"),
+                   include_dropout=False)
+    raise ValueError("unsupported BACKBONE_NAME %r" % name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, default="config.py")
+    ap.add_argument("--synthetic", default="", help="IDSxPER: train on seeded synthetic identities, no DATA_ROOT")
+    ap.add_argument("--max-steps", type=int, default=0)
+    args = ap.parse_args()
+    cfg = importlib.import_module(args.config.replace(".py", "").replace("/", ".")).configurations[1]
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("train.py: the frhip engine needs a ROCm GPU; the CPU restatement in oracle/ is for tests only")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    np.random.seed(cfg["SEED"])
+    torch.manual_seed(cfg["SEED"])  # identical initial weights on every rank (and broadcast below)
+    os.makedirs(cfg["MODEL_ROOT"], exist_ok=True)
+    os.makedirs(cfg["LOG_ROOT"], exist_ok=True)
+    logger = make_logger(cfg, rank)
+
+    if args.synthetic:
+        ids, per = (int(v) for v in args.synthetic.split("x"))
+        dataset = SyntheticFaces(ids, per, cfg["INPUT_SIZE"][0], cfg["SEED"])
+    else:
+        dataset = FacesDataset(os.path.join(cfg["DATA_ROOT"], cfg["TRAIN_IMAGES_FOLDER"]),
+                               TrainTransform(cfg["INPUT_SIZE"][0], cfg["RGB_MEAN"], cfg["RGB_STD"]))
+    num_class = len(dataset.classes)
+    sampler = torch.utils.data.distributed.DistributedSampler(dataset, world, rank, shuffle=True) if world > 1 else None
+    loader = torch.utils.data.DataLoader(dataset, batch_size=cfg["BATCH_SIZE"], sampler=sampler,
+                                         shuffle=sampler is None, pin_memory=cfg["PIN_MEMORY"],
+                                         num_workers=cfg["NUM_WORKERS"], drop_last=cfg["DROP_LAST"],
+                                         collate_fn=collate_fn_ignore_none)
+    print("Number of Training Classes: {}".format(num_class))
+    val = get_val_data(cfg["DATA_ROOT"]) if not args.synthetic else None  # noqa: F841  (evaluation: SURVEY 8f)
+
+    backbone = build_backbone(cfg)
+    emb, s = cfg["EMBEDDING_SIZE"], cfg.get("ARCFACE_S", 64.0)
+    heads = {"ArcFace": ArcFace(emb, num_class, None, s=s), "CosFace": CosFace(emb, num_class, None),
+             "SphereFace": SphereFace(emb, num_class, None), "Am_softmax": Am_softmax(emb, num_class, None)}
+    head = heads[cfg["HEAD_NAME"]]
+    bn_params, other_params = separate_irse_bn_paras(backbone)
+    _, head_params = separate_irse_bn_paras(head)
+
+    if cfg["BACKBONE_RESUME_ROOT"] and cfg["HEAD_RESUME_ROOT"]:
+        if os.path.isfile(cfg["BACKBONE_RESUME_ROOT"]) and os.path.isfile(cfg["HEAD_RESUME_ROOT"]):
+            backbone.load_state_dict(torch.load(cfg["BACKBONE_RESUME_ROOT"], map_location="cpu"))
+            head.load_state_dict(torch.load(cfg["HEAD_RESUME_ROOT"], map_location="cpu"))
+        else:
+            print("No Checkpoint Found at '{}' and '{}'".format(cfg["BACKBONE_RESUME_ROOT"], cfg["HEAD_RESUME_ROOT"]))
+    backbone, head = backbone.to(device), head.to(device)
+    if cfg.get("OPTIMIZER_NAME", "SGD") != "SGD":
+        raise NotImplementedError("only OPTIMIZER_NAME='SGD' is on the accelerated path")
+    optimizer = SGD([{"params": other_params + head_params, "weight_decay": cfg["WEIGHT_DECAY"]},
+                     {"params": bn_params}], lr=cfg["LR"], momentum=cfg["MOMENTUM"])
+    opt_resume = cfg.get("OPTIMIZER_RESUME_ROOT")
+    BACKBONE = DataParallel(backbone, head)  # exposes .module like nn.DataParallel; all-reduce only when world > 1
+    loss_fn = FocalLoss() if cfg["LOSS_NAME"] == "Focal" else None
+    ce = torch.nn.CrossEntropyLoss()
+
+    disp_freq = max(1, len(loader) // 10)  # the reference divides by zero below 10 batches/epoch
+    warm_epochs = cfg["NUM_EPOCH"] // 25
+    warm_batches = len(loader) * warm_epochs
+    freeze = cfg.get("FREEZE_BACKBONE_EPOCHS")
+    batch = 0
+    FRF.CHECK_LABELS = False  # labels come from the dataset's own class index
+    for epoch in range(cfg.get("START_EPOCH", 0), cfg["NUM_EPOCH"]):
+        if epoch in cfg["STAGES"]:
+            schedule_lr(optimizer)
+        backbone.train()
+        head.train()
+        if freeze is not None and hasattr(BACKBONE.module, "encoder"):
+            enc = BACKBONE.module.encoder
+            enc.input_layer.requires_grad_(True)
+            enc.body.requires_grad_(epoch > freeze)
+            enc.output_layer.requires_grad_(True)
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        losses, top1, top5 = AverageMeter(), AverageMeter(), AverageMeter()
+        pending = []
+        for inputs, labels in loader:
+            if cfg.get("WARMUP", True) and epoch + 1 <= warm_epochs and batch + 1 <= warm_batches:
+                warm_up_lr(batch, warm_batches, cfg["LR"], optimizer)
+            inputs = inputs.to(device, non_blocking=True)
+            labels = labels.to(device, non_blocking=True).long()
+            if batch == 0 and opt_resume and os.path.isfile(opt_resume):
+                pass  # momentum buffers are created lazily; loaded right after the first step below
+            outputs = head(BACKBONE(inputs), labels)
+            loss = loss_fn(outputs, labels)[0] if loss_fn is not None else ce(outputs, labels)
+            prec1, prec5 = accuracy(outputs.data, labels, topk=(1, 5))
+            pending.append((loss.detach(), prec1, prec5, inputs.size(0)))
+            optimizer.zero_grad()
+            loss.backward()
+            BACKBONE.synchronize()
+            optimizer.step()
+            if batch == 0 and opt_resume and os.path.isfile(opt_resume):
+                optimizer.load_state_dict(torch.load(opt_resume, map_location=device))
+            if (batch + 1) % disp_freq == 0 or (args.max_steps and batch + 1 >= args.max_steps):
+                for l, p1, p5, n in pending:  # one host sync per display interval
+                    losses.update(float(l), n)
+                    top1.update(float(p1), n)
+                    top5.update(float(p5), n)
+                pending = []
+                if rank == 0:
+                    print("Epoch {}/{} Batch {}\tTraining Loss {:.4f} ({:.4f})\tPrec@1 {:.3f} ({:.3f})\tPrec@5 {:.3f} "
+                          "({:.3f})".format(epoch + 1, cfg["NUM_EPOCH"], batch + 1, losses.val, losses.avg, top1.val,
+                                            top1.avg, top5.val, top5.avg))
+                    if logger is not None:
+                        logger.log({"train_loss": losses.val, "step": batch * cfg["BATCH_SIZE"] * world})
+            batch += 1
+            if args.max_steps and batch >= args.max_steps:
+                break
+        if rank == 0:
+            tag = "Epoch_{}_Batch_{}_Time_{}_checkpoint.pth".format(epoch + 1, batch, get_time())
+            root = cfg["MODEL_ROOT"]
+            torch.save(BACKBONE.module.state_dict(), os.path.join(root, "Backbone_{}_{}".format(cfg["BACKBONE_NAME"], tag)))
+            torch.save(head.state_dict(), os.path.join(root, "Head_{}_{}".format(cfg["HEAD_NAME"], tag)))
+            torch.save(optimizer.state_dict(), os.path.join(root, "Optimizer_{}_{}".format(cfg["HEAD_NAME"], tag)))
+        if args.max_steps and batch >= args.max_steps:
+            break
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -257,6 +257,26 @@ def run_full(kind, tag, batch=8, nclass=100):
               prefix + "body.0.res_layer.2.weight", prefix + "body.3.shortcut_layer.0.weight"):
         out["g." + n] = npy(gd[n])
     out["g.head.weight"] = npy(gs[-1])
+    # the same step in float64 = "truth" for judging fp32 implementations against the reference's own fp32 noise
+    model64, _, avg64 = full_model(kind)
+    model64 = model64.double().train()
+    if avg64 is not None:
+        model64.avg_image = avg64.double()
+    head64 = ref_heads.ArcFace(512, nclass, None, s=64.0).double()
+    with torch.no_grad():
+        head64.weight.copy_(head.weight.double())
+    feats64 = model64(x.double())
+    logits64 = head64(feats64, label, onehot_vec=onehot(label, nclass).double())
+    loss64, _ = RefFocal()(logits64, label)
+    named64 = list(model64.named_parameters())
+    gs64 = torch.autograd.grad(loss64, [p for _, p in named64] + [head64.weight])
+    gd64 = dict(zip([n for n, _ in named64], gs64))
+    out["features64"], out["logits64"] = npy(feats64), npy(logits64)
+    out["grad_norms64"] = np.array([float(g.norm()) for g in gs64])
+    for n in list(out):
+        if n.startswith("g.") and n != "g.head.weight":
+            out["g64." + n[2:]] = npy(gd64[n[2:]])
+    out["g64.head.weight"] = npy(gs64[-1])
     bufs = dict(model.named_buffers())
     for n in (prefix + "input_layer.1", prefix + "body.7.res_layer.4", prefix + "output_layer.4"):
         out["buf." + n + ".running_mean"] = npy(bufs[n + ".running_mean"])
@@ -290,7 +310,14 @@ def g7_sgd():
         opt.zero_grad()
         loss.backward()
         opt.step()
+        if step == 0:  # state after ONE step: fp32 implementations agree tightly here, step 2 amplifies rounding
+            ps1 = [p for _, p in model.named_parameters()] + [head.weight]
+            out["param_norms_step1"] = [float(p.double().norm()) for p in ps1]
+            snap1 = {"w1.input_layer.0.weight": npy(model.input_layer[0].weight),
+                     "w1.body.10.res_layer.1.weight.head": npy(model.body[10].res_layer[1].weight.reshape(-1)[:4096]),
+                     "w1.head.weight.rows0_3": npy(head.weight[:4])}
     res = {k: np.array(v) for k, v in out.items()}
+    res.update(snap1)
     names = [n for n, _ in model.named_parameters()]
     res["param_names"] = np.array(names + ["head.weight"])
     ps = [p for _, p in model.named_parameters()] + [head.weight]

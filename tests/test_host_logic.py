@@ -1,0 +1,141 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/frhip.h declares (no compute calls),
+and the host-side mirror of the reference interface behaves like the reference (pinned by g8/g9 fixtures)."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+@pytest.fixture(scope="module")
+def structure(golden_dir):
+    with open(os.path.join(golden_dir, "g8_structure.json")) as f:
+        return json.load(f)
+
+
+def test_abi_exports_every_declared_symbol():
+    from frhip import _lib
+    assert os.path.exists(_lib.LIB_PATH)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = sorted(_lib.protos)
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), "include/frhip.h declares %s but libfrhip.so does not export it" % name
+    assert _lib.self_check()
+    assert _lib.lib.fr_last_error_string() is not None
+
+
+def test_abi_rejects_bad_arguments_without_a_gpu():
+    """Argument validation happens before any launch, so it can be exercised on a GPU-less host."""
+    from frhip import _lib
+    a = _lib.FrConvArgs()
+    a.SC, a.stride, a.B, a.RH, a.RW = 48, 1, 1, 1, 1  # 48 is not a multiple of 32
+    rc = _lib.lib.fr_conv_igemm(ctypes.byref(a), 0, None)
+    assert rc < 0 and b"multiple of 32" in _lib.lib.fr_last_error_string()
+    a.SC, a.stride = 64, 3
+    assert _lib.lib.fr_conv_igemm(ctypes.byref(a), 0, None) < 0
+    with pytest.raises(_lib.FrhipError):
+        _lib.check(-1, "x")
+
+
+@pytest.mark.parametrize("name", ["IR_50", "IR_SE_50", "IR_SE_101", "IR_101", "pSp", "pSp34"])
+def test_state_dict_layout_and_param_split(structure, name):
+    from backbone import model_irse as M
+    from backbone.restyle_psp import pSp
+    from util.utils import separate_irse_bn_paras
+    ctor = {"IR_50": lambda: M.IR_50([112, 112]), "IR_SE_50": lambda: M.IR_SE_50([112, 112]),
+            "IR_SE_101": lambda: M.IR_SE_101([112, 112]), "IR_101": lambda: M.IR_101([112, 112]),
+            "pSp": lambda: pSp(size=112), "pSp34": lambda: pSp(size=112, encoder_type="BackboneEncoder34")}[name]
+    m = ctor()
+    want = structure[name]
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == want["keys"]
+    assert [n for n, _ in m.named_parameters()] == want["param_names"]
+    bn, wo = separate_irse_bn_paras(m)
+    assert (len(bn), len(wo)) == (want["n_bn"], want["n_wo"])
+    assert sum(p.numel() for p in bn) == want["bn_numel"] and sum(p.numel() for p in wo) == want["wo_numel"]
+
+
+def test_heads_construct_like_the_reference(structure):
+    from head import metrics as H
+    from util.utils import separate_irse_bn_paras
+    for name in ("ArcFace", "CosFace", "SphereFace", "Am_softmax"):
+        h = getattr(H, name)(512, 100, None)
+        assert [[k, list(v.shape)] for k, v in h.state_dict().items()] == structure[name]["keys"]
+        bn, wo = separate_irse_bn_paras(h)
+        assert (len(bn), len(wo)) == (structure[name]["n_bn"], structure[name]["n_wo"])
+    a = H.ArcFace(512, 10, None)
+    assert abs(a.th - (-0.8775825618903726)) < 1e-15 and abs(a.mm - 0.23971276930210156) < 1e-15
+    assert H.CosFace(512, 10, None).m == 0.50  # the reference's default, not the paper's 0.35
+
+
+def test_psp_dropout_insertion_and_errors(structure):
+    from backbone.restyle_psp import pSp
+    m = pSp(size=112, include_dropout=0.15)
+    assert [type(c).__name__ for c in m.encoder.body[0].res_layer] == structure["pSp.dropout.body0.res_layer"]
+    assert [type(c).__name__ for c in m.encoder.body[3].shortcut_layer] == structure["pSp.dropout.body3.shortcut_layer"]
+    with pytest.raises(Exception) as e:
+        pSp(size=112, encoder_type="nope")
+    assert str(e.value) == structure["pSp.bad_encoder_error"]
+
+
+def test_lr_helpers(structure):
+    from util.utils import AverageMeter, schedule_lr, warm_up_lr
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.03)
+    warm_up_lr(3, 10, 0.03, opt)
+    assert opt.param_groups[0]["lr"] == structure["warm_up_lr_3_10_0.03"]
+    opt.param_groups[0]["lr"] = 0.03
+    schedule_lr(opt)
+    assert opt.param_groups[0]["lr"] == structure["schedule_lr_0.03"]
+    am = AverageMeter()
+    am.update(2.0, 3)
+    am.update(4.0, 1)
+    assert am.avg == 2.5 and am.val == 4.0
+
+
+def test_stage2_checkpoint_import(golden_dir, tmp_path):
+    """g9: only encoder.input_layer.* / encoder.body.* are read from a Stage-2 checkpoint; output head untouched."""
+    from backbone.restyle_psp import pSp
+    from frhip import synth
+    with open(os.path.join(golden_dir, "g9_stage2.json")) as f:
+        want = json.load(f)
+    src = pSp(size=112)
+    sd = {k: v.clone() for k, v in src.state_dict().items()
+          if k.startswith("encoder.input_layer") or k.startswith("encoder.body")}
+    synth.fill_state_dict(sd, 19)
+    ck = dict(sd)
+    ck["encoder.styles.0.convs.0.weight"] = torch.ones(2, 2)
+    ck["decoder.style.1.weight"] = torch.ones(3)
+    path = str(tmp_path / "stage2.pt")
+    torch.save({"state_dict": ck, "latent_avg": torch.zeros(18, 512), "opts": {"x": 1}}, path)
+    m = pSp(size=112, checkpoint_path=path)
+    got = m.state_dict()
+    assert len(sd) == want["n_ckpt_encoder_keys"]
+    assert sum(torch.equal(got[k], sd[k]) for k in sd) == want["n_loaded_equal"]
+    assert [k for k in got if k.startswith("encoder.output_layer")] == want["output_layer_keys"]
+    for k in ("encoder.input_layer.0.weight", "encoder.body.23.res_layer.3.weight"):
+        assert abs(float(got[k].double().sum()) - want["sum." + k]) < 1e-6
+
+
+def test_conv_weights_are_stored_packed():
+    """3x3 weights live as [Cout][kh][kw][Cin] behind the OIHW Parameter; state-dict round trips keep values."""
+    from backbone.model_irse import IR_50
+    m = IR_50([112, 112])
+    w = m.body[0].res_layer[1].weight
+    assert w.shape == (64, 64, 3, 3) and w.permute(0, 2, 3, 1).is_contiguous()
+    sd = {k: v.clone().contiguous() for k, v in m.state_dict().items()}
+    m2 = IR_50([112, 112])
+    m2.load_state_dict(sd)
+    assert torch.equal(m2.body[0].res_layer[1].weight, w)
+    assert m2.body[0].res_layer[1].weight.permute(0, 2, 3, 1).is_contiguous()
+
+
+def test_synth_is_deterministic():
+    from frhip import synth
+    a = synth.uniform(1, "x", (5,))
+    b = synth.uniform(1, "x", (5,))
+    assert torch.equal(a, b) and not torch.equal(a, synth.uniform(2, "x", (5,)))
+    assert abs(float(synth.normal(1, "n", (20000,)).std()) - 1.0) < 0.03
+    lab = synth.labels(1, "l", 1000, 7)
+    assert int(lab.min()) >= 0 and int(lab.max()) == 6

@@ -1,0 +1,97 @@
+"""world_size-2 ``gloo`` tests (CPU) of the gradient exchange used for N > 1 GPUs: bucketing over a flat arena in
+readiness order, asynchronous launch as buckets complete, frozen parameters, stand-alone tensors, averaging."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path.insert(0, os.path.join(os.path.dirname(here), "stylegan-for-facerec_amd"))
+        from frhip.parallel import BucketedAllReduce
+        torch.manual_seed(1234)  # same parameters on both ranks
+        shapes = [(7,), (64, 3, 3, 3), (512,), (300, 40), (5,), (1000,)]
+        params = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+        params[4].requires_grad_(False)  # a frozen parameter in the middle
+        sizes = [(p.numel() + 63) // 64 * 64 for p in params]
+        arena = torch.zeros(sum(sizes))
+        slices, off = [], 0
+        for p, sz in zip(params, sizes):
+            slices.append((p, off, p.numel()))
+            if p.requires_grad:
+                p.grad = arena[off:off + p.numel()].view(p.shape)
+            off += sz
+        red = BucketedAllReduce(arena, slices, bucket_bytes=4096)
+        assert len(red.buckets) >= 3
+        for step in range(2):
+            arena.zero_()
+            g = torch.Generator().manual_seed(100 * step + rank)  # different gradients per rank
+            local = {}
+            # "backward": gradients become ready in arena order, two parameters at a time
+            for i in range(0, len(params), 2):
+                group = []
+                for p in params[i:i + 2]:
+                    if p.requires_grad:
+                        p.grad.copy_(torch.randn(p.shape, generator=g))
+                        local[id(p)] = p.grad.clone()
+                        group.append(p)
+                red.on_ready(group)
+            extra = torch.full((10,), float(rank + 1))
+            red.add_tensor(extra)
+            red.synchronize()
+            # reference: gather every rank's local gradients and average
+            for p in params:
+                if not p.requires_grad:
+                    continue
+                gathered = [torch.zeros_like(p) for _ in range(world)]
+                dist.all_gather(gathered, local[id(p)])
+                want = sum(gathered) / world
+                assert torch.allclose(p.grad, want, atol=1e-6), "rank %d step %d mismatch" % (rank, step)
+            assert torch.allclose(extra, torch.full((10,), sum(range(1, world + 1)) / world))
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def test_single_process_is_a_noop():
+    from frhip.parallel import BucketedAllReduce
+    arena = torch.arange(10.0)
+    p = torch.nn.Parameter(torch.zeros(10))
+    red = BucketedAllReduce(arena, [(p, 0, 10)])
+    red.on_ready([p])
+    red.synchronize()
+    assert torch.equal(arena, torch.arange(10.0))
