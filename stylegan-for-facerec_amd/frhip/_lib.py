@@ -9,6 +9,9 @@ import ctypes
 import os
 import re
 
+import torch  # noqa: F401  -- must precede the CDLL: libfrhip.so has to bind to the HIP runtime torch already loaded
+              #                (two runtime copies in one process do not share devices or streams)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(os.path.dirname(_HERE))
 HEADER = os.path.join(REPO_ROOT, "include", "frhip.h")
