@@ -133,6 +133,14 @@ def instrumented_step(step, x, y, dtype_name):
             name = "conv_igemm<%s,BN=%d,PRO=%d>" % (dtype_name if launch.args[1] == 1 else "f32",
                                                     64 if a.N <= 64 else 128, a.pro)
             flops = conv_flops(launch)
+        elif launch.name == "fr_conv3x3_strip":
+            a = launch.keep[0]
+            name = "conv3x3_strip<%d,%d,%d,PRO=%d>" % (a.SC, a.N, a.SW, a.pro)
+            flops = conv_flops(launch)
+        elif launch.name == "fr_conv_wgrad_strip":
+            a = launch.keep[0]
+            name = "conv_wgrad_strip<%d,PRO=%d>(%dx%d)" % (a.SW, a.pro, a.Cout, a.SC)
+            flops = wgrad_flops(launch)
         elif launch.name == "fr_conv_wgrad":
             a = launch.keep[0]
             name = "conv_wgrad<%s,%d,%d,PRO=%d>" % (dtype_name if launch.args[1] == 1 else "f32",

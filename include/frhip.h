@@ -75,6 +75,14 @@ typedef struct FrConvArgs {
  * :167,181-189); their autograd data-gradients with mode = 1. */
 int fr_conv_igemm(const FrConvArgs* args, int dtype, void* stream);
 
+/* Stride-1 3x3 convolution (bf16 only) with the input strip resident in LDS: same FrConvArgs contract as
+ * fr_conv_igemm (mode 1 = data gradient: mirrored taps, w = [Cin][tap][Cout]); epilogues STORE / STATS / PRELU_BWD /
+ * BNBWD.  Partial rows go to part[workgroup][2][N]; fr_conv3x3_strip_parts returns the number of workgroups for a
+ * shape, or 0 when the shape is not in the strip table (use fr_conv_igemm then).
+ * Replaces Conv2d(c, d, (3,3), (1,1), 1) of bottleneck_IR (backbone/model_irse.py:57-59) fwd + data gradient. */
+int fr_conv3x3_strip(const FrConvArgs* args, void* stream);
+int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W);
+
 typedef struct FrWgradArgs {
   const void* g;   /* gradient of the conv output: [B*GH*GW][ldg], columns = Cout */
   const void* src; /* conv input, NHWC [B,SH,SW,SC], pixel stride lda */
@@ -84,14 +92,21 @@ typedef struct FrWgradArgs {
   int32_t KH, KW, stride, pad;
   int32_t ldg, lda;
   int32_t pro; /* FR_PRO_* applied to src */
-  int32_t nsplit; /* pixel slices (gridDim.y) */
+  int32_t nsplit; /* pixel slices (gridDim.y) / strip groups */
   const float* pro_a;
   const float* pro_b;
+  float* slab;     /* fr_conv_wgrad_strip only: [nsplit][Cout][9][SC] fp32 partial gradients */
 } FrWgradArgs;
 
 /* Weight gradient  dw[co][tap][ci] += sum_p g[p][co] * pro(src[pixel(p,tap)][ci]).
  * Replaces the autograd weight-gradient of every Conv2d / Linear above. */
 int fr_conv_wgrad(const FrWgradArgs* args, int dtype, void* stream);
+
+/* Weight gradient of stride-1 3x3 convolutions (bf16) with both operand strips resident in LDS; partial results
+ * per strip group go to `slab`, a second launch adds them into dw (overwrites; deterministic, no atomics).
+ * fr_conv_wgrad_strip_supported tells whether a shape is served (else use fr_conv_wgrad). */
+int fr_conv_wgrad_strip(const FrWgradArgs* args, void* stream);
+int fr_conv_wgrad_strip_supported(int Cout, int Cin, int W);
 
 /* ---- stem: NCHW fp32 images (+ optional constant avg image, restyle_psp.py:445-447) -> im2col rows
  * out[(b,h,w)][(kh*3+kw)*C + c] in the compute dtype, K padded with zeros to ldk (32 or 64).

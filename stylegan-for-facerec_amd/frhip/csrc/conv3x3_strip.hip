@@ -1,0 +1,323 @@
+// frhip -- stride-1 3x3 convolution with the input strip resident in LDS (bf16, gfx950).
+//
+// The 3x3 stride-1 convolutions are >85 % of the IR-50 FLOPs.  In the generic implicit-GEMM
+// kernel every input element is gathered from L2 nine times (once per tap) and the BatchNorm / PReLU prologue
+// is re-applied each time; at 128x128 tiles that gather alone saturates the per-CU vector-memory path.  Here a
+// workgroup owns ROWS output rows of ONE image: it loads the (ROWS+2) x (W+2) x CIN input strip once, applies the
+// prologue once, and keeps it in LDS (up to 153 KB of the 160 KB) as a [pixel][channel] image whose pixel stride is
+// padded by 16 B.  The nine taps are then nine shifted views of the same LDS image: an A fragment is ONE
+// ds_read_b128 at (row base register + compile-time tap offset) -- no per-tap address arithmetic at all -- and the
+// odd 16-B-slot stride makes 16 consecutive pixels hit 16 different bank groups.  The main loop has NO barrier.  Weights never
+// touch LDS: every wave owns a private slice of output channels and streams its B fragments straight from
+// L2 into registers (16 B per lane, 3-deep register ring), so all 256 workgroups read the same 0.1-2.4 MB of
+// weights out of their XCD's L2.
+//
+// Epilogue: accumulators (+ fused PReLU-backward / BN-backward sums / BN statistics, same contracts as
+// fr_conv_igemm) are written as bf16 into an LDS tile [rows][COUT] (aliasing the dead input strip) and leave
+// as row-contiguous 16-B stores.
+//
+// Same reference arithmetic as fr_conv_igemm: Conv2d 3x3 s1 of bottleneck_IR (backbone/model_irse.py:57-59)
+// with BN apply (:57) or PReLU (:58) on the input, and its autograd data gradient (flip = 1: taps mirrored,
+// weights given as [Cin][tap][Cout]).
+#include "common.h"
+#include "frhip_internal.h"
+
+namespace {
+
+constexpr int NTH = 512;
+
+template <int CIN, int COUT, int W, int ROWS, int WN>
+struct SC {
+  static constexpr int H = W;
+  static constexpr int GW = W + 2;
+  static constexpr int GH = ROWS + 2;
+  static constexpr int CH = CIN / 8;                       // 16-B chunks per pixel
+  static constexpr int PSTR = CIN * 2 + 16;                // padded pixel stride: odd number of 16-B slots
+  static constexpr int IMG_BYTES = GH * GW * PSTR;
+  static constexpr int M = ROWS * W;
+  static constexpr int MT = (M + 15) / 16;
+  static constexpr int WM = 8 / WN;
+  static constexpr int TN = COUT / 16 / WN;
+  static constexpr int TM = (MT + WM - 1) / WM;
+  static constexpr int OSTR = COUT * 2 + 16;               // out-tile row stride, bytes
+  static constexpr int OUT_BYTES = (M * OSTR + 15) / 16 * 16;
+  static constexpr int RED_BYTES = WM * 2 * COUT * 4;
+  static constexpr int LDS = IMG_BYTES > OUT_BYTES + RED_BYTES ? IMG_BYTES : OUT_BYTES + RED_BYTES;
+  static constexpr int NS = H / ROWS;                      // strips per image
+  static_assert(H % ROWS == 0, "strip rows must divide the image");
+  static_assert(NTH % CH == 0, "threads must be a multiple of the chunks per pixel");
+  static_assert(COUT % (16 * WN) == 0 && 8 % WN == 0, "bad wave split");
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+template <int CIN, int COUT, int W, int ROWS, int WN, int PRO>
+__global__ __launch_bounds__(NTH) void conv3x3_strip_kernel(const FrConvArgs p) {
+  using C = SC<CIN, COUT, W, ROWS, WN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+  const int b = blockIdx.x / C::NS, strip = blockIdx.x - b * C::NS;
+  const int row0 = strip * ROWS;
+  const bf16_t* __restrict__ src = reinterpret_cast<const bf16_t*>(p.src);
+  const bf16_t* __restrict__ wgt = reinterpret_cast<const bf16_t*>(p.w);
+
+  // ------------------------------------------------------------------ strip -> LDS (prologue applied once)
+  {
+    constexpr int WP = W + 2;
+    constexpr int TOTAL = C::GH * WP * C::CH;
+    constexpr int UNR = 8;
+    const int ch = tid % C::CH;  // NTH is a multiple of CH: a thread always handles the same channel chunk
+    float pa[8], pb[8];
+    if (PRO != FR_PRO_NONE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pa[j] = p.pro_a[ch * 8 + j];
+        pb[j] = PRO == FR_PRO_BN ? p.pro_b[ch * 8 + j] : 0.f;
+      }
+    }
+    for (int base = 0; base < TOTAL; base += NTH * UNR) {
+      U128 v[UNR];
+      bool ok[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int idx = base + u * NTH + tid;
+        const int pc = idx / C::CH;
+        const int gh = pc / WP, gw = pc - gh * WP;
+        const int h = row0 + gh - 1, w = gw - 1;
+        ok[u] = idx < TOTAL && (unsigned)h < (unsigned)C::H && (unsigned)w < (unsigned)W;
+        v[u] = ok[u] ? ld16(src + ((size_t)(b * C::H + h) * W + w) * (size_t)p.lda + ch * 8) : zero16();
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int idx = base + u * NTH + tid;
+        if (idx < TOTAL) {
+          const int pc = idx / C::CH;
+          const int gh = pc / WP, gw = pc - gh * WP;
+          U128 x = v[u];
+          if (PRO != FR_PRO_NONE && ok[u]) {
+            float f[8];
+            unpack16<bf16_t>(x, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if (PRO == FR_PRO_BN) f[j] = fmaf(f[j], pa[j], pb[j]);
+              else f[j] = f[j] > 0.f ? f[j] : f[j] * pa[j];
+            }
+            x = pack16<bf16_t>(f);
+          }
+          st16(smem + (gh * C::GW + gw) * C::PSTR + ch * 16, x);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ main loop: 9 taps x CIN/32, no barriers
+  const int fr = lane & 15, fq = lane >> 4;
+  int abase[C::TM];  // LDS byte address of this lane's fragment for tap (0,0), channel chunk c0 = 0
+#pragma unroll
+  for (int i = 0; i < C::TM; ++i) {
+    int m = (wm * C::TM + i) * 16 + fr;
+    m = m < C::M ? m : 0;
+    const int h = m / W, w = m - h * W;
+    abase[i] = (h * C::GW + w) * C::PSTR + fq * 16;
+  }
+  const int n0 = wn * C::TN * 16;
+  const bf16_t* wrow[C::TN];
+#pragma unroll
+  for (int j = 0; j < C::TN; ++j) wrow[j] = wgt + (size_t)(n0 + j * 16 + fr) * 9 * CIN + fq * 8;
+
+  f32x4 acc[C::TM][C::TN];
+#pragma unroll
+  for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  s16x8 bq[3][C::TN];
+  const int flip = p.mode;
+#define LOAD_B(slot, c0_, tap_)                                                         \
+  {                                                                                     \
+    const int wt_ = flip ? 8 - (tap_) : (tap_);                                         \
+    _Pragma("unroll") for (int j = 0; j < C::TN; ++j)                                   \
+        bq[slot][j] = *reinterpret_cast<const s16x8*>(wrow[j] + wt_ * CIN + (c0_));     \
+  }
+  LOAD_B(0, 0, 0);
+  LOAD_B(1, 0, 1);
+  LOAD_B(2, 0, 2);
+  for (int c0 = 0; c0 < CIN; c0 += 32) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int slot = tap % 3;
+      constexpr int dummy_ = 0;
+      const int toff = ((tap / 3) * C::GW + (tap % 3)) * C::PSTR + dummy_;  // compile-time: ds_read offset field
+#pragma unroll
+      for (int i = 0; i < C::TM; ++i) {
+        if (wm * C::TM + i < C::MT) {  // wave-uniform
+          const s16x8 a = *reinterpret_cast<const s16x8*>(smem + abase[i] + toff);
+#pragma unroll
+          for (int j = 0; j < C::TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[slot][j], acc[i][j], 0, 0, 0);
+        }
+      }
+      int nt = tap + 3, nc = c0;
+      if (nt >= 9) {
+        nt -= 9;
+        nc += 32;
+      }
+      if (nc < CIN) LOAD_B(slot, nc, nt);
+    }
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i) abase[i] += 64;  // next 32 input channels
+  }
+#undef LOAD_B
+
+  // ------------------------------------------------------------------ epilogue
+  __syncthreads();  // every wave is done with the input strip; LDS is now the output tile
+  const int epi = p.epi;
+  const size_t rowbase = (size_t)(b * C::H + row0) * W;
+  constexpr int OCH = COUT / 8;
+  if (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD) {
+    const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
+    for (int idx = tid; idx < C::M * OCH; idx += NTH) {
+      const int r = idx / OCH, ch = idx - r * OCH;
+      st16(smem + r * C::OSTR + ch * 16, ld16(aux + (rowbase + r) * (size_t)p.ldaux + ch * 8));
+    }
+    __syncthreads();
+  }
+  float s0[C::TN], s1[C::TN], ea[C::TN], eb[C::TN];
+#pragma unroll
+  for (int j = 0; j < C::TN; ++j) {
+    s0[j] = s1[j] = 0.f;
+    const int n = n0 + j * 16 + fr;
+    ea[j] = (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD) ? p.epi_a[n] : 0.f;
+    eb[j] = (epi == FR_EPI_BNBWD) ? p.epi_b[n] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < C::TM; ++i) {
+    if (wm * C::TM + i >= C::MT) continue;
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) {
+      const int n = n0 + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = (wm * C::TM + i) * 16 + fq * 4 + r;
+        if (m >= C::M) continue;
+        bf16_t* cell = reinterpret_cast<bf16_t*>(smem + m * C::OSTR + n * 2);
+        float v = acc[i][j][r];
+        if (epi == FR_EPI_STATS) {
+          s0[j] += v;
+          s1[j] = fmaf(v, v, s1[j]);
+        } else if (epi == FR_EPI_PRELU_BWD) {
+          const float y = bf2f(*cell);
+          const bool pos = y > 0.f;
+          s0[j] += pos ? 0.f : v * y;
+          v = pos ? v : v * ea[j];
+        } else if (epi == FR_EPI_BNBWD) {
+          const float x = bf2f(*cell);
+          s0[j] += v;
+          s1[j] = fmaf(v, (x - ea[j]) * eb[j], s1[j]);
+        }
+        *cell = f2bf(v);
+      }
+    }
+  }
+  const bool stats = epi == FR_EPI_STATS || epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD;
+  float* red = reinterpret_cast<float*>(smem + C::OUT_BYTES);  // [WM][2][COUT]
+  if (stats) {
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) {
+      float a = s0[j], c = s1[j];
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      c += __shfl_xor(c, 16, 64);
+      c += __shfl_xor(c, 32, 64);
+      if (fq == 0) {
+        red[(wm * 2 + 0) * COUT + n0 + j * 16 + fr] = a;
+        red[(wm * 2 + 1) * COUT + n0 + j * 16 + fr] = c;
+      }
+    }
+  }
+  __syncthreads();
+  if (stats) {
+    for (int c = tid; c < 2 * COUT; c += NTH) {
+      const int k = c / COUT, n = c - k * COUT;
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < C::WM; ++g) s += red[(g * 2 + k) * COUT + n];
+      p.part[((size_t)blockIdx.x * 2 + k) * COUT + n] = s;
+    }
+  }
+  bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
+  for (int idx = tid; idx < C::M * OCH; idx += NTH) {
+    const int r = idx / OCH, ch = idx - r * OCH;
+    st16(out + (rowbase + r) * (size_t)p.ldc + ch * 8, ld16(smem + r * C::OSTR + ch * 16));
+  }
+}
+
+template <int CIN, int COUT, int W, int ROWS, int WN, int PRO>
+int launch(const FrConvArgs& a, hipStream_t st) {
+  using C = SC<CIN, COUT, W, ROWS, WN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, PRO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, PRO>), dim3(a.B * C::NS), dim3(NTH), C::LDS, st,
+                     a);
+  FR_LAUNCH_CHECK();
+}
+
+template <int CIN, int COUT, int W, int ROWS, int WN>
+int by_pro(const FrConvArgs& a, hipStream_t st) {
+  switch (a.pro) {
+    case FR_PRO_NONE: return launch<CIN, COUT, W, ROWS, WN, FR_PRO_NONE>(a, st);
+    case FR_PRO_BN: return launch<CIN, COUT, W, ROWS, WN, FR_PRO_BN>(a, st);
+    case FR_PRO_PRELU: return launch<CIN, COUT, W, ROWS, WN, FR_PRO_PRELU>(a, st);
+  }
+  return -1;
+}
+
+}  // namespace
+
+// Number of partial rows the kernel writes into `part` (= workgroups) for a supported shape, 0 if unsupported.
+extern "C" int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W) {
+#define SHAPE(ci, co, w, rows) \
+  if (Cin == ci && Cout == co && W == w) return B * (w / rows);
+  SHAPE(64, 64, 112, 4)
+  SHAPE(64, 64, 56, 7)
+  SHAPE(64, 128, 56, 7)
+  SHAPE(128, 64, 56, 7)
+  SHAPE(128, 128, 28, 14)
+  SHAPE(128, 256, 28, 7)
+  SHAPE(256, 128, 28, 7)
+  SHAPE(256, 256, 14, 14)
+  SHAPE(256, 512, 14, 7)
+  SHAPE(512, 256, 14, 7)
+  SHAPE(512, 512, 7, 7)
+#undef SHAPE
+  return 0;
+}
+
+extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
+  const FrConvArgs& a = *args;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.RH != a.SH || a.RW != a.SW || a.SH != a.SW ||
+      a.out_f32 || a.splitk > 1 || a.bias || a.epi == FR_EPI_MARGIN || a.epi == FR_EPI_ATOMIC)
+    FR_UNSUPPORTED("fr_conv3x3_strip: only square stride-1 3x3 bf16 convolutions");
+  if (a.lda % 8 || a.ldc % 8 || (a.aux && a.ldaux % 8)) FR_UNSUPPORTED("fr_conv3x3_strip: strides must be 16-byte multiples");
+#define SHAPE(ci, co, w, rows, wn) \
+  if (a.SC == ci && a.N == co && a.SW == w) return by_pro<ci, co, w, rows, wn>(a, st);
+  SHAPE(64, 64, 112, 4, 2)
+  SHAPE(64, 64, 56, 7, 2)
+  SHAPE(64, 128, 56, 7, 4)
+  SHAPE(128, 64, 56, 7, 2)
+  SHAPE(128, 128, 28, 14, 4)
+  SHAPE(128, 256, 28, 7, 8)
+  SHAPE(256, 128, 28, 7, 4)
+  SHAPE(256, 256, 14, 14, 8)
+  SHAPE(256, 512, 14, 7, 8)
+  SHAPE(512, 256, 14, 7, 8)
+  SHAPE(512, 512, 7, 7, 8)
+#undef SHAPE
+  FR_UNSUPPORTED("fr_conv3x3_strip: shape not in the strip table");
+}

@@ -1,0 +1,271 @@
+// frhip -- weight gradient of the stride-1 3x3 convolutions with both operand strips resident in LDS (bf16).
+//
+//   dw[co][tap][ci] = sum_{pixels p}  g[p][co] * pro(x[p + tap][ci])
+//
+// A workgroup owns one 64(co) x 64(ci) x 9(taps) block of dW and a *group* of image strips.  Per strip it loads
+// g[rows][64 co] and the haloed input x[(rows+2) x (W+2)][64 ci] into LDS once (prologue applied once), then runs
+// K = pixels through MFMA with all nine taps served from the same LDS image: the tap only shifts the row address of
+// the transposing LDS read (ds_read_b64_tr_b16), a compile-time offset.  Each g fragment is reused for 9 taps, so the
+// kernel needs ~1.2 LDS reads per MFMA and no barrier inside a strip.  Accumulators (2 x 9 tiles per wave) stay in
+// registers across all strips of the group; the group's partial dW goes to a slab and a second kernel adds the slabs
+// (deterministic, no float atomics).  Workgroups of one group sit on one XCD (block-id remap), so the strips they
+// share are fetched from HBM once and re-read from that XCD's L2.
+//
+// Reference arithmetic: autograd weight gradient of Conv2d(c, d, (3,3), (1,1), 1) in bottleneck_IR
+// (backbone/model_irse.py:57-59) with BN apply (:57) / PReLU (:58) folded into the input load.
+#include "common.h"
+#include "frhip_internal.h"
+
+namespace {
+
+constexpr int NTH = 512;
+constexpr int CT = 64;               // co and ci tile
+constexpr int TSTR = CT * 2 + 32;    // LDS row stride (bytes) of both tiles: conflict-free transposed reads
+
+template <int W, int ROWS, int NIMG>
+struct WC {
+  static constexpr int H = W;
+  static constexpr int GW = W + 2, GH = ROWS + 2;
+  static constexpr int MI = ROWS * W;                 // output pixels per image strip
+  static constexpr int M = MI * NIMG;                 // pixels per fill
+  static constexpr int NKS = (M + 31) / 32;
+  static constexpr int PXP = NKS * 32;
+  static constexpr int G_BYTES = PXP * TSTR;
+  static constexpr int APIX = NIMG * GH * GW;
+  static constexpr int A_BYTES = APIX * TSTR;
+  static constexpr int LDS = G_BYTES + A_BYTES;
+  static constexpr int NS = H / ROWS;                 // strips per image
+  static constexpr int GCH = M * 8, ACH = APIX * 8;   // 16-B chunks per fill
+  static constexpr int NLD = (GCH + ACH + NTH - 1) / NTH;
+  static_assert(H % ROWS == 0, "strip rows must divide the image");
+  static_assert(NIMG == 1 || ROWS == H, "several images per fill only for whole-image strips");
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
+
+__device__ __forceinline__ s16x8 tr_frag(const char* p0, const char* p1) {
+  const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)p0);
+  const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)p1);
+  const s16x4 ai = __builtin_bit_cast(s16x4, a), bi = __builtin_bit_cast(s16x4, b);
+  return (s16x8){ai[0], ai[1], ai[2], ai[3], bi[0], bi[1], bi[2], bi[3]};
+}
+
+template <int W, int ROWS, int NIMG, int PRO>
+__global__ __launch_bounds__(NTH) void conv_wgrad_strip_kernel(const FrWgradArgs p) {
+  using C = WC<W, ROWS, NIMG>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Gs = smem;
+  char* As = smem + C::G_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wci = wave & 3, wco = wave >> 2;
+
+  // block -> (group, tile): consecutive logical ids (= all tiles of a group) share an XCD
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int cit_n = p.SC / CT, tiles = (p.Cout / CT) * cit_n;
+  const int group = bid / tiles, tile = bid - group * tiles;
+  const int cot = tile / cit_n, cit = tile - cot * cit_n;
+  const int total_fills = (p.B * C::NS + NIMG - 1) / NIMG;
+  const int per = (total_fills + p.nsplit - 1) / p.nsplit;
+  const int f_begin = group * per;
+  int f_end = f_begin + per;
+  if (f_end > total_fills) f_end = total_fills;
+
+  const bf16_t* __restrict__ G = reinterpret_cast<const bf16_t*>(p.g);
+  const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(p.src);
+
+  // zero the padded pixel rows of the g tile once (rows >= M never get written again)
+  for (int idx = tid; idx < (C::PXP - C::M) * 8; idx += NTH)
+    st16(Gs + (C::M + idx / 8) * TSTR + (idx & 7) * 16, zero16());
+
+  const int ch = tid & 7;  // NTH % 8 == 0: a thread always handles the same 8-channel chunk
+  float pa[8], pb[8];
+  if (PRO != FR_PRO_NONE) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pa[j] = p.pro_a[cit * CT + ch * 8 + j];
+      pb[j] = PRO == FR_PRO_BN ? p.pro_b[cit * CT + ch * 8 + j] : 0.f;
+    }
+  }
+
+  U128 ld[C::NLD];
+  bool okv[C::NLD];
+  auto issue = [&](int f) {
+    // fill f covers images [img0, img0+NIMG) (whole images) or one strip of one image
+    const int img0 = NIMG > 1 ? f * NIMG : f / C::NS;
+    const int row0 = NIMG > 1 ? 0 : (f - img0 * C::NS) * ROWS;
+#pragma unroll
+    for (int u = 0; u < C::NLD; ++u) {
+      const int idx = u * NTH + tid;
+      const int c = idx >> 3;
+      bool ok = false;
+      const bf16_t* src = G;
+      if (idx < C::GCH) {  // g tile row c
+        const int im = c / C::MI, r = c - im * C::MI;
+        const int b = img0 + im;
+        ok = b < p.B;
+        src = G + ((size_t)(b * C::H + row0) * W + r) * (size_t)p.ldg + cot * CT + ch * 8;
+      } else if (idx < C::GCH + C::ACH) {
+        const int a = c - C::M;
+        const int im = a / (C::GH * C::GW), r = a - im * (C::GH * C::GW);
+        const int gh = r / C::GW, gw = r - gh * C::GW;
+        const int b = img0 + im, h = row0 + gh - 1, w = gw - 1;
+        ok = b < p.B && (unsigned)h < (unsigned)C::H && (unsigned)w < (unsigned)W;
+        src = X + ((size_t)(b * C::H + h) * W + w) * (size_t)p.lda + cit * CT + ch * 8;
+      }
+      okv[u] = ok;
+      ld[u] = ok ? ld16(src) : zero16();
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < C::NLD; ++u) {
+      const int idx = u * NTH + tid;
+      const int c = idx >> 3;
+      if (idx < C::GCH) {
+        st16(Gs + c * TSTR + ch * 16, ld[u]);
+      } else if (idx < C::GCH + C::ACH) {
+        U128 x = ld[u];
+        if (PRO != FR_PRO_NONE && okv[u]) {
+          float f[8];
+          unpack16<bf16_t>(x, f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (PRO == FR_PRO_BN) f[j] = fmaf(f[j], pa[j], pb[j]);
+            else f[j] = f[j] > 0.f ? f[j] : f[j] * pa[j];
+          }
+          x = pack16<bf16_t>(f);
+        }
+        st16(As + (c - C::M) * TSTR + ch * 16, x);
+      }
+    }
+  };
+
+  f32x4 acc[2][9];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[t][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int li = lane & 15, lq = lane >> 4;
+  const int colb = (4 * (li & 3)) * 2;  // byte offset of this lane's 4-channel group inside a 16-channel tile
+  if (f_begin < f_end) issue(f_begin);
+  for (int f = f_begin; f < f_end; ++f) {
+    __syncthreads();  // previous strip fully consumed
+    commit();
+    __syncthreads();
+    if (f + 1 < f_end) issue(f + 1);  // next strip's loads fly under this strip's MFMAs
+#pragma unroll 1
+    for (int ks = 0; ks < C::NKS; ++ks) {
+      const int m0 = ks * 32 + 4 * lq + (li >> 2), m1 = m0 + 16;
+      const char* g0 = Gs + m0 * TSTR + (wco * 32) * 2 + colb;
+      const char* g1 = Gs + m1 * TSTR + (wco * 32) * 2 + colb;
+      const s16x8 gf0 = tr_frag(g0, g1);
+      const s16x8 gf1 = tr_frag(g0 + 32, g1 + 32);
+      const char* a01[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        int m = e ? m1 : m0;
+        m = m < C::M ? m : C::M - 1;
+        const int im = m / C::MI, r = m - im * C::MI;
+        const int h = r / W, w = r - h * W;
+        a01[e] = As + ((im * C::GH + h) * C::GW + w) * TSTR + (wci * 16) * 2 + colb;
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int off = ((tap / 3) * C::GW + (tap % 3)) * TSTR;
+        const s16x8 af = tr_frag(a01[0] + off, a01[1] + off);
+        acc[0][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf0, af, acc[0][tap], 0, 0, 0);
+        acc[1][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf1, af, acc[1][tap], 0, 0, 0);
+      }
+    }
+  }
+
+  // slab[group][co][tap][ci]
+  float* __restrict__ slab = p.slab + (size_t)group * (size_t)p.Cout * 9 * (size_t)p.SC;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cot * CT + wco * 32 + t * 16 + lq * 4 + r;
+        const int ci = cit * CT + wci * 16 + li;
+        slab[((size_t)co * 9 + tap) * (size_t)p.SC + ci] = acc[t][tap][r];
+      }
+}
+
+__global__ void reduce_slabs_kernel(const float* __restrict__ slab, int groups, long long n4, float* __restrict__ out) {
+  // n4 = elements / 4
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 s = reinterpret_cast<const f32x4*>(slab)[i];
+    for (int g = 1; g < groups; ++g) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(slab)[(long long)g * n4 + i];
+      s += v;
+    }
+    reinterpret_cast<f32x4*>(out)[i] = s;
+  }
+}
+
+template <int W, int ROWS, int NIMG, int PRO>
+int launch(const FrWgradArgs& a, hipStream_t st) {
+  using C = WC<W, ROWS, NIMG>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<W, ROWS, NIMG, PRO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    attr_done = true;
+  }
+  const int tiles = (a.Cout / CT) * (a.SC / CT);
+  hipLaunchKernelGGL((conv_wgrad_strip_kernel<W, ROWS, NIMG, PRO>), dim3(tiles * a.nsplit), dim3(NTH), C::LDS, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fr_set_error(hipGetErrorString(e));
+    return (int)e;
+  }
+  const long long n4 = (long long)a.Cout * 9 * a.SC / 4;
+  long long g = (n4 + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)g), dim3(256), 0, st, a.slab, a.nsplit, n4, a.dw);
+  FR_LAUNCH_CHECK();
+}
+
+template <int W, int ROWS, int NIMG>
+int by_pro(const FrWgradArgs& a, hipStream_t st) {
+  switch (a.pro) {
+    case FR_PRO_NONE: return launch<W, ROWS, NIMG, FR_PRO_NONE>(a, st);
+    case FR_PRO_BN: return launch<W, ROWS, NIMG, FR_PRO_BN>(a, st);
+    case FR_PRO_PRELU: return launch<W, ROWS, NIMG, FR_PRO_PRELU>(a, st);
+  }
+  return -1;
+}
+
+}  // namespace
+
+// 1 when (W) is in the strip table and the channel counts are multiples of 64
+extern "C" int fr_conv_wgrad_strip_supported(int Cout, int Cin, int W) {
+  if (Cout % CT || Cin % CT) return 0;
+  return W == 112 || W == 56 || W == 28 || W == 14 || W == 7;
+}
+
+extern "C" int fr_conv_wgrad_strip(const FrWgradArgs* args, void* stream) {
+  const FrWgradArgs& a = *args;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.GH != a.SH || a.GW != a.SW || a.SH != a.SW ||
+      !fr_conv_wgrad_strip_supported(a.Cout, a.SC, a.SW))
+    FR_UNSUPPORTED("fr_conv_wgrad_strip: only square stride-1 3x3 bf16 convolutions with 64-multiple channels");
+  if (a.ldg % 8 || a.lda % 8 || !a.slab || a.nsplit < 1) FR_UNSUPPORTED("fr_conv_wgrad_strip: bad strides / slab");
+  switch (a.SW) {
+    case 112: return by_pro<112, 2, 1>(a, st);
+    case 56: return by_pro<56, 4, 1>(a, st);
+    case 28: return by_pro<28, 7, 1>(a, st);
+    case 14: return by_pro<14, 14, 1>(a, st);
+    case 7: return by_pro<7, 7, 4>(a, st);
+  }
+  FR_UNSUPPORTED("fr_conv_wgrad_strip: width not in the strip table");
+}

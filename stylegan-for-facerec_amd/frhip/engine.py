@@ -170,7 +170,8 @@ class BackbonePlan(object):
         self.stream_id = torch.cuda.current_stream().cuda_stream
         self.S = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
         self.generation = 0
-        self.seed_launches = []
+        self.use_strip = os.environ.get("FRHIP_NO_STRIP", "0") != "1"
+        self.slab, self._slab_users = None, []
         self._normalize_params()
         self._alloc()
         self._bind_params()
@@ -245,7 +246,8 @@ class BackbonePlan(object):
         self.g_xS = self._act(max_xs, 1).view(-1) if max_xs else None
         self.g_f32 = torch.empty(B, 512, device=dev)     # BN1d backward output (fp32)
         self.g_fT = self._act(B, 512)
-        self.part = torch.zeros(max(4 * 1024 * 1024, ((M0 + 127) // 128) * 2 * 64 + 4096), device=dev)
+        self.part = torch.zeros(max(4 * 1024 * 1024, ((M0 + 127) // 128) * 2 * 64 + 4096, B * 28 * 2 * 64 + 4096),
+                                device=dev)
         self.se_scratch = torch.zeros(2, 512 * 64, device=dev)  # dW1/dW2 sink while the SE weights are frozen
         self.zeros_c = torch.zeros(512, device=dev)
         self.sums = torch.zeros(3, 512, device=dev)      # scratch reduce target for frozen parameters
@@ -302,6 +304,38 @@ class BackbonePlan(object):
     def _conv_master(self, conv):
         return conv.weight
 
+    # ---- conv dispatch ----------------------------------------------------------------------------
+    def _conv(self, L, **kw):
+        """Append a convolution launch; returns the number of partial rows its epilogue writes.  bf16 stride-1
+        3x3 layers whose shape is in the strip table run with the input strip resident in LDS."""
+        if (self.fr == FR_BF16 and self.use_strip and kw["KH"] == 3 and kw["stride"] == 1 and kw["RH"] == kw["SH"]):
+            n = ops.strip_parts(kw["B"], kw["SC"], kw["N"], kw["SW"])
+            if n:
+                L.append(ops.conv_strip(self.stream, **kw))
+                return n
+        L.append(ops.conv(self.stream, self.fr, **kw))
+        return (kw["B"] * kw["RH"] * kw["RW"] + 127) // 128
+
+    def _wgrad(self, L, **kw):
+        """Append a weight-gradient launch: LDS-strip kernel for bf16 stride-1 3x3 layers, generic otherwise."""
+        if (self.fr == FR_BF16 and self.use_strip and kw["KH"] == 3 and kw["stride"] == 1 and
+                ops.wgrad_strip_supported(kw["Cout"], kw["SC"], kw["SW"])):
+            tiles = (kw["Cout"] // 64) * (kw["SC"] // 64)
+            rows = {112: 2, 56: 4, 28: 7, 14: 14, 7: 7}[kw["SW"]]
+            fills = kw["B"] * (kw["SW"] // rows) // (4 if kw["SW"] == 7 else 1)
+            groups = int(max(1, min(fills, 256 // tiles if tiles <= 256 else 1)))
+            need = groups * kw["Cout"] * 9 * kw["SC"]
+            if self.slab is None or self.slab.numel() < need:
+                self.slab = torch.empty(need, device=self.device)
+                for l in self._slab_users:  # re-point earlier launches at the grown buffer
+                    l.keep[0].slab = ops.ptr(self.slab)
+            kw = dict(kw, nsplit=groups, slab=self.slab)
+            l = ops.wgrad_strip(self.stream, **kw)
+            self._slab_users.append(l)
+            L.append(l)
+            return
+        L.append(ops.wgrad(self.stream, self.fr, **kw))
+
     # ---- forward -----------------------------------------------------------------------------------
     def _bn_train_launches(self, L, bn, part, nparts, count):
         m = bn.mod
@@ -352,14 +386,14 @@ class BackbonePlan(object):
                 P.append(ops.call("fr_pack_weight", w2, None, d["wt2"], u.depth, 9, u.depth, fr, st))
                 wp1, wp2 = w1, w2
             bn1, bn2 = d["bn1"], d["bn2"]
-            L.append(ops.conv(st, fr, src=x, w=wp1, out=d["y1"], B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H, SC=u.cin,
-                              N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.cin, ldc=u.depth,
-                              pro=ops.PRO_BN, pro_a=bn1.scale, pro_b=bn1.shift, epi=ops.EPI_STORE))
-            L.append(ops.conv(st, fr, src=d["y1"], w=wp2, out=d["y2"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H,
-                              SC=u.depth, N=u.depth, KH=3, KW=3, stride=u.stride, pad=1, mode=0, lda=u.depth,
-                              ldc=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight, epi=ops.EPI_STATS,
-                              part=self.part))
-            self._bn_train_launches(L, bn2, self.part, (rout + 127) // 128, rout)
+            self._conv(L, src=x, w=wp1, out=d["y1"], B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H, SC=u.cin,
+                       N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.cin, ldc=u.depth,
+                       pro=ops.PRO_BN, pro_a=bn1.scale, pro_b=bn1.shift, epi=ops.EPI_STORE)
+            np2 = self._conv(L, src=d["y1"], w=wp2, out=d["y2"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H,
+                             SC=u.depth, N=u.depth, KH=3, KW=3, stride=u.stride, pad=1, mode=0, lda=u.depth,
+                             ldc=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight, epi=ops.EPI_STATS,
+                             part=self.part)
+            self._bn_train_launches(L, bn2, self.part, np2, rout)
             if u.sc_conv is not None:
                 ws = self._conv_master(u.sc_conv)
                 if fr == FR_BF16:
@@ -543,33 +577,32 @@ class BackbonePlan(object):
                 ready += [u.sc_bn.weight, u.sc_bn.bias, u.sc_conv.weight]
             # conv2: data gradient with the PReLU backward epilogue, then the weight gradient
             g_y1 = self.g_y1[:rin * u.depth]
-            mt = (rin + 127) // 128
-            L.append(ops.conv(st, fr, src=g_y2, w=d["wt2"], out=g_y1, B=B, RH=u.H, RW=u.H, SH=u.Ho, SW=u.Ho,
-                              SC=u.depth, N=u.depth, KH=3, KW=3, stride=u.stride, pad=1, mode=1, lda=u.depth,
-                              ldc=u.depth, ldaux=u.depth, pro=0, epi=ops.EPI_PRELU_BWD, aux=d["y1"],
-                              epi_a=u.prelu.weight, part=self.part))
+            mt = self._conv(L, src=g_y2, w=d["wt2"], out=g_y1, B=B, RH=u.H, RW=u.H, SH=u.Ho, SW=u.Ho,
+                            SC=u.depth, N=u.depth, KH=3, KW=3, stride=u.stride, pad=1, mode=1, lda=u.depth,
+                            ldc=u.depth, ldaux=u.depth, pro=0, epi=ops.EPI_PRELU_BWD, aux=d["y1"],
+                            epi_a=u.prelu.weight, part=self.part)
             gsl = self.grad_of(u.prelu.weight)
             self._reduce(L, mt, 2, u.depth, gsl if gsl is not None else self.sums[2, :u.depth], None)
             gw2 = self.grad_of(u.conv2.weight)
             if gw2 is not None:
                 tiles = ((u.depth + 127) // 128) ** 2 * 9
-                L.append(ops.wgrad(st, fr, g=g_y2, src=d["y1"], dw=gw2, B=B, GH=u.Ho, GW=u.Ho, Cout=u.depth, SH=u.H,
-                                   SW=u.H, SC=u.depth, KH=3, KW=3, stride=u.stride, pad=1, ldg=u.depth, lda=u.depth,
-                                   pro=ops.PRO_PRELU, pro_a=u.prelu.weight, nsplit=_wgrad_slices(rout, tiles)))
+                self._wgrad(L, g=g_y2, src=d["y1"], dw=gw2, B=B, GH=u.Ho, GW=u.Ho, Cout=u.depth, SH=u.H,
+                            SW=u.H, SC=u.depth, KH=3, KW=3, stride=u.stride, pad=1, ldg=u.depth, lda=u.depth,
+                            pro=ops.PRO_PRELU, pro_a=u.prelu.weight, nsplit=_wgrad_slices(rout, tiles))
             # conv1: data gradient with the BN1-backward sums epilogue, then the weight gradient
             g_xh = self.g_xh[:rin * u.cin]
-            L.append(ops.conv(st, fr, src=g_y1, w=d["wt1"], out=g_xh, B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H,
-                              SC=u.depth, N=u.cin, KH=3, KW=3, stride=1, pad=1, mode=1, lda=u.depth, ldc=u.cin,
-                              ldaux=u.cin, pro=0, epi=ops.EPI_BNBWD, aux=x, epi_a=bn1.mean, epi_b=bn1.invstd,
-                              part=self.part))
+            mt = self._conv(L, src=g_y1, w=d["wt1"], out=g_xh, B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H,
+                            SC=u.depth, N=u.cin, KH=3, KW=3, stride=1, pad=1, mode=1, lda=u.depth, ldc=u.cin,
+                            ldaux=u.cin, pro=0, epi=ops.EPI_BNBWD, aux=x, epi_a=bn1.mean, epi_b=bn1.invstd,
+                            part=self.part)
             db, dg = self._bn_grads(bn1)
             self._reduce(L, mt, 2, u.cin, db, dg)
             gw1 = self.grad_of(u.conv1.weight)
             if gw1 is not None:
                 tiles = ((u.depth + 127) // 128) * ((u.cin + 127) // 128) * 9
-                L.append(ops.wgrad(st, fr, g=g_y1, src=x, dw=gw1, B=B, GH=u.H, GW=u.H, Cout=u.depth, SH=u.H, SW=u.H,
-                                   SC=u.cin, KH=3, KW=3, stride=1, pad=1, ldg=u.depth, lda=u.cin, pro=ops.PRO_BN,
-                                   pro_a=bn1.scale, pro_b=bn1.shift, nsplit=_wgrad_slices(rin, tiles)))
+                self._wgrad(L, g=g_y1, src=x, dw=gw1, B=B, GH=u.H, GW=u.H, Cout=u.depth, SH=u.H, SW=u.H,
+                            SC=u.cin, KH=3, KW=3, stride=1, pad=1, ldg=u.depth, lda=u.cin, pro=ops.PRO_BN,
+                            pro_a=bn1.scale, pro_b=bn1.shift, nsplit=_wgrad_slices(rin, tiles))
             ready += [u.prelu.weight, u.conv2.weight, u.bn1.weight, u.bn1.bias, u.conv1.weight]
             # unit input gradient = BN1 backward of g_xh + shortcut gradient
             nxt = 1 - cur

@@ -72,9 +72,30 @@ def conv(stream, dtype, **kw):
     return Launch("fr_conv_igemm", [ctypes.byref(a), dtype, stream], keep=(a, kw))
 
 
+def conv_strip(stream, **kw):
+    """fr_conv3x3_strip (bf16, stride-1 3x3, input strip resident in LDS).  Same FrConvArgs fields as conv()."""
+    a = _fill(_lib.FrConvArgs(), **kw)
+    return Launch("fr_conv3x3_strip", [ctypes.byref(a), stream], keep=(a, kw))
+
+
+def strip_parts(B, cin, cout, w):
+    """Workgroups (= partial-sum rows) of the strip kernel for a shape; 0 when the shape is not in its table."""
+    return int(lib.fr_conv3x3_strip_parts(int(B), int(cin), int(cout), int(w)))
+
+
 def wgrad(stream, dtype, **kw):
     a = _fill(_lib.FrWgradArgs(), **kw)
     return Launch("fr_conv_wgrad", [ctypes.byref(a), dtype, stream], keep=(a, kw))
+
+
+def wgrad_strip(stream, **kw):
+    """fr_conv_wgrad_strip (bf16 stride-1 3x3; needs kw['slab'] and kw['nsplit'] = strip groups)."""
+    a = _fill(_lib.FrWgradArgs(), **kw)
+    return Launch("fr_conv_wgrad_strip", [ctypes.byref(a), stream], keep=(a, kw))
+
+
+def wgrad_strip_supported(cout, cin, w):
+    return bool(lib.fr_conv_wgrad_strip_supported(int(cout), int(cin), int(w)))
 
 
 def bn_apply(stream, dtype, **kw):

@@ -360,3 +360,142 @@ def test_bn_apply_and_backward(K, name, dtype, tol):
     np.testing.assert_allclose(s0.cpu(), gb, rtol=tol * 5, atol=tol * 20)
     np.testing.assert_allclose(s1.cpu(), gg, rtol=tol * 5, atol=tol * 20)
     assert relerr(from_nhwc(gxd), gx) < tol * 2
+
+
+STRIP_SHAPES = [(64, 64, 112), (64, 64, 56), (64, 128, 56), (128, 64, 56), (128, 128, 28), (128, 256, 28),
+                (256, 128, 28), (256, 256, 14), (256, 512, 14), (512, 256, 14), (512, 512, 7)]
+
+
+@pytest.mark.parametrize("cin,cout,W", STRIP_SHAPES, ids=["%d_%d_%d" % s for s in STRIP_SHAPES])
+def test_conv3x3_strip(K, cin, cout, W):
+    """LDS-resident-strip 3x3 s1 conv (bf16): forward with BN prologue + statistics, and the mirrored-tap data
+    gradient with the PReLU-backward and BN-backward epilogues, every shape of its dispatch table, B = 3."""
+    B, dtype, tol = 3, torch.bfloat16, 4e-2
+    assert K.strip_parts(B, cin, cout, W) > 0
+    st = K.current_stream_ptr()
+    x = q(synth.normal(31, "sx", (B, cin, W, W)), dtype)
+    w = q(synth.normal(31, "sw", (cout, cin, 3, 3), std=0.05), dtype)
+    pa = synth.uniform(31, "spa", (cin,), 0.5, 1.5)
+    pb = synth.uniform(31, "spb", (cin,), -0.5, 0.5)
+    xin = q(x * pa.view(1, -1, 1, 1) + pb.view(1, -1, 1, 1), dtype)
+    ref = F.conv2d(xin, w, padding=1)
+    xd = nhwc(x, dtype)
+    out = torch.zeros(B, W, W, cout, device="cuda", dtype=dtype)
+    nparts = K.strip_parts(B, cin, cout, W)
+    part = torch.zeros(nparts, 2, cout, device="cuda")
+    common = dict(B=B, RH=W, RW=W, SH=W, SW=W, KH=3, KW=3, stride=1, pad=1)
+    K.conv_strip(st, src=xd, w=pack_w(w, dtype), out=out, SC=cin, N=cout, mode=0, lda=cin, ldc=cout, pro=K.PRO_BN,
+                 pro_a=pa.cuda(), pro_b=pb.cuda(), epi=K.EPI_STATS, part=part, **common)()
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(out), ref) < tol
+    s = part.sum(0).cpu()
+    np.testing.assert_allclose(s[0], ref.sum((0, 2, 3)), rtol=5e-2, atol=5e-2 * float(ref.abs().sum() / cout))
+    np.testing.assert_allclose(s[1], (ref * ref).sum((0, 2, 3)), rtol=5e-2)
+    # data gradient: g [B, cout, W, W] -> gx [B, cin, W, W] with weights given as [cin][tap][cout]
+    g = q(synth.normal(31, "sg", (B, cout, W, W)), dtype)
+    xg = synth.normal(31, "sxx", (B, cin, W, W)).requires_grad_(True)
+    (gx,) = torch.autograd.grad(F.conv2d(xg, w, padding=1), [xg], g)
+    wt = w.permute(1, 2, 3, 0).reshape(cin, 9, cout).contiguous().to("cuda", dtype)
+    aux = q(synth.normal(31, "sa", (B, cin, W, W)), dtype)
+    slope = synth.uniform(31, "ss", (cin,), 0.1, 0.4)
+    mean = synth.uniform(31, "sm", (cin,), -0.3, 0.3)
+    invstd = synth.uniform(31, "si", (cin,), 0.5, 2.0)
+    gd, auxd = nhwc(g, dtype), nhwc(aux, dtype)
+    nparts = K.strip_parts(B, cout, cin, W)
+    assert nparts > 0 or (cout, cin, W) not in STRIP_SHAPES
+    if nparts == 0:
+        return
+    for epi in ("prelu", "bnbwd"):
+        o = torch.zeros(B, W, W, cin, device="cuda", dtype=dtype)
+        part = torch.zeros(nparts, 2, cin, device="cuda")
+        kw = dict(src=gd, w=wt, out=o, SC=cout, N=cin, mode=1, lda=cout, ldc=cin, ldaux=cin, pro=0, aux=auxd, part=part,
+                  **common)
+        if epi == "prelu":
+            K.conv_strip(st, epi=K.EPI_PRELU_BWD, epi_a=slope.cuda(), **kw)()
+            torch.cuda.synchronize()
+            want = torch.where(aux > 0, gx, gx * slope.view(1, -1, 1, 1))
+            assert relerr(from_nhwc(o), want) < tol
+            np.testing.assert_allclose(part.sum(0)[0].cpu(), (gx * aux * (aux <= 0)).sum((0, 2, 3)), rtol=5e-2,
+                                       atol=5e-2 * float((gx * aux).abs().sum() / cin))
+        else:
+            K.conv_strip(st, epi=K.EPI_BNBWD, epi_a=mean.cuda(), epi_b=invstd.cuda(), **kw)()
+            torch.cuda.synchronize()
+            xh = (aux - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+            assert relerr(from_nhwc(o), gx) < tol
+            np.testing.assert_allclose(part.sum(0)[0].cpu(), gx.sum((0, 2, 3)), rtol=5e-2,
+                                       atol=5e-2 * float(gx.abs().sum() / cin))
+            np.testing.assert_allclose(part.sum(0)[1].cpu(), (gx * xh).sum((0, 2, 3)), rtol=5e-2,
+                                       atol=5e-2 * float((gx * xh).abs().sum() / cin))
+
+
+def test_bf16_engine_with_and_without_strip_agree():
+    """The LDS-strip convolutions and the generic implicit-GEMM path are two implementations of the same layers: a
+    full bf16 IR-50 step must give (nearly) the same features and gradients through either."""
+    import os
+    from backbone.model_irse import IR_50
+    from head.metrics import ArcFace
+    from loss.focal import FocalLoss
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    res = []
+    for no_strip in ("0", "1"):
+        os.environ["FRHIP_NO_STRIP"] = no_strip
+        m = IR_50([112, 112])
+        synth.fill_state_dict(m.state_dict(), 15)
+        m.output_layer[1].p = 0.0
+        m.compute_dtype = torch.bfloat16
+        m = m.cuda().train()
+        head = ArcFace(512, 100, None).cuda()
+        with torch.no_grad():
+            head.weight.copy_(synth.uniform(16, "full.head", (100, 512), -0.1, 0.1))
+        x = synth.uniform(16, "full.x", (4, 3, 112, 112)).cuda()
+        y = synth.labels(16, "full.label", 4, 100).cuda()
+        feats = m(x)
+        loss, _ = FocalLoss()(head(feats, y), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((feats.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}))
+    os.environ.pop("FRHIP_NO_STRIP")
+    (f0, g0), (f1, g1) = res
+    assert float(torch.nn.functional.cosine_similarity(f0, f1, dim=1).min()) > 0.999
+    for n in ("body.23.res_layer.3.weight", "body.10.res_layer.1.weight", "body.0.res_layer.2.weight",
+              "input_layer.0.weight", "body.7.res_layer.0.weight"):
+        d = float((g0[n] - g1[n]).norm() / (g1[n].norm() + 1e-12))
+        c = float(torch.nn.functional.cosine_similarity(g0[n].reshape(1, -1), g1[n].reshape(1, -1)))
+        assert d < 0.3 and c > 0.95, (n, d, c)  # two bf16 implementations, batch 4: rounding noise only
+
+
+WGS_SHAPES = [(64, 64, 112, "bn"), (64, 64, 56, "prelu"), (128, 64, 56, "bn"), (128, 128, 28, "prelu"),
+              (256, 128, 28, "bn"), (256, 256, 14, "prelu"), (512, 256, 14, "bn"), (512, 512, 7, "prelu"),
+              (128, 128, 28, "none")]
+
+
+@pytest.mark.parametrize("cout,cin,W,pro", WGS_SHAPES, ids=["%d_%d_%d_%s" % s for s in WGS_SHAPES])
+@pytest.mark.parametrize("groups", [1, 3])
+def test_conv_wgrad_strip(K, cout, cin, W, pro, groups):
+    """LDS-strip weight gradient (bf16) vs CPU autograd; B = 5 exercises the ragged last fill of the 7x7 case."""
+    B, dtype, tol = 5 if W <= 14 else 2, torch.bfloat16, 4e-2
+    assert K.wgrad_strip_supported(cout, cin, W)
+    x = q(synth.normal(41, "wsx", (B, cin, W, W)), dtype)
+    pa = synth.uniform(41, "wspa", (cin,), 0.5, 1.5)
+    pb = synth.uniform(41, "wspb", (cin,), -0.5, 0.5)
+    if pro == "bn":
+        xin = x * pa.view(1, -1, 1, 1) + pb.view(1, -1, 1, 1)
+    elif pro == "prelu":
+        xin = F.prelu(x, pa * 0.25)
+    else:
+        xin = x
+    xin = q(xin, dtype)
+    w = synth.normal(41, "wsw", (cout, cin, 3, 3), std=0.1).requires_grad_(True)
+    y = F.conv2d(xin, w, padding=1)
+    g = q(synth.normal(41, "wsg", tuple(y.shape)), dtype)
+    (gw,) = torch.autograd.grad(y, [w], g)
+    dw = torch.full((cout, 9, cin), 7.0, device="cuda")  # must be overwritten, not accumulated
+    slab = torch.zeros(groups * cout * 9 * cin, device="cuda")
+    a_dev = (pa * 0.25 if pro == "prelu" else pa).cuda()
+    K.wgrad_strip(K.current_stream_ptr(), g=nhwc(g, dtype), src=nhwc(x, dtype), dw=dw, slab=slab, B=B, GH=W, GW=W,
+                  Cout=cout, SH=W, SW=W, SC=cin, KH=3, KW=3, stride=1, pad=1, ldg=cout, lda=cin,
+                  pro={"none": 0, "bn": 1, "prelu": 2}[pro], nsplit=groups, pro_a=a_dev, pro_b=pb.cuda())()
+    torch.cuda.synchronize()
+    got = dw.cpu().reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    assert relerr(got, gw) < tol
