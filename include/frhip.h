@@ -78,10 +78,10 @@ int fr_conv_igemm(const FrConvArgs* args, int dtype, void* stream);
 /* Stride-1 3x3 convolution (bf16 only) with the input strip resident in LDS: same FrConvArgs contract as
  * fr_conv_igemm (mode 1 = data gradient: mirrored taps, w = [Cin][tap][Cout]); epilogues STORE / STATS / PRELU_BWD /
  * BNBWD.  Partial rows go to part[workgroup][2][N]; fr_conv3x3_strip_parts returns the number of workgroups for a
- * shape, or 0 when the shape is not in the strip table (use fr_conv_igemm then).
+ * shape and epilogue, or 0 when that combination is not served (use fr_conv_igemm then).
  * Replaces Conv2d(c, d, (3,3), (1,1), 1) of bottleneck_IR (backbone/model_irse.py:57-59) fwd + data gradient. */
 int fr_conv3x3_strip(const FrConvArgs* args, void* stream);
-int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W);
+int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi);
 
 typedef struct FrWgradArgs {
   const void* g;   /* gradient of the conv output: [B*GH*GW][ldg], columns = Cout */

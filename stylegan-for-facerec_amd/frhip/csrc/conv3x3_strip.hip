@@ -33,7 +33,10 @@ struct SC {
   static constexpr int GH = ROWS + 2;
   static constexpr int CH = CIN / 8;                       // 16-B chunks per pixel
   static constexpr int PSTR = CIN * 2 + 16;                // padded pixel stride: odd number of 16-B slots
-  static constexpr int IMG_BYTES = GH * GW * PSTR;
+  // row stride: + 224 B so that the 16-B slot index keeps counting across an image-row wrap (slot(h+1, 0) ==
+  // slot(h, W) mod 16): 16 consecutive output pixels of an M tile then always hit 16 different bank groups
+  static constexpr int RSTR = GW * PSTR + 224;
+  static constexpr int IMG_BYTES = GH * RSTR + 128;         // + slack for the ring's reads past the last chunk
   static constexpr int M = ROWS * W;
   static constexpr int MT = (M + 15) / 16;
   static constexpr int WM = 8 / WN;
@@ -54,7 +57,8 @@ template <int CIN, int COUT, int W, int ROWS, int WN, int PRO>
 __global__ __launch_bounds__(NTH) void conv3x3_strip_kernel(const FrConvArgs p) {
   using C = SC<CIN, COUT, W, ROWS, WN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: keeps the tile loops branch-free
   const int wn = wave % WN, wm = wave / WN;
   const int b = blockIdx.x / C::NS, strip = blockIdx.x - b * C::NS;
   const int row0 = strip * ROWS;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(NTH) void conv3x3_strip_kernel(const FrConvArgs p) 
             }
             x = pack16<bf16_t>(f);
           }
-          st16(smem + (gh * C::GW + gw) * C::PSTR + ch * 16, x);
+          st16(smem + gh * C::RSTR + gw * C::PSTR + ch * 16, x);
         }
       }
     }
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(NTH) void conv3x3_strip_kernel(const FrConvArgs p) 
     int m = (wm * C::TM + i) * 16 + fr;
     m = m < C::M ? m : 0;
     const int h = m / W, w = m - h * W;
-    abase[i] = (h * C::GW + w) * C::PSTR + fq * 16;
+    abase[i] = h * C::RSTR + w * C::PSTR + fq * 16;
   }
   const int n0 = wn * C::TN * 16;
   const bf16_t* wrow[C::TN];
@@ -132,44 +136,59 @@ __global__ __launch_bounds__(NTH) void conv3x3_strip_kernel(const FrConvArgs p) 
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // B fragments: 3-deep register ring: tap t's weights are requested during tap t-3 (address clamped instead of
+  // branching at the end, so the body stays one basic block and hipcc's counted vmcnt waits stay exact).  A fragments: D-deep ring of ds_read_b128, refilled one (tap, tile) step ahead of
+  // use by D steps; sched_group_barrier pins the 1 read : TN MFMA interleave.
   s16x8 bq[3][C::TN];
   const int flip = p.mode;
-#define LOAD_B(slot, c0_, tap_)                                                         \
-  {                                                                                     \
-    const int wt_ = flip ? 8 - (tap_) : (tap_);                                         \
-    _Pragma("unroll") for (int j = 0; j < C::TN; ++j)                                   \
-        bq[slot][j] = *reinterpret_cast<const s16x8*>(wrow[j] + wt_ * CIN + (c0_));     \
-  }
-  LOAD_B(0, 0, 0);
-  LOAD_B(1, 0, 1);
-  LOAD_B(2, 0, 2);
+  auto load_b = [&](int slot, int c0, int tap) {
+    const int wt = flip ? 8 - tap : tap;
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) bq[slot][j] = *reinterpret_cast<const s16x8*>(wrow[j] + wt * CIN + c0);
+  };
+  constexpr int NSTEP = 9 * C::TM;
+  // ring depth must divide NSTEP (slots line up across the channel loop): 9 when registers allow, else 3
+  constexpr int D = (C::TM * C::TN * 4 + 3 * C::TN * 4 > 120) ? 3 : 9;
+  s16x8 ring[D];
+  auto a_addr = [&](int step) -> const s16x8* {  // step in [0, 2*NSTEP): second half = next 32 input channels
+    const int cadd = step >= NSTEP ? 64 : 0;
+    const int st = step >= NSTEP ? step - NSTEP : step;
+    const int tap = st / C::TM, i = st - tap * C::TM;
+    return reinterpret_cast<const s16x8*>(smem + abase[i] + (tap / 3) * C::RSTR + (tap % 3) * C::PSTR + cadd);
+  };
+  load_b(0, 0, 0);
+  load_b(1, 0, 1);
+  load_b(2, 0, 2);
+#pragma unroll
+  for (int d = 0; d < D; ++d) ring[d] = *a_addr(d);
   for (int c0 = 0; c0 < CIN; c0 += 32) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int st = 0; st < NSTEP; ++st) {
+      const int tap = st / C::TM, i = st - tap * C::TM;
       const int slot = tap % 3;
-      constexpr int dummy_ = 0;
-      const int toff = ((tap / 3) * C::GW + (tap % 3)) * C::PSTR + dummy_;  // compile-time: ds_read offset field
+      const s16x8 a = ring[st % D];
 #pragma unroll
-      for (int i = 0; i < C::TM; ++i) {
-        if (wm * C::TM + i < C::MT) {  // wave-uniform
-          const s16x8 a = *reinterpret_cast<const s16x8*>(smem + abase[i] + toff);
-#pragma unroll
-          for (int j = 0; j < C::TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[slot][j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < C::TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[slot][j], acc[i][j], 0, 0, 0);
+      ring[st % D] = *a_addr(st + D);  // past the last channel chunk this reads (never used) bytes inside LDS
+      if (i == C::TM - 1) {
+        int nt = tap + 3, nc = c0;
+        if (nt >= 9) {
+          nt -= 9;
+          nc += 32;
         }
+        nc = nc < CIN ? nc : CIN - 32;  // clamp instead of branching: the count of loads in flight stays static
+        load_b(slot, nc, nt);
       }
-      int nt = tap + 3, nc = c0;
-      if (nt >= 9) {
-        nt -= 9;
-        nc += 32;
-      }
-      if (nc < CIN) LOAD_B(slot, nc, nt);
+      __builtin_amdgcn_sched_group_barrier(0x008, C::TN, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+      // pin the weight requests three taps ahead of their use: without the fence the scheduler sinks the loads
+      // down to their consumer (shorter live ranges) and every tap then waits a full L2 round trip
+      if (i == C::TM - 1) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int i = 0; i < C::TM; ++i) abase[i] += 64;  // next 32 input channels
   }
-#undef LOAD_B
-
   // ------------------------------------------------------------------ epilogue
   __syncthreads();  // every wave is done with the input strip; LDS is now the output tile
   const int epi = p.epi;
@@ -280,7 +299,8 @@ int by_pro(const FrConvArgs& a, hipStream_t st) {
 }  // namespace
 
 // Number of partial rows the kernel writes into `part` (= workgroups) for a supported shape, 0 if unsupported.
-extern "C" int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W) {
+extern "C" int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi) {
+  if (Cin == 256 && Cout == 512 && W == 14 && epi != FR_EPI_STORE) return 0;
 #define SHAPE(ci, co, w, rows) \
   if (Cin == ci && Cout == co && W == w) return B * (w / rows);
   SHAPE(64, 64, 112, 4)
@@ -291,7 +311,7 @@ extern "C" int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W) {
   SHAPE(128, 256, 28, 7)
   SHAPE(256, 128, 28, 7)
   SHAPE(256, 256, 14, 14)
-  SHAPE(256, 512, 14, 7)
+  SHAPE(256, 512, 14, 14)
   SHAPE(512, 256, 14, 7)
   SHAPE(512, 512, 7, 7)
 #undef SHAPE
@@ -315,9 +335,19 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
   SHAPE(128, 256, 28, 7, 8)
   SHAPE(256, 128, 28, 7, 4)
   SHAPE(256, 256, 14, 14, 8)
-  SHAPE(256, 512, 14, 7, 8)
   SHAPE(512, 256, 14, 7, 8)
   SHAPE(512, 512, 7, 7, 8)
 #undef SHAPE
+  if (a.SC == 256 && a.N == 512 && a.SW == 14 && a.epi == FR_EPI_STORE) {
+    // 256 -> 512 @14 (one layer per network): two passes over 256 output channels each keep the accumulators of the
+    // 256x256 instance (no register spills); the strip is simply loaded twice
+    FrConvArgs h = a;
+    h.N = 256;
+    int rc = by_pro<256, 256, 14, 14, 8>(h, st);
+    if (rc) return rc;
+    h.w = reinterpret_cast<const bf16_t*>(a.w) + (size_t)256 * 9 * 256;
+    h.out = reinterpret_cast<bf16_t*>(a.out) + 256;
+    return by_pro<256, 256, 14, 14, 8>(h, st);
+  }
   FR_UNSUPPORTED("fr_conv3x3_strip: shape not in the strip table");
 }

@@ -37,6 +37,7 @@ struct WC {
   static constexpr int NS = H / ROWS;                 // strips per image
   static constexpr int GCH = M * 8, ACH = APIX * 8;   // 16-B chunks per fill
   static constexpr int NLD = (GCH + ACH + NTH - 1) / NTH;
+  static constexpr int KUNR = NLD > 8 ? 1 : NKS;      // the wide strips keep more prefetch registers live
   static_assert(H % ROWS == 0, "strip rows must divide the image");
   static_assert(NIMG == 1 || ROWS == H, "several images per fill only for whole-image strips");
   static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(NTH) void conv_wgrad_strip_kernel(const FrWgradArgs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Gs = smem;
   char* As = smem + C::G_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wci = wave & 3, wco = wave >> 2;
 
   // block -> (group, tile): consecutive logical ids (= all tiles of a group) share an XCD
@@ -160,7 +162,8 @@ __global__ __launch_bounds__(NTH) void conv_wgrad_strip_kernel(const FrWgradArgs
     commit();
     __syncthreads();
     if (f + 1 < f_end) issue(f + 1);  // next strip's loads fly under this strip's MFMAs
-#pragma unroll 1
+    // fully unrolled where registers allow (reads of step k+1 are then scheduled under the MFMAs of step k)
+#pragma unroll C::KUNR
     for (int ks = 0; ks < C::NKS; ++ks) {
       const int m0 = ks * 32 + 4 * lq + (li >> 2), m1 = m0 + 16;
       const char* g0 = Gs + m0 * TSTR + (wco * 32) * 2 + colb;

@@ -309,7 +309,7 @@ class BackbonePlan(object):
         """Append a convolution launch; returns the number of partial rows its epilogue writes.  bf16 stride-1
         3x3 layers whose shape is in the strip table run with the input strip resident in LDS."""
         if (self.fr == FR_BF16 and self.use_strip and kw["KH"] == 3 and kw["stride"] == 1 and kw["RH"] == kw["SH"]):
-            n = ops.strip_parts(kw["B"], kw["SC"], kw["N"], kw["SW"])
+            n = ops.strip_parts(kw["B"], kw["SC"], kw["N"], kw["SW"], kw.get("epi", 0))
             if n:
                 L.append(ops.conv_strip(self.stream, **kw))
                 return n

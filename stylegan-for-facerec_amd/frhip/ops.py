@@ -78,9 +78,9 @@ def conv_strip(stream, **kw):
     return Launch("fr_conv3x3_strip", [ctypes.byref(a), stream], keep=(a, kw))
 
 
-def strip_parts(B, cin, cout, w):
-    """Workgroups (= partial-sum rows) of the strip kernel for a shape; 0 when the shape is not in its table."""
-    return int(lib.fr_conv3x3_strip_parts(int(B), int(cin), int(cout), int(w)))
+def strip_parts(B, cin, cout, w, epi=EPI_STORE):
+    """Workgroups (= partial-sum rows) of the strip kernel for a shape + epilogue; 0 when it is not served."""
+    return int(lib.fr_conv3x3_strip_parts(int(B), int(cin), int(cout), int(w), int(epi)))
 
 
 def wgrad(stream, dtype, **kw):

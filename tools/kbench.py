@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Stand-alone timing of single HIP kernels at training shapes (for A/B tuning and rocprofv3 --pmc runs).
+
+    python tools/kbench.py strip 256 256 14          # conv3x3_strip fwd, B=256
+    python tools/kbench.py wgs 256 256 14            # conv_wgrad_strip
+    python tools/kbench.py igemm 256 256 14 --stride 1
+    python tools/kbench.py all                       # the IR-50 layer table, strip vs igemm
+
+Prints TFLOP/s from HIP events over --iters launches (random bf16 data, never zeros: DVFS).
+"""
+import argparse
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "stylegan-for-facerec_amd"))
+import torch  # noqa: E402
+
+from frhip import ops  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def timeit(launch, iters, flops):
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, flops / ms / 1e9
+
+
+def rnd(*shape):
+    return (torch.rand(*shape, device="cuda") * 2 - 1).to(BF)
+
+
+def conv_case(kind, cin, cout, W, B, stride=1, pro=1, epi=1, mode=0, iters=20):
+    st = ops.current_stream_ptr()
+    Ho = W // stride
+    if mode == 0:
+        src, RH, SH, SC, N = rnd(B, W, W, cin), Ho, W, cin, cout
+        w = rnd(cout, 9, cin) * 0.05
+    else:  # data gradient: src = g [B,Ho,Ho,cout] -> out [B,W,W,cin]
+        src, RH, SH, SC, N = rnd(B, Ho, Ho, cout), W, Ho, cout, cin
+        w = rnd(cin, 9, cout) * 0.05
+    out = torch.empty(B, RH, RH, N, device="cuda", dtype=BF)
+    aux = rnd(B, RH, RH, N)
+    part = torch.zeros(4 * 1024 * 1024, device="cuda")
+    va, vb = torch.rand(512, device="cuda") + 0.5, torch.rand(512, device="cuda") - 0.5
+    kw = dict(src=src, w=w, out=out, B=B, RH=RH, RW=RH, SH=SH, SW=SH, SC=SC, N=N, KH=3, KW=3, stride=stride, pad=1,
+              mode=mode, lda=SC, ldc=N, ldaux=N, pro=pro, pro_a=va, pro_b=vb, epi=epi, epi_a=va, epi_b=vb, aux=aux,
+              part=part)
+    flops = 2.0 * B * RH * RH * N * 9 * SC
+    if kind == "strip":
+        l = ops.conv_strip(st, **kw)
+    else:
+        l = ops.conv(st, ops.FR_BF16, **kw)
+    return timeit(l, iters, flops)
+
+
+def wgrad_case(kind, cout, cin, W, B, stride=1, pro=1, iters=20):
+    st = ops.current_stream_ptr()
+    Ho = W // stride
+    g, x = rnd(B, Ho, Ho, cout), rnd(B, W, W, cin)
+    dw = torch.zeros(cout, 9, cin, device="cuda")
+    va, vb = torch.rand(512, device="cuda") + 0.5, torch.rand(512, device="cuda") - 0.5
+    kw = dict(g=g, src=x, dw=dw, B=B, GH=Ho, GW=Ho, Cout=cout, SH=W, SW=W, SC=cin, KH=3, KW=3, stride=stride, pad=1,
+              ldg=cout, lda=cin, pro=pro, pro_a=va, pro_b=vb)
+    flops = 2.0 * B * Ho * Ho * cout * cin * 9
+    if kind == "wgs":
+        tiles = (cout // 64) * (cin // 64)
+        rows = {112: 2, 56: 4, 28: 7, 14: 14, 7: 7}[W]
+        fills = B * (W // rows) // (4 if W == 7 else 1)
+        groups = max(1, min(fills, 256 // tiles))
+        slab = torch.empty(groups * cout * 9 * cin, device="cuda")
+        l = ops.wgrad_strip(st, nsplit=groups, slab=slab, **kw)
+    else:
+        tiles = ((cout + 127) // 128) * ((cin + 127) // 128) * 9
+        l = ops.wgrad(st, ops.FR_BF16, nsplit=max(1, min(256, 768 // tiles)), **kw)
+    return timeit(l, iters, flops)
+
+
+LAYERS = [(64, 64, 112), (64, 64, 56), (64, 128, 56), (128, 128, 28), (128, 256, 28), (256, 256, 14), (256, 512, 14),
+          (512, 512, 7)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("kind")
+    ap.add_argument("dims", nargs="*", type=int)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--stride", type=int, default=1)
+    ap.add_argument("--pro", type=int, default=1)
+    ap.add_argument("--epi", type=int, default=1)
+    ap.add_argument("--mode", type=int, default=0)
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    if a.kind == "all":
+        for cin, cout, W in LAYERS:
+            r = ["%3d->%3d @%3d" % (cin, cout, W)]
+            for kind in ("strip", "igemm"):
+                ms, tf = conv_case(kind, cin, cout, W, a.batch, iters=a.iters, epi=0 if cout == 512 and cin == 256 else 1)
+                r.append("%s fwd %.3f ms %6.0f TF/s" % (kind, ms, tf))
+            ms, tf = conv_case("strip", cin, cout, W, a.batch, pro=0, epi=3, mode=1, iters=a.iters)
+            r.append("strip dgrad %.3f ms %6.0f TF/s" % (ms, tf))
+            for kind in ("wgs", "wgrad"):
+                ms, tf = wgrad_case(kind, cout, cin, W, a.batch, iters=a.iters)
+                r.append("%s %.3f ms %6.0f TF/s" % (kind, ms, tf))
+            print(" | ".join(r), flush=True)
+        return
+    if a.kind in ("strip", "igemm"):
+        cin, cout, W = a.dims
+        ms, tf = conv_case(a.kind, cin, cout, W, a.batch, a.stride, a.pro, a.epi, a.mode, a.iters)
+    else:
+        cout, cin, W = a.dims
+        ms, tf = wgrad_case(a.kind, cout, cin, W, a.batch, a.stride, a.pro, a.iters)
+    print("%s %s B=%d: %.4f ms  %.1f TFLOP/s" % (a.kind, a.dims, a.batch, ms, tf))
+
+
+if __name__ == "__main__":
+    main()
