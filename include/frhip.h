@@ -47,13 +47,16 @@ typedef struct FrConvArgs {
   int32_t SH, SW, SC;  /* source tensor geometry; SC % 32 == 0 */
   int32_t N;           /* output columns */
   int32_t KH, KW, stride, pad;
-  int32_t mode;        /* 0: sh = rh*stride+kh-pad (forward); 1: sh = (rh+pad-kh)/stride (data gradient) */
+  int32_t mode;        /* 0: sh = rh*stride+kh-pad (forward); 1: sh = (rh+pad-kh)/stride (data gradient);
+                          2: stride-2 3x3 data gradient for the output pixels (2i+par_h, 2j+par_w) only: rows = B*RH/2*RW/2,
+                             the taps that hit no input pixel are skipped; run once per parity class */
   int32_t lda, ldc, ldaux;
   int32_t pro;         /* FR_PRO_* */
   int32_t epi;         /* FR_EPI_* */
   int32_t out_f32;
   int32_t splitk;      /* >1: K loop split over gridDim.z, requires FR_EPI_ATOMIC + out_f32 */
   int32_t stride_log2; /* filled in by the library */
+  int32_t par_h, par_w; /* mode 2: parity class of the output pixels */
   int32_t margin_kind; /* 0 ArcFace, 1 CosFace */
   int32_t easy_margin;
   float cos_m, sin_m, th, mm, scale;

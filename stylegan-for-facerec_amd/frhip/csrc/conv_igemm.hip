@@ -68,7 +68,11 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
   const int nb_count = (p.N + BN - 1) / BN;
   const int mb = bid / nb_count, nb = bid - mb * nb_count;
   const int m0 = mb * BM, n0 = nb * BN;
-  const int M = p.B * p.RH * p.RW;
+  // mode 2: stride-2 3x3 data gradient restricted to the output pixels of one parity class (par_h, par_w).  Rows
+  // enumerate (b, i, j) with output pixel (2i+par_h, 2j+par_w); only the taps that land on an input pixel are visited
+  // (1, 2, 2 or 4 of the 9), so the four classes together do 9/4 taps per pixel instead of 9.
+  const int RH2 = p.mode == 2 ? p.RH >> 1 : p.RH, RW2 = p.mode == 2 ? p.RW >> 1 : p.RW;
+  const int M = p.B * RH2 * RW2;
 
   const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
   const T* __restrict__ wgt = reinterpret_cast<const T*>(p.w);
@@ -82,16 +86,19 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
     const int row = tid / C::CPR + i * (NT / C::CPR);
     const int m = m0 + row;
     if (m < M) {
-      const int b = m / (p.RH * p.RW);
-      const int rem = m - b * (p.RH * p.RW);
-      const int rh = rem / p.RW, rw = rem - rh * p.RW;
+      const int b = m / (RH2 * RW2);
+      const int rem = m - b * (RH2 * RW2);
+      const int rh = rem / RW2, rw = rem - rh * RW2;
       a_pix0[i] = b * p.SH * p.SW;
       if (p.mode == 0) {
         a_h0[i] = rh * p.stride - p.pad;
         a_w0[i] = rw * p.stride - p.pad;
-      } else {
+      } else if (p.mode == 1) {
         a_h0[i] = rh + p.pad;
         a_w0[i] = rw + p.pad;
+      } else {
+        a_h0[i] = rh;
+        a_w0[i] = rw;
       }
     } else {
       a_pix0[i] = -1;
@@ -103,7 +110,9 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
 
   const int taps = p.KH * p.KW;
   const int kchunks = p.SC / BK;  // K steps per tap
-  const int nk_total = taps * kchunks;
+  const int vkw = p.mode == 2 ? (p.par_w ? 2 : 1) : p.KW;  // taps actually visited along w / h
+  const int vkh = p.mode == 2 ? (p.par_h ? 2 : 1) : p.KH;
+  const int nk_total = vkh * vkw * kchunks;
   int ks_begin = 0, ks_end = nk_total;
   if (gridDim.z > 1) {
     ks_begin = (int)(((long long)nk_total * blockIdx.z) / gridDim.z);
@@ -115,9 +124,17 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
   float pa[VEC], pb[VEC];  // prologue coefficients for this thread's channel chunk
 
   auto gload = [&](int ks) {
-    const int tap = ks / kchunks;
-    const int c0 = (ks - tap * kchunks) * BK;
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int vtap = ks / kchunks;
+    const int c0 = (ks - vtap * kchunks) * BK;
+    int kh = vtap / vkw, kw = vtap - kh * vkw;
+    int dh = 0, dw = 0;
+    if (p.mode == 2) {  // odd output rows see taps 0 and 2 (input row i+1 and i), even rows only tap 1 (input row i)
+      dh = p.par_h ? 1 - kh : 0;
+      dw = p.par_w ? 1 - kw : 0;
+      kh = p.par_h ? 2 * kh : 1;
+      kw = p.par_w ? 2 * kw : 1;
+    }
+    const int tap = kh * p.KW + kw;
     const int ca = c0 + a_cc * VEC;
 #pragma unroll
     for (int i = 0; i < C::NA; ++i) {
@@ -126,6 +143,9 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
       if (p.mode == 0) {
         sh = a_h0[i] + kh;
         sw = a_w0[i] + kw;
+      } else if (p.mode == 2) {
+        sh = a_h0[i] + dh;
+        sw = a_w0[i] + dw;
       } else {
         const int nh = a_h0[i] - kh, nw = a_w0[i] - kw;
         ok = ok && nh >= 0 && nw >= 0 && ((nh | nw) & (p.stride - 1)) == 0;
@@ -279,7 +299,14 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
         v[j + 3] = t[3];
       }
       const bool full = (n + VEC <= p.N);
-      const size_t ooff = (size_t)m * (size_t)p.ldc + n;
+      size_t mrow = (size_t)m;  // row of out / aux this GEMM row maps to
+      if (p.mode == 2) {
+        const int b = m / (RH2 * RW2);
+        const int rem = m - b * (RH2 * RW2);
+        const int i2 = rem / RW2, j2 = rem - i2 * RW2;
+        mrow = ((size_t)b * p.RH + 2 * i2 + p.par_h) * (size_t)p.RW + 2 * j2 + p.par_w;
+      }
+      const size_t ooff = mrow * (size_t)p.ldc + n;
       if (epi == FR_EPI_ATOMIC) {
         float* o = reinterpret_cast<float*>(p.out) + ooff;
 #pragma unroll
@@ -299,7 +326,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
         }
       } else if (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD) {
         float x[VEC];
-        const T* ap = reinterpret_cast<const T*>(p.aux) + (size_t)m * (size_t)p.ldaux + n;
+        const T* ap = reinterpret_cast<const T*>(p.aux) + mrow * (size_t)p.ldaux + n;
         if (full) {
           unpack16<T>(ld16(ap), x);
         } else {
@@ -410,7 +437,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
 template <typename T, int BN, int PRO>
 int launch(const FrConvArgs& a, hipStream_t st) {
   using C = Cfg<T, BN>;
-  const int M = a.B * a.RH * a.RW;
+  const int M = a.mode == 2 ? a.B * (a.RH / 2) * (a.RW / 2) : a.B * a.RH * a.RW;
   const int mbs = (M + BM - 1) / BM, nbs = (a.N + BN - 1) / BN;
   dim3 grid(mbs * nbs, 1, a.splitk > 1 ? a.splitk : 1);
   static bool attr_done = false;
@@ -443,6 +470,8 @@ extern "C" int fr_conv_igemm(const FrConvArgs* args, int dtype, void* stream) {
   FrConvArgs a = *args;
   if (a.SC % BK != 0) FR_UNSUPPORTED("fr_conv_igemm: source channels must be a multiple of 32");
   if (a.stride != 1 && a.stride != 2) FR_UNSUPPORTED("fr_conv_igemm: stride must be 1 or 2");
+  if (a.mode == 2 && (a.stride != 2 || a.KH != 3 || a.KW != 3 || a.pad != 1 || (a.RH & 1) || (a.RW & 1) || a.epi == FR_EPI_MARGIN))
+    FR_UNSUPPORTED("fr_conv_igemm: mode 2 is the stride-2 3x3 pad-1 data gradient on even-sized outputs");
   if ((long long)a.B * a.RH * a.RW >= (1ll << 31) / 4) FR_UNSUPPORTED("fr_conv_igemm: too many rows");
   if (a.splitk > 1 && (a.epi != FR_EPI_ATOMIC || !a.out_f32))
     FR_UNSUPPORTED("fr_conv_igemm: split-K needs the fp32 atomic epilogue");

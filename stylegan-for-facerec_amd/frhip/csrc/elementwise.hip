@@ -73,23 +73,49 @@ __global__ void stem_im2col_kernel(const float* __restrict__ x, const float* __r
   }
 }
 
-// ------------------------------------------------------------------------------------------ BN finalize
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float momentum, float* running_mean, float* running_var, long long* nbt,
-                                   float* mean, float* invstd, float* scale, float* shift) {
-  // one wave per channel: lanes stride over the partial rows, double accumulate
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int i = lane; i < nparts; i += 64) {
-    s += (double)part[((size_t)i * 2 + 0) * C + c];
-    q += (double)part[((size_t)i * 2 + 1) * C + c];
+// ------------------------------------------------------------------------------------------ partial-row reduction
+// part is [nparts][KC] fp32.  A block owns 8 consecutive columns: thread (row-lane rl = tid/8, column cl = tid%8)
+// strides over the rows (32-B coalesced segments, 32 independent loads in flight per column), accumulates in
+// double, and the 32 row-lanes are combined with wave shuffles + one LDS step.  Returns the total in the threads
+// with tid < 8 (column tid); other threads return garbage.
+__device__ __forceinline__ double reduce_rows8(const float* __restrict__ part, int nparts, int KC, int col0,
+                                               double* lds /* [4][8] */) {
+  const int tid = threadIdx.x, cl = tid & 7, rl = tid >> 3;  // 256 threads: 32 row-lanes x 8 columns
+  const int col = col0 + cl;
+  double s = 0.0;
+  if (col < KC) {
+    int r = rl;
+    for (; r + 96 < nparts; r += 128) {  // 4 independent loads per trip
+      const float a = part[(size_t)r * KC + col], b = part[(size_t)(r + 32) * KC + col];
+      const float c = part[(size_t)(r + 64) * KC + col], d = part[(size_t)(r + 96) * KC + col];
+      s += ((double)a + (double)b) + ((double)c + (double)d);
+    }
+    for (; r < nparts; r += 32) s += (double)part[(size_t)r * KC + col];
   }
-  s = wave_sum_d(s);
-  q = wave_sum_d(q);
-  if (lane == 0) {
+  // lanes of a wave: 8 row-lanes x 8 columns -> fold the row-lane bits (lane bits 3..5)
+  s += __shfl_xor(s, 8, 64);
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  const int wave = tid >> 6;
+  if ((tid & 63) < 8) lds[wave * 8 + cl] = s;
+  __syncthreads();
+  if (tid < 8) s = lds[tid] + lds[8 + tid] + lds[16 + tid] + lds[24 + tid];
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------ BN finalize
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C,
+                                                          double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float momentum,
+                                                          float* running_mean, float* running_var, long long* nbt,
+                                                          float* mean, float* invstd, float* scale, float* shift) {
+  __shared__ double lds[2][32];
+  // part row layout [2][C]: columns c (sum) and C + c (sum of squares); a block finalises 8 channels
+  const int c0 = blockIdx.x * 8;
+  const double s = reduce_rows8(part, nparts, 2 * C, c0, lds[0]);
+  const double q = reduce_rows8(part, nparts, 2 * C, C + c0, lds[1]);
+  const int c = c0 + threadIdx.x;
+  if (threadIdx.x < 8 && c < C) {
     const double m = s / count;
     double var = q / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -120,16 +146,14 @@ __global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, const fl
   shift[c] = beta[c] - rm[c] * gamma[c] * is;
 }
 
-__global__ void reduce_parts_kernel(const float* __restrict__ part, int nparts, int K, int C, float* o0, float* o1,
-                                    float* o2) {
-  const int lane = threadIdx.x & 63;
-  const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (idx >= K * C) return;
-  const int k = idx / C, c = idx - k * C;
-  double s = 0.0;
-  for (int i = lane; i < nparts; i += 64) s += (double)part[((size_t)i * K + k) * C + c];
-  s = wave_sum_d(s);
-  if (lane == 0) {
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int nparts, int K, int C,
+                                                           float* o0, float* o1, float* o2) {
+  __shared__ double lds[32];
+  const int col0 = blockIdx.x * 8;  // over the K*C columns of a partial row
+  const double s = reduce_rows8(part, nparts, K * C, col0, lds);
+  const int idx = col0 + threadIdx.x;
+  if (threadIdx.x < 8 && idx < K * C) {
+    const int k = idx / C, c = idx - k * C;
     float* o = k == 0 ? o0 : (k == 1 ? o1 : o2);
     if (o) o[c] = (float)s;
   }
@@ -610,7 +634,7 @@ extern "C" int fr_bn_finalize(const float* part, int nparts, int C, double count
                               const float* beta, float eps, float momentum, float* running_mean,
                               float* running_var, int64_t* nbt, float* mean, float* invstd, float* scale,
                               float* shift, void* stream) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, nparts, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, part, nparts, C,
                      count, gamma, beta, eps, momentum, running_mean, running_var, (long long*)nbt, mean, invstd,
                      scale, shift);
   FR_LAUNCH_CHECK();
@@ -626,7 +650,7 @@ extern "C" int fr_bn_eval_coeffs(const float* rm, const float* rv, const float* 
 extern "C" int fr_reduce_parts(const float* part, int nparts, int K, int C, float* o0, float* o1, float* o2,
                                void* stream) {
   if (K < 1 || K > 3) FR_UNSUPPORTED("fr_reduce_parts: K must be 1..3");
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((K * C + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, nparts, K,
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((K * C + 7) / 8), dim3(256), 0, (hipStream_t)stream, part, nparts, K,
                      C, o0, o1, o2);
   FR_LAUNCH_CHECK();
 }

@@ -564,9 +564,11 @@ class BackbonePlan(object):
                 s0, s1 = self._s01(bnS, db, dg)
                 L.append(ops.bn_bwd_apply(st, fr, gx=g_yS, gamma=u.sc_bn.weight, s0=s0, s1=s1,
                                           inv_count=1.0 / rout, **common))
-                g_xS = self.g_xS[:rin * u.cin]
-                L.append(ops.conv(st, fr, src=g_yS, w=d["wtS"], out=g_xS, B=B, RH=u.H, RW=u.H, SH=u.Ho, SW=u.Ho,
-                                  SC=u.depth, N=u.cin, KH=1, KW=1, stride=u.stride, pad=0, mode=1, lda=u.depth,
+                # 1x1 stride-s data gradient = dense GEMM on the Ho x Ho grid; it lands on the pixels (s*i, s*j) of
+                # the unit input, which the final bn_bwd_apply adds as a strided scatter (add_kind 2)
+                g_xS = self.g_xS[:rout * u.cin]
+                L.append(ops.conv(st, fr, src=g_yS, w=d["wtS"], out=g_xS, B=B, RH=u.Ho, RW=u.Ho, SH=u.Ho, SW=u.Ho,
+                                  SC=u.depth, N=u.cin, KH=1, KW=1, stride=1, pad=0, mode=0, lda=u.depth,
                                   ldc=u.cin, pro=0, epi=ops.EPI_STORE))
                 gws = self.grad_of(u.sc_conv.weight)
                 if gws is not None:
@@ -577,10 +579,17 @@ class BackbonePlan(object):
                 ready += [u.sc_bn.weight, u.sc_bn.bias, u.sc_conv.weight]
             # conv2: data gradient with the PReLU backward epilogue, then the weight gradient
             g_y1 = self.g_y1[:rin * u.depth]
-            mt = self._conv(L, src=g_y2, w=d["wt2"], out=g_y1, B=B, RH=u.H, RW=u.H, SH=u.Ho, SW=u.Ho,
-                            SC=u.depth, N=u.depth, KH=3, KW=3, stride=u.stride, pad=1, mode=1, lda=u.depth,
-                            ldc=u.depth, ldaux=u.depth, pro=0, epi=ops.EPI_PRELU_BWD, aux=d["y1"],
-                            epi_a=u.prelu.weight, part=self.part)
+            c2 = dict(src=g_y2, w=d["wt2"], out=g_y1, B=B, RH=u.H, RW=u.H, SH=u.Ho, SW=u.Ho, SC=u.depth, N=u.depth,
+                      KH=3, KW=3, stride=u.stride, pad=1, lda=u.depth, ldc=u.depth, ldaux=u.depth, pro=0,
+                      epi=ops.EPI_PRELU_BWD, aux=d["y1"], epi_a=u.prelu.weight)
+            if u.stride == 2 and u.H % 2 == 0:
+                # one launch per output-pixel parity class: 9/4 taps per pixel instead of 9 (3/4 of them misses)
+                mtc = (B * (u.H // 2) ** 2 + 127) // 128
+                for c, (ph, pw) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+                    self._conv(L, mode=2, par_h=ph, par_w=pw, part=self.part[c * mtc * 2 * u.depth:], **c2)
+                mt = 4 * mtc
+            else:
+                mt = self._conv(L, mode=1, part=self.part, **c2)
             gsl = self.grad_of(u.prelu.weight)
             self._reduce(L, mt, 2, u.depth, gsl if gsl is not None else self.sums[2, :u.depth], None)
             gw2 = self.grad_of(u.conv2.weight)
@@ -612,7 +621,7 @@ class BackbonePlan(object):
                       rows=rin, inv_count=1.0 / rin, C=u.cin, rows_per_image=u.H * u.H,
                       nblocks=ops.grid_blocks(rin, u.cin, fr))
             if u.sc_conv is not None:
-                kw.update(add=g_xS, add_kind=1)
+                kw.update(add=g_xS, add_kind=2, H=u.H, W=u.H, add_stride=u.stride)
             elif u.stride == 1:
                 kw.update(add=g_out, add_kind=1)
             else:

@@ -501,3 +501,31 @@ def test_conv_wgrad_strip(K, cout, cin, W, pro, groups):
     torch.cuda.synchronize()
     got = dw.cpu().reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
     assert relerr(got, gw) < tol
+
+
+@pytest.mark.parametrize("name,dtype,tol", DT)
+def test_conv_dgrad_stride2_by_parity(K, name, dtype, tol):
+    """mode 2: the stride-2 3x3 data gradient as four parity-class launches (only the taps that hit an input pixel),
+    with the PReLU-backward epilogue; must equal autograd through the strided convolution."""
+    B, H, cin, cout = 3, 12, 64, 128
+    x = synth.normal(51, "px", (B, cin, H, H)).requires_grad_(True)
+    w = q(synth.normal(51, "pw", (cout, cin, 3, 3), std=0.1), dtype)
+    y = F.conv2d(x, w, stride=2, padding=1)
+    g = q(synth.normal(51, "pg", tuple(y.shape)), dtype)
+    (gx,) = torch.autograd.grad(y, [x], g)
+    aux = q(synth.normal(51, "pa", (B, cin, H, H)), dtype)
+    slope = synth.uniform(51, "ps", (cin,), 0.1, 0.4)
+    want = torch.where(aux > 0, gx, gx * slope.view(1, -1, 1, 1))
+    fr = K.fr_dtype(torch.empty(0, dtype=dtype))
+    wt = w.permute(1, 2, 3, 0).reshape(cin, 9, cout).contiguous().to("cuda", dtype)
+    out = torch.zeros(B, H, H, cin, device="cuda", dtype=dtype)
+    mtc = (B * (H // 2) ** 2 + 127) // 128
+    part = torch.zeros(4 * mtc, 2, cin, device="cuda")
+    for c, (ph, pw) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+        K.conv(K.current_stream_ptr(), fr, src=nhwc(g, dtype), w=wt, out=out, B=B, RH=H, RW=H, SH=H // 2, SW=H // 2,
+               SC=cout, N=cin, KH=3, KW=3, stride=2, pad=1, mode=2, par_h=ph, par_w=pw, lda=cout, ldc=cin, ldaux=cin,
+               pro=0, epi=K.EPI_PRELU_BWD, aux=nhwc(aux, dtype), epi_a=slope.cuda(), part=part[c * mtc:])()
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(out), want) < tol
+    np.testing.assert_allclose(part.sum(0)[0].cpu(), (gx * aux * (aux <= 0)).sum((0, 2, 3)), rtol=tol * 10,
+                               atol=tol * 10 * float((gx * aux).abs().sum() / cin))
