@@ -95,7 +95,11 @@ def make_step(model, head, loss_fn, opt, dp):
 
 
 def conv_flops(launch):
+    """Algorithmic FLOPs of one fr_conv_igemm / fr_conv3x3_strip launch (2 per MAC actually needed)."""
     a = launch.keep[0]
+    if a.mode == 2:  # one parity class of a stride-2 data gradient: (1|2) x (1|2) of the 9 taps, a quarter of the rows
+        taps = (2 if a.par_h else 1) * (2 if a.par_w else 1)
+        return 2.0 * a.B * (a.RH // 2) * (a.RW // 2) * a.N * taps * a.SC
     M = a.B * a.RH * a.RW
     return 2.0 * M * a.N * a.KH * a.KW * a.SC
 

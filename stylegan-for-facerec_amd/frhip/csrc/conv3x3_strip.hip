@@ -47,6 +47,8 @@ struct SC {
   static constexpr int RED_BYTES = WM * 2 * COUT * 4;
   static constexpr int LDS = IMG_BYTES > OUT_BYTES + RED_BYTES ? IMG_BYTES : OUT_BYTES + RED_BYTES;
   static constexpr int NS = H / ROWS;                      // strips per image
+  static constexpr bool PF = false;  // register-prefetch of the next strip: measured slower (spills, serial strips) -- off
+  static constexpr int MAXGRID = PF ? 1024 : (1 << 30);    // prefetching workgroups walk several strips each
   static_assert(H % ROWS == 0, "strip rows must divide the image");
   static_assert(NTH % CH == 0, "threads must be a multiple of the chunks per pixel");
   static_assert(COUT % (16 * WN) == 0 && 8 % WN == 0, "bad wave split");
@@ -60,18 +62,26 @@ __global__ __launch_bounds__(NTH) void conv3x3_strip_kernel(const FrConvArgs p) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: keeps the tile loops branch-free
   const int wn = wave % WN, wm = wave / WN;
-  const int b = blockIdx.x / C::NS, strip = blockIdx.x - b * C::NS;
-  const int row0 = strip * ROWS;
   const bf16_t* __restrict__ src = reinterpret_cast<const bf16_t*>(p.src);
   const bf16_t* __restrict__ wgt = reinterpret_cast<const bf16_t*>(p.w);
+  bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
 
-  // ------------------------------------------------------------------ strip -> LDS (prologue applied once)
-  {
-    constexpr int WP = W + 2;
-    constexpr int TOTAL = C::GH * WP * C::CH;
-    constexpr int UNR = 8;
-    const int ch = tid % C::CH;  // NTH is a multiple of CH: a thread always handles the same channel chunk
-    float pa[8], pb[8];
+  // A workgroup walks a contiguous run of strips (gridDim.x may be smaller than the strip count).  With 64 input
+  // channels the strip is small enough to keep the NEXT strip's 16-B chunks in registers while this one computes,
+  // so the HBM fetch of strip s+1 overlaps the MFMAs and the epilogue of strip s.
+  constexpr bool PREFETCH = C::PF;
+  const int total = p.B * C::NS;
+  const int per = PREFETCH ? (total + gridDim.x - 1) / gridDim.x : 1;  // without prefetch: one strip per workgroup
+  const int s_begin = blockIdx.x * per;
+  const int s_end = PREFETCH ? (s_begin + per < total ? s_begin + per : total) : s_begin + 1;
+
+  constexpr int WP = W + 2;
+  constexpr int TOTAL = C::GH * WP * C::CH;
+  constexpr int NLD = (TOTAL + NTH - 1) / NTH;
+  const int ch = tid % C::CH;  // NTH is a multiple of CH: a thread always handles the same channel chunk
+  float pa[8], pb[8];  // prologue coefficients of this thread's channel chunk: re-read per strip (L1 hits) rather
+                       // than kept live across the MFMA loop
+  auto load_pro = [&]() {
     if (PRO != FR_PRO_NONE) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -79,169 +89,217 @@ __global__ __launch_bounds__(NTH) void conv3x3_strip_kernel(const FrConvArgs p) 
         pb[j] = PRO == FR_PRO_BN ? p.pro_b[ch * 8 + j] : 0.f;
       }
     }
+  };
+  // chunk u of this thread (idx = u*NTH + tid) -> source validity / address / LDS address
+  auto chunk_src = [&](int s, int idx, bool& ok) -> const bf16_t* {
+    const int b = s / C::NS, row0 = (s - b * C::NS) * ROWS;
+    const int pc = idx / C::CH;
+    const int gh = pc / WP, gw = pc - gh * WP;
+    const int h = row0 + gh - 1, w = gw - 1;
+    ok = idx < TOTAL && (unsigned)h < (unsigned)C::H && (unsigned)w < (unsigned)W;
+    return src + ((size_t)(b * C::H + h) * W + w) * (size_t)p.lda + ch * 8;
+  };
+  auto chunk_store = [&](int idx, U128 x, bool ok) {
+    if (idx < TOTAL) {
+      const int pc = idx / C::CH;
+      const int gh = pc / WP, gw = pc - gh * WP;
+      if (PRO != FR_PRO_NONE && ok) {
+        float f[8];
+        unpack16<bf16_t>(x, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (PRO == FR_PRO_BN) f[j] = fmaf(f[j], pa[j], pb[j]);
+          else f[j] = f[j] > 0.f ? f[j] : f[j] * pa[j];
+        }
+        x = pack16<bf16_t>(f);
+      }
+      st16(smem + gh * C::RSTR + gw * C::PSTR + ch * 16, x);
+    }
+  };
+  constexpr int NPF = PREFETCH ? NLD : 1;
+  U128 ldv[NPF];      // PREFETCH only: the next strip, in flight while this one computes
+  unsigned okmask = 0;
+  auto issue = [&](int s) {
+    okmask = 0;
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+      bool ok;
+      const bf16_t* ptr = chunk_src(s, u * NTH + tid, ok);
+      ldv[u] = ok ? ld16(ptr) : zero16();
+      okmask |= ok ? (1u << u) : 0u;
+    }
+  };
+  auto commit = [&]() {
+    load_pro();
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) chunk_store(u * NTH + tid, ldv[u], (okmask >> u) & 1u);
+  };
+  auto load_now = [&](int s) {  // !PREFETCH: stream the strip through 8 registers at a time
+    constexpr int UNR = 8;
+    load_pro();
     for (int base = 0; base < TOTAL; base += NTH * UNR) {
       U128 v[UNR];
       bool ok[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        const int idx = base + u * NTH + tid;
-        const int pc = idx / C::CH;
-        const int gh = pc / WP, gw = pc - gh * WP;
-        const int h = row0 + gh - 1, w = gw - 1;
-        ok[u] = idx < TOTAL && (unsigned)h < (unsigned)C::H && (unsigned)w < (unsigned)W;
-        v[u] = ok[u] ? ld16(src + ((size_t)(b * C::H + h) * W + w) * (size_t)p.lda + ch * 8) : zero16();
+        const bf16_t* ptr = chunk_src(s, base + u * NTH + tid, ok[u]);
+        v[u] = ok[u] ? ld16(ptr) : zero16();
       }
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int idx = base + u * NTH + tid;
-        if (idx < TOTAL) {
-          const int pc = idx / C::CH;
-          const int gh = pc / WP, gw = pc - gh * WP;
-          U128 x = v[u];
-          if (PRO != FR_PRO_NONE && ok[u]) {
-            float f[8];
-            unpack16<bf16_t>(x, f);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              if (PRO == FR_PRO_BN) f[j] = fmaf(f[j], pa[j], pb[j]);
-              else f[j] = f[j] > 0.f ? f[j] : f[j] * pa[j];
-            }
-            x = pack16<bf16_t>(f);
-          }
-          st16(smem + gh * C::RSTR + gw * C::PSTR + ch * 16, x);
-        }
-      }
+      for (int u = 0; u < UNR; ++u) chunk_store(base + u * NTH + tid, v[u], ok[u]);
     }
-  }
-  __syncthreads();
+  };
 
-  // ------------------------------------------------------------------ main loop: 9 taps x CIN/32, no barriers
   const int fr = lane & 15, fq = lane >> 4;
-  int abase[C::TM];  // LDS byte address of this lane's fragment for tap (0,0), channel chunk c0 = 0
-#pragma unroll
-  for (int i = 0; i < C::TM; ++i) {
-    int m = (wm * C::TM + i) * 16 + fr;
-    m = m < C::M ? m : 0;
-    const int h = m / W, w = m - h * W;
-    abase[i] = h * C::RSTR + w * C::PSTR + fq * 16;
-  }
   const int n0 = wn * C::TN * 16;
   const bf16_t* wrow[C::TN];
 #pragma unroll
   for (int j = 0; j < C::TN; ++j) wrow[j] = wgt + (size_t)(n0 + j * 16 + fr) * 9 * CIN + fq * 8;
-
-  f32x4 acc[C::TM][C::TN];
-#pragma unroll
-  for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-    for (int j = 0; j < C::TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // B fragments: 3-deep register ring: tap t's weights are requested during tap t-3 (address clamped instead of
-  // branching at the end, so the body stays one basic block and hipcc's counted vmcnt waits stay exact).  A fragments: D-deep ring of ds_read_b128, refilled one (tap, tile) step ahead of
-  // use by D steps; sched_group_barrier pins the 1 read : TN MFMA interleave.
-  s16x8 bq[3][C::TN];
   const int flip = p.mode;
-  auto load_b = [&](int slot, int c0, int tap) {
-    const int wt = flip ? 8 - tap : tap;
-#pragma unroll
-    for (int j = 0; j < C::TN; ++j) bq[slot][j] = *reinterpret_cast<const s16x8*>(wrow[j] + wt * CIN + c0);
-  };
-  constexpr int NSTEP = 9 * C::TM;
-  // ring depth must divide NSTEP (slots line up across the channel loop): 9 when registers allow, else 3
-  constexpr int D = (C::TM * C::TN * 4 + 3 * C::TN * 4 > 120) ? 3 : 9;
-  s16x8 ring[D];
-  auto a_addr = [&](int step) -> const s16x8* {  // step in [0, 2*NSTEP): second half = next 32 input channels
-    const int cadd = step >= NSTEP ? 64 : 0;
-    const int st = step >= NSTEP ? step - NSTEP : step;
-    const int tap = st / C::TM, i = st - tap * C::TM;
-    return reinterpret_cast<const s16x8*>(smem + abase[i] + (tap / 3) * C::RSTR + (tap % 3) * C::PSTR + cadd);
-  };
-  load_b(0, 0, 0);
-  load_b(1, 0, 1);
-  load_b(2, 0, 2);
-#pragma unroll
-  for (int d = 0; d < D; ++d) ring[d] = *a_addr(d);
-  for (int c0 = 0; c0 < CIN; c0 += 32) {
-#pragma unroll
-    for (int st = 0; st < NSTEP; ++st) {
-      const int tap = st / C::TM, i = st - tap * C::TM;
-      const int slot = tap % 3;
-      const s16x8 a = ring[st % D];
-#pragma unroll
-      for (int j = 0; j < C::TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[slot][j], acc[i][j], 0, 0, 0);
-      ring[st % D] = *a_addr(st + D);  // past the last channel chunk this reads (never used) bytes inside LDS
-      if (i == C::TM - 1) {
-        int nt = tap + 3, nc = c0;
-        if (nt >= 9) {
-          nt -= 9;
-          nc += 32;
-        }
-        nc = nc < CIN ? nc : CIN - 32;  // clamp instead of branching: the count of loads in flight stays static
-        load_b(slot, nc, nt);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, C::TN, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
-      // pin the weight requests three taps ahead of their use: without the fence the scheduler sinks the loads
-      // down to their consumer (shorter live ranges) and every tap then waits a full L2 round trip
-      if (i == C::TM - 1) __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int i = 0; i < C::TM; ++i) abase[i] += 64;  // next 32 input channels
-  }
-  // ------------------------------------------------------------------ epilogue
-  __syncthreads();  // every wave is done with the input strip; LDS is now the output tile
   const int epi = p.epi;
-  const size_t rowbase = (size_t)(b * C::H + row0) * W;
+  const bool stats = epi == FR_EPI_STATS || epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD;
+  float s0[C::TN], s1[C::TN];  // column sums accumulate over all strips of this workgroup
+#pragma unroll
+  for (int j = 0; j < C::TN; ++j) s0[j] = s1[j] = 0.f;
   constexpr int OCH = COUT / 8;
-  if (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD) {
-    const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
-    for (int idx = tid; idx < C::M * OCH; idx += NTH) {
-      const int r = idx / OCH, ch = idx - r * OCH;
-      st16(smem + r * C::OSTR + ch * 16, ld16(aux + (rowbase + r) * (size_t)p.ldaux + ch * 8));
-    }
+
+  if (PREFETCH && s_begin < s_end) issue(s_begin);
+  for (int s = s_begin; s < s_end; ++s) {
+    const int b = s / C::NS, row0 = (s - b * C::NS) * ROWS;
+    // ---------------------------------------------------------------- strip -> LDS (prologue applied once)
+    __syncthreads();  // the previous strip's output tile has left LDS
+    if (PREFETCH) commit();
+    else load_now(s);
     __syncthreads();
-  }
-  float s0[C::TN], s1[C::TN], ea[C::TN], eb[C::TN];
+    if (PREFETCH && s + 1 < s_end) issue(s + 1);
+
+    // ---------------------------------------------------------------- main loop: 9 taps x CIN/32, no barriers
+    int abase[C::TM];  // LDS byte address of this lane's fragment for tap (0,0), channel chunk c0 = 0
 #pragma unroll
-  for (int j = 0; j < C::TN; ++j) {
-    s0[j] = s1[j] = 0.f;
-    const int n = n0 + j * 16 + fr;
-    ea[j] = (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD) ? p.epi_a[n] : 0.f;
-    eb[j] = (epi == FR_EPI_BNBWD) ? p.epi_b[n] : 0.f;
-  }
+    for (int i = 0; i < C::TM; ++i) {
+      int m = (wm * C::TM + i) * 16 + fr;
+      m = m < C::M ? m : 0;
+      const int h = m / W, w = m - h * W;
+      abase[i] = h * C::RSTR + w * C::PSTR + fq * 16;
+    }
+    f32x4 acc[C::TM][C::TN];
 #pragma unroll
-  for (int i = 0; i < C::TM; ++i) {
-    if (wm * C::TM + i >= C::MT) continue;
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // B fragments: 3-deep register ring: tap t's weights are requested during tap t-3 (address clamped instead of
+    // branching at the end, so the body stays one basic block and hipcc's counted vmcnt waits stay exact).  A
+    // fragments: D-deep ring of ds_read_b128, refilled D (tap, tile) steps ahead of use; sched_group_barrier pins
+    // the 1 read : TN MFMA interleave.
+    s16x8 bq[3][C::TN];
+    auto load_b = [&](int slot, int c0, int tap) {
+      const int wt = flip ? 8 - tap : tap;
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) bq[slot][j] = *reinterpret_cast<const s16x8*>(wrow[j] + wt * CIN + c0);
+    };
+    constexpr int NSTEP = 9 * C::TM;
+    // ring depth must divide NSTEP (slots line up across the channel loop): 9 when registers allow, else 3
+    constexpr int D = (PREFETCH || C::TM * C::TN * 4 + 3 * C::TN * 4 > 100) ? 3 : 9;
+    s16x8 ring[D];
+    auto a_addr = [&](int step) -> const s16x8* {  // step in [0, 2*NSTEP): second half = next 32 input channels
+      const int cadd = step >= NSTEP ? 64 : 0;
+      const int st = step >= NSTEP ? step - NSTEP : step;
+      const int tap = st / C::TM, i = st - tap * C::TM;
+      return reinterpret_cast<const s16x8*>(smem + abase[i] + (tap / 3) * C::RSTR + (tap % 3) * C::PSTR + cadd);
+    };
+    load_b(0, 0, 0);
+    load_b(1, 0, 1);
+    load_b(2, 0, 2);
+#pragma unroll
+    for (int d = 0; d < D; ++d) ring[d] = *a_addr(d);
+    for (int c0 = 0; c0 < CIN; c0 += 32) {
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        const int tap = st / C::TM, i = st - tap * C::TM;
+        const int slot = tap % 3;
+        const s16x8 a = ring[st % D];
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[slot][j], acc[i][j], 0, 0, 0);
+        ring[st % D] = *a_addr(st + D);  // past the last channel chunk this reads (never used) bytes inside LDS
+        if (i == C::TM - 1) {
+          int nt = tap + 3, nc = c0;
+          if (nt >= 9) {
+            nt -= 9;
+            nc += 32;
+          }
+          nc = nc < CIN ? nc : CIN - 32;  // clamp instead of branching: the count of loads in flight stays static
+          load_b(slot, nc, nt);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, C::TN, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+        // pin the weight requests three taps ahead of their use: without the fence the scheduler sinks the loads
+        // down to their consumer (shorter live ranges) and every tap then waits a full L2 round trip
+        if (i == C::TM - 1) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < C::TM; ++i) abase[i] += 64;  // next 32 input channels
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    __syncthreads();  // every wave is done with the input strip; LDS is now the output tile
+    const size_t rowbase = (size_t)(b * C::H + row0) * W;
+    if (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD) {
+      const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
+      for (int idx = tid; idx < C::M * OCH; idx += NTH) {
+        const int r = idx / OCH, c8 = idx - r * OCH;
+        st16(smem + r * C::OSTR + c8 * 16, ld16(aux + (rowbase + r) * (size_t)p.ldaux + c8 * 8));
+      }
+      __syncthreads();
+    }
+    float ea[C::TN], eb[C::TN];
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) {
       const int n = n0 + j * 16 + fr;
+      ea[j] = (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD) ? p.epi_a[n] : 0.f;
+      eb[j] = (epi == FR_EPI_BNBWD) ? p.epi_b[n] : 0.f;
+    }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = (wm * C::TM + i) * 16 + fq * 4 + r;
-        if (m >= C::M) continue;
-        bf16_t* cell = reinterpret_cast<bf16_t*>(smem + m * C::OSTR + n * 2);
-        float v = acc[i][j][r];
-        if (epi == FR_EPI_STATS) {
-          s0[j] += v;
-          s1[j] = fmaf(v, v, s1[j]);
-        } else if (epi == FR_EPI_PRELU_BWD) {
-          const float y = bf2f(*cell);
-          const bool pos = y > 0.f;
-          s0[j] += pos ? 0.f : v * y;
-          v = pos ? v : v * ea[j];
-        } else if (epi == FR_EPI_BNBWD) {
-          const float x = bf2f(*cell);
-          s0[j] += v;
-          s1[j] = fmaf(v, (x - ea[j]) * eb[j], s1[j]);
+    for (int i = 0; i < C::TM; ++i) {
+      if (wm * C::TM + i >= C::MT) continue;
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) {
+        const int n = n0 + j * 16 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = (wm * C::TM + i) * 16 + fq * 4 + r;
+          if (m >= C::M) continue;
+          bf16_t* cell = reinterpret_cast<bf16_t*>(smem + m * C::OSTR + n * 2);
+          float v = acc[i][j][r];
+          if (epi == FR_EPI_STATS) {
+            s0[j] += v;
+            s1[j] = fmaf(v, v, s1[j]);
+          } else if (epi == FR_EPI_PRELU_BWD) {
+            const float y = bf2f(*cell);
+            const bool pos = y > 0.f;
+            s0[j] += pos ? 0.f : v * y;
+            v = pos ? v : v * ea[j];
+          } else if (epi == FR_EPI_BNBWD) {
+            const float x = bf2f(*cell);
+            s0[j] += v;
+            s1[j] = fmaf(v, (x - ea[j]) * eb[j], s1[j]);
+          }
+          *cell = f2bf(v);
         }
-        *cell = f2bf(v);
       }
     }
+    __syncthreads();
+    for (int idx = tid; idx < C::M * OCH; idx += NTH) {
+      const int r = idx / OCH, c8 = idx - r * OCH;
+      st16(out + (rowbase + r) * (size_t)p.ldc + c8 * 8, ld16(smem + r * C::OSTR + c8 * 16));
+    }
   }
-  const bool stats = epi == FR_EPI_STATS || epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD;
-  float* red = reinterpret_cast<float*>(smem + C::OUT_BYTES);  // [WM][2][COUT]
+
+  // ------------------------------------------------------------------ column sums of the whole run of strips
   if (stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [WM][2][COUT]
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) {
       float a = s0[j], c = s1[j];
@@ -254,21 +312,14 @@ __global__ __launch_bounds__(NTH) void conv3x3_strip_kernel(const FrConvArgs p) 
         red[(wm * 2 + 1) * COUT + n0 + j * 16 + fr] = c;
       }
     }
-  }
-  __syncthreads();
-  if (stats) {
+    __syncthreads();
     for (int c = tid; c < 2 * COUT; c += NTH) {
       const int k = c / COUT, n = c - k * COUT;
-      float s = 0.f;
+      float t = 0.f;
 #pragma unroll
-      for (int g = 0; g < C::WM; ++g) s += red[(g * 2 + k) * COUT + n];
-      p.part[((size_t)blockIdx.x * 2 + k) * COUT + n] = s;
+      for (int g = 0; g < C::WM; ++g) t += red[(g * 2 + k) * COUT + n];
+      p.part[((size_t)blockIdx.x * 2 + k) * COUT + n] = t;
     }
-  }
-  bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
-  for (int idx = tid; idx < C::M * OCH; idx += NTH) {
-    const int r = idx / OCH, ch = idx - r * OCH;
-    st16(out + (rowbase + r) * (size_t)p.ldc + ch * 8, ld16(smem + r * C::OSTR + ch * 16));
   }
 }
 
@@ -281,8 +332,9 @@ int launch(const FrConvArgs& a, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, PRO>), dim3(a.B * C::NS), dim3(NTH), C::LDS, st,
-                     a);
+  const int strips = a.B * C::NS;
+  hipLaunchKernelGGL((conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, PRO>),
+                     dim3(strips < C::MAXGRID ? strips : C::MAXGRID), dim3(NTH), C::LDS, st, a);
   FR_LAUNCH_CHECK();
 }
 
@@ -301,8 +353,11 @@ int by_pro(const FrConvArgs& a, hipStream_t st) {
 // Number of partial rows the kernel writes into `part` (= workgroups) for a supported shape, 0 if unsupported.
 extern "C" int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi) {
   if (Cin == 256 && Cout == 512 && W == 14 && epi != FR_EPI_STORE) return 0;
-#define SHAPE(ci, co, w, rows) \
-  if (Cin == ci && Cout == co && W == w) return B * (w / rows);
+#define SHAPE(ci, co, w, rows)                \
+  if (Cin == ci && Cout == co && W == w) {   \
+    const int strips = B * (w / rows);       \
+    return ci == 64 && co == 64 && strips > 1024 ? 1024 : strips; \
+  }
   SHAPE(64, 64, 112, 4)
   SHAPE(64, 64, 56, 7)
   SHAPE(64, 128, 56, 7)
