@@ -218,6 +218,16 @@ int fr_dropout_bwd(void* g, long long rows, int C, int HW, float p, uint64_t see
 /* ---- weight packing: fp32 master [Cout][taps][Cin] (channels-last storage of the OIHW Parameter)
  *   wp [Cout][taps][Cin] compute dtype (NULL to skip), wt [Cin][taps][Cout] compute dtype (NULL to skip) */
 int fr_pack_weight(const float* w, void* wp, void* wt, int Cout, int taps, int Cin, int dtype, void* stream);
+/* the same for every convolution of the network in one launch: table_dev = device array of records, chunks_dev =
+ * device array of (tensor index, tile index) pairs, tile index over taps x ceil(Cout/32) x ceil(Cin/32) */
+typedef struct FrPackTensor {
+  const float* w;
+  void* wp; /* may be NULL */
+  void* wt; /* may be NULL */
+  int32_t Cout, taps, Cin, pad_;
+} FrPackTensor;
+int fr_pack_weights_multi(const FrPackTensor* table_dev, const int32_t* chunks_dev, int nchunks, int dtype,
+                          void* stream);
 /* Linear(25088,512): torch layout [O][C*HW] (c-major) <-> NHWC-flatten [O][HW*C]; dir 0: torch->packed
  * (dtype out, optional transposed copy wt [HW*C][O]), dir 1: packed fp32 grad -> torch fp32 grad */
 int fr_permute_linear(const float* in, void* out, void* wt, int O, int C, int HW, int dir, int dtype,
@@ -275,7 +285,7 @@ int fr_fill_rows(float* out, const float* bias, long long rows, int C, void* str
 /* ---- misc */
 int fr_abi_version(void);
 /* sizeof() of the argument structs as compiled, for binding self-checks: 0 FrConvArgs, 1 FrWgradArgs,
- * 2 FrApplyArgs, 3 FrBnBwdArgs, 4 FrSgdTensor */
+ * 2 FrApplyArgs, 3 FrBnBwdArgs, 4 FrSgdTensor, 5 FrPackTensor */
 int fr_struct_size(int which);
 const char* fr_last_error_string(void);
 

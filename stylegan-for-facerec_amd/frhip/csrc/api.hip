@@ -19,6 +19,7 @@ extern "C" int fr_struct_size(int which) {
     case 2: return (int)sizeof(FrApplyArgs);
     case 3: return (int)sizeof(FrBnBwdArgs);
     case 4: return (int)sizeof(FrSgdTensor);
+    case 5: return (int)sizeof(FrPackTensor);
   }
   return -1;
 }

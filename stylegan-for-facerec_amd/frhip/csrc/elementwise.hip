@@ -538,6 +538,36 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
   }
 }
 
+// all convolution weights of the network in ONE launch: chunk = (tensor index, 32x32 tile index)
+template <typename T>
+__global__ void pack_weights_multi_kernel(const FrPackTensor* __restrict__ table, const int2* __restrict__ chunks) {
+  __shared__ float tile[32][33];
+  const int2 ch = chunks[blockIdx.x];
+  const FrPackTensor t = table[ch.x];
+  const int tx_n = (t.Cin + 31) / 32, ty_n = (t.Cout + 31) / 32;
+  const int tap = ch.y / (tx_n * ty_n), rem = ch.y - tap * (tx_n * ty_n);
+  const int ci0 = (rem % tx_n) * 32, co0 = (rem / tx_n) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  T* wp = reinterpret_cast<T*>(t.wp);
+  T* wt = reinterpret_cast<T*>(t.wt);
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    float v = 0.f;
+    if (co < t.Cout && ci < t.Cin) {
+      v = t.w[((size_t)co * t.taps + tap) * t.Cin + ci];
+      if (wp) Elt<T>::st(wp + ((size_t)co * t.taps + tap) * t.Cin + ci, v);
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  if (wt) {
+    for (int r = ty; r < 32; r += 8) {
+      const int ci = ci0 + r, co = co0 + tx;
+      if (co < t.Cout && ci < t.Cin) Elt<T>::st(wt + ((size_t)ci * t.taps + tap) * t.Cout + co, tile[tx][r]);
+    }
+  }
+}
+
 // Linear(25088,512): dir 0: torch fp32 [O][C*HW] -> packed T [O][HW*C] (+ transposed T [HW*C][O])
 //                    dir 1: packed fp32 grad [O][HW*C] -> torch fp32 grad [O][C*HW]
 template <typename T>
@@ -546,17 +576,20 @@ __global__ void permute_linear_kernel(const float* __restrict__ in, T* __restric
   const long long total = (long long)O * C * HW;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    // i indexes the packed layout: o, hw, c  (c fastest)
-    const int c = (int)(i % C);
-    const int hw = (int)((i / C) % HW);
-    const int o = (int)(i / ((long long)C * HW));
-    const long long it = (long long)o * C * HW + (long long)c * HW + hw;  // torch layout index
     if (dir == 0) {
-      const float v = in[it];
+      // i indexes the packed layout (o, hw, c; c fastest): coalesced packed writes, HW-strided fp32 reads
+      const int c = (int)(i % C);
+      const int hw = (int)((i / C) % HW);
+      const int o = (int)(i / ((long long)C * HW));
+      const float v = in[(long long)o * C * HW + (long long)c * HW + hw];
       Elt<T>::st(out + i, v);
       if (wt) Elt<T>::st(wt + ((long long)hw * C + c) * O + o, v);
     } else {
-      gout[it] = in[i];
+      // i indexes the packed layout (o, hw, c; c fastest): coalesced reads of the packed gradient
+      const int c = (int)(i % C);
+      const int hw = (int)((i / C) % HW);
+      const int o = (int)(i / ((long long)C * HW));
+      gout[(long long)o * C * HW + (long long)c * HW + hw] = in[i];
     }
   }
 }
@@ -777,6 +810,19 @@ extern "C" int fr_pack_weight(const float* w, void* wp, void* wt, int Cout, int 
              hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, grid, dim3(256), 0, st, w, (bf16_t*)wp, (bf16_t*)wt,
                                 Cout, taps, Cin),
              "fr_pack_weight");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_pack_weights_multi(const FrPackTensor* table_dev, const int32_t* chunks_dev, int nchunks, int dtype,
+                                     void* stream) {
+  if (nchunks <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(pack_weights_multi_kernel<float>, dim3(nchunks), dim3(256), 0, st, table_dev,
+                                (const int2*)chunks_dev),
+             hipLaunchKernelGGL(pack_weights_multi_kernel<bf16_t>, dim3(nchunks), dim3(256), 0, st, table_dev,
+                                (const int2*)chunks_dev),
+             "fr_pack_weights_multi");
   FR_LAUNCH_CHECK();
 }
 

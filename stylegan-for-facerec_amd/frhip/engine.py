@@ -355,6 +355,7 @@ class BackbonePlan(object):
         B, S, st, fr = self.B, self.S, self.stream, self.fr
         P = []  # weight packing (runs every step: master weights change)
         L = []
+        self._pack_reqs = []  # (master, wp|None, wt|None, Cout, taps, Cin) -> one multi-tensor launch
         sc, sb, sp = self.stem
         # ---- stem: im2col -> GEMM(+stats) -> BN+PReLU apply (+stats for unit 0's BN1)
         w0 = sc.weight
@@ -378,12 +379,12 @@ class BackbonePlan(object):
             rin, rout = B * u.H * u.H, B * u.Ho * u.Ho
             w1, w2 = self._conv_master(u.conv1), self._conv_master(u.conv2)
             if fr == FR_BF16:
-                P.append(ops.call("fr_pack_weight", w1, d["wp1"], d["wt1"], u.depth, 9, u.cin, fr, st))
-                P.append(ops.call("fr_pack_weight", w2, d["wp2"], d["wt2"], u.depth, 9, u.depth, fr, st))
+                self._pack_reqs.append((w1, d["wp1"], d["wt1"], u.depth, 9, u.cin))
+                self._pack_reqs.append((w2, d["wp2"], d["wt2"], u.depth, 9, u.depth))
                 wp1, wp2 = d["wp1"], d["wp2"]
             else:
-                P.append(ops.call("fr_pack_weight", w1, None, d["wt1"], u.depth, 9, u.cin, fr, st))
-                P.append(ops.call("fr_pack_weight", w2, None, d["wt2"], u.depth, 9, u.depth, fr, st))
+                self._pack_reqs.append((w1, None, d["wt1"], u.depth, 9, u.cin))
+                self._pack_reqs.append((w2, None, d["wt2"], u.depth, 9, u.depth))
                 wp1, wp2 = w1, w2
             bn1, bn2 = d["bn1"], d["bn2"]
             self._conv(L, src=x, w=wp1, out=d["y1"], B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H, SC=u.cin,
@@ -397,10 +398,10 @@ class BackbonePlan(object):
             if u.sc_conv is not None:
                 ws = self._conv_master(u.sc_conv)
                 if fr == FR_BF16:
-                    P.append(ops.call("fr_pack_weight", ws, d["wpS"], d["wtS"], u.depth, 1, u.cin, fr, st))
+                    self._pack_reqs.append((ws, d["wpS"], d["wtS"], u.depth, 1, u.cin))
                     wps = d["wpS"]
                 else:
-                    P.append(ops.call("fr_pack_weight", ws, None, d["wtS"], u.depth, 1, u.cin, fr, st))
+                    self._pack_reqs.append((ws, None, d["wtS"], u.depth, 1, u.cin))
                     wps = ws
                 L.append(ops.conv(st, fr, src=x, w=wps, out=d["yS"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H, SC=u.cin,
                                   N=u.depth, KH=1, KW=1, stride=u.stride, pad=0, mode=0, lda=u.cin, ldc=u.depth,
@@ -445,7 +446,24 @@ class BackbonePlan(object):
         self._bn_train_launches(L, self.bn1d, self.part, nbf, B)
         L.append(ops.bn_apply(st, FR_F32, x=self.f, out=self.feat, scale=self.bn1d.scale, shift=self.bn1d.shift, B=B,
                               H=1, W=1, C=512, res_kind=0, res_stride=1, nblocks=nbf))
+        P.append(self._pack_launch())
         self.pack_list, self.fwd_list = P, L
+
+    def _pack_launch(self):
+        """One launch that writes the compute-dtype and transposed copies of every conv weight of the network."""
+        n = len(self._pack_reqs)
+        arr = (_lib.FrPackTensor * n)()
+        chunks = []
+        for i, (w, wp, wt, cout, taps, cin) in enumerate(self._pack_reqs):
+            arr[i].w, arr[i].wp, arr[i].wt = w.data_ptr(), (wp.data_ptr() if wp is not None else None), wt.data_ptr()
+            arr[i].Cout, arr[i].taps, arr[i].Cin = cout, taps, cin
+            tiles = taps * ((cout + 31) // 32) * ((cin + 31) // 32)
+            chunks.extend((i, t) for t in range(tiles))
+        self._pack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        self._pack_chunks = torch.tensor(chunks, dtype=torch.int32).reshape(-1).to(self.device)
+        table = ctypes.cast(ctypes.c_void_p(self._pack_table.data_ptr()), ctypes.POINTER(_lib.FrPackTensor))
+        return ops.Launch("fr_pack_weights_multi", [table, ops.ptr(self._pack_chunks), len(chunks), self.fr,
+                                                    self.stream], keep=(self._pack_reqs,))
 
     # ---- backward ----------------------------------------------------------------------------------
     def _reduce(self, L, nparts, K, C, o0, o1, o2=None):
@@ -757,6 +775,10 @@ class BackboneRunner(object):
         if x.shape[2] != S or x.shape[3] != S:
             raise _lib.FrhipError("frhip: expected %dx%d inputs, got %s" % (S, S, tuple(x.shape)))
         self._avg = None if avg_image is None else avg_image.to(x.device).contiguous().float()
+        have = x.shape[1] + (0 if self._avg is None else self._avg.shape[0])
+        if have != self.in_channels:
+            raise RuntimeError("frhip: the stem expects %d input channels, got %d from the batch%s" % (
+                self.in_channels, x.shape[1], "" if self._avg is None else " + %d from avg_image" % self._avg.shape[0]))
         params = [p for p in self.module.parameters()]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _BackboneFn.apply(self, x, *params)

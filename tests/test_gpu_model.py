@@ -179,3 +179,75 @@ def test_cpu_tensor_fails_loudly():
     m = IR_50([112, 112])
     with pytest.raises(FrhipError):
         m(torch.zeros(2, 3, 112, 112))
+
+
+@pytest.mark.parametrize("kind,batch", [("pSp", 5), ("IR_SE_101", 3)])
+def test_bf16_se_models_train_step(kind, batch):
+    """IR-SE variants (pSp 6-channel stem, IR-SE-101) on the bf16 path incl. the LDS-strip kernels and the SE kernels:
+    finite loss, every trainable parameter receives a finite, non-zero gradient, and features track the fp32 path."""
+    _need_gpu()
+    from head.metrics import CosFace
+    from loss.focal import FocalLoss
+    model, _ = build(kind)
+    model.train()
+    inner = model.encoder if kind == "pSp" else model
+    x = synth.uniform(16, "full.x", (batch, 3, 112, 112)).cuda()
+    label = synth.labels(16, "full.label", batch, 100).cuda()
+    with torch.no_grad():
+        f32 = model(x).clone()
+    inner.compute_dtype = torch.bfloat16
+    head = CosFace(512, 100, None).cuda()
+    feats = model(x)
+    loss, _ = FocalLoss()(head(feats, label), label)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    cos = torch.nn.functional.cosine_similarity(f32, feats.detach(), dim=1)
+    assert float(cos.min()) > 0.97, float(cos.min())
+    for n, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        if not n.endswith("output_layer.3.bias"):  # cancelled exactly by the BatchNorm1d that follows
+            assert float(p.grad.abs().sum()) > 0, n
+
+
+def test_eval_mode_forward_matches_oracle():
+    """Inference: BN on running statistics, dropout off (fp32 path vs the CPU oracle in eval mode)."""
+    _need_gpu()
+    from oracle import irse_ref as O
+    model, _ = build("IR_50")
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model.eval()
+    x = synth.uniform(16, "full.x", (3, 3, 112, 112))
+    with torch.no_grad():
+        got = model(x.cuda()).cpu()
+        ref = O.backbone_forward(sd, x, 50, False, bn_train=False)
+    assert float((got - ref).abs().max()) < 1e-3
+
+
+def test_wrong_channel_count_raises():
+    _need_gpu()
+    from backbone.restyle_psp import pSp
+    m = pSp(size=112).cuda()  # no avg_image: a 3-channel batch cannot feed the 6-channel stem
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 3, 112, 112, device="cuda"))
+
+
+def test_train_driver_runs_end_to_end(tmp_path):
+    """stylegan-for-facerec_amd/train.py on synthetic identities: config parsing, param groups, freeze logic,
+    fused SGD, checkpoint files with the reference's names."""
+    _need_gpu()
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stylegan-for-facerec_amd")
+    env = dict(os.environ, PYTHONPATH=root)
+    cmd = [sys.executable, "train.py", "--config", "configs/config_synthetic_smoke.py", "--synthetic", "12x10",
+           "--max-steps", "3"]
+    cfg_patch = ("import configs.config_synthetic_smoke as c; c.configurations[1].update(BATCH_SIZE=20, "
+                 "MODEL_ROOT=r'%s', LOG_ROOT=r'%s')" % (tmp_path / "model", tmp_path / "log"))
+    code = ("import sys, runpy; sys.argv=%r; %s; runpy.run_path('train.py', run_name='__main__')" % (cmd[1:], cfg_patch))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    files = sorted(os.listdir(tmp_path / "model"))
+    assert any(f.startswith("Backbone_IR_50_ReStyle_Epoch_1_Batch_3_") for f in files), files
+    assert any(f.startswith("Head_ArcFace_Epoch_1_") for f in files) and any(f.startswith("Optimizer_ArcFace_") for f in files)
+    assert "Training Loss" in out.stdout
