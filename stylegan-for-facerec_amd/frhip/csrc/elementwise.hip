@@ -170,9 +170,10 @@ __global__ __launch_bounds__(NT) void channel_stats_kernel(const T* __restrict__
   float acc[2][VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = 0.f;
-  for (long long r = (long long)blockIdx.x * rtc + rt; r < rows; r += (long long)gridDim.x * rtc) {
+  const int nrows = (int)rows, rstep = gridDim.x * rtc;
+  for (int r = blockIdx.x * rtc + rt; r < nrows; r += rstep) {
     float f[VEC];
-    unpack16<T>(ld16(x + r * C + cc * VEC), f);
+    unpack16<T>(ld16(x + (size_t)r * C + cc * VEC), f);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       acc[0][j] += f[j];
@@ -207,10 +208,12 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const FrApplyArgs p) {
   for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = 0.f;
   const long long rows = (long long)p.B * p.H * p.W;
   const int HW = p.H * p.W;
-  for (long long r = (long long)blockIdx.x * rtc + rt; r < rows; r += (long long)gridDim.x * rtc) {
+  const bool need_b = p.se != nullptr || (p.res_kind == 1 && p.res_stride > 1);
+  const int nrows = (int)rows, rstep = gridDim.x * rtc;  // rows < 2^31: 32-bit row arithmetic (64-bit divides are slow)
+  for (int r = blockIdx.x * rtc + rt; r < nrows; r += rstep) {
     float f[VEC];
-    unpack16<T>(ld16(x + r * C + c0), f);
-    const int b = (int)(r / HW);
+    unpack16<T>(ld16(x + (size_t)r * C + c0), f);
+    const int b = need_b ? r / HW : 0;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) f[j] = fmaf(f[j], sc[j], sh[j]);
     if (p.se) {
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const FrApplyArgs p) {
     if (p.res_kind != 0) {
       long long rr = r;
       if (p.res_kind == 1 && p.res_stride > 1) {
-        const int rem = (int)(r - (long long)b * HW);
+        const int rem = r - b * HW;
         const int h = rem / p.W, w = rem - h * p.W;
         rr = ((long long)b * (p.H * p.res_stride) + (long long)h * p.res_stride) * (p.W * p.res_stride) +
              (long long)w * p.res_stride;
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const FrApplyArgs p) {
       for (int j = 0; j < VEC; ++j) f[j] += fmaf(g[j], rs[j], rh[j]);
     }
     const U128 o = pack16<T>(f);
-    st16(out + r * C + c0, o);
+    st16(out + (size_t)r * C + c0, o);
     if (p.part) {
       float q[VEC];
       unpack16<T>(o, q);  // statistics of what the next layer will actually read
@@ -292,11 +295,12 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const FrBnBwdArgs p) 
   float acc[3][VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.f;
-  for (long long r = (long long)blockIdx.x * rtc + rt; r < p.rows; r += (long long)gridDim.x * rtc) {
+  const int nrows = (int)p.rows, rstep = gridDim.x * rtc;
+  for (int r = blockIdx.x * rtc + rt; r < nrows; r += rstep) {
     float gv[VEC], xv[VEC], gp[VEC], st[VEC];
-    unpack16<T>(ld16(g + r * C + c0), gv);
-    unpack16<T>(ld16(x + r * C + c0), xv);
-    const int b = (int)(r / p.rows_per_image);
+    unpack16<T>(ld16(g + (size_t)r * C + c0), gv);
+    unpack16<T>(ld16(x + (size_t)r * C + c0), xv);
+    const int b = p.se ? r / p.rows_per_image : 0;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) st[j] = 0.f;
     bn_bwd_gprime<T>(p, gv, xv, b, c0, sc, sh, sl, gp, st);
@@ -331,23 +335,25 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const FrBnBwdArgs p) {
     a[j] = p.s0[c0 + j] * p.inv_count;
     bb[j] = p.s1[c0 + j] * p.inv_count;
   }
-  for (long long r = (long long)blockIdx.x * rtc + rt; r < p.rows; r += (long long)gridDim.x * rtc) {
+  const int nrows = (int)p.rows, rstep = gridDim.x * rtc;
+  const bool need_b = p.se != nullptr || p.add_kind == 2;
+  for (int r = blockIdx.x * rtc + rt; r < nrows; r += rstep) {
     float gv[VEC], xv[VEC], gp[VEC];
-    unpack16<T>(ld16(g + r * C + c0), gv);
-    unpack16<T>(ld16(x + r * C + c0), xv);
-    const int b = (int)(r / p.rows_per_image);
+    unpack16<T>(ld16(g + (size_t)r * C + c0), gv);
+    unpack16<T>(ld16(x + (size_t)r * C + c0), xv);
+    const int b = need_b ? r / p.rows_per_image : 0;
     bn_bwd_gprime<T>(p, gv, xv, b, c0, sc, sh, sl, gp, nullptr);
     float o[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) o[j] = coef[j] * (gp[j] - a[j] - (xv[j] - mu[j]) * is[j] * bb[j]);
     if (p.add_kind == 1) {
       float e[VEC];
-      unpack16<T>(ld16(add + r * C + c0), e);
+      unpack16<T>(ld16(add + (size_t)r * C + c0), e);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) o[j] += e[j];
     } else if (p.add_kind == 2) {
       // identity shortcut MaxPool2d(1, s): the gradient lands on pixels with h % s == 0 and w % s == 0
-      const int rem = (int)(r - (long long)b * p.rows_per_image);
+      const int rem = r - b * p.rows_per_image;
       const int h = rem / p.W, w = rem - h * p.W;
       const int s = p.add_stride;
       if (h % s == 0 && w % s == 0) {
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const FrBnBwdArgs p) {
         for (int j = 0; j < VEC; ++j) o[j] += e[j];
       }
     }
-    st16(gx + r * C + c0, pack16<T>(o));
+    st16(gx + (size_t)r * C + c0, pack16<T>(o));
   }
 }
 
