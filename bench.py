@@ -129,9 +129,18 @@ def instrumented_step(step, x, y, dtype_name):
     finally:
         ops.Launch.__call__ = orig_call
     fams = {}
+    detail = []
     for launch, e0, e1 in records:
         ms = e0.elapsed_time(e1)
         name, flops = launch.name, 0.0
+        if launch.name in ("fr_conv_igemm", "fr_conv_wgrad"):
+            a = launch.keep[0]
+            if launch.name == "fr_conv_igemm":
+                detail.append(("igemm M=%d N=%d K=%dx%d s%d mode%d pro%d epi%d splitk%d" % (
+                    a.B * a.RH * a.RW, a.N, a.KH * a.KW, a.SC, a.stride, a.mode, a.pro, a.epi, a.splitk), round(ms, 4)))
+            else:
+                detail.append(("wgrad P=%d Cout=%d taps%d Cin=%d s%d pro%d nsplit%d" % (
+                    a.B * a.GH * a.GW, a.Cout, a.KH * a.KW, a.SC, a.stride, a.pro, a.nsplit), round(ms, 4)))
         if launch.name == "fr_conv_igemm":
             a = launch.keep[0]
             name = "conv_igemm<%s,BN=%d,PRO=%d>" % (dtype_name if launch.args[1] == 1 else "f32",
@@ -155,6 +164,7 @@ def instrumented_step(step, x, y, dtype_name):
         f[0] += 1
         f[1] += ms
         f[2] += flops
+    instrumented_step.detail = detail
     return fams
 
 
@@ -220,12 +230,14 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback for the product path)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    force_dp = os.environ.get("FRHIP_FORCE_DP", "0") == "1"  # exercise the RCCL path with a single rank (tests)
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     model, head, loss_fn, opt, x, y = build_job(args, device, rank)
     dp = None
-    if world > 1:
+    if world > 1 or force_dp:
         from frhip.parallel import DataParallel
         dp = DataParallel(model, head)
     step = make_step(model, head, loss_fn, opt, dp)
@@ -272,8 +284,9 @@ def main():
             total_ms = sum(v[1] for v in fams.values())
             if args.kernel_table:
                 with open(args.kernel_table, "w") as f:
-                    json.dump({k: {"launches": v[0], "ms": round(v[1], 4), "tflops": round(v[2] / 1e12, 4)}
-                               for k, v in table}, f, indent=1)
+                    d = {k: {"launches": v[0], "ms": round(v[1], 4), "tflops": round(v[2] / 1e12, 4)} for k, v in table}
+                    d["_generic_gemm_launches"] = getattr(instrumented_step, "detail", [])
+                    json.dump(d, f, indent=1)
             if dom is not None:
                 name, (cnt, kms, flops) = dom
                 ach = flops / (kms * 1e-3) / 1e12
@@ -285,7 +298,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.classes)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

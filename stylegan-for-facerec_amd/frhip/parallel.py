@@ -18,6 +18,8 @@ ring, far below the backward time, so bucket size (32 MB default) is chosen for 
 The class is engine-agnostic (any flat arena + readiness callbacks), which is what the world_size-2 ``gloo`` tests
 on CPU exercise.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -27,6 +29,7 @@ class BucketedAllReduce(object):
         """arena: flat tensor; slices: [(param, offset, numel)] in readiness order, offsets increasing."""
         self.arena, self.group = arena, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = dist.is_initialized() and os.environ.get("FRHIP_FORCE_DP", "0") == "1"  # 1-rank self test
         self.avg_native = dist.is_initialized() and dist.get_backend(group) == "nccl"
         self.buckets = []  # (start, end, [param ids])
         start, ids, nbytes = 0, [], 0
@@ -51,7 +54,7 @@ class BucketedAllReduce(object):
         self.works = []
 
     def _launch(self, t):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.avg_native:
             self.works.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
