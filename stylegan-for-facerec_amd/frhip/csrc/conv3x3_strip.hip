@@ -19,15 +19,18 @@
 // Same reference arithmetic as fr_conv_igemm: Conv2d 3x3 s1 of bottleneck_IR (backbone/model_irse.py:57-59)
 // with BN apply (:57) or PReLU (:58) on the input, and its autograd data gradient (flip = 1: taps mirrored,
 // weights given as [Cin][tap][Cout]).
+#include <stdlib.h>
+
 #include "common.h"
 #include "frhip_internal.h"
 
 namespace {
 
-constexpr int NTH = 512;
 
-template <int CIN, int COUT, int W, int ROWS, int WN>
+template <int CIN, int COUT, int W, int ROWS, int WN, int NW>
 struct SC {
+  static constexpr int NTH = NW * 64;                      // 8 waves: one workgroup per CU; 4 waves: two co-resident
+                                                           // workgroups whose load / epilogue phases overlap each other's MFMAs
   static constexpr int H = W;
   static constexpr int GW = W + 2;
   static constexpr int GH = ROWS + 2;
@@ -39,7 +42,7 @@ struct SC {
   static constexpr int IMG_BYTES = GH * RSTR + 128;         // + slack for the ring's reads past the last chunk
   static constexpr int M = ROWS * W;
   static constexpr int MT = (M + 15) / 16;
-  static constexpr int WM = 8 / WN;
+  static constexpr int WM = NW / WN;
   static constexpr int TN = COUT / 16 / WN;
   static constexpr int TM = (MT + WM - 1) / WM;
   static constexpr int OSTR = COUT * 2 + 16;               // out-tile row stride, bytes
@@ -51,13 +54,14 @@ struct SC {
   static constexpr int MAXGRID = PF ? 1024 : (1 << 30);    // prefetching workgroups walk several strips each
   static_assert(H % ROWS == 0, "strip rows must divide the image");
   static_assert(NTH % CH == 0, "threads must be a multiple of the chunks per pixel");
-  static_assert(COUT % (16 * WN) == 0 && 8 % WN == 0, "bad wave split");
+  static_assert(COUT % (16 * WN) == 0 && NW % WN == 0, "bad wave split");
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-template <int CIN, int COUT, int W, int ROWS, int WN, int PRO>
-__global__ __launch_bounds__(NTH) void conv3x3_strip_kernel(const FrConvArgs p) {
-  using C = SC<CIN, COUT, W, ROWS, WN>;
+template <int CIN, int COUT, int W, int ROWS, int WN, int NW, int PRO>
+__global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvArgs p) {
+  using C = SC<CIN, COUT, W, ROWS, WN, NW>;
+  constexpr int NTH = C::NTH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: keeps the tile loops branch-free
@@ -323,54 +327,70 @@ __global__ __launch_bounds__(NTH) void conv3x3_strip_kernel(const FrConvArgs p) 
   }
 }
 
-template <int CIN, int COUT, int W, int ROWS, int WN, int PRO>
+template <int CIN, int COUT, int W, int ROWS, int WN, int NW, int PRO>
 int launch(const FrConvArgs& a, hipStream_t st) {
-  using C = SC<CIN, COUT, W, ROWS, WN>;
+  using C = SC<CIN, COUT, W, ROWS, WN, NW>;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, PRO>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, PRO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     attr_done = true;
   }
   const int strips = a.B * C::NS;
-  hipLaunchKernelGGL((conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, PRO>),
-                     dim3(strips < C::MAXGRID ? strips : C::MAXGRID), dim3(NTH), C::LDS, st, a);
+  hipLaunchKernelGGL((conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, PRO>),
+                     dim3(strips < C::MAXGRID ? strips : C::MAXGRID), dim3(C::NTH), C::LDS, st, a);
   FR_LAUNCH_CHECK();
 }
 
-template <int CIN, int COUT, int W, int ROWS, int WN>
+template <int CIN, int COUT, int W, int ROWS, int WN, int NW = 8>
 int by_pro(const FrConvArgs& a, hipStream_t st) {
   switch (a.pro) {
-    case FR_PRO_NONE: return launch<CIN, COUT, W, ROWS, WN, FR_PRO_NONE>(a, st);
-    case FR_PRO_BN: return launch<CIN, COUT, W, ROWS, WN, FR_PRO_BN>(a, st);
-    case FR_PRO_PRELU: return launch<CIN, COUT, W, ROWS, WN, FR_PRO_PRELU>(a, st);
+    case FR_PRO_NONE: return launch<CIN, COUT, W, ROWS, WN, NW, FR_PRO_NONE>(a, st);
+    case FR_PRO_BN: return launch<CIN, COUT, W, ROWS, WN, NW, FR_PRO_BN>(a, st);
+    case FR_PRO_PRELU: return launch<CIN, COUT, W, ROWS, WN, NW, FR_PRO_PRELU>(a, st);
   }
   return -1;
 }
 
 }  // namespace
 
+// Shape table.  Variant 1 (default) serves the 64- and 128-channel layers with 4-wave workgroups on shorter strips so
+// that two workgroups are resident per CU and overlap each other's load / epilogue phases; variant 0
+// (FRHIP_STRIP_VARIANT=0) is the one-workgroup-per-CU table.
+static int strip_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FRHIP_STRIP_VARIANT");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
+// rows per strip for a shape (0 = not served)
+static int strip_rows(int Cin, int Cout, int W) {
+  const bool v1 = strip_variant() == 1;
+#define SHAPE(ci, co, w, rows0, rows1) \
+  if (Cin == ci && Cout == co && W == w) return v1 ? rows1 : rows0;
+  SHAPE(64, 64, 112, 4, 2)
+  SHAPE(64, 64, 56, 7, 7)
+  SHAPE(64, 128, 56, 7, 7)
+  SHAPE(128, 64, 56, 7, 7)
+  SHAPE(128, 128, 28, 14, 7)
+  SHAPE(128, 256, 28, 7, 7)
+  SHAPE(256, 128, 28, 7, 7)
+  SHAPE(256, 256, 14, 14, 14)
+  SHAPE(256, 512, 14, 14, 14)
+  SHAPE(512, 256, 14, 7, 7)
+  SHAPE(512, 512, 7, 7, 7)
+#undef SHAPE
+  return 0;
+}
+
 // Number of partial rows the kernel writes into `part` (= workgroups) for a supported shape, 0 if unsupported.
 extern "C" int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi) {
   if (Cin == 256 && Cout == 512 && W == 14 && epi != FR_EPI_STORE) return 0;
-#define SHAPE(ci, co, w, rows)                \
-  if (Cin == ci && Cout == co && W == w) {   \
-    const int strips = B * (w / rows);       \
-    return ci == 64 && co == 64 && strips > 1024 ? 1024 : strips; \
-  }
-  SHAPE(64, 64, 112, 4)
-  SHAPE(64, 64, 56, 7)
-  SHAPE(64, 128, 56, 7)
-  SHAPE(128, 64, 56, 7)
-  SHAPE(128, 128, 28, 14)
-  SHAPE(128, 256, 28, 7)
-  SHAPE(256, 128, 28, 7)
-  SHAPE(256, 256, 14, 14)
-  SHAPE(256, 512, 14, 14)
-  SHAPE(512, 256, 14, 7)
-  SHAPE(512, 512, 7, 7)
-#undef SHAPE
-  return 0;
+  const int rows = strip_rows(Cin, Cout, W);
+  return rows ? B * (W / rows) : 0;
 }
 
 extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
@@ -380,29 +400,38 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
       a.out_f32 || a.splitk > 1 || a.bias || a.epi == FR_EPI_MARGIN || a.epi == FR_EPI_ATOMIC)
     FR_UNSUPPORTED("fr_conv3x3_strip: only square stride-1 3x3 bf16 convolutions");
   if (a.lda % 8 || a.ldc % 8 || (a.aux && a.ldaux % 8)) FR_UNSUPPORTED("fr_conv3x3_strip: strides must be 16-byte multiples");
-#define SHAPE(ci, co, w, rows, wn) \
-  if (a.SC == ci && a.N == co && a.SW == w) return by_pro<ci, co, w, rows, wn>(a, st);
-  SHAPE(64, 64, 112, 4, 2)
-  SHAPE(64, 64, 56, 7, 2)
-  SHAPE(64, 128, 56, 7, 4)
-  SHAPE(128, 64, 56, 7, 2)
-  SHAPE(128, 128, 28, 14, 4)
-  SHAPE(128, 256, 28, 7, 8)
-  SHAPE(256, 128, 28, 7, 4)
-  SHAPE(256, 256, 14, 14, 8)
-  SHAPE(512, 256, 14, 7, 8)
-  SHAPE(512, 512, 7, 7, 8)
+  const bool v1 = strip_variant() == 1;
+#define SHAPE(ci, co, w, rows, wn, nw) \
+  if (a.SC == ci && a.N == co && a.SW == w) return by_pro<ci, co, w, rows, wn, nw>(a, st);
+  if (v1) {  // measured (tools/kbench.py, B=256): 1.1-1.45x over the 8-wave instances at these three shapes
+    SHAPE(64, 64, 112, 2, 2, 4)
+    SHAPE(64, 64, 56, 7, 2, 4)
+    SHAPE(128, 128, 28, 7, 4, 4)
+  } else {
+    SHAPE(64, 64, 112, 4, 2, 8)
+    SHAPE(64, 64, 56, 7, 2, 8)
+    SHAPE(128, 128, 28, 14, 4, 8)
+  }
+  SHAPE(256, 256, 14, 14, 8, 8)  // 4-wave half-height strips lose here (0.10 vs 0.058 ms): register spills, 2x weights
+  SHAPE(64, 128, 56, 7, 4, 8)
+  SHAPE(128, 64, 56, 7, 2, 8)
+  SHAPE(128, 256, 28, 7, 8, 8)
+  SHAPE(256, 128, 28, 7, 4, 8)
+  SHAPE(512, 256, 14, 7, 8, 8)
+  SHAPE(512, 512, 7, 7, 8, 8)
 #undef SHAPE
   if (a.SC == 256 && a.N == 512 && a.SW == 14 && a.epi == FR_EPI_STORE) {
-    // 256 -> 512 @14 (one layer per network): two passes over 256 output channels each keep the accumulators of the
-    // 256x256 instance (no register spills); the strip is simply loaded twice
+    // 256 -> 512 @14 (one layer per network): two passes over 256 output channels each reuse the 256x256 instance
+    // (a 512-wide accumulator tile would spill); the strip is simply loaded twice
     FrConvArgs h = a;
     h.N = 256;
-    int rc = by_pro<256, 256, 14, 14, 8>(h, st);
-    if (rc) return rc;
-    h.w = reinterpret_cast<const bf16_t*>(a.w) + (size_t)256 * 9 * 256;
-    h.out = reinterpret_cast<bf16_t*>(a.out) + 256;
-    return by_pro<256, 256, 14, 14, 8>(h, st);
+    for (int half = 0; half < 2; ++half) {
+      h.w = reinterpret_cast<const bf16_t*>(a.w) + (size_t)half * 256 * 9 * 256;
+      h.out = reinterpret_cast<bf16_t*>(a.out) + half * 256;
+      const int rc = by_pro<256, 256, 14, 14, 8, 8>(h, st);
+      if (rc) return rc;
+    }
+    return 0;
   }
   FR_UNSUPPORTED("fr_conv3x3_strip: shape not in the strip table");
 }

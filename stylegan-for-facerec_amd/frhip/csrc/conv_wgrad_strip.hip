@@ -13,17 +13,20 @@
 //
 // Reference arithmetic: autograd weight gradient of Conv2d(c, d, (3,3), (1,1), 1) in bottleneck_IR
 // (backbone/model_irse.py:57-59) with BN apply (:57) / PReLU (:58) folded into the input load.
+#include <stdlib.h>
+
 #include "common.h"
 #include "frhip_internal.h"
 
 namespace {
 
-constexpr int NTH = 512;
 constexpr int CT = 64;               // co and ci tile
 constexpr int TSTR = CT * 2 + 32;    // LDS row stride (bytes) of both tiles: conflict-free transposed reads
 
-template <int W, int ROWS, int NIMG>
+template <int W, int ROWS, int NIMG, int NW>
 struct WC {
+  static constexpr int NTH = NW * 64;                 // 8 waves (2 co halves x 4 ci tiles) or 4 waves (4 ci tiles, all co)
+  static constexpr int TCO = 4 / (NW / 4);            // co tiles (16 wide) per wave
   static constexpr int H = W;
   static constexpr int GW = W + 2, GH = ROWS + 2;
   static constexpr int MI = ROWS * W;                 // output pixels per image strip
@@ -37,7 +40,9 @@ struct WC {
   static constexpr int NS = H / ROWS;                 // strips per image
   static constexpr int GCH = M * 8, ACH = APIX * 8;   // 16-B chunks per fill
   static constexpr int NLD = (GCH + ACH + NTH - 1) / NTH;
-  static constexpr int KUNR = NLD > 8 ? 1 : NKS;      // the wide strips keep more prefetch registers live
+  static constexpr bool PF = NW == 8;                 // 8 waves: register-prefetch the next strip; 4 waves: two
+                                                      // resident workgroups overlap each other instead
+  static constexpr int KUNR = (NLD > 8 || !PF) ? 1 : NKS;  // the wide strips keep more prefetch registers live
   static_assert(H % ROWS == 0, "strip rows must divide the image");
   static_assert(NIMG == 1 || ROWS == H, "several images per fill only for whole-image strips");
   static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -52,15 +57,17 @@ __device__ __forceinline__ s16x8 tr_frag(const char* p0, const char* p1) {
   return (s16x8){ai[0], ai[1], ai[2], ai[3], bi[0], bi[1], bi[2], bi[3]};
 }
 
-template <int W, int ROWS, int NIMG, int PRO>
-__global__ __launch_bounds__(NTH) void conv_wgrad_strip_kernel(const FrWgradArgs p) {
-  using C = WC<W, ROWS, NIMG>;
+template <int W, int ROWS, int NIMG, int NW, int PRO>
+__global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_strip_kernel(const FrWgradArgs p) {
+  using C = WC<W, ROWS, NIMG, NW>;
+  constexpr int NTH = C::NTH;
+  constexpr int TCO = C::TCO;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Gs = smem;
   char* As = smem + C::G_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wci = wave & 3, wco = wave >> 2;
+  const int wci = wave & 3, wco = wave >> 2;  // wco is 0 when NW == 4 (the wave then owns all four co tiles)
 
   // block -> (group, tile): consecutive logical ids (= all tiles of a group) share an XCD
   const int nblk = gridDim.x;
@@ -95,14 +102,15 @@ __global__ __launch_bounds__(NTH) void conv_wgrad_strip_kernel(const FrWgradArgs
     }
   }
 
-  U128 ld[C::NLD];
-  bool okv[C::NLD];
+  constexpr int NPF = C::PF ? C::NLD : 1;
+  U128 ld[NPF];
+  bool okv[NPF];
   auto issue = [&](int f) {
     // fill f covers images [img0, img0+NIMG) (whole images) or one strip of one image
     const int img0 = NIMG > 1 ? f * NIMG : f / C::NS;
     const int row0 = NIMG > 1 ? 0 : (f - img0 * C::NS) * ROWS;
 #pragma unroll
-    for (int u = 0; u < C::NLD; ++u) {
+    for (int u = 0; u < NPF; ++u) {
       const int idx = u * NTH + tid;
       const int c = idx >> 3;
       bool ok = false;
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(NTH) void conv_wgrad_strip_kernel(const FrWgradArgs
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int u = 0; u < C::NLD; ++u) {
+    for (int u = 0; u < NPF; ++u) {
       const int idx = u * NTH + tid;
       const int c = idx >> 3;
       if (idx < C::GCH) {
@@ -148,28 +156,82 @@ __global__ __launch_bounds__(NTH) void conv_wgrad_strip_kernel(const FrWgradArgs
     }
   };
 
-  f32x4 acc[2][9];
+  auto load_now = [&](int f) {  // !PF: stream the strip through 8 registers at a time
+    const int img0 = NIMG > 1 ? f * NIMG : f / C::NS;
+    const int row0 = NIMG > 1 ? 0 : (f - img0 * C::NS) * ROWS;
+    constexpr int UNR = 8;
+    for (int base = 0; base < C::GCH + C::ACH; base += NTH * UNR) {
+      U128 v[UNR];
+      bool ok[UNR];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+      for (int u = 0; u < UNR; ++u) {
+        const int idx = base + u * NTH + tid;
+        const int c = idx >> 3;
+        ok[u] = false;
+        const bf16_t* src = G;
+        if (idx < C::GCH) {
+          const int im = c / C::MI, r = c - im * C::MI;
+          const int b = img0 + im;
+          ok[u] = b < p.B;
+          src = G + ((size_t)(b * C::H + row0) * W + r) * (size_t)p.ldg + cot * CT + ch * 8;
+        } else if (idx < C::GCH + C::ACH) {
+          const int a = c - C::M;
+          const int im = a / (C::GH * C::GW), r = a - im * (C::GH * C::GW);
+          const int gh = r / C::GW, gw = r - gh * C::GW;
+          const int b = img0 + im, h = row0 + gh - 1, w = gw - 1;
+          ok[u] = b < p.B && (unsigned)h < (unsigned)C::H && (unsigned)w < (unsigned)W;
+          src = X + ((size_t)(b * C::H + h) * W + w) * (size_t)p.lda + cit * CT + ch * 8;
+        }
+        v[u] = ok[u] ? ld16(src) : zero16();
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int idx = base + u * NTH + tid;
+        const int c = idx >> 3;
+        if (idx < C::GCH) {
+          st16(Gs + c * TSTR + ch * 16, v[u]);
+        } else if (idx < C::GCH + C::ACH) {
+          U128 x = v[u];
+          if (PRO != FR_PRO_NONE && ok[u]) {
+            float fl[8];
+            unpack16<bf16_t>(x, fl);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if (PRO == FR_PRO_BN) fl[j] = fmaf(fl[j], pa[j], pb[j]);
+              else fl[j] = fl[j] > 0.f ? fl[j] : fl[j] * pa[j];
+            }
+            x = pack16<bf16_t>(fl);
+          }
+          st16(As + (c - C::M) * TSTR + ch * 16, x);
+        }
+      }
+    }
+  };
+
+  f32x4 acc[TCO][9];
+#pragma unroll
+  for (int t = 0; t < TCO; ++t)
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[t][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int li = lane & 15, lq = lane >> 4;
   const int colb = (4 * (li & 3)) * 2;  // byte offset of this lane's 4-channel group inside a 16-channel tile
-  if (f_begin < f_end) issue(f_begin);
+  if (C::PF && f_begin < f_end) issue(f_begin);
   for (int f = f_begin; f < f_end; ++f) {
     __syncthreads();  // previous strip fully consumed
-    commit();
+    if (C::PF) commit();
+    else load_now(f);
     __syncthreads();
-    if (f + 1 < f_end) issue(f + 1);  // next strip's loads fly under this strip's MFMAs
+    if (C::PF && f + 1 < f_end) issue(f + 1);  // next strip's loads fly under this strip's MFMAs
     // fully unrolled where registers allow (reads of step k+1 are then scheduled under the MFMAs of step k)
 #pragma unroll C::KUNR
     for (int ks = 0; ks < C::NKS; ++ks) {
       const int m0 = ks * 32 + 4 * lq + (li >> 2), m1 = m0 + 16;
       const char* g0 = Gs + m0 * TSTR + (wco * 32) * 2 + colb;
       const char* g1 = Gs + m1 * TSTR + (wco * 32) * 2 + colb;
-      const s16x8 gf0 = tr_frag(g0, g1);
-      const s16x8 gf1 = tr_frag(g0 + 32, g1 + 32);
+      s16x8 gf[TCO];
+#pragma unroll
+      for (int t = 0; t < TCO; ++t) gf[t] = tr_frag(g0 + t * 32, g1 + t * 32);
       const char* a01[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -183,8 +245,9 @@ __global__ __launch_bounds__(NTH) void conv_wgrad_strip_kernel(const FrWgradArgs
       for (int tap = 0; tap < 9; ++tap) {
         const int off = ((tap / 3) * C::GW + (tap % 3)) * TSTR;
         const s16x8 af = tr_frag(a01[0] + off, a01[1] + off);
-        acc[0][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf0, af, acc[0][tap], 0, 0, 0);
-        acc[1][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf1, af, acc[1][tap], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TCO; ++t)
+          acc[t][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[t], af, acc[t][tap], 0, 0, 0);
       }
     }
   }
@@ -192,7 +255,7 @@ __global__ __launch_bounds__(NTH) void conv_wgrad_strip_kernel(const FrWgradArgs
   // slab[group][co][tap][ci]
   float* __restrict__ slab = p.slab + (size_t)group * (size_t)p.Cout * 9 * (size_t)p.SC;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < TCO; ++t)
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -215,17 +278,18 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slab, int groups, 
   }
 }
 
-template <int W, int ROWS, int NIMG, int PRO>
+template <int W, int ROWS, int NIMG, int NW, int PRO>
 int launch(const FrWgradArgs& a, hipStream_t st) {
-  using C = WC<W, ROWS, NIMG>;
+  using C = WC<W, ROWS, NIMG, NW>;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<W, ROWS, NIMG, PRO>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<W, ROWS, NIMG, NW, PRO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     attr_done = true;
   }
   const int tiles = (a.Cout / CT) * (a.SC / CT);
-  hipLaunchKernelGGL((conv_wgrad_strip_kernel<W, ROWS, NIMG, PRO>), dim3(tiles * a.nsplit), dim3(NTH), C::LDS, st, a);
+  hipLaunchKernelGGL((conv_wgrad_strip_kernel<W, ROWS, NIMG, NW, PRO>), dim3(tiles * a.nsplit), dim3(C::NTH), C::LDS, st,
+                     a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     fr_set_error(hipGetErrorString(e));
@@ -238,12 +302,12 @@ int launch(const FrWgradArgs& a, hipStream_t st) {
   FR_LAUNCH_CHECK();
 }
 
-template <int W, int ROWS, int NIMG>
+template <int W, int ROWS, int NIMG, int NW>
 int by_pro(const FrWgradArgs& a, hipStream_t st) {
   switch (a.pro) {
-    case FR_PRO_NONE: return launch<W, ROWS, NIMG, FR_PRO_NONE>(a, st);
-    case FR_PRO_BN: return launch<W, ROWS, NIMG, FR_PRO_BN>(a, st);
-    case FR_PRO_PRELU: return launch<W, ROWS, NIMG, FR_PRO_PRELU>(a, st);
+    case FR_PRO_NONE: return launch<W, ROWS, NIMG, NW, FR_PRO_NONE>(a, st);
+    case FR_PRO_BN: return launch<W, ROWS, NIMG, NW, FR_PRO_BN>(a, st);
+    case FR_PRO_PRELU: return launch<W, ROWS, NIMG, NW, FR_PRO_PRELU>(a, st);
   }
   return -1;
 }
@@ -263,12 +327,14 @@ extern "C" int fr_conv_wgrad_strip(const FrWgradArgs* args, void* stream) {
       !fr_conv_wgrad_strip_supported(a.Cout, a.SC, a.SW))
     FR_UNSUPPORTED("fr_conv_wgrad_strip: only square stride-1 3x3 bf16 convolutions with 64-multiple channels");
   if (a.ldg % 8 || a.lda % 8 || !a.slab || a.nsplit < 1) FR_UNSUPPORTED("fr_conv_wgrad_strip: bad strides / slab");
+  // 4-wave workgroups (two resident per CU, NW = 4) were measured at about half the throughput of the 8-wave form
+  // with register prefetch (tools/kbench.py, B = 256) and are not instantiated.
   switch (a.SW) {
-    case 112: return by_pro<112, 2, 1>(a, st);
-    case 56: return by_pro<56, 4, 1>(a, st);
-    case 28: return by_pro<28, 7, 1>(a, st);
-    case 14: return by_pro<14, 14, 1>(a, st);
-    case 7: return by_pro<7, 7, 4>(a, st);
+    case 112: return by_pro<112, 2, 1, 8>(a, st);
+    case 56: return by_pro<56, 4, 1, 8>(a, st);
+    case 28: return by_pro<28, 7, 1, 8>(a, st);
+    case 14: return by_pro<14, 14, 1, 8>(a, st);
+    case 7: return by_pro<7, 7, 4, 8>(a, st);
   }
   FR_UNSUPPORTED("fr_conv_wgrad_strip: width not in the strip table");
 }
