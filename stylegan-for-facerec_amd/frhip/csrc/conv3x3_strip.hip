@@ -58,7 +58,7 @@ struct SC {
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-template <int CIN, int COUT, int W, int ROWS, int WN, int NW, int PRO>
+template <int CIN, int COUT, int W, int ROWS, int WN, int NW, int NSPL, int PRO>
 __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvArgs p) {
   using C = SC<CIN, COUT, W, ROWS, WN, NW>;
   constexpr int NTH = C::NTH;
@@ -74,9 +74,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
   // channels the strip is small enough to keep the NEXT strip's 16-B chunks in registers while this one computes,
   // so the HBM fetch of strip s+1 overlaps the MFMAs and the epilogue of strip s.
   constexpr bool PREFETCH = C::PF;
+  // NSPL > 1: the output channels are split over NSPL workgroups per strip (COUT is the per-workgroup width); keeps
+  // the accumulator tile small enough for two co-resident 4-wave workgroups per CU
+  static_assert(NSPL == 1 || !C::PF, "N split only without strip prefetch");
+  const int nh = NSPL > 1 ? blockIdx.x % NSPL : 0;
+  const int ncol0 = nh * COUT;
+  const int sblk = NSPL > 1 ? blockIdx.x / NSPL : blockIdx.x;
   const int total = p.B * C::NS;
   const int per = PREFETCH ? (total + gridDim.x - 1) / gridDim.x : 1;  // without prefetch: one strip per workgroup
-  const int s_begin = blockIdx.x * per;
+  const int s_begin = sblk * per;
   const int s_end = PREFETCH ? (s_begin + per < total ? s_begin + per : total) : s_begin + 1;
 
   constexpr int WP = W + 2;
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
   const int n0 = wn * C::TN * 16;
   const bf16_t* wrow[C::TN];
 #pragma unroll
-  for (int j = 0; j < C::TN; ++j) wrow[j] = wgt + (size_t)(n0 + j * 16 + fr) * 9 * CIN + fq * 8;
+  for (int j = 0; j < C::TN; ++j) wrow[j] = wgt + (size_t)(ncol0 + n0 + j * 16 + fr) * 9 * CIN + fq * 8;
   const int flip = p.mode;
   const int epi = p.epi;
   const bool stats = epi == FR_EPI_STATS || epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD;
@@ -253,14 +259,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
       const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
       for (int idx = tid; idx < C::M * OCH; idx += NTH) {
         const int r = idx / OCH, c8 = idx - r * OCH;
-        st16(smem + r * C::OSTR + c8 * 16, ld16(aux + (rowbase + r) * (size_t)p.ldaux + c8 * 8));
+        st16(smem + r * C::OSTR + c8 * 16, ld16(aux + (rowbase + r) * (size_t)p.ldaux + ncol0 + c8 * 8));
       }
       __syncthreads();
     }
     float ea[C::TN], eb[C::TN];
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) {
-      const int n = n0 + j * 16 + fr;
+      const int n = ncol0 + n0 + j * 16 + fr;
       ea[j] = (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD) ? p.epi_a[n] : 0.f;
       eb[j] = (epi == FR_EPI_BNBWD) ? p.epi_b[n] : 0.f;
     }
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
     __syncthreads();
     for (int idx = tid; idx < C::M * OCH; idx += NTH) {
       const int r = idx / OCH, c8 = idx - r * OCH;
-      st16(out + (rowbase + r) * (size_t)p.ldc + c8 * 8, ld16(smem + r * C::OSTR + c8 * 16));
+      st16(out + (rowbase + r) * (size_t)p.ldc + ncol0 + c8 * 8, ld16(smem + r * C::OSTR + c8 * 16));
     }
   }
 
@@ -322,32 +328,32 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
       float t = 0.f;
 #pragma unroll
       for (int g = 0; g < C::WM; ++g) t += red[(g * 2 + k) * COUT + n];
-      p.part[((size_t)blockIdx.x * 2 + k) * COUT + n] = t;
+      p.part[((size_t)sblk * 2 + k) * (COUT * NSPL) + ncol0 + n] = t;
     }
   }
 }
 
-template <int CIN, int COUT, int W, int ROWS, int WN, int NW, int PRO>
+template <int CIN, int COUT, int W, int ROWS, int WN, int NW, int NSPL, int PRO>
 int launch(const FrConvArgs& a, hipStream_t st) {
   using C = SC<CIN, COUT, W, ROWS, WN, NW>;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, PRO>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, NSPL, PRO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     attr_done = true;
   }
   const int strips = a.B * C::NS;
-  hipLaunchKernelGGL((conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, PRO>),
-                     dim3(strips < C::MAXGRID ? strips : C::MAXGRID), dim3(C::NTH), C::LDS, st, a);
+  hipLaunchKernelGGL((conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, NSPL, PRO>),
+                     dim3((strips < C::MAXGRID ? strips : C::MAXGRID) * NSPL), dim3(C::NTH), C::LDS, st, a);
   FR_LAUNCH_CHECK();
 }
 
-template <int CIN, int COUT, int W, int ROWS, int WN, int NW = 8>
+template <int CIN, int COUT, int W, int ROWS, int WN, int NW = 8, int NSPL = 1>
 int by_pro(const FrConvArgs& a, hipStream_t st) {
   switch (a.pro) {
-    case FR_PRO_NONE: return launch<CIN, COUT, W, ROWS, WN, NW, FR_PRO_NONE>(a, st);
-    case FR_PRO_BN: return launch<CIN, COUT, W, ROWS, WN, NW, FR_PRO_BN>(a, st);
-    case FR_PRO_PRELU: return launch<CIN, COUT, W, ROWS, WN, NW, FR_PRO_PRELU>(a, st);
+    case FR_PRO_NONE: return launch<CIN, COUT, W, ROWS, WN, NW, NSPL, FR_PRO_NONE>(a, st);
+    case FR_PRO_BN: return launch<CIN, COUT, W, ROWS, WN, NW, NSPL, FR_PRO_BN>(a, st);
+    case FR_PRO_PRELU: return launch<CIN, COUT, W, ROWS, WN, NW, NSPL, FR_PRO_PRELU>(a, st);
   }
   return -1;
 }
@@ -368,7 +374,7 @@ static int strip_variant() {
 
 // rows per strip for a shape (0 = not served)
 static int strip_rows(int Cin, int Cout, int W) {
-  const bool v1 = strip_variant() == 1;
+  const bool v1 = strip_variant() >= 1;
 #define SHAPE(ci, co, w, rows0, rows1) \
   if (Cin == ci && Cout == co && W == w) return v1 ? rows1 : rows0;
   SHAPE(64, 64, 112, 4, 2)
@@ -400,7 +406,7 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
       a.out_f32 || a.splitk > 1 || a.bias || a.epi == FR_EPI_MARGIN || a.epi == FR_EPI_ATOMIC)
     FR_UNSUPPORTED("fr_conv3x3_strip: only square stride-1 3x3 bf16 convolutions");
   if (a.lda % 8 || a.ldc % 8 || (a.aux && a.ldaux % 8)) FR_UNSUPPORTED("fr_conv3x3_strip: strides must be 16-byte multiples");
-  const bool v1 = strip_variant() == 1;
+  const bool v1 = strip_variant() >= 1;
 #define SHAPE(ci, co, w, rows, wn, nw) \
   if (a.SC == ci && a.N == co && a.SW == w) return by_pro<ci, co, w, rows, wn, nw>(a, st);
   if (v1) {  // measured (tools/kbench.py, B=256): 1.1-1.45x over the 8-wave instances at these three shapes
@@ -412,7 +418,10 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
     SHAPE(64, 64, 56, 7, 2, 8)
     SHAPE(128, 128, 28, 14, 4, 8)
   }
-  SHAPE(256, 256, 14, 14, 8, 8)  // 4-wave half-height strips lose here (0.10 vs 0.058 ms): register spills, 2x weights
+  // 256 -> 256 @14 (half of all FLOPs): 8 waves x (13 x 2) accumulator tiles on the whole image.  Measured and rejected
+  // at B=256 (tools/kbench.py): 4-wave half-height strips 0.101 ms, the same with the channels split over two
+  // workgroups (NSPL = 2, no spills) 0.093 ms, 8 waves x (7 x 4) tiles 0.114 ms (spills) -- against 0.062 ms here.
+  SHAPE(256, 256, 14, 14, 8, 8)
   SHAPE(64, 128, 56, 7, 4, 8)
   SHAPE(128, 64, 56, 7, 2, 8)
   SHAPE(128, 256, 28, 7, 8, 8)
