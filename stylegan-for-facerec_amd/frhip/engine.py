@@ -681,9 +681,7 @@ class BackbonePlan(object):
         B, S = self.B, self.S
         st = self.stream
         avg = avg_image
-        rc = _lib.lib.fr_stem_im2col(ops.ptr(x), ops.ptr(avg), ops.ptr(self.X0), B, S, S, self.in_channels,
-                                     self.avg_channels, self.K0, self.fr, st)
-        _lib.check(rc, "fr_stem_im2col")
+        ops.call("fr_stem_im2col", x, avg, self.X0, B, S, S, self.in_channels, self.avg_channels, self.K0, self.fr, st)()
         od = self.out[1]
         p = float(od.p) if od.training else 0.0
         self.l_drop_fwd.args[7] = p

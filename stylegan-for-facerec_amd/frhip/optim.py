@@ -79,9 +79,8 @@ class SGD(torch.optim.Optimizer):
                 continue
             raw, ch, n = tab
             table = ctypes.cast(ctypes.c_void_p(raw.data_ptr()), ctypes.POINTER(_lib.FrSgdTensor))  # device array
-            rc = _lib.lib.fr_sgd_step(table, ctypes.c_void_p(ch.data_ptr()), n,
-                                      float(group["lr"]), float(group["momentum"]), st)
-            _lib.check(rc, "fr_sgd_step")
+            ops.Launch("fr_sgd_step", [table, ctypes.c_void_p(ch.data_ptr()), n, float(group["lr"]),
+                                       float(group["momentum"]), st])()
         return loss
 
 
