@@ -35,10 +35,16 @@ struct SC {
   static constexpr int GW = W + 2;
   static constexpr int GH = ROWS + 2;
   static constexpr int CH = CIN / 8;                       // 16-B chunks per pixel
-  static constexpr int PSTR = CIN * 2 + 16;                // padded pixel stride: odd number of 16-B slots
-  // row stride: + 224 B so that the 16-B slot index keeps counting across an image-row wrap (slot(h+1, 0) ==
-  // slot(h, W) mod 16): 16 consecutive output pixels of an M tile then always hit 16 different bank groups
-  static constexpr int RSTR = GW * PSTR + 224;
+  // Pixel stride = CIN*2 + 32 B: an even number of 16-B slots per pixel, so within every hardware lane group of a
+  // ds_read_b128 the 8 rows that read k-chunk q=0/2 land on even slots and the 8 rows reading q=1/3 (+16 B) on odd
+  // slots -- measured conflict-free (tools/lds_probe.hip: 6.9 cycles vs 8.0 for CIN*2+16 and 32 for CIN*2).
+  // (64-channel strips keep the 16-B pad: the extra 16 B per pixel would push the 56x56 strip past 80 KB and cost the
+  // second resident workgroup, which is worth far more there than the 15 % on LDS reads.)
+  static constexpr int PPAD = CIN == 64 ? 16 : 32;
+  static constexpr int PSTR = CIN * 2 + PPAD;
+  // Row stride: + 192 B so that the slot index keeps counting across an image-row wrap (slot(h+1, 0) == slot(h, W)
+  // mod 16): the 16 consecutive output pixels of an M tile behave like 16 consecutive pixels of one row.
+  static constexpr int RSTR = GW * PSTR + (PPAD == 32 ? 192 : 224);
   static constexpr int IMG_BYTES = GH * RSTR + 128;         // + slack for the ring's reads past the last chunk
   static constexpr int M = ROWS * W;
   static constexpr int MT = (M + 15) / 16;
