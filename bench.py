@@ -278,6 +278,10 @@ def main():
         flops_img = IR50_FLOPS_PER_IMG + 6.0 * 512 * args.classes
         step_tflops = flops_img * ips / world / 1e12
         if not args.no_roofline:
+            # per-kernel timing needs the weight gradients back on the main stream (no co-running kernels)
+            model._runner[0].single_stream = True
+            step(x, y)
+            torch.cuda.synchronize()
             fams = instrumented_step(step, x, y, args.dtype)
             table = sorted(fams.items(), key=lambda kv: -kv[1][1])
             dom = next(((k, v) for k, v in table if v[2] > 0), None)

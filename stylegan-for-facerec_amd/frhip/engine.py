@@ -155,11 +155,33 @@ def _wgrad_slices(pixels, tiles):
     return int(max(1, min(want, 256, pixels // 256 if pixels >= 256 else 1)))
 
 
+class _EvRecord(object):
+    """List entry: record an event on a stream (weight-gradient side stream bookkeeping)."""
+    __slots__ = ("ev", "stream")
+
+    def __init__(self, ev, stream):
+        self.ev, self.stream = ev, stream
+
+    def __call__(self):
+        self.ev.record(self.stream)
+
+
+class _EvWait(object):
+    """List entry: make a stream wait for an event."""
+    __slots__ = ("ev", "stream")
+
+    def __init__(self, stream, ev):
+        self.ev, self.stream = ev, stream
+
+    def __call__(self):
+        self.stream.wait_event(self.ev)
+
+
 # ------------------------------------------------------------------------------------------------ the plan
 
 
 class BackbonePlan(object):
-    def __init__(self, module, B, dtype, device, in_channels, avg_channels):
+    def __init__(self, module, B, dtype, device, in_channels, avg_channels, single_stream=False):
         self.module, self.B, self.device = module, B, device
         self.tdtype = dtype
         self.fr = FR_F32 if dtype == torch.float32 else FR_BF16
@@ -167,7 +189,14 @@ class BackbonePlan(object):
         self.stem, self.units, self.out = describe(module)
         self.in_channels, self.avg_channels = in_channels, avg_channels
         self.stream = ops.current_stream_ptr()
-        self.stream_id = torch.cuda.current_stream().cuda_stream
+        self.stream1_t = torch.cuda.current_stream()
+        self.stream_id = self.stream1_t.cuda_stream
+        # Weight gradients feed nothing downstream in backward, so they run on a side stream: an MFMA-bound wgrad
+        # kernel and the HBM-bound BN-backward / residual passes of the next unit then share the CUs (measured with
+        # tools/overlap_probe.py: ~2/3 of an elementwise pass hides under a wgrad strip kernel).
+        self.dual = os.environ.get("FRHIP_SINGLE_STREAM", "0") != "1" and not single_stream
+        self.stream2_t = torch.cuda.Stream(device=device) if self.dual else self.stream1_t
+        self.stream2 = ctypes.c_void_p(self.stream2_t.cuda_stream)
         self.S = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
         self.generation = 0
         self.use_strip = os.environ.get("FRHIP_NO_STRIP", "0") != "1"
@@ -239,9 +268,13 @@ class BackbonePlan(object):
         self.gWlin = torch.zeros(512, self.feat_in, device=dev)
         # backward scratch (sized for the largest unit)
         self.g_pp = [self._act(max_in, 1).view(-1), self._act(max_in, 1).view(-1)]   # unit input/output gradients
-        self.g_y2 = self._act(max_out, 1).view(-1)
-        self.g_yS = self._act(max_out, 1).view(-1) if max_xs else None
-        self.g_y1 = self._act(max(max_mid, M0 * 64), 1).view(-1)
+        # gradients consumed by the side-stream wgrads are double-buffered by unit parity (the next unit must not
+        # overwrite what a still-running weight gradient reads)
+        nset = 2 if self.dual else 1
+        self.g_y2s = [self._act(max_out, 1).view(-1) for _ in range(nset)]
+        self.g_ySs = [self._act(max_out, 1).view(-1) if max_xs else None for _ in range(nset)]
+        self.g_y1s = [self._act(max(max_mid, M0 * 64), 1).view(-1) for _ in range(nset)]
+        self.g_y1 = self.g_y1s[0]
         self.g_xh = self._act(max_in, 1).view(-1)
         self.g_xS = self._act(max_xs, 1).view(-1) if max_xs else None
         self.g_f32 = torch.empty(B, 512, device=dev)     # BN1d backward output (fp32)
@@ -316,6 +349,13 @@ class BackbonePlan(object):
         L.append(ops.conv(self.stream, self.fr, **kw))
         return (kw["B"] * kw["RH"] * kw["RW"] + 127) // 128
 
+    def _side_after_main(self, L):
+        """Order the side stream behind everything enqueued on the main stream so far."""
+        if self.dual:
+            ev = torch.cuda.Event()
+            L.append(_EvRecord(ev, self.stream1_t))
+            L.append(_EvWait(self.stream2_t, ev))
+
     def _wgrad(self, L, **kw):
         """Append a weight-gradient launch: LDS-strip kernel for bf16 stride-1 3x3 layers, generic otherwise."""
         if (self.fr == FR_BF16 and self.use_strip and kw["KH"] == 3 and kw["stride"] == 1 and
@@ -330,11 +370,14 @@ class BackbonePlan(object):
                 for l in self._slab_users:  # re-point earlier launches at the grown buffer
                     l.keep[0].slab = ops.ptr(self.slab)
             kw = dict(kw, nsplit=groups, slab=self.slab)
-            l = ops.wgrad_strip(self.stream, **kw)
+            l = ops.wgrad_strip(self.stream2, **kw)
+            l.tstream = self.stream2_t
             self._slab_users.append(l)
             L.append(l)
             return
-        L.append(ops.wgrad(self.stream, self.fr, **kw))
+        l = ops.wgrad(self.stream2, self.fr, **kw)
+        l.tstream = self.stream2_t
+        L.append(l)
 
     # ---- forward -----------------------------------------------------------------------------------
     def _bn_train_launches(self, L, bn, part, nparts, count):
@@ -537,15 +580,19 @@ class BackbonePlan(object):
         cur = 0
         g_out = self.g_pp[cur][:rows_o * C]
         L.append(ops.bn_bwd_apply(st, fr, gx=g_out, gamma=ob.weight, s0=s0, s1=s1, inv_count=1.0 / rows_o, **common))
-        self.ready_marks.append((len(L), [ob1.weight, ob1.bias, ol.weight, ol.bias, ob.weight, ob.bias]))
+        self.ready_marks.append((len(L), [ob1.weight, ob1.bias, ol.weight, ol.bias, ob.weight, ob.bias], None))
         # ---- residual units in reverse
+        unit_done = {}  # unit index -> event recorded on the side stream after its weight gradients
         for i in range(len(self.units) - 1, -1, -1):
             u, d = self.units[i], self.ubuf[i]
             x = self.ubuf[i - 1]["out"] if i > 0 else self.z0
             rin, rout = B * u.H * u.H, B * u.Ho * u.Ho
             HWo = u.Ho * u.Ho
             bn1, bn2 = d["bn1"], d["bn2"]
-            g_y2 = self.g_y2[:rout * u.depth]
+            par = i & 1 if self.dual else 0
+            g_y2 = self.g_y2s[par][:rout * u.depth]
+            if self.dual and i + 2 in unit_done:
+                L.append(_EvWait(self.stream1_t, unit_done[i + 2]))  # that unit's wgrads read this buffer set
             nb = ops.grid_blocks(rout, u.depth, fr)
             ready = [u.bn2.weight, u.bn2.bias]
             se_kw = {}
@@ -573,7 +620,7 @@ class BackbonePlan(object):
             g_xS = None
             if u.sc_conv is not None:
                 bnS = d["bnS"]
-                g_yS = self.g_yS[:rout * u.depth]
+                g_yS = self.g_ySs[par][:rout * u.depth]
                 db, dg = self._bn_grads(bnS)
                 common = dict(g=g_out, x=d["yS"], mean=bnS.mean, invstd=bnS.invstd, rows=rout, C=u.depth,
                               rows_per_image=HWo, nblocks=nb)
@@ -591,12 +638,13 @@ class BackbonePlan(object):
                 gws = self.grad_of(u.sc_conv.weight)
                 if gws is not None:
                     tiles = ((u.depth + 127) // 128) * ((u.cin + 127) // 128)
-                    L.append(ops.wgrad(st, fr, g=g_yS, src=x, dw=gws, B=B, GH=u.Ho, GW=u.Ho, Cout=u.depth, SH=u.H,
-                                       SW=u.H, SC=u.cin, KH=1, KW=1, stride=u.stride, pad=0, ldg=u.depth, lda=u.cin,
-                                       pro=0, nsplit=_wgrad_slices(rout, tiles)))
+                    self._side_after_main(L)
+                    self._wgrad(L, g=g_yS, src=x, dw=gws, B=B, GH=u.Ho, GW=u.Ho, Cout=u.depth, SH=u.H,
+                                SW=u.H, SC=u.cin, KH=1, KW=1, stride=u.stride, pad=0, ldg=u.depth, lda=u.cin,
+                                pro=0, nsplit=_wgrad_slices(rout, tiles))
                 ready += [u.sc_bn.weight, u.sc_bn.bias, u.sc_conv.weight]
             # conv2: data gradient with the PReLU backward epilogue, then the weight gradient
-            g_y1 = self.g_y1[:rin * u.depth]
+            g_y1 = self.g_y1s[par][:rin * u.depth]
             c2 = dict(src=g_y2, w=d["wt2"], out=g_y1, B=B, RH=u.H, RW=u.H, SH=u.Ho, SW=u.Ho, SC=u.depth, N=u.depth,
                       KH=3, KW=3, stride=u.stride, pad=1, lda=u.depth, ldc=u.depth, ldaux=u.depth, pro=0,
                       epi=ops.EPI_PRELU_BWD, aux=d["y1"], epi_a=u.prelu.weight)
@@ -613,6 +661,7 @@ class BackbonePlan(object):
             gw2 = self.grad_of(u.conv2.weight)
             if gw2 is not None:
                 tiles = ((u.depth + 127) // 128) ** 2 * 9
+                self._side_after_main(L)  # g_y2 (BN2 backward) and y1 are final on the main stream
                 self._wgrad(L, g=g_y2, src=d["y1"], dw=gw2, B=B, GH=u.Ho, GW=u.Ho, Cout=u.depth, SH=u.H,
                             SW=u.H, SC=u.depth, KH=3, KW=3, stride=u.stride, pad=1, ldg=u.depth, lda=u.depth,
                             pro=ops.PRO_PRELU, pro_a=u.prelu.weight, nsplit=_wgrad_slices(rout, tiles))
@@ -627,6 +676,7 @@ class BackbonePlan(object):
             gw1 = self.grad_of(u.conv1.weight)
             if gw1 is not None:
                 tiles = ((u.depth + 127) // 128) * ((u.cin + 127) // 128) * 9
+                self._side_after_main(L)  # g_y1 (conv2 data gradient) is final on the main stream
                 self._wgrad(L, g=g_y1, src=x, dw=gw1, B=B, GH=u.H, GW=u.H, Cout=u.depth, SH=u.H, SW=u.H,
                             SC=u.cin, KH=3, KW=3, stride=1, pad=1, ldg=u.depth, lda=u.cin, pro=ops.PRO_BN,
                             pro_a=bn1.scale, pro_b=bn1.shift, nsplit=_wgrad_slices(rin, tiles))
@@ -645,7 +695,12 @@ class BackbonePlan(object):
             else:
                 kw.update(add=g_out, add_kind=2, H=u.H, W=u.H, add_stride=u.stride)
             L.append(ops.bn_bwd_apply(st, fr, **kw))
-            self.ready_marks.append((len(L), ready))
+            done = None
+            if self.dual:
+                done = torch.cuda.Event()
+                L.append(_EvRecord(done, self.stream2_t))
+                unit_done[i] = done
+            self.ready_marks.append((len(L), ready, done))
             g_out, cur = g_x, nxt
         # ---- stem: z0 = PReLU(BN0(y0)); y0 = X0 * W0p^T
         sc, sb, sp = self.stem
@@ -658,7 +713,9 @@ class BackbonePlan(object):
         L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
         self._reduce(L, nb, 3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64])
         s0, s1 = self._s01(self.bn0, db, dg)
-        g_y0 = self.g_y1[:self.M0 * 64]
+        g_y0 = self.g_y1s[-1][:self.M0 * 64]  # unit 0's wgrads (side stream) still read set 0
+        if self.dual and 1 in unit_done:
+            L.append(_EvWait(self.stream1_t, unit_done[1]))  # set 1 was last read by unit 1's weight gradients
         L.append(ops.bn_bwd_apply(st, fr, gx=g_y0, gamma=sb.weight, s0=s0, s1=s1, inv_count=1.0 / self.M0, **common))
         gw0 = self.grad_of(sc.weight)
         if gw0 is not None:
@@ -668,7 +725,9 @@ class BackbonePlan(object):
                                nsplit=_wgrad_slices(self.M0, 1)))
             L.append(ops.call("fr_unpack_stem_grad", self.gW0p, gw0, gw0.stride(0), gw0.stride(1), gw0.stride(2),
                               gw0.stride(3), 64, sc.weight.shape[1], self.K0, st))
-        self.ready_marks.append((len(L), [sb.weight, sb.bias, sp.weight, sc.weight]))
+        if self.dual and unit_done:
+            L.append(_EvWait(self.stream1_t, unit_done[min(unit_done)]))  # join: the side stream is FIFO
+        self.ready_marks.append((len(L), [sb.weight, sb.bias, sp.weight, sc.weight], None))
         self.bwd_list = L
 
     # ---- execution ---------------------------------------------------------------------------------
@@ -704,9 +763,11 @@ class BackbonePlan(object):
             ops.run(self.bwd_list)
             return
         pos = 0
-        for end, params in self.ready_marks:
+        for end, params, done in self.ready_marks:
             ops.run(self.bwd_list[pos:end])
             pos = end
+            if done is not None:
+                self.stream1_t.wait_event(done)  # the collective is ordered behind the main stream only
             on_ready([p for p in params if p.requires_grad])
         ops.run(self.bwd_list[pos:])
 
@@ -743,15 +804,16 @@ class BackboneRunner(object):
         self.plans = {}
         self.compute_dtype = None
         self.on_grads_ready = None
+        self.single_stream = False  # True: weight gradients stay on the main stream (per-kernel profiling)
         self.step_seed = 0x5EED
 
     def _get_plan(self, x, avg_channels):
         dtype = self.compute_dtype or getattr(self.module, "compute_dtype", None) or compute_dtype_default()
-        key = (x.shape[0], dtype, x.device, avg_channels)
+        key = (x.shape[0], dtype, x.device, avg_channels, self.single_stream)
         plan = self.plans.get(key)
         if plan is None or not plan.check_current():
             plan = BackbonePlan(self.module, x.shape[0], dtype, x.device, self.in_channels - avg_channels,
-                                avg_channels)
+                                avg_channels, single_stream=self.single_stream)
             self.plans = {key: plan}  # one live plan: activations of a 256-batch are several GB
         return plan
 

@@ -39,13 +39,14 @@ def current_stream_ptr():
 
 
 class Launch(object):
-    __slots__ = ("fn", "args", "name", "keep")
+    __slots__ = ("fn", "args", "name", "keep", "tstream")
 
     def __init__(self, name, args, keep=None):
         self.fn = getattr(lib, name)
         self.args = list(args)
         self.name = name
         self.keep = keep
+        self.tstream = None  # torch stream the launch targets when it is not the current one
 
     def __call__(self):
         rc = self.fn(*self.args)
