@@ -141,6 +141,18 @@ def instrumented_step(step, x, y, dtype_name):
             else:
                 detail.append(("wgrad P=%d Cout=%d taps%d Cin=%d s%d pro%d nsplit%d" % (
                     a.B * a.GH * a.GW, a.Cout, a.KH * a.KW, a.SC, a.stride, a.pro, a.nsplit), round(ms, 4)))
+        if launch.name in ("fr_bn_apply", "fr_bn_bwd_reduce", "fr_bn_bwd_apply"):
+            a = launch.keep[0]
+            elt = 2 if launch.args[1] == 1 else 4
+            if launch.name == "fr_bn_apply":
+                rows, passes = a.B * a.H * a.W, 2 + (1 if a.res_kind else 0)
+            else:
+                rows = a.rows
+                passes = 2 if launch.name == "fr_bn_bwd_reduce" else 3 + (1 if a.add_kind == 1 else 0)
+            gbytes = rows * a.C * elt * passes / 1e9
+            detail.append(("%s rows=%d C=%d passes=%d blocks=%d %.1fMB" % (launch.name[3:], rows, a.C, passes, a.nblocks,
+                                                                          gbytes * 1e3),
+                           round(ms, 4), round(gbytes / (ms * 1e-3), 1)))
         if launch.name == "fr_conv_igemm":
             a = launch.keep[0]
             name = "conv_igemm<%s,BN=%d,PRO=%d>" % (dtype_name if launch.args[1] == 1 else "f32",
@@ -289,7 +301,7 @@ def main():
             if args.kernel_table:
                 with open(args.kernel_table, "w") as f:
                     d = {k: {"launches": v[0], "ms": round(v[1], 4), "tflops": round(v[2] / 1e12, 4)} for k, v in table}
-                    d["_generic_gemm_launches"] = getattr(instrumented_step, "detail", [])
+                    d["_launch_detail"] = getattr(instrumented_step, "detail", [])
                     json.dump(d, f, indent=1)
             if dom is not None:
                 name, (cnt, kms, flops) = dom

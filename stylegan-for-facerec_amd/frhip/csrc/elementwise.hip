@@ -368,6 +368,183 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const FrBnBwdArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ lean bf16 variants
+// The plain cases of the three kernels above (no PReLU slope, no SE gate, no strided identity scatter) are what the
+// bf16 training step launches ~110 times.  They are latency x concurrency bound at the 14x14 / 7x7 stages (25-MB
+// tensors, ~6 grid-stride iterations per thread), so these variants trade vector width for rows in flight: a thread
+// owns 4 channels (8-byte loads) of UNR rows per iteration.  The per-channel coefficients shrink to 4 registers per
+// array and are shared by all rows in flight, the kernels fit 64 VGPRs (8 waves per SIMD, and a wave of them fits
+// beside a resident strip workgroup of the side stream), and 4x the bytes are in flight per CU.  Same arithmetic,
+// same operation order, same part[blk][k][C] layout as the general kernels.
+constexpr int LV = 4;    // channels per thread
+constexpr int LUNR = 4;  // rows in flight per thread
+
+__device__ __forceinline__ uint2 pack4bf(const float* f) {
+  uint2 u;
+  u.x = pack2bf(f[0], f[1]);
+  u.y = pack2bf(f[2], f[3]);
+  return u;
+}
+__device__ __forceinline__ void unpack4bf(const uint2& u, float* f) {
+  f[0] = __uint_as_float(u.x << 16);
+  f[1] = __uint_as_float(u.x & 0xFFFF0000u);
+  f[2] = __uint_as_float(u.y << 16);
+  f[3] = __uint_as_float(u.y & 0xFFFF0000u);
+}
+
+__device__ __forceinline__ uint2 ld8(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+
+// RES: 0 none, 1 identity (same geometry), 2 conv shortcut with its BN folded (rscale/rshift)
+template <int RES, bool STATS>
+__global__ __launch_bounds__(NT, 6) void bn_apply_lean_kernel(const FrApplyArgs p) {
+  __shared__ float red[STATS ? NT * 2 * LV : 1];
+  const int C = p.C, cpr = C / LV, tid = threadIdx.x;
+  const int cc = tid % cpr, rt = tid / cpr, rtc = NT / cpr, c0 = cc * LV;
+  const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(p.x) + c0;
+  const bf16_t* __restrict__ res = reinterpret_cast<const bf16_t*>(p.res) + c0;
+  bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out) + c0;
+  float sc[LV], sh[LV], rs[LV], rh[LV];
+#pragma unroll
+  for (int j = 0; j < LV; ++j) {
+    sc[j] = p.scale[c0 + j];
+    sh[j] = p.shift[c0 + j];
+    rs[j] = RES == 2 ? p.rscale[c0 + j] : 1.f;
+    rh[j] = RES == 2 ? p.rshift[c0 + j] : 0.f;
+  }
+  float acc[2][LV];
+#pragma unroll
+  for (int j = 0; j < LV; ++j) acc[0][j] = acc[1][j] = 0.f;
+  const int nrows = p.B * p.H * p.W, rstep = gridDim.x * rtc * LUNR;
+  for (int r0 = blockIdx.x * rtc * LUNR + rt; r0 < nrows; r0 += rstep) {
+    uint2 xr[LUNR], gr[LUNR];  // raw (packed) rows in flight; unpacked one row at a time
+#pragma unroll
+    for (int u = 0; u < LUNR; ++u) {
+      const int r = r0 + u * rtc;
+      if (r < nrows) {
+        xr[u] = ld8(x + (size_t)r * C);
+        if (RES != 0) gr[u] = ld8(res + (size_t)r * C);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < LUNR; ++u) {
+      const int r = r0 + u * rtc;
+      if (r < nrows) {
+        float f[LV], g[LV];
+        unpack4bf(xr[u], f);
+        if (RES != 0) unpack4bf(gr[u], g);
+#pragma unroll
+        for (int j = 0; j < LV; ++j) {
+          f[j] = fmaf(f[j], sc[j], sh[j]);
+          if (RES != 0) f[j] += fmaf(g[j], rs[j], rh[j]);
+        }
+        const uint2 o = pack4bf(f);
+        *reinterpret_cast<uint2*>(out + (size_t)r * C) = o;
+        if (STATS) {
+          float q[LV];
+          unpack4bf(o, q);  // statistics of what the next layer will actually read
+#pragma unroll
+          for (int j = 0; j < LV; ++j) {
+            acc[0][j] += q[j];
+            acc[1][j] = fmaf(q[j], q[j], acc[1][j]);
+          }
+        }
+      }
+    }
+  }
+  if (STATS) block_col_reduce<2, LV>(acc, red, p.part + (size_t)blockIdx.x * 2 * C, C, cpr, tid);
+}
+
+__global__ __launch_bounds__(NT, 8) void bn_bwd_reduce_lean_kernel(const FrBnBwdArgs p) {
+  __shared__ float red[NT * 3 * LV];
+  const int C = p.C, cpr = C / LV, tid = threadIdx.x;
+  const int cc = tid % cpr, rt = tid / cpr, rtc = NT / cpr, c0 = cc * LV;
+  const bf16_t* __restrict__ g = reinterpret_cast<const bf16_t*>(p.g) + c0;
+  const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(p.x) + c0;
+  float mu[LV], is[LV];
+#pragma unroll
+  for (int j = 0; j < LV; ++j) {
+    mu[j] = p.mean[c0 + j];
+    is[j] = p.invstd[c0 + j];
+  }
+  float acc[3][LV];
+#pragma unroll
+  for (int j = 0; j < LV; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.f;
+  const int nrows = (int)p.rows, rstep = gridDim.x * rtc * LUNR;
+  for (int r0 = blockIdx.x * rtc * LUNR + rt; r0 < nrows; r0 += rstep) {
+    uint2 gr[LUNR], xr[LUNR];
+#pragma unroll
+    for (int u = 0; u < LUNR; ++u) {
+      const int r = r0 + u * rtc;
+      if (r < nrows) {
+        gr[u] = ld8(g + (size_t)r * C);
+        xr[u] = ld8(x + (size_t)r * C);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < LUNR; ++u) {
+      if (r0 + u * rtc < nrows) {
+        float gv[LV], xv[LV];
+        unpack4bf(gr[u], gv);
+        unpack4bf(xr[u], xv);
+#pragma unroll
+        for (int j = 0; j < LV; ++j) {
+          acc[0][j] += gv[j];
+          acc[1][j] = fmaf(gv[j], (xv[j] - mu[j]) * is[j], acc[1][j]);
+        }
+      }
+    }
+  }
+  block_col_reduce<3, LV>(acc, red, p.part + (size_t)blockIdx.x * 3 * C, C, cpr, tid);
+}
+
+template <bool ADD>
+__global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdArgs p) {
+  const int C = p.C, cpr = C / LV, tid = threadIdx.x;
+  const int cc = tid % cpr, rt = tid / cpr, rtc = NT / cpr, c0 = cc * LV;
+  const bf16_t* __restrict__ g = reinterpret_cast<const bf16_t*>(p.g) + c0;
+  const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(p.x) + c0;
+  const bf16_t* __restrict__ add = reinterpret_cast<const bf16_t*>(p.add) + c0;
+  bf16_t* __restrict__ gx = reinterpret_cast<bf16_t*>(p.gx) + c0;
+  float mu[LV], is[LV], coef[LV], a[LV], bb[LV];
+#pragma unroll
+  for (int j = 0; j < LV; ++j) {
+    mu[j] = p.mean[c0 + j];
+    is[j] = p.invstd[c0 + j];
+    coef[j] = (p.gamma ? p.gamma[c0 + j] : 1.f) * is[j];
+    a[j] = p.s0[c0 + j] * p.inv_count;
+    bb[j] = p.s1[c0 + j] * p.inv_count;
+  }
+  const int nrows = (int)p.rows, rstep = gridDim.x * rtc * LUNR;
+  for (int r0 = blockIdx.x * rtc * LUNR + rt; r0 < nrows; r0 += rstep) {
+    uint2 gr[LUNR], xr[LUNR], er[LUNR];
+#pragma unroll
+    for (int u = 0; u < LUNR; ++u) {
+      const int r = r0 + u * rtc;
+      if (r < nrows) {
+        gr[u] = ld8(g + (size_t)r * C);
+        xr[u] = ld8(x + (size_t)r * C);
+        if (ADD) er[u] = ld8(add + (size_t)r * C);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < LUNR; ++u) {
+      const int r = r0 + u * rtc;
+      if (r < nrows) {
+        float gv[LV], xv[LV], e[LV], o[LV];
+        unpack4bf(gr[u], gv);
+        unpack4bf(xr[u], xv);
+        if (ADD) unpack4bf(er[u], e);
+#pragma unroll
+        for (int j = 0; j < LV; ++j) {
+          o[j] = coef[j] * (gv[j] - a[j] - (xv[j] - mu[j]) * is[j] * bb[j]);
+          if (ADD) o[j] += e[j];
+        }
+        *reinterpret_cast<uint2*>(gx + (size_t)r * C) = pack4bf(o);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ SE
 // pooled[b][c] = mean_hw(x*scale+shift) = scale*mean_hw(x)+shift : one block per (image, 64-channel... ) simple:
 // grid = B blocks, threads [row-thread][chunk] over the image's HW rows.
@@ -653,6 +830,11 @@ inline bool chan_ok(int C, int dtype) {
   return C % vec == 0 && cpr <= NT && NT % cpr == 0;
 }
 
+inline bool lean_ok(int C) {  // 4-channel threads: C/4 threads per row must tile the 256-thread block
+  const int cpr = C / 4;
+  return C % 4 == 0 && cpr <= NT && NT % cpr == 0;
+}
+
 }  // namespace
 
 extern "C" int fr_stem_im2col(const float* x, const float* avg, void* out, int B, int H, int W, int C, int Cavg,
@@ -711,6 +893,22 @@ extern "C" int fr_bn_apply(const FrApplyArgs* args, int dtype, void* stream) {
   if (!chan_ok(args->C, dtype)) FR_UNSUPPORTED("fr_bn_apply: unsupported channel count");
   if (args->nblocks < 1) FR_UNSUPPORTED("fr_bn_apply: nblocks < 1");
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == FR_BF16 && lean_ok(args->C) && !args->se && !args->slope &&
+      !(args->res_kind == 1 && args->res_stride > 1) && (long long)args->B * args->H * args->W < (1ll << 31)) {
+    const dim3 grid(args->nblocks), blk(NT);
+#define LEAN_APPLY(RES, ST) hipLaunchKernelGGL((bn_apply_lean_kernel<RES, ST>), grid, blk, 0, st, *args)
+    if (args->part) {
+      if (args->res_kind == 0) LEAN_APPLY(0, true);
+      else if (args->res_kind == 1) LEAN_APPLY(1, true);
+      else LEAN_APPLY(2, true);
+    } else {
+      if (args->res_kind == 0) LEAN_APPLY(0, false);
+      else if (args->res_kind == 1) LEAN_APPLY(1, false);
+      else LEAN_APPLY(2, false);
+    }
+#undef LEAN_APPLY
+    FR_LAUNCH_CHECK();
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(args->nblocks), dim3(NT), 0, st, *args),
              hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(args->nblocks), dim3(NT), 0, st, *args),
              "fr_bn_apply");
@@ -720,6 +918,10 @@ extern "C" int fr_bn_apply(const FrApplyArgs* args, int dtype, void* stream) {
 extern "C" int fr_bn_bwd_reduce(const FrBnBwdArgs* args, int dtype, void* stream) {
   if (!chan_ok(args->C, dtype)) FR_UNSUPPORTED("fr_bn_bwd_reduce: unsupported channel count");
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == FR_BF16 && lean_ok(args->C) && !args->se && !args->slope && args->rows < (1ll << 31)) {
+    hipLaunchKernelGGL(bn_bwd_reduce_lean_kernel, dim3(args->nblocks), dim3(NT), 0, st, *args);
+    FR_LAUNCH_CHECK();
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(args->nblocks), dim3(NT), 0, st, *args),
              hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(args->nblocks), dim3(NT), 0, st, *args),
              "fr_bn_bwd_reduce");
@@ -729,6 +931,12 @@ extern "C" int fr_bn_bwd_reduce(const FrBnBwdArgs* args, int dtype, void* stream
 extern "C" int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream) {
   if (!chan_ok(args->C, dtype)) FR_UNSUPPORTED("fr_bn_bwd_apply: unsupported channel count");
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == FR_BF16 && lean_ok(args->C) && !args->se && !args->slope && args->add_kind != 2 &&
+      args->rows < (1ll << 31)) {
+    if (args->add_kind == 1) hipLaunchKernelGGL(bn_bwd_apply_lean_kernel<true>, dim3(args->nblocks), dim3(NT), 0, st, *args);
+    else hipLaunchKernelGGL(bn_bwd_apply_lean_kernel<false>, dim3(args->nblocks), dim3(NT), 0, st, *args);
+    FR_LAUNCH_CHECK();
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(args->nblocks), dim3(NT), 0, st, *args),
              hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(args->nblocks), dim3(NT), 0, st, *args),
              "fr_bn_bwd_apply");

@@ -195,7 +195,10 @@ class BackbonePlan(object):
         # kernel and the HBM-bound BN-backward / residual passes of the next unit then share the CUs (measured with
         # tools/overlap_probe.py: ~2/3 of an elementwise pass hides under a wgrad strip kernel).
         self.dual = os.environ.get("FRHIP_SINGLE_STREAM", "0") != "1" and not single_stream
-        self.stream2_t = torch.cuda.Stream(device=device) if self.dual else self.stream1_t
+        # the side stream is low priority: weight gradients fill the CUs the main chain (dgrads, BN/PReLU backward)
+        # leaves idle instead of splitting the machine with it (FRHIP_SIDE_PRIORITY overrides, HIP: 1 low .. -1 high)
+        prio = int(os.environ.get("FRHIP_SIDE_PRIORITY", "1"))
+        self.stream2_t = torch.cuda.Stream(device=device, priority=prio) if self.dual else self.stream1_t
         self.stream2 = ctypes.c_void_p(self.stream2_t.cuda_stream)
         self.S = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
         self.generation = 0
