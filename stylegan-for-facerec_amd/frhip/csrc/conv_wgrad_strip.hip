@@ -269,11 +269,17 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_strip_kernel(const FrWg
 __global__ void reduce_slabs_kernel(const float* __restrict__ slab, int groups, long long n4, float* __restrict__ out) {
   // n4 = elements / 4
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    f32x4 s = reinterpret_cast<const f32x4*>(slab)[i];
-    for (int g = 1; g < groups; ++g) {
-      const f32x4 v = reinterpret_cast<const f32x4*>(slab)[(long long)g * n4 + i];
-      s += v;
+    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(slab) + i;
+    f32x4 s = src[0];
+    int g = 1;
+    for (; g + 8 <= groups; g += 8) {  // 8 independent loads in flight; the summation order stays g = 0, 1, 2, ...
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(long long)(g + u) * n4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
     }
+    for (; g < groups; ++g) s += src[(long long)g * n4];
     reinterpret_cast<f32x4*>(out)[i] = s;
   }
 }

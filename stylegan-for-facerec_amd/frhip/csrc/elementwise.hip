@@ -74,46 +74,78 @@ __global__ void stem_im2col_kernel(const float* __restrict__ x, const float* __r
 }
 
 // ------------------------------------------------------------------------------------------ partial-row reduction
-// part is [nparts][KC] fp32.  A block owns 8 consecutive columns: thread (row-lane rl = tid/8, column cl = tid%8)
-// strides over the rows (32-B coalesced segments, 32 independent loads in flight per column), accumulates in
-// double, and the 32 row-lanes are combined with wave shuffles + one LDS step.  Returns the total in the threads
-// with tid < 8 (column tid); other threads return garbage.
-__device__ __forceinline__ double reduce_rows8(const float* __restrict__ part, int nparts, int KC, int col0,
-                                               double* lds /* [4][8] */) {
-  const int tid = threadIdx.x, cl = tid & 7, rl = tid >> 3;  // 256 threads: 32 row-lanes x 8 columns
-  const int col = col0 + cl;
-  double s = 0.0;
-  if (col < KC) {
-    int r = rl;
-    for (; r + 96 < nparts; r += 128) {  // 4 independent loads per trip
-      const float a = part[(size_t)r * KC + col], b = part[(size_t)(r + 32) * KC + col];
-      const float c = part[(size_t)(r + 64) * KC + col], d = part[(size_t)(r + 96) * KC + col];
-      s += ((double)a + (double)b) + ((double)c + (double)d);
+// part is [nparts][KC] fp32.  A block of RT threads owns 8 consecutive columns (per column set): thread (row-lane
+// rl = tid/8, column cl = tid%8) strides over the rows (32-B coalesced segments), accumulates in double, and the
+// row-lanes are combined with wave shuffles + one LDS step.  The totals are valid in the threads with tid < 8
+// (column tid).  Fixed summation order: deterministic for a given nparts.
+constexpr int RT = 256;  // threads of the partial-sum reduction kernels: small workgroups, so that they still find
+                         // a slot on CUs that hold a resident strip workgroup of the side stream
+
+template <int NCOLSETS>
+__device__ __forceinline__ void reduce_rows8(const float* __restrict__ part, int nparts, int KC,
+                                             const int (&col0)[NCOLSETS], double (&out)[NCOLSETS],
+                                             double* lds /* [NCOLSETS][RW][8] */) {
+  // RT threads = RT/8 row-lanes x 8 columns; NCOLSETS column groups are reduced in the same sweep so that all their
+  // loads are in flight together (the kernels below are pure latency: a few hundred KB per workgroup)
+  const int tid = threadIdx.x, cl = tid & 7, rl = tid >> 3;
+  constexpr int RL = RT / 8, RW = RT / 64;
+  double s[NCOLSETS];
+#pragma unroll
+  for (int k = 0; k < NCOLSETS; ++k) s[k] = 0.0;
+  int r = rl;
+  constexpr int U = 8;  // U x NCOLSETS independent loads per trip
+  for (; r + (U - 1) * RL < nparts; r += U * RL) {
+    float v[NCOLSETS][U];
+#pragma unroll
+    for (int k = 0; k < NCOLSETS; ++k)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        v[k][u] = col0[k] + cl < KC ? part[(size_t)(r + u * RL) * KC + col0[k] + cl] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NCOLSETS; ++k) {
+      double t = 0.0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) t += (double)v[k][u];
+      s[k] += t;
     }
-    for (; r < nparts; r += 32) s += (double)part[(size_t)r * KC + col];
   }
+  for (; r < nparts; r += RL)
+#pragma unroll
+    for (int k = 0; k < NCOLSETS; ++k)
+      if (col0[k] + cl < KC) s[k] += (double)part[(size_t)r * KC + col0[k] + cl];
   // lanes of a wave: 8 row-lanes x 8 columns -> fold the row-lane bits (lane bits 3..5)
-  s += __shfl_xor(s, 8, 64);
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
   const int wave = tid >> 6;
-  if ((tid & 63) < 8) lds[wave * 8 + cl] = s;
+#pragma unroll
+  for (int k = 0; k < NCOLSETS; ++k) {
+    double t = s[k];
+    t += __shfl_xor(t, 8, 64);
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    if ((tid & 63) < 8) lds[(k * RW + wave) * 8 + cl] = t;
+  }
   __syncthreads();
-  if (tid < 8) s = lds[tid] + lds[8 + tid] + lds[16 + tid] + lds[24 + tid];
-  return s;
+#pragma unroll
+  for (int k = 0; k < NCOLSETS; ++k) {
+    double t = 0.0;
+    if (tid < 8)
+      for (int w = 0; w < RW; ++w) t += lds[(k * RW + w) * 8 + tid];
+    out[k] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------ BN finalize
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C,
-                                                          double count, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps, float momentum,
-                                                          float* running_mean, float* running_var, long long* nbt,
-                                                          float* mean, float* invstd, float* scale, float* shift) {
-  __shared__ double lds[2][32];
+__global__ __launch_bounds__(RT) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C,
+                                                         double count, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, float momentum,
+                                                         float* running_mean, float* running_var, long long* nbt,
+                                                         float* mean, float* invstd, float* scale, float* shift) {
+  __shared__ double lds[2 * (RT / 64) * 8];
   // part row layout [2][C]: columns c (sum) and C + c (sum of squares); a block finalises 8 channels
   const int c0 = blockIdx.x * 8;
-  const double s = reduce_rows8(part, nparts, 2 * C, c0, lds[0]);
-  const double q = reduce_rows8(part, nparts, 2 * C, C + c0, lds[1]);
+  const int cols[2] = {c0, C + c0};
+  double sq[2];
+  reduce_rows8<2>(part, nparts, 2 * C, cols, sq, lds);
+  const double s = sq[0], q = sq[1];
   const int c = c0 + threadIdx.x;
   if (threadIdx.x < 8 && c < C) {
     const double m = s / count;
@@ -146,11 +178,14 @@ __global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, const fl
   shift[c] = beta[c] - rm[c] * gamma[c] * is;
 }
 
-__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int nparts, int K, int C,
-                                                           float* o0, float* o1, float* o2) {
-  __shared__ double lds[32];
+__global__ __launch_bounds__(RT) void reduce_parts_kernel(const float* __restrict__ part, int nparts, int K, int C,
+                                                          float* o0, float* o1, float* o2) {
+  __shared__ double lds[(RT / 64) * 8];
   const int col0 = blockIdx.x * 8;  // over the K*C columns of a partial row
-  const double s = reduce_rows8(part, nparts, K * C, col0, lds);
+  const int cols[1] = {col0};
+  double tot[1];
+  reduce_rows8<1>(part, nparts, K * C, cols, tot, lds);
+  const double s = tot[0];
   const int idx = col0 + threadIdx.x;
   if (threadIdx.x < 8 && idx < K * C) {
     const int k = idx / C, c = idx - k * C;
@@ -777,6 +812,46 @@ __global__ void permute_linear_kernel(const float* __restrict__ in, T* __restric
   }
 }
 
+// Tiled forms (C % 64 == 0): a block moves one (o, 64-channel) tile through LDS so that both the torch-layout side
+// (64*HW contiguous floats) and the packed side (64 contiguous channels per pixel) are accessed in full segments.
+// The tile is [64][HW | 1] floats: an odd row length keeps both access patterns bank-conflict free.
+template <typename T>
+__global__ __launch_bounds__(256) void permute_linear_tile_kernel(const float* __restrict__ in, T* __restrict__ out,
+                                                                  float* __restrict__ gout, int C, int HW, int dir) {
+  extern __shared__ float ptile[];
+  const int HWP = HW | 1;
+  const int o = blockIdx.y, c0 = blockIdx.x * 64, n = 64 * HW;
+  const size_t torch_base = ((size_t)o * C + c0) * HW;  // [o][c0..c0+63][hw]: n contiguous floats
+  const size_t packed_base = (size_t)o * HW * C + c0;   // [o][hw][c0..c0+63]
+  if (dir == 0) {
+    for (int i = threadIdx.x; i < n; i += 256) ptile[(i / HW) * HWP + i % HW] = in[torch_base + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const int hw = i >> 6, c = i & 63;
+      Elt<T>::st(out + packed_base + (size_t)hw * C + c, ptile[c * HWP + hw]);
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const int hw = i >> 6, c = i & 63;
+      ptile[c * HWP + hw] = in[packed_base + (size_t)hw * C + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) gout[torch_base + i] = ptile[(i / HW) * HWP + i % HW];
+  }
+}
+
+// out[k][r] = in[r][k] for an [R][K] matrix, 64 x 64 tiles
+template <typename T>
+__global__ __launch_bounds__(256) void transpose2d_kernel(const T* __restrict__ in, T* __restrict__ out, int R, int K) {
+  __shared__ T tt[64][66];
+  const int k0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int j = ty; j < 64; j += 4)
+    if (r0 + j < R && k0 + tx < K) tt[j][tx] = in[(size_t)(r0 + j) * K + k0 + tx];
+  __syncthreads();
+  for (int j = ty; j < 64; j += 4)
+    if (k0 + j < K && r0 + tx < R) out[(size_t)(k0 + j) * R + r0 + tx] = tt[tx][j];
+}
+
 template <typename T>
 __global__ void pack_stem_kernel(const float* __restrict__ w, long long s_o, long long s_c, long long s_h,
                                  long long s_w, T* __restrict__ wp, int Cout, int C, int ldk) {
@@ -855,7 +930,7 @@ extern "C" int fr_bn_finalize(const float* part, int nparts, int C, double count
                               const float* beta, float eps, float momentum, float* running_mean,
                               float* running_var, int64_t* nbt, float* mean, float* invstd, float* scale,
                               float* shift, void* stream) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, part, nparts, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(RT), 0, (hipStream_t)stream, part, nparts, C,
                      count, gamma, beta, eps, momentum, running_mean, running_var, (long long*)nbt, mean, invstd,
                      scale, shift);
   FR_LAUNCH_CHECK();
@@ -871,7 +946,7 @@ extern "C" int fr_bn_eval_coeffs(const float* rm, const float* rv, const float* 
 extern "C" int fr_reduce_parts(const float* part, int nparts, int K, int C, float* o0, float* o1, float* o2,
                                void* stream) {
   if (K < 1 || K > 3) FR_UNSUPPORTED("fr_reduce_parts: K must be 1..3");
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((K * C + 7) / 8), dim3(256), 0, (hipStream_t)stream, part, nparts, K,
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((K * C + 7) / 8), dim3(RT), 0, (hipStream_t)stream, part, nparts, K,
                      C, o0, o1, o2);
   FR_LAUNCH_CHECK();
 }
@@ -1043,6 +1118,25 @@ extern "C" int fr_pack_weights_multi(const FrPackTensor* table_dev, const int32_
 extern "C" int fr_permute_linear(const float* in, void* out, void* wt, int O, int C, int HW, int dir, int dtype,
                                  void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  if (C % 64 == 0 && 64 * (HW | 1) * 4 <= 64 * 1024) {
+    const dim3 grid(C / 64, O), tgrid((C * HW + 63) / 64, (O + 63) / 64);
+    const size_t lds = (size_t)64 * (HW | 1) * sizeof(float);
+    if (dir == 1) {
+      hipLaunchKernelGGL(permute_linear_tile_kernel<float>, grid, dim3(256), lds, st, in, (float*)nullptr, (float*)out,
+                         C, HW, 1);
+    } else if (dtype == FR_F32) {
+      hipLaunchKernelGGL(permute_linear_tile_kernel<float>, grid, dim3(256), lds, st, in, (float*)out, (float*)nullptr,
+                         C, HW, 0);
+      if (wt) hipLaunchKernelGGL(transpose2d_kernel<float>, tgrid, dim3(256), 0, st, (const float*)out, (float*)wt, O, C * HW);
+    } else if (dtype == FR_BF16) {
+      hipLaunchKernelGGL(permute_linear_tile_kernel<bf16_t>, grid, dim3(256), lds, st, in, (bf16_t*)out,
+                         (float*)nullptr, C, HW, 0);
+      if (wt) hipLaunchKernelGGL(transpose2d_kernel<bf16_t>, tgrid, dim3(256), 0, st, (const bf16_t*)out, (bf16_t*)wt, O, C * HW);
+    } else {
+      FR_UNSUPPORTED("fr_permute_linear: bad dtype");
+    }
+    FR_LAUNCH_CHECK();
+  }
   const int grid = grid_for((long long)O * C * HW, 256, 8192);
   if (dir == 1) {
     hipLaunchKernelGGL(permute_linear_kernel<float>, dim3(grid), dim3(256), 0, st, in, (float*)nullptr,

@@ -314,6 +314,7 @@ class BackbonePlan(object):
         params = self._param_list()
         total = sum((p.numel() + 63) // 64 * 64 for p in params)
         self.arena = torch.zeros(total, device=self.device)
+        self.arena._frhip_grad_arena = True  # lets frhip.optim.SGD.zero_grad clear all views with one fill
         self.gviews = {}
         self.arena_slices = []
         off = 0

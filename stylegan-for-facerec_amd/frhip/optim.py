@@ -19,14 +19,22 @@ class SGD(torch.optim.Optimizer):
         self._tables = []  # per group: (table_dev, chunks_dev, nchunks)
 
     def zero_grad(self, set_to_none=False):
-        """Keeps gradient buffers alive (the engine writes into them); zeroing is one memset per tensor."""
+        """Keeps gradient buffers alive (the engine writes into them).  Gradients that are views of an engine
+        gradient arena are cleared with ONE fill of the arena instead of one launch per parameter."""
+        arenas = {}
         for group in self.param_groups:
             for p in group["params"]:
-                if p.grad is not None:
-                    if set_to_none:
-                        p.grad = None
-                    else:
-                        p.grad.zero_()
+                g = p.grad
+                if g is None:
+                    continue
+                if set_to_none:
+                    p.grad = None
+                elif g._is_view() and getattr(g._base, "_frhip_grad_arena", False):
+                    arenas[id(g._base)] = g._base
+                else:
+                    g.zero_()
+        for a in arenas.values():
+            a.zero_()
 
     def _build(self):
         chunk = _lib.lib.fr_sgd_chunk_elems()

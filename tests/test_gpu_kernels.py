@@ -362,6 +362,112 @@ def test_bn_apply_and_backward(K, name, dtype, tol):
     assert relerr(from_nhwc(gxd), gx) < tol * 2
 
 
+@pytest.mark.parametrize("C,H", [(64, 9), (128, 5), (512, 3)])
+@pytest.mark.parametrize("res_kind", [0, 1, 2])
+def test_bn_lean_bf16_variants(K, C, H, res_kind):
+    """The 4-channel x 4-row bf16 kernels (same-geometry shortcut, folded shortcut BN, add in the backward) on row
+    counts that are not a multiple of the rows in flight, against the same arithmetic in fp32 on the CPU."""
+    dtype, tol = torch.bfloat16, 4e-2
+    B = 3
+    rows = B * H * H
+    x = q(synth.normal(21, "lx", (B, C, H, H)), dtype)
+    res = q(synth.normal(21, "lr", (B, C, H, H)), dtype)
+    scale, shift = synth.uniform(21, "ls", (C,), 0.5, 1.5), synth.uniform(21, "lh", (C,), -0.2, 0.2)
+    rscale, rshift = synth.uniform(21, "lrs", (C,), 0.5, 1.5), synth.uniform(21, "lrh", (C,), -0.2, 0.2)
+    v = lambda t: t.view(1, C, 1, 1)  # noqa: E731
+    y = x * v(scale) + v(shift)
+    if res_kind == 1:
+        y = y + res
+    elif res_kind == 2:
+        y = y + (res * v(rscale) + v(rshift))
+    fr, st = K.fr_dtype(torch.empty(0, dtype=dtype)), K.current_stream_ptr()
+    nb = 7
+    out = torch.zeros(B, H, H, C, device="cuda", dtype=dtype)
+    part = torch.zeros(nb, 2, C, device="cuda")
+    kw = dict(x=nhwc(x, dtype), out=out, scale=scale.cuda(), shift=shift.cuda(), part=part, B=B, H=H, W=H, C=C,
+              res_kind=res_kind, res_stride=1, nblocks=nb)
+    if res_kind:
+        kw["res"] = nhwc(res, dtype)
+    if res_kind == 2:
+        kw.update(rscale=rscale.cuda(), rshift=rshift.cuda())
+    K.bn_apply(st, fr, **kw)()
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(out), y) < tol
+    o32 = from_nhwc(out)
+    np.testing.assert_allclose(part.sum(0)[0].cpu(), o32.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+    np.testing.assert_allclose(part.sum(0)[1].cpu(), (o32 * o32).sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+    # backward of a training-mode BN on x, with the shortcut gradient added (add_kind 1) when res_kind != 0
+    xg = x.clone().requires_grad_(True)
+    gamma = synth.uniform(21, "lg", (C,), 0.8, 1.2).requires_grad_(True)
+    beta = torch.zeros(C, requires_grad=True)
+    z = F.batch_norm(xg, None, None, gamma, beta, True, 0.1, 1e-5)
+    g = q(synth.normal(21, "lgo", tuple(z.shape)), dtype)
+    gx, gg, gb = torch.autograd.grad(z, [xg, gamma, beta], g)
+    if res_kind:
+        gx = gx + res
+    mean = x.mean((0, 2, 3))
+    invstd = 1.0 / torch.sqrt(x.var((0, 2, 3), unbiased=False) + 1e-5)
+    common = dict(g=nhwc(g, dtype), x=nhwc(x, dtype), mean=mean.cuda(), invstd=invstd.cuda(), rows=rows, C=C,
+                  rows_per_image=H * H, nblocks=nb)
+    part3 = torch.zeros(nb, 3, C, device="cuda")
+    K.bn_bwd_reduce(st, fr, part=part3, **common)()
+    s0, s1 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    K.call("fr_reduce_parts", part3, nb, 3, C, s0, s1, None, st)()
+    gxd = torch.zeros(B, H, H, C, device="cuda", dtype=dtype)
+    extra = dict(add=nhwc(res, dtype), add_kind=1) if res_kind else {}
+    K.bn_bwd_apply(st, fr, gx=gxd, gamma=gamma.detach().cuda(), s0=s0, s1=s1, inv_count=1.0 / rows, **common, **extra)()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(s0.cpu(), gb, rtol=tol * 5, atol=tol * 20)
+    np.testing.assert_allclose(s1.cpu(), gg, rtol=tol * 5, atol=tol * 20)
+    assert relerr(from_nhwc(gxd), gx) < tol * 2
+
+
+@pytest.mark.parametrize("nparts", [1, 5, 130, 1024, 3000])
+def test_partial_sum_reductions_are_exact_in_double(K, nparts):
+    """fr_bn_finalize / fr_reduce_parts over many partial rows == float64 column sums."""
+    C = 72  # not a multiple of the 8 columns a workgroup owns * anything special; exercises the column guard
+    part = synth.normal(23, "pp%d" % nparts, (nparts, 3, C)).abs() + 0.5
+    pd = part.cuda()
+    st = K.current_stream_ptr()
+    o = [torch.zeros(C, device="cuda") for _ in range(3)]
+    K.call("fr_reduce_parts", pd, nparts, 3, C, o[0], o[1], o[2], st)()
+    ref = part.double().sum(0)
+    for k in range(3):
+        np.testing.assert_allclose(o[k].cpu().double(), ref[k], rtol=2e-7)
+    count = 1000.0 * nparts
+    p2 = pd[:, :2].contiguous()
+    p2[:, 1] += 4.0 * nparts  # keep the variance positive
+    mean, invstd, scale, shift = (torch.zeros(C, device="cuda") for _ in range(4))
+    K.call("fr_bn_finalize", p2, nparts, C, count, None, None, 1e-5, 0.1, None, None, None, mean, invstd, scale, shift,
+           st)()
+    torch.cuda.synchronize()
+    s = p2.cpu().double().sum(0)
+    m = s[0] / count
+    var = s[1] / count - m * m
+    np.testing.assert_allclose(mean.cpu().double(), m, rtol=1e-6)
+    np.testing.assert_allclose(invstd.cpu().double(), 1.0 / torch.sqrt(var + 1e-5), rtol=1e-6)
+
+
+@pytest.mark.parametrize("name,dtype,tol", DT)
+def test_permute_linear_layouts(K, name, dtype, tol):
+    """Linear(C*HW, O) weight: torch [O][C*HW] -> packed [O][HW*C] and its transpose; gradient back (dir 1)."""
+    O, C, HW = 70, 128, 49
+    w = q(synth.normal(25, "plw", (O, C * HW)), dtype)
+    fr, st = K.fr_dtype(torch.empty(0, dtype=dtype)), K.current_stream_ptr()
+    out = torch.zeros(O, HW * C, device="cuda", dtype=dtype)
+    wt = torch.zeros(HW * C, O, device="cuda", dtype=dtype)
+    K.call("fr_permute_linear", w.cuda(), out, wt, O, C, HW, 0, fr, st)()
+    ref = w.view(O, C, HW).permute(0, 2, 1).reshape(O, HW * C)
+    torch.cuda.synchronize()
+    assert torch.equal(out.float().cpu(), ref)
+    assert torch.equal(wt.float().cpu(), ref.t())
+    g = synth.normal(25, "plg", (O, HW * C))
+    gout = torch.zeros(O, C * HW, device="cuda")
+    K.call("fr_permute_linear", g.cuda(), gout, None, O, C, HW, 1, K.FR_F32, st)()
+    torch.cuda.synchronize()
+    assert torch.equal(gout.cpu(), g.view(O, HW, C).permute(0, 2, 1).reshape(O, C * HW))
+
+
 STRIP_SHAPES = [(64, 64, 112), (64, 64, 56), (64, 128, 56), (128, 64, 56), (128, 128, 28), (128, 256, 28),
                 (256, 128, 28), (256, 256, 14), (256, 512, 14), (512, 256, 14), (512, 512, 7)]
 
