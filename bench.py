@@ -98,7 +98,7 @@ def conv_flops(launch):
     """Algorithmic FLOPs of one fr_conv_igemm / fr_conv3x3_strip launch (2 per MAC actually needed)."""
     a = launch.keep[0]
     if a.mode == 2:  # one parity class of a stride-2 data gradient: (1|2) x (1|2) of the 9 taps, a quarter of the rows
-        taps = (2 if a.par_h else 1) * (2 if a.par_w else 1)
+        taps = 9 if a.par_h < 0 else (2 if a.par_h else 1) * (2 if a.par_w else 1)  # par -1: all four classes
         return 2.0 * a.B * (a.RH // 2) * (a.RW // 2) * a.N * taps * a.SC
     M = a.B * a.RH * a.RW
     return 2.0 * M * a.N * a.KH * a.KW * a.SC
@@ -161,6 +161,10 @@ def instrumented_step(step, x, y, dtype_name):
         elif launch.name == "fr_conv3x3_strip":
             a = launch.keep[0]
             name = "conv3x3_strip<%d,%d,%d,PRO=%d>" % (a.SC, a.N, a.SW, a.pro)
+            flops = conv_flops(launch)
+        elif launch.name == "fr_conv3x3_s2_strip":
+            a = launch.keep[0]
+            name = "conv3x3_s2_strip<%d,%s,PRO=%d>" % (a.SC, "fwd%d" % a.RW if a.mode == 0 else "dgrad%d" % a.SW, a.pro)
             flops = conv_flops(launch)
         elif launch.name == "fr_conv_wgrad_strip":
             a = launch.keep[0]

@@ -56,7 +56,8 @@ typedef struct FrConvArgs {
   int32_t out_f32;
   int32_t splitk;      /* >1: K loop split over gridDim.z, requires FR_EPI_ATOMIC + out_f32 */
   int32_t stride_log2; /* filled in by the library */
-  int32_t par_h, par_w; /* mode 2: parity class of the output pixels */
+  int32_t par_h, par_w; /* mode 2: parity class of the output pixels; (-1, -1) = all four classes in one launch,
+                           part rows ordered [class = 2*par_h + par_w][M tile] */
   int32_t margin_kind; /* 0 ArcFace, 1 CosFace */
   int32_t easy_margin;
   float cos_m, sin_m, th, mm, scale;
@@ -85,6 +86,15 @@ int fr_conv_igemm(const FrConvArgs* args, int dtype, void* stream);
  * Replaces Conv2d(c, d, (3,3), (1,1), 1) of bottleneck_IR (backbone/model_irse.py:57-59) fwd + data gradient. */
 int fr_conv3x3_strip(const FrConvArgs* args, void* stream);
 int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi);
+
+/* Stride-2 3x3 convolution (bf16, Cin == Cout: the first unit of every IR stage) on LDS-resident parity planes:
+ * mode 0 = forward (SH = 2*RH), mode 2 with par_h = par_w = -1 = data gradient of all four output parity classes
+ * (RH = 2*SH, w = [Cin][tap][Cout]).  Same FrConvArgs contract and epilogues as fr_conv_igemm; partial rows:
+ * forward part[workgroup][2][N], gradient part[class][workgroup][2][N].  fr_conv3x3_s2_strip_parts returns the
+ * number of partial rows for (B, channels, low-res width WL, mode), 0 when the shape is not served.
+ * Replaces Conv2d(d, d, (3,3), stride 2, 1) of bottleneck_IR (backbone/model_irse.py:59) fwd + data gradient. */
+int fr_conv3x3_s2_strip(const FrConvArgs* args, void* stream);
+int fr_conv3x3_s2_strip_parts(int B, int Cin, int Cout, int WL, int mode);
 
 typedef struct FrWgradArgs {
   const void* g;   /* gradient of the conv output: [B*GH*GW][ldg], columns = Cout */

@@ -1,0 +1,424 @@
+// frhip -- the stride-2 3x3 convolution of the first unit of every stage (bottleneck_IR conv2 with stride 2,
+// backbone/model_irse.py:57-59) and its data gradient, as LDS-resident strips (bf16, gfx950).
+//
+// Both directions are written on the LOW-resolution grid (HL x WL = the output of the forward convolution).  A
+// stride-2 window touches the four parity planes x[2i+ph][2j+pw] of the high-resolution image with 1, 2, 2 and 4 of
+// its 9 taps, and inside one plane those taps are plain neighbour offsets (0 / -1 rows and columns).  So
+//   forward (KIND 0):   y[i][j] = sum over the 4 planes of a small stride-1 "convolution" of that plane -- a workgroup
+//                       owning ROWS low-res rows of one image stages one plane at a time in LDS (prologue applied once)
+//                       and accumulates all four into the same MFMA accumulators;
+//   data gradient (KIND 1): dx[2i+ph][2j+pw] = the same kind of sum over the low-res gradient g (offsets 0 / +1) with
+//                       the taps of class (ph, pw) -- the g strip is staged once and the four output classes are
+//                       produced one after the other, each with its own fused epilogue (PReLU backward of
+//                       model_irse.py:58 / BN-backward sums) and 9/4 taps per pixel instead of 9.
+// Everything else follows conv3x3_strip.hip: A fragments are single ds_read_b128 at (row register + immediate tap
+// offset) out of a conflict-free padded [pixel][channel] image, weights stream L2 -> registers (2-deep ring, requested
+// two tap-steps ahead), no barrier inside a tap list, bf16 results leave through an LDS tile as row-contiguous
+// 16-byte stores.  Same contracts as fr_conv_igemm (mode 0 stride 2 / mode 2): bit-compatible layouts of src, w,
+// out, aux and the column partial sums.
+#include "common.h"
+#include "frhip_internal.h"
+
+namespace {
+
+template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND>
+struct S2 {
+  static constexpr int NTH = NW * 64;
+  static constexpr int HL = WL;
+  static constexpr int GW = WL + 1;                        // one halo column (left: forward, right: gradient)
+  static constexpr int GH = ROWS + 1;                      // one halo row
+  static constexpr int CH = CIN / 8;
+  static constexpr int PPAD = CIN == 64 ? 16 : 32;         // see conv3x3_strip.hip: conflict-free pixel stride
+  static constexpr int PSTR = CIN * 2 + PPAD;
+  // row stride: the 16-byte slot index keeps counting across a row wrap of an M tile (slot(h+1, 0) == slot(h, WL) mod 16)
+  static constexpr int RSTR = GW * PSTR + (256 - PSTR % 256) % 256;
+  static constexpr int IMG_BYTES = GH * RSTR + 512;        // + slack for ring reads past the last channel chunk
+  static constexpr int M = ROWS * WL;
+  static constexpr int MT = (M + 15) / 16;
+  static constexpr int WM = NW / WN;
+  static constexpr int TN = COUT / 16 / WN;
+  static constexpr int TM = (MT + WM - 1) / WM;
+  static constexpr int OSTR = COUT * 2 + 16;
+  static constexpr int OUT_BYTES = (M * OSTR + 15) / 16 * 16;
+  static constexpr int RED_BYTES = WM * 2 * COUT * 4;
+  // forward: the output tile reuses the (dead) plane image; gradient: the g strip stays live across the four classes
+  static constexpr int OUT_OFF = KIND == 0 ? 0 : (IMG_BYTES + 15) / 16 * 16;
+  static constexpr int LDS = KIND == 0 ? (IMG_BYTES > OUT_BYTES + RED_BYTES ? IMG_BYTES : OUT_BYTES + RED_BYTES)
+                                       : OUT_OFF + OUT_BYTES + RED_BYTES;
+  static constexpr int NS = HL / ROWS;
+  static_assert(HL % ROWS == 0, "strip rows must divide the low-res image");
+  static_assert(NTH % CH == 0, "threads must be a multiple of the chunks per pixel");
+  static_assert(COUT % (16 * WN) == 0 && NW % WN == 0, "bad wave split");
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+// Tap list of plane / class P = 2*ph + pw: NT = (ph ? 2 : 1) * (pw ? 2 : 1) taps; tap t -> (kernel tap index, LDS row
+// and column offset).  Forward: kernel row kh reads high-res row 2i+kh-1 = plane row i-1 (kh = 0, ph = 1), i (kh = 1,
+// ph = 0) or i (kh = 2, ph = 1); the image holds rows row0-1 .. row0+ROWS-1, so the LDS row offset is 0 or 1.
+// Gradient: dx row 2i+ph collects g rows i+1 (kh = 0) and i (kh = 2) for ph = 1, g row i (kh = 1) for ph = 0; the
+// image holds rows row0 .. row0+ROWS.
+template <int KIND, int P>
+struct Taps {
+  static constexpr int PH = P >> 1, PW = P & 1;
+  static constexpr int NH = PH ? 2 : 1, NWD = PW ? 2 : 1, NT = NH * NWD;
+  static constexpr int kh(int t) { return PH ? 2 * (t / NWD) : 1; }
+  static constexpr int kw(int t) { return PW ? 2 * (t % NWD) : 1; }
+  static constexpr int ktap(int t) { return kh(t) * 3 + kw(t); }
+  static constexpr int roff(int t) { return KIND == 0 ? (PH ? t / NWD : 1) : (PH ? 1 - t / NWD : 0); }
+  static constexpr int coff(int t) { return KIND == 0 ? (PW ? t % NWD : 1) : (PW ? 1 - t % NWD : 0); }
+};
+
+// acc += sum over the taps of (KIND, P) and all CIN channels, A from the LDS image, B from global/L2.
+template <class C, int CIN, int KIND, int P>
+__device__ __forceinline__ void mma_taps(const char* smem, const int (&abase0)[C::TM], f32x4 (&acc)[C::TM][C::TN],
+                                         const bf16_t* const (&wrow)[C::TN]) {
+  using T = Taps<KIND, P>;
+  constexpr int NT = T::NT;
+  constexpr int UC = NT == 1 ? 2 : 1;  // 32-channel chunks per unrolled body (so that a body holds >= 2 tap-steps)
+  constexpr int QB = UC * NT;          // tap-steps per body: 2, 2, 2, 4
+  constexpr int DB = 2;                // weight ring depth == request distance in tap-steps
+  constexpr int NSTEP = QB * C::TM;
+  constexpr int D = C::TM;             // A ring depth (divides NSTEP)
+  static_assert((CIN / 32) % UC == 0 && QB % DB == 0, "bad body shape");
+  int abase[C::TM];
+#pragma unroll
+  for (int i = 0; i < C::TM; ++i) abase[i] = abase0[i];
+  s16x8 bq[DB][C::TN];
+  s16x8 ring[D];
+  auto load_b = [&](int slot, int c0, int q) {
+    const int t = q % NT, u = q / NT;
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j)
+      bq[slot][j] = *reinterpret_cast<const s16x8*>(wrow[j] + T::ktap(t) * CIN + c0 + u * 32);
+  };
+  auto a_addr = [&](int step) -> const s16x8* {  // step in [0, 2*NSTEP): second half = next body
+    const int wrap = step >= NSTEP ? 1 : 0;
+    const int st = wrap ? step - NSTEP : step;
+    const int q = st / C::TM, i = st - q * C::TM;
+    const int t = q % NT, u = q / NT;
+    return reinterpret_cast<const s16x8*>(smem + abase[i] + T::roff(t) * C::RSTR + T::coff(t) * C::PSTR + u * 64 +
+                                          wrap * UC * 64);
+  };
+#pragma unroll
+  for (int d = 0; d < DB; ++d) load_b(d, 0, d);
+#pragma unroll
+  for (int d = 0; d < D; ++d) ring[d] = *a_addr(d);
+  for (int c0 = 0; c0 < CIN; c0 += 32 * UC) {
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+      const int q = st / C::TM, i = st - q * C::TM;
+      const int slot = q % DB;
+      const s16x8 a = ring[st % D];
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[slot][j], acc[i][j], 0, 0, 0);
+      ring[st % D] = *a_addr(st + D);  // past the last chunk this reads (never used) bytes inside the LDS slack
+      if (i == C::TM - 1) {
+        int nq = q + DB, nc = c0;
+        if (nq >= QB) {
+          nq -= QB;
+          nc += 32 * UC;
+        }
+        nc = nc < CIN ? nc : CIN - 32 * UC;  // clamp instead of branching: the count of loads in flight stays static
+        load_b(slot, nc, nq);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, C::TN, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+      if (i == C::TM - 1) __builtin_amdgcn_sched_barrier(0);  // keep the weight requests two tap-steps ahead
+    }
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i) abase[i] += 64 * UC;
+  }
+}
+
+template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND, int PRO>
+__global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs p) {
+  using C = S2<CIN, COUT, WL, ROWS, WN, NW, KIND>;
+  constexpr int NTH = C::NTH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const otile = smem + C::OUT_OFF;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave % WN, wm = wave / WN;
+  const bf16_t* __restrict__ src = reinterpret_cast<const bf16_t*>(p.src);
+  const bf16_t* __restrict__ wgt = reinterpret_cast<const bf16_t*>(p.w);
+  bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
+
+  const int sblk = blockIdx.x;
+  const int b = sblk / C::NS, row0 = (sblk - b * C::NS) * ROWS;
+
+  // ------------------------------------------------------------------ image loader (prologue applied once)
+  constexpr int TOTAL = C::GH * C::GW * C::CH;
+  const int ch = tid % C::CH;
+  float pa[8], pb[8];
+  if (PRO != FR_PRO_NONE) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pa[j] = p.pro_a[ch * 8 + j];
+      pb[j] = PRO == FR_PRO_BN ? p.pro_b[ch * 8 + j] : 0.f;
+    }
+  }
+  auto load_image = [&](int ph, int pw) {
+    constexpr int UNR = 8;
+    for (int base = 0; base < TOTAL; base += NTH * UNR) {
+      U128 v[UNR];
+      bool ok[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int idx = base + u * NTH + tid;
+        const int pc = idx / C::CH;
+        const int gh = pc / C::GW, gw = pc - gh * C::GW;
+        size_t pix;
+        if (KIND == 0) {  // plane (ph, pw) of the high-res input: low-res rows row0-1 .. row0+ROWS-1, columns -1 .. WL-1
+          const int i = row0 + gh - 1, j = gw - 1;
+          ok[u] = idx < TOTAL && i >= 0 && j >= 0;
+          pix = ((size_t)(b * 2 * C::HL + 2 * i + ph) * (2 * WL) + 2 * j + pw);
+        } else {          // low-res gradient rows row0 .. row0+ROWS, columns 0 .. WL
+          const int i = row0 + gh, j = gw;
+          ok[u] = idx < TOTAL && i < C::HL && j < WL;
+          pix = ((size_t)(b * C::HL + i) * WL + j);
+        }
+        v[u] = ok[u] ? ld16(src + pix * (size_t)p.lda + ch * 8) : zero16();
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int idx = base + u * NTH + tid;
+        if (idx < TOTAL) {
+          const int pc = idx / C::CH;
+          const int gh = pc / C::GW, gw = pc - gh * C::GW;
+          U128 x = v[u];
+          if (PRO != FR_PRO_NONE && ok[u]) {
+            float f[8];
+            unpack16<bf16_t>(x, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if (PRO == FR_PRO_BN) f[j] = fmaf(f[j], pa[j], pb[j]);
+              else f[j] = f[j] > 0.f ? f[j] : f[j] * pa[j];
+            }
+            x = pack16<bf16_t>(f);
+          }
+          st16(smem + gh * C::RSTR + gw * C::PSTR + ch * 16, x);
+        }
+      }
+    }
+  };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n0 = wn * C::TN * 16;
+  const bf16_t* wrow[C::TN];
+#pragma unroll
+  for (int j = 0; j < C::TN; ++j) wrow[j] = wgt + (size_t)(n0 + j * 16 + fr) * 9 * CIN + fq * 8;
+  int abase[C::TM];
+#pragma unroll
+  for (int i = 0; i < C::TM; ++i) {
+    int m = (wm * C::TM + i) * 16 + fr;
+    m = m < C::M ? m : 0;
+    const int h = m / WL, w = m - h * WL;
+    abase[i] = h * C::RSTR + w * C::PSTR + fq * 16;
+  }
+  const int epi = p.epi;
+  const bool stats = epi == FR_EPI_STATS || epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD;
+  constexpr int OCH = COUT / 8;
+  f32x4 acc[C::TM][C::TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+
+  // ------------------------------------------------------------------ epilogue of one output class
+  // cls < 0: forward (output pixel = low-res pixel); cls = 2*ph + pw: gradient class (output pixel (2i+ph, 2j+pw))
+  auto epilogue = [&](int cls) {
+    const int ph = cls < 0 ? 0 : cls >> 1, pw = cls < 0 ? 0 : cls & 1;
+    auto dst_pix = [&](int r) -> size_t {
+      const int h = r / WL, w = r - h * WL;
+      if (KIND == 0) return (size_t)(b * C::HL + row0 + h) * WL + w;
+      return (size_t)(b * 2 * C::HL + 2 * (row0 + h) + ph) * (2 * WL) + 2 * w + pw;
+    };
+    if (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD) {
+      const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
+      for (int idx = tid; idx < C::M * OCH; idx += NTH) {
+        const int r = idx / OCH, c8 = idx - r * OCH;
+        st16(otile + r * C::OSTR + c8 * 16, ld16(aux + dst_pix(r) * (size_t)p.ldaux + c8 * 8));
+      }
+      __syncthreads();
+    }
+    float ea[C::TN], eb[C::TN], s0[C::TN], s1[C::TN];
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) {
+      const int n = n0 + j * 16 + fr;
+      ea[j] = (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD) ? p.epi_a[n] : 0.f;
+      eb[j] = (epi == FR_EPI_BNBWD) ? p.epi_b[n] : 0.f;
+      s0[j] = s1[j] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i) {
+      if (wm * C::TM + i >= C::MT) continue;
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) {
+        const int n = n0 + j * 16 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = (wm * C::TM + i) * 16 + fq * 4 + r;
+          if (m >= C::M) continue;
+          bf16_t* cell = reinterpret_cast<bf16_t*>(otile + m * C::OSTR + n * 2);
+          float v = acc[i][j][r];
+          if (epi == FR_EPI_STATS) {
+            s0[j] += v;
+            s1[j] = fmaf(v, v, s1[j]);
+          } else if (epi == FR_EPI_PRELU_BWD) {
+            const float y = bf2f(*cell);
+            const bool pos = y > 0.f;
+            s0[j] += pos ? 0.f : v * y;
+            v = pos ? v : v * ea[j];
+          } else if (epi == FR_EPI_BNBWD) {
+            const float x = bf2f(*cell);
+            s0[j] += v;
+            s1[j] = fmaf(v, (x - ea[j]) * eb[j], s1[j]);
+          }
+          *cell = f2bf(v);
+        }
+      }
+    }
+    float* red = reinterpret_cast<float*>(otile + C::OUT_BYTES);  // [WM][2][COUT]
+    if (stats) {
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) {
+        float a = s0[j], c = s1[j];
+        a += __shfl_xor(a, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        c += __shfl_xor(c, 16, 64);
+        c += __shfl_xor(c, 32, 64);
+        if (fq == 0) {
+          red[(wm * 2 + 0) * COUT + n0 + j * 16 + fr] = a;
+          red[(wm * 2 + 1) * COUT + n0 + j * 16 + fr] = c;
+        }
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < C::M * OCH; idx += NTH) {
+      const int r = idx / OCH, c8 = idx - r * OCH;
+      st16(out + dst_pix(r) * (size_t)p.ldc + c8 * 8, ld16(otile + r * C::OSTR + c8 * 16));
+    }
+    if (stats) {
+      const size_t prow = (size_t)(cls < 0 ? 0 : cls) * gridDim.x + sblk;  // gradient: rows ordered [class][workgroup]
+      for (int c = tid; c < 2 * COUT; c += NTH) {
+        const int k = c / COUT, n = c - k * COUT;
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < C::WM; ++g) t += red[(g * 2 + k) * COUT + n];
+        p.part[(prow * 2 + k) * COUT + n] = t;
+      }
+    }
+    __syncthreads();  // the tile and the reduction scratch are free again
+  };
+
+  if (KIND == 0) {
+    zero_acc();
+    load_image(0, 0);
+    __syncthreads();
+    mma_taps<C, CIN, 0, 0>(smem, abase, acc, wrow);
+    __syncthreads();  // every wave is done reading the plane
+    load_image(0, 1);
+    __syncthreads();
+    mma_taps<C, CIN, 0, 1>(smem, abase, acc, wrow);
+    __syncthreads();
+    load_image(1, 0);
+    __syncthreads();
+    mma_taps<C, CIN, 0, 2>(smem, abase, acc, wrow);
+    __syncthreads();
+    load_image(1, 1);
+    __syncthreads();
+    mma_taps<C, CIN, 0, 3>(smem, abase, acc, wrow);
+    __syncthreads();  // LDS is now the output tile
+    epilogue(-1);
+  } else {
+    load_image(0, 0);
+    __syncthreads();
+    zero_acc();
+    mma_taps<C, CIN, 1, 0>(smem, abase, acc, wrow);
+    epilogue(0);
+    zero_acc();
+    mma_taps<C, CIN, 1, 1>(smem, abase, acc, wrow);
+    epilogue(1);
+    zero_acc();
+    mma_taps<C, CIN, 1, 2>(smem, abase, acc, wrow);
+    epilogue(2);
+    zero_acc();
+    mma_taps<C, CIN, 1, 3>(smem, abase, acc, wrow);
+    epilogue(3);
+  }
+}
+
+template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND, int PRO>
+int launch(const FrConvArgs& a, hipStream_t st) {
+  using C = S2<CIN, COUT, WL, ROWS, WN, NW, KIND>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_s2_kernel<CIN, COUT, WL, ROWS, WN, NW, KIND, PRO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv3x3_s2_kernel<CIN, COUT, WL, ROWS, WN, NW, KIND, PRO>), dim3(a.B * C::NS), dim3(C::NTH), C::LDS,
+                     st, a);
+  FR_LAUNCH_CHECK();
+}
+
+template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND>
+int by_pro(const FrConvArgs& a, hipStream_t st) {
+  switch (a.pro) {
+    case FR_PRO_NONE: return launch<CIN, COUT, WL, ROWS, WN, NW, KIND, FR_PRO_NONE>(a, st);
+    case FR_PRO_BN: return launch<CIN, COUT, WL, ROWS, WN, NW, KIND, FR_PRO_BN>(a, st);
+    case FR_PRO_PRELU: return launch<CIN, COUT, WL, ROWS, WN, NW, KIND, FR_PRO_PRELU>(a, st);
+  }
+  return -1;
+}
+
+// low-res rows per workgroup for a served shape (0 = not served): the four IR stage transitions
+int s2_rows(int C, int WL) {
+  if (C == 64 && WL == 56) return 2;
+  if (C == 128 && WL == 28) return 4;
+  if (C == 256 && WL == 14) return 7;
+  if (C == 512 && WL == 7) return 7;
+  return 0;
+}
+
+}  // namespace
+
+// Partial-sum rows the kernel writes for a supported (B, C -> C, low-res width) problem; 0 when not served.
+// mode 0: forward (one row per workgroup); mode 2: data gradient (4 classes x workgroups, ordered [class][workgroup]).
+extern "C" int fr_conv3x3_s2_strip_parts(int B, int Cin, int Cout, int WL, int mode) {
+  if (Cin != Cout) return 0;
+  const int rows = s2_rows(Cin, WL);
+  if (!rows) return 0;
+  const int wgs = B * (WL / rows);
+  return mode == 2 ? 4 * wgs : wgs;
+}
+
+extern "C" int fr_conv3x3_s2_strip(const FrConvArgs* args, void* stream) {
+  const FrConvArgs& a = *args;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a.KH != 3 || a.KW != 3 || a.stride != 2 || a.pad != 1 || a.out_f32 || a.splitk > 1 || a.bias ||
+      a.epi == FR_EPI_MARGIN || a.epi == FR_EPI_ATOMIC || (a.mode != 0 && a.mode != 2))
+    FR_UNSUPPORTED("fr_conv3x3_s2_strip: stride-2 3x3 pad-1 bf16 convolution (mode 0) or its data gradient (mode 2)");
+  if (a.mode == 2 && (a.par_h >= 0 || a.par_w >= 0))
+    FR_UNSUPPORTED("fr_conv3x3_s2_strip: the data gradient produces all four parity classes (par_h = par_w = -1)");
+  if (a.lda % 8 || a.ldc % 8 || (a.aux && a.ldaux % 8)) FR_UNSUPPORTED("fr_conv3x3_s2_strip: strides must be 16-byte multiples");
+  // low-res grid: forward output / gradient input
+  const int WLo = a.mode == 0 ? a.RW : a.SW, HLo = a.mode == 0 ? a.RH : a.SH;
+  const int WHi = a.mode == 0 ? a.SW : a.RW, HHi = a.mode == 0 ? a.SH : a.RH;
+  if (WLo != HLo || WHi != 2 * WLo || HHi != 2 * HLo || a.SC != a.N)
+    FR_UNSUPPORTED("fr_conv3x3_s2_strip: square images, high-res side = 2 x low-res side, Cin == Cout");
+#define SHAPE(c, wl, rows, wn, nw)                                   \
+  if (a.SC == c && WLo == wl) {                                      \
+    if (a.mode == 0) return by_pro<c, c, wl, rows, wn, nw, 0>(a, st); \
+    return by_pro<c, c, wl, rows, wn, nw, 1>(a, st);                  \
+  }
+  SHAPE(64, 56, 2, 2, 4)
+  SHAPE(128, 28, 4, 4, 8)
+  SHAPE(256, 14, 7, 8, 8)
+  SHAPE(512, 7, 7, 8, 8)
+#undef SHAPE
+  FR_UNSUPPORTED("fr_conv3x3_s2_strip: shape not in the table");
+}

@@ -67,10 +67,15 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
   }
   const int nb_count = (p.N + BN - 1) / BN;
   const int mb = bid / nb_count, nb = bid - mb * nb_count;
+  const int mb_count = nblk / nb_count;
   const int m0 = mb * BM, n0 = nb * BN;
   // mode 2: stride-2 3x3 data gradient restricted to the output pixels of one parity class (par_h, par_w).  Rows
   // enumerate (b, i, j) with output pixel (2i+par_h, 2j+par_w); only the taps that land on an input pixel are visited
   // (1, 2, 2 or 4 of the 9), so the four classes together do 9/4 taps per pixel instead of 9.
+  // par_h = par_w = -1: all four classes in ONE launch, class = blockIdx.y (their short K loops and fat epilogues then
+  // overlap each other instead of running as four dependent launches); part rows are [class][M tile].
+  const int par_h = p.par_h < 0 ? (int)(blockIdx.y >> 1) : p.par_h;
+  const int par_w = p.par_w < 0 ? (int)(blockIdx.y & 1) : p.par_w;
   const int RH2 = p.mode == 2 ? p.RH >> 1 : p.RH, RW2 = p.mode == 2 ? p.RW >> 1 : p.RW;
   const int M = p.B * RH2 * RW2;
 
@@ -110,8 +115,8 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
 
   const int taps = p.KH * p.KW;
   const int kchunks = p.SC / BK;  // K steps per tap
-  const int vkw = p.mode == 2 ? (p.par_w ? 2 : 1) : p.KW;  // taps actually visited along w / h
-  const int vkh = p.mode == 2 ? (p.par_h ? 2 : 1) : p.KH;
+  const int vkw = p.mode == 2 ? (par_w ? 2 : 1) : p.KW;  // taps actually visited along w / h
+  const int vkh = p.mode == 2 ? (par_h ? 2 : 1) : p.KH;
   const int nk_total = vkh * vkw * kchunks;
   int ks_begin = 0, ks_end = nk_total;
   if (gridDim.z > 1) {
@@ -129,10 +134,10 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
     int kh = vtap / vkw, kw = vtap - kh * vkw;
     int dh = 0, dw = 0;
     if (p.mode == 2) {  // odd output rows see taps 0 and 2 (input row i+1 and i), even rows only tap 1 (input row i)
-      dh = p.par_h ? 1 - kh : 0;
-      dw = p.par_w ? 1 - kw : 0;
-      kh = p.par_h ? 2 * kh : 1;
-      kw = p.par_w ? 2 * kw : 1;
+      dh = par_h ? 1 - kh : 0;
+      dw = par_w ? 1 - kw : 0;
+      kh = par_h ? 2 * kh : 1;
+      kw = par_w ? 2 * kw : 1;
     }
     const int tap = kh * p.KW + kw;
     const int ca = c0 + a_cc * VEC;
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
         const int b = m / (RH2 * RW2);
         const int rem = m - b * (RH2 * RW2);
         const int i2 = rem / RW2, j2 = rem - i2 * RW2;
-        mrow = ((size_t)b * p.RH + 2 * i2 + p.par_h) * (size_t)p.RW + 2 * j2 + p.par_w;
+        mrow = ((size_t)b * p.RH + 2 * i2 + par_h) * (size_t)p.RW + 2 * j2 + par_w;
       }
       const size_t ooff = mrow * (size_t)p.ldc + n;
       if (epi == FR_EPI_ATOMIC) {
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
       if (n0 + col < p.N) {
         float s = 0.f;
         for (int g = 0; g < nred; ++g) s += Red[(k * 16 + g) * BN + col];
-        p.part[((size_t)mb * 2 + k) * (size_t)p.N + n0 + col] = s;
+        p.part[(((size_t)blockIdx.y * mb_count + mb) * 2 + k) * (size_t)p.N + n0 + col] = s;
       }
     }
   }
@@ -439,7 +444,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
   using C = Cfg<T, BN>;
   const int M = a.mode == 2 ? a.B * (a.RH / 2) * (a.RW / 2) : a.B * a.RH * a.RW;
   const int mbs = (M + BM - 1) / BM, nbs = (a.N + BN - 1) / BN;
-  dim3 grid(mbs * nbs, 1, a.splitk > 1 ? a.splitk : 1);
+  dim3 grid(mbs * nbs, a.mode == 2 && a.par_h < 0 ? 4 : 1, a.splitk > 1 ? a.splitk : 1);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BN, PRO>),
@@ -472,6 +477,8 @@ extern "C" int fr_conv_igemm(const FrConvArgs* args, int dtype, void* stream) {
   if (a.stride != 1 && a.stride != 2) FR_UNSUPPORTED("fr_conv_igemm: stride must be 1 or 2");
   if (a.mode == 2 && (a.stride != 2 || a.KH != 3 || a.KW != 3 || a.pad != 1 || (a.RH & 1) || (a.RW & 1) || a.epi == FR_EPI_MARGIN))
     FR_UNSUPPORTED("fr_conv_igemm: mode 2 is the stride-2 3x3 pad-1 data gradient on even-sized outputs");
+  if (a.mode == 2 && ((a.par_h < 0) != (a.par_w < 0) || a.par_h > 1 || a.par_w > 1))
+    FR_UNSUPPORTED("fr_conv_igemm: parity class must be (0|1, 0|1) or (-1, -1) for all four in one launch");
   if ((long long)a.B * a.RH * a.RW >= (1ll << 31) / 4) FR_UNSUPPORTED("fr_conv_igemm: too many rows");
   if (a.splitk > 1 && (a.epi != FR_EPI_ATOMIC || !a.out_f32))
     FR_UNSUPPORTED("fr_conv_igemm: split-K needs the fp32 atomic epilogue");

@@ -203,6 +203,7 @@ class BackbonePlan(object):
         self.S = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
         self.generation = 0
         self.use_strip = os.environ.get("FRHIP_NO_STRIP", "0") != "1"
+        self.use_s2 = os.environ.get("FRHIP_NO_S2_STRIP", "0") != "1"  # stride-2 strip kernels (A/B switch)
         self.slab, self._slab_users = None, []
         self._normalize_params()
         self._alloc()
@@ -350,7 +351,16 @@ class BackbonePlan(object):
             if n:
                 L.append(ops.conv_strip(self.stream, **kw))
                 return n
+        if (self.fr == FR_BF16 and self.use_strip and self.use_s2 and kw["KH"] == 3 and kw["stride"] == 2 and
+                kw.get("mode", 0) in (0, 2)):
+            mode = kw.get("mode", 0)
+            n = ops.s2_strip_parts(kw["B"], kw["SC"], kw["N"], kw["RW"] if mode == 0 else kw["SW"], mode)
+            if n:
+                L.append(ops.conv_s2_strip(self.stream, **kw))
+                return n
         L.append(ops.conv(self.stream, self.fr, **kw))
+        if kw.get("mode", 0) == 2:  # all four parity classes in one launch: [class][M tile] partial rows
+            return 4 * ((kw["B"] * (kw["RH"] // 2) * (kw["RW"] // 2) + 127) // 128)
         return (kw["B"] * kw["RH"] * kw["RW"] + 127) // 128
 
     def _side_after_main(self, L):
@@ -654,10 +664,8 @@ class BackbonePlan(object):
                       epi=ops.EPI_PRELU_BWD, aux=d["y1"], epi_a=u.prelu.weight)
             if u.stride == 2 and u.H % 2 == 0:
                 # one launch per output-pixel parity class: 9/4 taps per pixel instead of 9 (3/4 of them misses)
-                mtc = (B * (u.H // 2) ** 2 + 127) // 128
-                for c, (ph, pw) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
-                    self._conv(L, mode=2, par_h=ph, par_w=pw, part=self.part[c * mtc * 2 * u.depth:], **c2)
-                mt = 4 * mtc
+                # (all four classes in one launch: par = -1; partial rows come back as [class][M tile])
+                mt = self._conv(L, mode=2, par_h=-1, par_w=-1, part=self.part, **c2)
             else:
                 mt = self._conv(L, mode=1, part=self.part, **c2)
             gsl = self.grad_of(u.prelu.weight)

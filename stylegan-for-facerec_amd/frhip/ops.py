@@ -84,6 +84,17 @@ def strip_parts(B, cin, cout, w, epi=EPI_STORE):
     return int(lib.fr_conv3x3_strip_parts(int(B), int(cin), int(cout), int(w), int(epi)))
 
 
+def conv_s2_strip(stream, **kw):
+    """fr_conv3x3_s2_strip (bf16 stride-2 3x3, Cin == Cout): mode 0 forward, mode 2 (par -1) data gradient."""
+    a = _fill(_lib.FrConvArgs(), **kw)
+    return Launch("fr_conv3x3_s2_strip", [ctypes.byref(a), stream], keep=(a, kw))
+
+
+def s2_strip_parts(B, cin, cout, wl, mode):
+    """Partial-sum rows of the stride-2 strip kernel for a shape; 0 when it is not served."""
+    return int(lib.fr_conv3x3_s2_strip_parts(int(B), int(cin), int(cout), int(wl), int(mode)))
+
+
 def wgrad(stream, dtype, **kw):
     a = _fill(_lib.FrWgradArgs(), **kw)
     return Launch("fr_conv_wgrad", [ctypes.byref(a), dtype, stream], keep=(a, kw))

@@ -610,9 +610,11 @@ def test_conv_wgrad_strip(K, cout, cin, W, pro, groups):
 
 
 @pytest.mark.parametrize("name,dtype,tol", DT)
-def test_conv_dgrad_stride2_by_parity(K, name, dtype, tol):
-    """mode 2: the stride-2 3x3 data gradient as four parity-class launches (only the taps that hit an input pixel),
-    with the PReLU-backward epilogue; must equal autograd through the strided convolution."""
+@pytest.mark.parametrize("fused", [False, True], ids=["four_launches", "one_launch"])
+def test_conv_dgrad_stride2_by_parity(K, name, dtype, tol, fused):
+    """mode 2: the stride-2 3x3 data gradient by output-pixel parity class (only the taps that hit an input pixel),
+    as four launches or as one launch over all classes (par = -1), with the PReLU-backward epilogue; must equal
+    autograd through the strided convolution."""
     B, H, cin, cout = 3, 12, 64, 128
     x = synth.normal(51, "px", (B, cin, H, H)).requires_grad_(True)
     w = q(synth.normal(51, "pw", (cout, cin, 3, 3), std=0.1), dtype)
@@ -627,7 +629,7 @@ def test_conv_dgrad_stride2_by_parity(K, name, dtype, tol):
     out = torch.zeros(B, H, H, cin, device="cuda", dtype=dtype)
     mtc = (B * (H // 2) ** 2 + 127) // 128
     part = torch.zeros(4 * mtc, 2, cin, device="cuda")
-    for c, (ph, pw) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+    for c, (ph, pw) in enumerate(((-1, -1),) if fused else ((0, 0), (0, 1), (1, 0), (1, 1))):
         K.conv(K.current_stream_ptr(), fr, src=nhwc(g, dtype), w=wt, out=out, B=B, RH=H, RW=H, SH=H // 2, SW=H // 2,
                SC=cout, N=cin, KH=3, KW=3, stride=2, pad=1, mode=2, par_h=ph, par_w=pw, lda=cout, ldc=cin, ldaux=cin,
                pro=0, epi=K.EPI_PRELU_BWD, aux=nhwc(aux, dtype), epi_a=slope.cuda(), part=part[c * mtc:])()
@@ -635,3 +637,69 @@ def test_conv_dgrad_stride2_by_parity(K, name, dtype, tol):
     assert relerr(from_nhwc(out), want) < tol
     np.testing.assert_allclose(part.sum(0)[0].cpu(), (gx * aux * (aux <= 0)).sum((0, 2, 3)), rtol=tol * 10,
                                atol=tol * 10 * float((gx * aux).abs().sum() / cin))
+
+
+S2_SHAPES = [(64, 56), (128, 28), (256, 14), (512, 7)]
+
+
+@pytest.mark.parametrize("C,WL", S2_SHAPES, ids=["%d_%d" % s for s in S2_SHAPES])
+@pytest.mark.parametrize("pro", ["none", "bn", "prelu"])
+def test_conv3x3_s2_strip_forward(K, C, WL, pro):
+    """fr_conv3x3_s2_strip mode 0: stride-2 3x3 forward on LDS parity planes (+ prologue, + BN statistics) vs
+    F.conv2d on the CPU, and vs the generic implicit-GEMM kernel's partial-sum contract (column totals)."""
+    dtype, tol = torch.bfloat16, 4e-2
+    B, H = 3, 2 * WL
+    x = q(synth.normal(61, "sx", (B, C, H, H)), dtype)
+    w = q(synth.normal(61, "sw", (C, C, 3, 3), std=0.05), dtype)
+    pa = synth.uniform(61, "spa", (C,), 0.5, 1.5)
+    pb = synth.uniform(61, "spb", (C,), -0.3, 0.3)
+    v = lambda t: t.view(1, C, 1, 1)  # noqa: E731
+    if pro == "bn":
+        xin = q(x * v(pa) + v(pb), dtype)
+    elif pro == "prelu":
+        xin = q(torch.where(x > 0, x, x * v(pa * 0.25)), dtype)
+    else:
+        xin = x
+    y = F.conv2d(xin, w, stride=2, padding=1)
+    n = K.s2_strip_parts(B, C, C, WL, 0)
+    assert n > 0
+    out = torch.zeros(B, WL, WL, C, device="cuda", dtype=dtype)
+    part = torch.zeros(n, 2, C, device="cuda")
+    a_dev = (pa * 0.25 if pro == "prelu" else pa).cuda()
+    K.conv_s2_strip(K.current_stream_ptr(), src=nhwc(x, dtype), w=pack_w(w, dtype), out=out, B=B, RH=WL, RW=WL, SH=H,
+                    SW=H, SC=C, N=C, KH=3, KW=3, stride=2, pad=1, mode=0, lda=C, ldc=C,
+                    pro={"none": 0, "bn": 1, "prelu": 2}[pro], pro_a=a_dev, pro_b=pb.cuda(), epi=K.EPI_STATS,
+                    part=part)()
+    torch.cuda.synchronize()
+    got = from_nhwc(out)
+    assert relerr(got, y) < tol
+    np.testing.assert_allclose(part.sum(0)[0].cpu(), y.sum((0, 2, 3)), rtol=tol, atol=tol * float(y.abs().sum() / C))
+    np.testing.assert_allclose(part.sum(0)[1].cpu(), (y * y).sum((0, 2, 3)), rtol=tol)
+
+
+@pytest.mark.parametrize("C,WL", S2_SHAPES, ids=["%d_%d" % s for s in S2_SHAPES])
+def test_conv3x3_s2_strip_dgrad(K, C, WL):
+    """fr_conv3x3_s2_strip mode 2: all four parity classes of the stride-2 data gradient with the PReLU-backward
+    epilogue, vs autograd through F.conv2d(stride=2)."""
+    dtype, tol = torch.bfloat16, 4e-2
+    B, H = 2, 2 * WL
+    x = synth.normal(63, "dx", (B, C, H, H)).requires_grad_(True)
+    w = q(synth.normal(63, "dw", (C, C, 3, 3), std=0.05), dtype)
+    y = F.conv2d(x, w, stride=2, padding=1)
+    g = q(synth.normal(63, "dg", tuple(y.shape)), dtype)
+    (gx,) = torch.autograd.grad(y, [x], g)
+    aux = q(synth.normal(63, "da", (B, C, H, H)), dtype)
+    slope = synth.uniform(63, "ds", (C,), 0.1, 0.4)
+    want = torch.where(aux > 0, gx, gx * slope.view(1, -1, 1, 1))
+    wt = w.permute(1, 2, 3, 0).reshape(C, 9, C).contiguous().to("cuda", dtype)
+    out = torch.zeros(B, H, H, C, device="cuda", dtype=dtype)
+    n = K.s2_strip_parts(B, C, C, WL, 2)
+    assert n > 0 and n % 4 == 0
+    part = torch.zeros(n, 2, C, device="cuda")
+    K.conv_s2_strip(K.current_stream_ptr(), src=nhwc(g, dtype), w=wt, out=out, B=B, RH=H, RW=H, SH=WL, SW=WL, SC=C, N=C,
+                    KH=3, KW=3, stride=2, pad=1, mode=2, par_h=-1, par_w=-1, lda=C, ldc=C, ldaux=C, pro=0,
+                    epi=K.EPI_PRELU_BWD, aux=nhwc(aux, dtype), epi_a=slope.cuda(), part=part)()
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(out), want) < tol
+    np.testing.assert_allclose(part.sum(0)[0].cpu(), (gx * aux * (aux <= 0)).sum((0, 2, 3)), rtol=tol * 10,
+                               atol=tol * 10 * float((gx * aux).abs().sum() / C))
