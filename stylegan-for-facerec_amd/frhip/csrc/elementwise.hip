@@ -90,8 +90,13 @@ __device__ __forceinline__ void reduce_rows8(const float* __restrict__ part, int
   const int tid = threadIdx.x, cl = tid & 7, rl = tid >> 3;
   constexpr int RL = RT / 8, RW = RT / 64;
   double s[NCOLSETS];
+  const float* colp[NCOLSETS];  // out-of-range columns read the last valid one (branch-free loads) and are zeroed below
 #pragma unroll
-  for (int k = 0; k < NCOLSETS; ++k) s[k] = 0.0;
+  for (int k = 0; k < NCOLSETS; ++k) {
+    s[k] = 0.0;
+    const int c = col0[k] + cl;
+    colp[k] = part + (c < KC ? c : KC - 1);
+  }
   int r = rl;
   constexpr int U = 8;  // U x NCOLSETS independent loads per trip
   for (; r + (U - 1) * RL < nparts; r += U * RL) {
@@ -99,8 +104,7 @@ __device__ __forceinline__ void reduce_rows8(const float* __restrict__ part, int
 #pragma unroll
     for (int k = 0; k < NCOLSETS; ++k)
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        v[k][u] = col0[k] + cl < KC ? part[(size_t)(r + u * RL) * KC + col0[k] + cl] : 0.f;
+      for (int u = 0; u < U; ++u) v[k][u] = colp[k][(size_t)(r + u * RL) * KC];
 #pragma unroll
     for (int k = 0; k < NCOLSETS; ++k) {
       double t = 0.0;
@@ -111,8 +115,10 @@ __device__ __forceinline__ void reduce_rows8(const float* __restrict__ part, int
   }
   for (; r < nparts; r += RL)
 #pragma unroll
-    for (int k = 0; k < NCOLSETS; ++k)
-      if (col0[k] + cl < KC) s[k] += (double)part[(size_t)r * KC + col0[k] + cl];
+    for (int k = 0; k < NCOLSETS; ++k) s[k] += (double)colp[k][(size_t)r * KC];
+#pragma unroll
+  for (int k = 0; k < NCOLSETS; ++k)
+    if (col0[k] + cl >= KC) s[k] = 0.0;
   // lanes of a wave: 8 row-lanes x 8 columns -> fold the row-lane bits (lane bits 3..5)
   const int wave = tid >> 6;
 #pragma unroll
