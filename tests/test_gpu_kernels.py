@@ -472,11 +472,15 @@ STRIP_SHAPES = [(64, 64, 112), (64, 64, 56), (64, 128, 56), (128, 64, 56), (128,
                 (256, 128, 28), (256, 256, 14), (256, 512, 14), (512, 256, 14), (512, 512, 7)]
 
 
-@pytest.mark.parametrize("cin,cout,W", STRIP_SHAPES, ids=["%d_%d_%d" % s for s in STRIP_SHAPES])
-def test_conv3x3_strip(K, cin, cout, W):
+STRIP_CASES = [s + (3,) for s in STRIP_SHAPES] + [(512, 512, 7, 4)]  # even batch: two images per workgroup at 7x7
+
+
+@pytest.mark.parametrize("cin,cout,W,B", STRIP_CASES, ids=["%d_%d_%d_b%d" % s for s in STRIP_CASES])
+def test_conv3x3_strip(K, cin, cout, W, B):
     """LDS-resident-strip 3x3 s1 conv (bf16): forward with BN prologue + statistics, and the mirrored-tap data
-    gradient with the PReLU-backward and BN-backward epilogues, every shape of its dispatch table, B = 3."""
-    B, dtype, tol = 3, torch.bfloat16, 4e-2
+    gradient with the PReLU-backward and BN-backward epilogues, every shape of its dispatch table (B = 3; the 7x7
+    stage also with an even batch, which takes the two-images-per-workgroup / split-channel instance)."""
+    dtype, tol = torch.bfloat16, 4e-2
     assert K.strip_parts(B, cin, cout, W) > 0
     st = K.current_stream_ptr()
     x = q(synth.normal(31, "sx", (B, cin, W, W)), dtype)
