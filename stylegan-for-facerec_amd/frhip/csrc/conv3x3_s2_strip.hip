@@ -16,6 +16,8 @@
 // two tap-steps ahead), no barrier inside a tap list, bf16 results leave through an LDS tile as row-contiguous
 // 16-byte stores.  Same contracts as fr_conv_igemm (mode 0 stride 2 / mode 2): bit-compatible layouts of src, w,
 // out, aux and the column partial sums.
+#include <type_traits>
+
 #include "common.h"
 #include "frhip_internal.h"
 
@@ -111,7 +113,7 @@ __device__ __forceinline__ void mma_taps(const char* smem, const int (&abase0)[C
       const s16x8 a = ring[st % D];
 #pragma unroll
       for (int j = 0; j < C::TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[slot][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[slot][j], a, acc[i][j], 0, 0, 0);  // = (W X^T) tile
       ring[st % D] = *a_addr(st + D);  // past the last chunk this reads (never used) bytes inside the LDS slack
       if (i == C::TM - 1) {
         int nq = q + DB, nc = c0;
@@ -244,57 +246,82 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
       }
       __syncthreads();
     }
-    float ea[C::TN], eb[C::TN], s0[C::TN], s1[C::TN];
-#pragma unroll
-    for (int j = 0; j < C::TN; ++j) {
-      const int n = n0 + j * 16 + fr;
-      ea[j] = (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD) ? p.epi_a[n] : 0.f;
-      eb[j] = (epi == FR_EPI_BNBWD) ? p.epi_b[n] : 0.f;
-      s0[j] = s1[j] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < C::TM; ++i) {
-      if (wm * C::TM + i >= C::MT) continue;
-#pragma unroll
-      for (int j = 0; j < C::TN; ++j) {
-        const int n = n0 + j * 16 + fr;
-#pragma unroll
+    // weights were the MFMA A operand: a lane holds four consecutive channels (fq*4 + r) of one pixel (fr) per tile
+    float* red = reinterpret_cast<float*>(otile + C::OUT_BYTES);  // [WM][2][COUT] column sums, behind the output tile
+    // The epilogue kind is a run-time argument, but inside the per-element loops it must be a compile-time constant:
+    // with `epi` tested per element the compiler emitted a scalar branch per accumulator (8000 instructions, ~10 us).
+    auto cells = [&](auto tag) {
+      constexpr int E = decltype(tag)::value;
+      float ea[C::TN][4], eb[C::TN][4], s0[C::TN][4], s1[C::TN][4];
+  #pragma unroll
+      for (int j = 0; j < C::TN; ++j)
+  #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int m = (wm * C::TM + i) * 16 + fq * 4 + r;
-          if (m >= C::M) continue;
-          bf16_t* cell = reinterpret_cast<bf16_t*>(otile + m * C::OSTR + n * 2);
-          float v = acc[i][j][r];
-          if (epi == FR_EPI_STATS) {
-            s0[j] += v;
-            s1[j] = fmaf(v, v, s1[j]);
-          } else if (epi == FR_EPI_PRELU_BWD) {
-            const float y = bf2f(*cell);
-            const bool pos = y > 0.f;
-            s0[j] += pos ? 0.f : v * y;
-            v = pos ? v : v * ea[j];
-          } else if (epi == FR_EPI_BNBWD) {
-            const float x = bf2f(*cell);
-            s0[j] += v;
-            s1[j] = fmaf(v, (x - ea[j]) * eb[j], s1[j]);
+          const int n = n0 + j * 16 + fq * 4 + r;
+          ea[j][r] = (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD) ? p.epi_a[n] : 0.f;
+          eb[j][r] = (E == FR_EPI_BNBWD) ? p.epi_b[n] : 0.f;
+          s0[j][r] = s1[j][r] = 0.f;
+        }
+  #pragma unroll
+      for (int i = 0; i < C::TM; ++i) {
+        const int m = (wm * C::TM + i) * 16 + fr;
+        if (wm * C::TM + i >= C::MT || m >= C::M) continue;
+  #pragma unroll
+        for (int j = 0; j < C::TN; ++j) {
+          uint2* cell = reinterpret_cast<uint2*>(otile + m * C::OSTR + (n0 + j * 16 + fq * 4) * 2);
+          float v[4], x[4];
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+          if (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD) {
+            const uint2 u = *cell;
+            x[0] = __uint_as_float(u.x << 16);
+            x[1] = __uint_as_float(u.x & 0xFFFF0000u);
+            x[2] = __uint_as_float(u.y << 16);
+            x[3] = __uint_as_float(u.y & 0xFFFF0000u);
           }
-          *cell = f2bf(v);
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (E == FR_EPI_STATS) {
+              s0[j][r] += v[r];
+              s1[j][r] = fmaf(v[r], v[r], s1[j][r]);
+            } else if (E == FR_EPI_PRELU_BWD) {
+              const bool pos = x[r] > 0.f;
+              s0[j][r] += pos ? 0.f : v[r] * x[r];
+              v[r] = pos ? v[r] : v[r] * ea[j][r];
+            } else if (E == FR_EPI_BNBWD) {
+              s0[j][r] += v[r];
+              s1[j][r] = fmaf(v[r], (x[r] - ea[j][r]) * eb[j][r], s1[j][r]);
+            }
+          }
+          uint2 o;
+          o.x = pack2bf(v[0], v[1]);
+          o.y = pack2bf(v[2], v[3]);
+          *cell = o;
         }
       }
-    }
-    float* red = reinterpret_cast<float*>(otile + C::OUT_BYTES);  // [WM][2][COUT]
-    if (stats) {
-#pragma unroll
-      for (int j = 0; j < C::TN; ++j) {
-        float a = s0[j], c = s1[j];
-        a += __shfl_xor(a, 16, 64);
-        a += __shfl_xor(a, 32, 64);
-        c += __shfl_xor(c, 16, 64);
-        c += __shfl_xor(c, 32, 64);
-        if (fq == 0) {
-          red[(wm * 2 + 0) * COUT + n0 + j * 16 + fr] = a;
-          red[(wm * 2 + 1) * COUT + n0 + j * 16 + fr] = c;
-        }
+      if (E != FR_EPI_STORE) {
+  #pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float a = s0[j][r], c = s1[j][r];
+  #pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+              a += __shfl_xor(a, o, 64);
+              c += __shfl_xor(c, o, 64);
+            }
+            if (fr == 0) {
+              red[(wm * 2 + 0) * COUT + n0 + j * 16 + fq * 4 + r] = a;
+              red[(wm * 2 + 1) * COUT + n0 + j * 16 + fq * 4 + r] = c;
+            }
+          }
       }
+    };
+    switch (epi) {
+      case FR_EPI_STATS: cells(std::integral_constant<int, FR_EPI_STATS>{}); break;
+      case FR_EPI_PRELU_BWD: cells(std::integral_constant<int, FR_EPI_PRELU_BWD>{}); break;
+      case FR_EPI_BNBWD: cells(std::integral_constant<int, FR_EPI_BNBWD>{}); break;
+      default: cells(std::integral_constant<int, FR_EPI_STORE>{}); break;
     }
     __syncthreads();
     for (int idx = tid; idx < C::M * OCH; idx += NTH) {
