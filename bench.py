@@ -287,7 +287,7 @@ def main():
         "config": {"workload": "IR-50 + ArcFace(%d ids) + Focal + SGD train step, synthetic 112x112x3, bs=%d/GPU"
                                % (args.classes, args.batch),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                   "images_per_sec_per_gpu": round(ips / world, 1), "final_loss": round(loss_val, 4)},
+                   "images_per_sec_per_gpu": round(ips / world, 1), "final_loss": float("%.3e" % loss_val)},
     }
     if rank == 0:
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
