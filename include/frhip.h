@@ -127,6 +127,15 @@ int fr_conv_wgrad_strip_supported(int Cout, int Cin, int W);
 int fr_stem_im2col(const float* x, const float* avg, void* out, int B, int H, int W, int C, int Cavg, int ldk,
                    int dtype, void* stream);
 
+/* The stem GEMMs over those rows (bf16, K = ldk = 32 or 64, 64 output channels), shaped for 3.2 M rows x 64 columns:
+ * fr_stem_gemm : out[M][64] = X[M][K] * Wp[64][K]^T, part[nblocks][2][64] = column sums / sums of squares of out
+ *                (the EPI_STATS contract of fr_conv_igemm with nblocks partial rows);
+ * fr_stem_wgrad: slab[nblocks][64][K] = per-workgroup partial of g[M][64]^T * X[M][K] (add them with fr_reduce_parts,
+ *                K = 1, C = 64*K).
+ * Replace the GEMM half of input_layer Conv2d(3|6,64,3,1,1) (model_irse.py:140) forward and its weight gradient. */
+int fr_stem_gemm(const void* X, const void* Wp, void* out, float* part, long long M, int K, int nblocks, void* stream);
+int fr_stem_wgrad(const void* G, const void* X, float* slab, long long M, int K, int nblocks, void* stream);
+
 /* ---- BatchNorm statistics (train mode; torch defaults eps 1e-5, momentum 0.1 -- SURVEY App. B 13)
  * part: [nparts][2][C] partial (sum, sum of squares) rows; count = elements per channel.
  * Writes mean, invstd, scale = gamma*invstd, shift = beta - mean*scale; updates running stats (unbiased var)

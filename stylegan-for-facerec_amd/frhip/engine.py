@@ -203,6 +203,7 @@ class BackbonePlan(object):
         self.S = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
         self.generation = 0
         self.use_strip = os.environ.get("FRHIP_NO_STRIP", "0") != "1"
+        self.use_stem_gemm = self.fr == FR_BF16 and os.environ.get("FRHIP_NO_STEM_GEMM", "0") != "1"
         self.use_s2 = os.environ.get("FRHIP_NO_S2_STRIP", "0") != "1"  # stride-2 strip kernels (A/B switch)
         self.slab, self._slab_users = None, []
         self._normalize_params()
@@ -419,10 +420,14 @@ class BackbonePlan(object):
         P.append(ops.call("fr_pack_stem", w0, w0.stride(0), w0.stride(1), w0.stride(2), w0.stride(3), self.W0p, 64,
                           w0.shape[1], self.K0, fr, st))
         self.l_im2col = None  # bound per call (input pointer changes)
-        mt0 = (self.M0 + 127) // 128
-        L.append(ops.conv(st, fr, src=self.X0, w=self.W0p, out=self.y0, B=self.M0, RH=1, RW=1, SH=1, SW=1, SC=self.K0,
-                          N=64, KH=1, KW=1, stride=1, pad=0, mode=0, lda=self.K0, ldc=64, pro=0, epi=ops.EPI_STATS,
-                          part=self.part))
+        if self.use_stem_gemm:  # 3.2 M rows x 64 columns x K0: the row-streaming kernels of stem_gemm.hip
+            mt0 = int(min(2048, (self.M0 + 63) // 64))
+            L.append(ops.call("fr_stem_gemm", self.X0, self.W0p, self.y0, self.part, self.M0, self.K0, mt0, st))
+        else:
+            mt0 = (self.M0 + 127) // 128
+            L.append(ops.conv(st, fr, src=self.X0, w=self.W0p, out=self.y0, B=self.M0, RH=1, RW=1, SH=1, SW=1,
+                              SC=self.K0, N=64, KH=1, KW=1, stride=1, pad=0, mode=0, lda=self.K0, ldc=64, pro=0,
+                              epi=ops.EPI_STATS, part=self.part))
         self._bn_train_launches(L, self.bn0, self.part, mt0, self.M0)
         nb = ops.grid_blocks(self.M0, 64, fr)
         first_bn = self.ubuf[0]["bn1"]
@@ -731,10 +736,15 @@ class BackbonePlan(object):
         L.append(ops.bn_bwd_apply(st, fr, gx=g_y0, gamma=sb.weight, s0=s0, s1=s1, inv_count=1.0 / self.M0, **common))
         gw0 = self.grad_of(sc.weight)
         if gw0 is not None:
-            L.append(ops.call("fr_fill_rows", self.gW0p, None, 64, self.K0, st))
-            L.append(ops.wgrad(st, fr, g=g_y0, src=self.X0, dw=self.gW0p, B=self.M0, GH=1, GW=1, Cout=64, SH=1, SW=1,
-                               SC=self.K0, KH=1, KW=1, stride=1, pad=0, ldg=64, lda=self.K0, pro=0,
-                               nsplit=_wgrad_slices(self.M0, 1)))
+            if self.use_stem_gemm:
+                nsl = int(min(1024 if self.K0 == 32 else 512, (self.M0 + 63) // 64))  # partials live in self.part
+                L.append(ops.call("fr_stem_wgrad", g_y0, self.X0, self.part, self.M0, self.K0, nsl, st))
+                L.append(ops.call("fr_reduce_parts", self.part, nsl, 1, 64 * self.K0, self.gW0p, None, None, st))
+            else:
+                L.append(ops.call("fr_fill_rows", self.gW0p, None, 64, self.K0, st))
+                L.append(ops.wgrad(st, fr, g=g_y0, src=self.X0, dw=self.gW0p, B=self.M0, GH=1, GW=1, Cout=64, SH=1,
+                                   SW=1, SC=self.K0, KH=1, KW=1, stride=1, pad=0, ldg=64, lda=self.K0, pro=0,
+                                   nsplit=_wgrad_slices(self.M0, 1)))
             L.append(ops.call("fr_unpack_stem_grad", self.gW0p, gw0, gw0.stride(0), gw0.stride(1), gw0.stride(2),
                               gw0.stride(3), 64, sc.weight.shape[1], self.K0, st))
         if self.dual and unit_done:

@@ -707,3 +707,33 @@ def test_conv3x3_s2_strip_dgrad(K, C, WL):
     assert relerr(from_nhwc(out), want) < tol
     np.testing.assert_allclose(part.sum(0)[0].cpu(), (gx * aux * (aux <= 0)).sum((0, 2, 3)), rtol=tol * 10,
                                atol=tol * 10 * float((gx * aux).abs().sum() / C))
+
+
+@pytest.mark.parametrize("Kp", [32, 64])
+@pytest.mark.parametrize("M", [16, 1000, 4099])
+def test_stem_gemm_and_wgrad(K, Kp, M):
+    """fr_stem_gemm / fr_stem_wgrad: the 64-column input-layer GEMMs over im2col rows (row counts that are not a
+    multiple of the 16-row tile or the 64-row staging chunk), forward + column statistics + weight gradient."""
+    dtype, tol = torch.bfloat16, 4e-2
+    x = q(synth.normal(71, "gx%d" % M, (M, Kp)), dtype)
+    w = q(synth.normal(71, "gw", (64, Kp), std=0.2), dtype)
+    y = x @ w.t()
+    st = K.current_stream_ptr()
+    nb = 5
+    out = torch.zeros(M, 64, device="cuda", dtype=dtype)
+    part = torch.zeros(nb, 2, 64, device="cuda")
+    K.call("fr_stem_gemm", x.to("cuda", dtype), w.to("cuda", dtype), out, part, M, Kp, nb, st)()
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert relerr(got, y) < tol
+    np.testing.assert_allclose(part.sum(0)[0].cpu(), got.sum(0), rtol=1e-3, atol=1e-2)
+    np.testing.assert_allclose(part.sum(0)[1].cpu(), (got * got).sum(0), rtol=1e-3, atol=1e-2)
+    g = q(synth.normal(71, "gg%d" % M, (M, 64)), dtype)
+    want = g.t() @ x
+    ns = 7
+    slab = torch.zeros(ns, 64, Kp, device="cuda")
+    K.call("fr_stem_wgrad", g.to("cuda", dtype), x.to("cuda", dtype), slab, M, Kp, ns, st)()
+    dw = torch.zeros(64 * Kp, device="cuda")
+    K.call("fr_reduce_parts", slab, ns, 1, 64 * Kp, dw, None, None, st)()
+    torch.cuda.synchronize()
+    assert relerr(dw.cpu().view(64, Kp), want) < tol
