@@ -55,8 +55,12 @@ def conv_case(kind, cin, cout, W, B, stride=1, pro=1, epi=1, mode=0, iters=20):
     kw = dict(src=src, w=w, out=out, B=B, RH=RH, RW=RH, SH=SH, SW=SH, SC=SC, N=N, KH=3, KW=3, stride=stride, pad=1,
               mode=mode, lda=SC, ldc=N, ldaux=N, pro=pro, pro_a=va, pro_b=vb, epi=epi, epi_a=va, epi_b=vb, aux=aux,
               part=part)
-    flops = 2.0 * B * RH * RH * N * 9 * SC
-    if kind == "strip":
+    flops = 2.0 * B * Ho * Ho * N * 9 * SC  # stride 2: both directions do 9 taps per LOW-res pixel
+    if kind == "s2":  # stride-2 parity-plane kernel: mode 0 forward (W = input side), mode 2 all-class data gradient
+        if mode == 2:
+            kw.update(par_h=-1, par_w=-1)
+        l = ops.conv_s2_strip(st, **kw)
+    elif kind == "strip":
         l = ops.conv_strip(st, **kw)
     else:
         l = ops.conv(st, ops.FR_BF16, **kw)
@@ -113,7 +117,7 @@ def main():
                 r.append("%s %.3f ms %6.0f TF/s" % (kind, ms, tf))
             print(" | ".join(r), flush=True)
         return
-    if a.kind in ("strip", "igemm"):
+    if a.kind in ("strip", "igemm", "s2"):
         cin, cout, W = a.dims
         ms, tf = conv_case(a.kind, cin, cout, W, a.batch, a.stride, a.pro, a.epi, a.mode, a.iters)
     else:
