@@ -23,18 +23,23 @@ namespace {
 constexpr int CT = 64;               // co and ci tile
 constexpr int TSTR = CT * 2 + 32;    // LDS row stride (bytes) of both tiles: conflict-free transposed reads
 
-template <int W, int ROWS, int NIMG, int NW>
+// S2: the stride-2 convolution of a stage transition (model_irse.py:59).  W / ROWS then describe the LOW-resolution
+// grid (= the gradient g); the input tile holds the four parity planes x[2i+ph][2j+pw] of the strip, each
+// (ROWS+1) x (W+1) pixels with one halo row / column (plane row -1, column -1), and tap (kh, kw) reads plane
+// (kh != 1, kw != 1) at row offset (kh > 0), column offset (kw > 0) -- still a compile-time address offset.
+template <int W, int ROWS, int NIMG, int NW, bool S2 = false>
 struct WC {
   static constexpr int NTH = NW * 64;                 // 8 waves (2 co halves x 4 ci tiles) or 4 waves (4 ci tiles, all co)
   static constexpr int TCO = 4 / (NW / 4);            // co tiles (16 wide) per wave
   static constexpr int H = W;
-  static constexpr int GW = W + 2, GH = ROWS + 2;
+  static constexpr int GW = S2 ? W + 1 : W + 2, GH = S2 ? ROWS + 1 : ROWS + 2;
+  static constexpr int PLANE = GH * GW;               // S2: pixels of one parity plane
   static constexpr int MI = ROWS * W;                 // output pixels per image strip
   static constexpr int M = MI * NIMG;                 // pixels per fill
   static constexpr int NKS = (M + 31) / 32;
   static constexpr int PXP = NKS * 32;
   static constexpr int G_BYTES = PXP * TSTR;
-  static constexpr int APIX = NIMG * GH * GW;
+  static constexpr int APIX = NIMG * GH * GW * (S2 ? 4 : 1);
   static constexpr int A_BYTES = APIX * TSTR;
   static constexpr int LDS = G_BYTES + A_BYTES;
   static constexpr int NS = H / ROWS;                 // strips per image
@@ -50,6 +55,15 @@ struct WC {
 
 typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
 
+// pixel offset of tap (kh, kw) inside the input tile, relative to the tile position of output pixel (h, w)
+template <class C, bool S2>
+__device__ __forceinline__ constexpr int tap_pix(int tap) {
+  const int kh = tap / 3, kw = tap % 3;
+  if (!S2) return kh * C::GW + kw;
+  const int plane = (kh != 1 ? 2 : 0) + (kw != 1 ? 1 : 0);
+  return plane * C::PLANE + (kh > 0 ? 1 : 0) * C::GW + (kw > 0 ? 1 : 0);
+}
+
 __device__ __forceinline__ s16x8 tr_frag(const char* p0, const char* p1) {
   const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)p0);
   const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)p1);
@@ -57,9 +71,9 @@ __device__ __forceinline__ s16x8 tr_frag(const char* p0, const char* p1) {
   return (s16x8){ai[0], ai[1], ai[2], ai[3], bi[0], bi[1], bi[2], bi[3]};
 }
 
-template <int W, int ROWS, int NIMG, int NW, int PRO>
+template <int W, int ROWS, int NIMG, int NW, int PRO, bool S2 = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_strip_kernel(const FrWgradArgs p) {
-  using C = WC<W, ROWS, NIMG, NW>;
+  using C = WC<W, ROWS, NIMG, NW, S2>;
   constexpr int NTH = C::NTH;
   constexpr int TCO = C::TCO;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,6 +116,27 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_strip_kernel(const FrWg
     }
   }
 
+  // input-tile pixel a of the fill starting at (img0, row0) -> source address / validity
+  auto xsrc = [&](int a, int img0, int row0, const bf16_t*& sp) -> bool {
+    constexpr int IPIX = C::GH * C::GW * (S2 ? 4 : 1);
+    const int im = a / IPIX;
+    int r = a - im * IPIX;
+    const int b = img0 + im;
+    if (S2) {
+      const int plane = r / C::PLANE;
+      r -= plane * C::PLANE;
+      const int gh = r / C::GW, gw = r - gh * C::GW;
+      const int i = row0 + gh - 1, j = gw - 1;  // plane coordinates; high-res pixel (2i + ph, 2j + pw)
+      const int h = 2 * i + (plane >> 1), w = 2 * j + (plane & 1);
+      sp = X + ((size_t)(b * 2 * C::H + h) * (2 * W) + w) * (size_t)p.lda + cit * CT + ch * 8;
+      return b < p.B && i >= 0 && j >= 0;
+    }
+    const int gh = r / C::GW, gw = r - gh * C::GW;
+    const int h = row0 + gh - 1, w = gw - 1;
+    sp = X + ((size_t)(b * C::H + h) * W + w) * (size_t)p.lda + cit * CT + ch * 8;
+    return b < p.B && (unsigned)h < (unsigned)C::H && (unsigned)w < (unsigned)W;
+  };
+
   constexpr int NPF = C::PF ? C::NLD : 1;
   U128 ld[NPF];
   bool okv[NPF];
@@ -122,11 +157,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_strip_kernel(const FrWg
         src = G + ((size_t)(b * C::H + row0) * W + r) * (size_t)p.ldg + cot * CT + ch * 8;
       } else if (idx < C::GCH + C::ACH) {
         const int a = c - C::M;
-        const int im = a / (C::GH * C::GW), r = a - im * (C::GH * C::GW);
-        const int gh = r / C::GW, gw = r - gh * C::GW;
-        const int b = img0 + im, h = row0 + gh - 1, w = gw - 1;
-        ok = b < p.B && (unsigned)h < (unsigned)C::H && (unsigned)w < (unsigned)W;
-        src = X + ((size_t)(b * C::H + h) * W + w) * (size_t)p.lda + cit * CT + ch * 8;
+        const bf16_t* sp;
+        ok = xsrc(a, img0, row0, sp);
+        src = sp;
       }
       okv[u] = ok;
       ld[u] = ok ? ld16(src) : zero16();
@@ -176,11 +209,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_strip_kernel(const FrWg
           src = G + ((size_t)(b * C::H + row0) * W + r) * (size_t)p.ldg + cot * CT + ch * 8;
         } else if (idx < C::GCH + C::ACH) {
           const int a = c - C::M;
-          const int im = a / (C::GH * C::GW), r = a - im * (C::GH * C::GW);
-          const int gh = r / C::GW, gw = r - gh * C::GW;
-          const int b = img0 + im, h = row0 + gh - 1, w = gw - 1;
-          ok[u] = b < p.B && (unsigned)h < (unsigned)C::H && (unsigned)w < (unsigned)W;
-          src = X + ((size_t)(b * C::H + h) * W + w) * (size_t)p.lda + cit * CT + ch * 8;
+          const bf16_t* sp;
+          ok[u] = xsrc(a, img0, row0, sp);
+          src = sp;
         }
         v[u] = ok[u] ? ld16(src) : zero16();
       }
@@ -239,11 +270,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_strip_kernel(const FrWg
         m = m < C::M ? m : C::M - 1;
         const int im = m / C::MI, r = m - im * C::MI;
         const int h = r / W, w = r - h * W;
-        a01[e] = As + ((im * C::GH + h) * C::GW + w) * TSTR + (wci * 16) * 2 + colb;
+        a01[e] = As + ((im * (S2 ? 4 : 1) * C::GH + h) * C::GW + w) * TSTR + (wci * 16) * 2 + colb;
       }
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const int off = ((tap / 3) * C::GW + (tap % 3)) * TSTR;
+        const int off = tap_pix<C, S2>(tap) * TSTR;
         const s16x8 af = tr_frag(a01[0] + off, a01[1] + off);
 #pragma unroll
         for (int t = 0; t < TCO; ++t)
@@ -284,17 +315,17 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slab, int groups, 
   }
 }
 
-template <int W, int ROWS, int NIMG, int NW, int PRO>
+template <int W, int ROWS, int NIMG, int NW, int PRO, bool S2 = false>
 int launch(const FrWgradArgs& a, hipStream_t st) {
-  using C = WC<W, ROWS, NIMG, NW>;
+  using C = WC<W, ROWS, NIMG, NW, S2>;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<W, ROWS, NIMG, NW, PRO>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<W, ROWS, NIMG, NW, PRO, S2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     attr_done = true;
   }
   const int tiles = (a.Cout / CT) * (a.SC / CT);
-  hipLaunchKernelGGL((conv_wgrad_strip_kernel<W, ROWS, NIMG, NW, PRO>), dim3(tiles * a.nsplit), dim3(C::NTH), C::LDS, st,
+  hipLaunchKernelGGL((conv_wgrad_strip_kernel<W, ROWS, NIMG, NW, PRO, S2>), dim3(tiles * a.nsplit), dim3(C::NTH), C::LDS, st,
                      a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -308,12 +339,12 @@ int launch(const FrWgradArgs& a, hipStream_t st) {
   FR_LAUNCH_CHECK();
 }
 
-template <int W, int ROWS, int NIMG, int NW>
+template <int W, int ROWS, int NIMG, int NW, bool S2 = false>
 int by_pro(const FrWgradArgs& a, hipStream_t st) {
   switch (a.pro) {
-    case FR_PRO_NONE: return launch<W, ROWS, NIMG, NW, FR_PRO_NONE>(a, st);
-    case FR_PRO_BN: return launch<W, ROWS, NIMG, NW, FR_PRO_BN>(a, st);
-    case FR_PRO_PRELU: return launch<W, ROWS, NIMG, NW, FR_PRO_PRELU>(a, st);
+    case FR_PRO_NONE: return launch<W, ROWS, NIMG, NW, FR_PRO_NONE, S2>(a, st);
+    case FR_PRO_BN: return launch<W, ROWS, NIMG, NW, FR_PRO_BN, S2>(a, st);
+    case FR_PRO_PRELU: return launch<W, ROWS, NIMG, NW, FR_PRO_PRELU, S2>(a, st);
   }
   return -1;
 }
@@ -329,10 +360,21 @@ extern "C" int fr_conv_wgrad_strip_supported(int Cout, int Cin, int W) {
 extern "C" int fr_conv_wgrad_strip(const FrWgradArgs* args, void* stream) {
   const FrWgradArgs& a = *args;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a.ldg % 8 || a.lda % 8 || !a.slab || a.nsplit < 1) FR_UNSUPPORTED("fr_conv_wgrad_strip: bad strides / slab");
+  if (a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad == 1 && a.GH == a.GW && a.SH == 2 * a.GH && a.SW == 2 * a.GW &&
+      a.Cout % CT == 0 && a.SC % CT == 0) {
+    // stride 2: the input tile holds the four parity planes of the strip (see WC)
+    switch (a.GW) {
+      case 56: return by_pro<56, 2, 1, 8, true>(a, st);
+      case 28: return by_pro<28, 4, 1, 8, true>(a, st);
+      case 14: return by_pro<14, 7, 1, 8, true>(a, st);
+      case 7: return by_pro<7, 7, 2, 8, true>(a, st);
+    }
+    FR_UNSUPPORTED("fr_conv_wgrad_strip: stride-2 width not in the strip table");
+  }
   if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.GH != a.SH || a.GW != a.SW || a.SH != a.SW ||
       !fr_conv_wgrad_strip_supported(a.Cout, a.SC, a.SW))
-    FR_UNSUPPORTED("fr_conv_wgrad_strip: only square stride-1 3x3 bf16 convolutions with 64-multiple channels");
-  if (a.ldg % 8 || a.lda % 8 || !a.slab || a.nsplit < 1) FR_UNSUPPORTED("fr_conv_wgrad_strip: bad strides / slab");
+    FR_UNSUPPORTED("fr_conv_wgrad_strip: square 3x3 bf16 convolutions, stride 1 or 2, 64-multiple channels");
   // 4-wave workgroups (two resident per CU, NW = 4) were measured at about half the throughput of the 8-wave form
   // with register prefetch (tools/kbench.py, B = 256) and are not instantiated.
   switch (a.SW) {

@@ -379,19 +379,29 @@ class BackbonePlan(object):
             rows = {112: 2, 56: 4, 28: 7, 14: 14, 7: 7}[kw["SW"]]
             fills = kw["B"] * (kw["SW"] // rows) // (4 if kw["SW"] == 7 else 1)
             groups = int(max(1, min(fills, 256 // tiles if tiles <= 256 else 1)))
-            need = groups * kw["Cout"] * 9 * kw["SC"]
-            if self.slab is None or self.slab.numel() < need:
-                self.slab = torch.empty(need, device=self.device)
-                for l in self._slab_users:  # re-point earlier launches at the grown buffer
-                    l.keep[0].slab = ops.ptr(self.slab)
-            kw = dict(kw, nsplit=groups, slab=self.slab)
-            l = ops.wgrad_strip(self.stream2, **kw)
-            l.tstream = self.stream2_t
-            self._slab_users.append(l)
-            L.append(l)
+            self._slab_launch(L, dict(kw, nsplit=groups), groups * kw["Cout"] * 9 * kw["SC"])
+            return
+        if (self.fr == FR_BF16 and self.use_strip and self.use_s2 and kw["KH"] == 3 and kw["stride"] == 2 and
+                kw["GW"] in (56, 28, 14, 7) and kw["SW"] == 2 * kw["GW"] and kw["Cout"] % 64 == 0 and kw["SC"] % 64 == 0):
+            # stride-2 layers: the same kernel on the four parity planes of the input (conv_wgrad_strip.hip, S2)
+            tiles = (kw["Cout"] // 64) * (kw["SC"] // 64)
+            rows, nimg = {56: (2, 1), 28: (4, 1), 14: (7, 1), 7: (7, 2)}[kw["GW"]]
+            fills = (kw["B"] * (kw["GW"] // rows) + nimg - 1) // nimg
+            groups = int(max(1, min(fills, 256 // tiles if tiles <= 256 else 1)))
+            self._slab_launch(L, dict(kw, nsplit=groups), groups * kw["Cout"] * 9 * kw["SC"])
             return
         l = ops.wgrad(self.stream2, self.fr, **kw)
         l.tstream = self.stream2_t
+        L.append(l)
+
+    def _slab_launch(self, L, kw, need):
+        if self.slab is None or self.slab.numel() < need:
+            self.slab = torch.empty(need, device=self.device)
+            for l in self._slab_users:  # re-point earlier launches at the grown buffer
+                l.keep[0].slab = ops.ptr(self.slab)
+        l = ops.wgrad_strip(self.stream2, **dict(kw, slab=self.slab))
+        l.tstream = self.stream2_t
+        self._slab_users.append(l)
         L.append(l)
 
     # ---- forward -----------------------------------------------------------------------------------

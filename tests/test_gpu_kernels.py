@@ -737,3 +737,26 @@ def test_stem_gemm_and_wgrad(K, Kp, M):
     K.call("fr_reduce_parts", slab, ns, 1, 64 * Kp, dw, None, None, st)()
     torch.cuda.synchronize()
     assert relerr(dw.cpu().view(64, Kp), want) < tol
+
+
+@pytest.mark.parametrize("C,WL", S2_SHAPES, ids=["%d_%d" % s for s in S2_SHAPES])
+@pytest.mark.parametrize("groups", [1, 3])
+def test_conv_wgrad_strip_stride2(K, C, WL, groups):
+    """fr_conv_wgrad_strip on a stride-2 layer (input tile = four parity planes) with the PReLU prologue, vs autograd."""
+    dtype, tol = torch.bfloat16, 4e-2
+    B, H = 3, 2 * WL
+    x = q(synth.normal(65, "wx", (B, C, H, H)), dtype)
+    slope = synth.uniform(65, "ws", (C,), 0.1, 0.4)
+    xin = q(torch.where(x > 0, x, x * slope.view(1, -1, 1, 1)), dtype)
+    w = synth.normal(65, "ww", (C, C, 3, 3), std=0.05).requires_grad_(True)
+    y = F.conv2d(xin, w, stride=2, padding=1)
+    g = q(synth.normal(65, "wg", tuple(y.shape)), dtype)
+    (gw,) = torch.autograd.grad(y, [w], g)
+    dw = torch.zeros(C, 9, C, device="cuda")
+    slab = torch.zeros(groups * C * 9 * C, device="cuda")
+    K.wgrad_strip(K.current_stream_ptr(), g=nhwc(g, dtype), src=nhwc(x, dtype), dw=dw, slab=slab, B=B, GH=WL, GW=WL,
+                  Cout=C, SH=H, SW=H, SC=C, KH=3, KW=3, stride=2, pad=1, ldg=C, lda=C, pro=2, nsplit=groups,
+                  pro_a=slope.cuda())()
+    torch.cuda.synchronize()
+    got = dw.cpu().reshape(C, 3, 3, C).permute(0, 3, 1, 2)
+    assert relerr(got, gw) < tol
