@@ -115,9 +115,10 @@ typedef struct FrWgradArgs {
  * Replaces the autograd weight-gradient of every Conv2d / Linear above. */
 int fr_conv_wgrad(const FrWgradArgs* args, int dtype, void* stream);
 
-/* Weight gradient of stride-1 3x3 convolutions (bf16) with both operand strips resident in LDS; partial results
- * per strip group go to `slab`, a second launch adds them into dw (overwrites; deterministic, no atomics).
- * fr_conv_wgrad_strip_supported tells whether a shape is served (else use fr_conv_wgrad). */
+/* Weight gradient of 3x3 convolutions (bf16) with both operand strips resident in LDS; partial results per strip
+ * group go to `slab`, a second launch adds them into dw (overwrites; deterministic, no atomics).  Stride 1 (GH == SH):
+ * fr_conv_wgrad_strip_supported tells whether a shape is served (else use fr_conv_wgrad).  Stride 2 (SH == 2*GH,
+ * GW in {56, 28, 14, 7}, channels multiples of 64): the input tile holds the four parity planes of the strip. */
 int fr_conv_wgrad_strip(const FrWgradArgs* args, void* stream);
 int fr_conv_wgrad_strip_supported(int Cout, int Cin, int W);
 
