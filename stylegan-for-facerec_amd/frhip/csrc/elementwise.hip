@@ -495,17 +495,23 @@ __global__ __launch_bounds__(NT, 6) void bn_apply_lean_kernel(const FrApplyArgs 
   if (STATS) block_col_reduce<2, LV>(acc, red, p.part + (size_t)blockIdx.x * 2 * C, C, cpr, tid);
 }
 
-__global__ __launch_bounds__(NT, 8) void bn_bwd_reduce_lean_kernel(const FrBnBwdArgs p) {
+// SLOPE: BN followed by PReLU (the stem, model_irse.py:141-142): g' = g * prelu'(u), u = x*scale + shift, and the third
+// partial row collects the slope gradient sum g*u*[u <= 0]
+template <bool SLOPE>
+__global__ __launch_bounds__(NT, 6) void bn_bwd_reduce_lean_kernel(const FrBnBwdArgs p) {
   __shared__ float red[NT * 3 * LV];
   const int C = p.C, cpr = C / LV, tid = threadIdx.x;
   const int cc = tid % cpr, rt = tid / cpr, rtc = NT / cpr, c0 = cc * LV;
   const bf16_t* __restrict__ g = reinterpret_cast<const bf16_t*>(p.g) + c0;
   const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(p.x) + c0;
-  float mu[LV], is[LV];
+  float mu[LV], is[LV], sc[LV], sh[LV], sl[LV];
 #pragma unroll
   for (int j = 0; j < LV; ++j) {
     mu[j] = p.mean[c0 + j];
     is[j] = p.invstd[c0 + j];
+    sc[j] = SLOPE ? p.scale[c0 + j] : 1.f;
+    sh[j] = SLOPE ? p.shift[c0 + j] : 0.f;
+    sl[j] = SLOPE ? p.slope[c0 + j] : 1.f;
   }
   float acc[3][LV];
 #pragma unroll
@@ -529,8 +535,15 @@ __global__ __launch_bounds__(NT, 8) void bn_bwd_reduce_lean_kernel(const FrBnBwd
         unpack4bf(xr[u], xv);
 #pragma unroll
         for (int j = 0; j < LV; ++j) {
-          acc[0][j] += gv[j];
-          acc[1][j] = fmaf(gv[j], (xv[j] - mu[j]) * is[j], acc[1][j]);
+          float v = gv[j];
+          if (SLOPE) {  // same operation order as bn_bwd_gprime
+            const float uu = fmaf(xv[j], sc[j], sh[j]);
+            const bool pos = uu > 0.f;
+            acc[2][j] += pos ? 0.f : v * uu;
+            v = pos ? v : v * sl[j];
+          }
+          acc[0][j] += v;
+          acc[1][j] = fmaf(v, (xv[j] - mu[j]) * is[j], acc[1][j]);
         }
       }
     }
@@ -999,8 +1012,10 @@ extern "C" int fr_bn_apply(const FrApplyArgs* args, int dtype, void* stream) {
 extern "C" int fr_bn_bwd_reduce(const FrBnBwdArgs* args, int dtype, void* stream) {
   if (!chan_ok(args->C, dtype)) FR_UNSUPPORTED("fr_bn_bwd_reduce: unsupported channel count");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == FR_BF16 && lean_ok(args->C) && !args->se && !args->slope && args->rows < (1ll << 31)) {
-    hipLaunchKernelGGL(bn_bwd_reduce_lean_kernel, dim3(args->nblocks), dim3(NT), 0, st, *args);
+  if (dtype == FR_BF16 && lean_ok(args->C) && !args->se && args->rows < (1ll << 31) &&
+      (!args->slope || (args->scale && args->shift))) {
+    if (args->slope) hipLaunchKernelGGL(bn_bwd_reduce_lean_kernel<true>, dim3(args->nblocks), dim3(NT), 0, st, *args);
+    else hipLaunchKernelGGL(bn_bwd_reduce_lean_kernel<false>, dim3(args->nblocks), dim3(NT), 0, st, *args);
     FR_LAUNCH_CHECK();
   }
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(args->nblocks), dim3(NT), 0, st, *args),

@@ -760,3 +760,38 @@ def test_conv_wgrad_strip_stride2(K, C, WL, groups):
     torch.cuda.synchronize()
     got = dw.cpu().reshape(C, 3, 3, C).permute(0, 3, 1, 2)
     assert relerr(got, gw) < tol
+
+
+@pytest.mark.parametrize("name,dtype,tol", DT)
+def test_bn_prelu_backward(K, name, dtype, tol):
+    """Stem pattern BN -> PReLU (model_irse.py:141-142): backward sums (incl. the slope gradient) and input gradient
+    vs autograd; the bf16 reduce takes the lean SLOPE variant."""
+    B, H, C = 3, 7, 64
+    rows = B * H * H
+    x = q(synth.normal(81, "px", (B, C, H, H)), dtype).requires_grad_(True)
+    gamma = synth.uniform(81, "pg", (C,), 0.8, 1.2).requires_grad_(True)
+    beta = synth.uniform(81, "pb", (C,), -0.3, 0.3).requires_grad_(True)
+    slope = synth.uniform(81, "ps", (C,), 0.1, 0.4).requires_grad_(True)
+    z = F.prelu(F.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-5), slope)
+    g = q(synth.normal(81, "pgo", tuple(z.shape)), dtype)
+    gx, gg, gb, gs = torch.autograd.grad(z, [x, gamma, beta, slope], g)
+    xd = x.detach()
+    mean = xd.mean((0, 2, 3))
+    invstd = 1.0 / torch.sqrt(xd.var((0, 2, 3), unbiased=False) + 1e-5)
+    scale = (gamma.detach() * invstd)
+    shift = beta.detach() - mean * scale
+    fr, st = K.fr_dtype(torch.empty(0, dtype=dtype)), K.current_stream_ptr()
+    nb = 6
+    common = dict(g=nhwc(g, dtype), x=nhwc(xd, dtype), mean=mean.cuda(), invstd=invstd.cuda(), scale=scale.cuda(),
+                  shift=shift.cuda(), slope=slope.detach().cuda(), rows=rows, C=C, rows_per_image=H * H, nblocks=nb)
+    part = torch.zeros(nb, 3, C, device="cuda")
+    K.bn_bwd_reduce(st, fr, part=part, **common)()
+    s0, s1, s2 = (torch.zeros(C, device="cuda") for _ in range(3))
+    K.call("fr_reduce_parts", part, nb, 3, C, s0, s1, s2, st)()
+    gxd = torch.zeros(B, H, H, C, device="cuda", dtype=dtype)
+    K.bn_bwd_apply(st, fr, gx=gxd, gamma=gamma.detach().cuda(), s0=s0, s1=s1, inv_count=1.0 / rows, **common)()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(s0.cpu(), gb, rtol=tol * 5, atol=tol * 20)
+    np.testing.assert_allclose(s1.cpu(), gg, rtol=tol * 5, atol=tol * 20)
+    np.testing.assert_allclose(s2.cpu(), gs, rtol=tol * 5, atol=tol * 20)
+    assert relerr(from_nhwc(gxd), gx) < tol * 2
