@@ -315,6 +315,16 @@ def main():
                                    "avg_launch_ms": round(kms / cnt, 4),
                                    "share_of_step": round(kms / total_ms, 3),
                                    "step_achieved": round(step_tflops, 2), "step_frac": round(step_tflops / peak, 4)}
+                # HBM bytes per launch cannot be counted from inside this process; they come from the committed
+                # rocprofv3 --pmc passes on the same kernel instance (tools/pmc_traffic.py writes the summary)
+                pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_dominant_kernel.json")
+                if os.path.exists(pmc):
+                    with open(pmc) as f:
+                        rec = json.load(f)
+                    if rec.get("kernel") == name:
+                        out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                        out["roofline"]["traffic_algorithmic"] = rec["algorithmic_bytes_per_launch"]
+                        out["roofline"]["traffic_source"] = "profiles/r01_pmc_dominant_kernel.json"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.classes)
         print(json.dumps(out))
