@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must precede the CDLL: libfrhip.so has to bind to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(os.path.dirname(_HERE))
 HEADER = os.path.join(REPO_ROOT, "include", "frhip.h")
-LIB_PATH = os.path.join(_HERE, "lib", "libfrhip.so")
+LIB_PATH = os.environ.get("FRHIP_LIB") or os.path.join(_HERE, "lib", "libfrhip.so")  # FRHIP_LIB: A/B builds
 
 _SCALARS = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,
