@@ -64,8 +64,6 @@ struct SC {
   static constexpr int RED_BYTES = WM * 2 * COUT * 4;
   static constexpr int LDS = IMG_BYTES > OUT_BYTES + RED_BYTES ? IMG_BYTES : OUT_BYTES + RED_BYTES;
   static constexpr int NS = H / ROWS;                      // strips per image
-  static constexpr bool PF = false;  // register-prefetch of the next strip: measured slower (spills, serial strips) -- off
-  static constexpr int MAXGRID = PF ? 1024 : (1 << 30);    // prefetching workgroups walk several strips each
   static_assert(H % ROWS == 0, "strip rows must divide the image");
   static_assert(NIMG == 1 || ROWS == W, "multi-image workgroups own whole images");
   static_assert(NTH % CH == 0, "threads must be a multiple of the chunks per pixel");
@@ -87,24 +85,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
   const bf16_t* __restrict__ wgt = reinterpret_cast<const bf16_t*>(p.w);
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
 
-  // A workgroup walks a contiguous run of strips (gridDim.x may be smaller than the strip count).  With 64 input
-  // channels the strip is small enough to keep the NEXT strip's 16-B chunks in registers while this one computes,
-  // so the HBM fetch of strip s+1 overlaps the MFMAs and the epilogue of strip s.
-  constexpr bool PREFETCH = C::PF;
-  // NSPL > 1: the output channels are split over NSPL workgroups per strip (COUT is the per-workgroup width); keeps
-  // the accumulator tile small enough for two co-resident 4-wave workgroups per CU
-  static_assert((NSPL == 1 && NIMG == 1 && KSPL == 1) || !C::PF, "N / image / channel splits only without strip prefetch");
+  // One strip per workgroup.  (Walking several strips with the next one register-prefetched under the MFMAs was
+  // measured slower -- spills, and the strips of a workgroup serialise -- and is gone.)
+  // NSPL > 1: the output channels are split over NSPL workgroups per strip (COUT is the per-workgroup width)
   const int nh = NSPL > 1 ? blockIdx.x % NSPL : 0;
   const int ncol0 = nh * COUT;
   const int sblk = NSPL > 1 ? blockIdx.x / NSPL : blockIdx.x;
-  const int total = p.B * C::NS / NIMG;  // strips; a multi-image strip = NIMG consecutive images
-  const int per = PREFETCH ? (total + gridDim.x - 1) / gridDim.x : 1;  // without prefetch: one strip per workgroup
-  const int s_begin = sblk * per;
-  const int s_end = PREFETCH ? (s_begin + per < total ? s_begin + per : total) : s_begin + 1;
+  const int s = sblk;  // strip index; a multi-image strip = NIMG consecutive images
 
   constexpr int WP = W + 2;
   constexpr int TOTAL = NIMG * C::GH * WP * C::CH;
-  constexpr int NLD = (TOTAL + NTH - 1) / NTH;
   const int ch = tid % C::CH;  // NTH is a multiple of CH: a thread always handles the same channel chunk
   float pa[8], pb[8];  // prologue coefficients of this thread's channel chunk: re-read per strip (L1 hits) rather
                        // than kept live across the MFMA loop
@@ -157,25 +147,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
       st16(smem + ioff + gh * C::RSTR + gw * C::PSTR + ch * 16, x);
     }
   };
-  constexpr int NPF = PREFETCH ? NLD : 1;
-  U128 ldv[NPF];      // PREFETCH only: the next strip, in flight while this one computes
-  unsigned okmask = 0;
-  auto issue = [&](int s) {
-    okmask = 0;
-#pragma unroll
-    for (int u = 0; u < NPF; ++u) {
-      bool ok;
-      const bf16_t* ptr = chunk_src(s, u * NTH + tid, ok);
-      ldv[u] = ok ? ld16(ptr) : zero16();
-      okmask |= ok ? (1u << u) : 0u;
-    }
-  };
-  auto commit = [&]() {
-    load_pro();
-#pragma unroll
-    for (int u = 0; u < NPF; ++u) chunk_store(u * NTH + tid, ldv[u], (okmask >> u) & 1u);
-  };
-  auto load_now = [&](int s) {  // !PREFETCH: stream the strip through 8 registers at a time
+  auto load_now = [&](int s) {  // stream the strip through 8 registers at a time
     constexpr int UNR = 8;
     load_pro();
     for (int base = 0; base < TOTAL; base += NTH * UNR) {
@@ -199,11 +171,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
   const int flip = p.mode;
   const int epi = p.epi;
   const bool stats = epi == FR_EPI_STATS || epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD;
-  static_assert(!PREFETCH, "the column sums below are per strip: one strip per workgroup");
   constexpr int OCH = COUT / 8;
 
-  if (PREFETCH && s_begin < s_end) issue(s_begin);
-  for (int s = s_begin; s < s_end; ++s) {
+  {
     const int b = NIMG > 1 ? s * NIMG : s / C::NS;  // first image of the strip
     const int row0 = NIMG > 1 ? 0 : (s - b * C::NS) * ROWS;
     f32x4 acc[C::TM][C::TN];
@@ -215,10 +185,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
     for (kc = 0; kc < KSPL; ++kc) {
     // ---------------------------------------------------------------- strip -> LDS (prologue applied once)
     __syncthreads();  // the previous strip's output tile has left LDS / the previous channel stage has been consumed
-    if (PREFETCH) commit();
-    else load_now(s);
+    load_now(s);
     __syncthreads();
-    if (PREFETCH && s + 1 < s_end) issue(s + 1);
 
     // ---------------------------------------------------------------- main loop: 9 taps x CK/32, no barriers
     int abase[C::TM];  // LDS byte address of this lane's fragment for tap (0,0), channel chunk c0 = 0
@@ -248,7 +216,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
     };
     constexpr int NSTEP = 9 * C::TM;
     // ring depth must divide NSTEP (slots line up across the channel loop): 9 when registers allow, else 3
-    constexpr int D = (PREFETCH || KSPL > 1 || C::TM * C::TN * 4 + 3 * C::TN * 4 > 100) ? 3 : 9;
+    constexpr int D = (KSPL > 1 || C::TM * C::TN * 4 + 3 * C::TN * 4 > 100) ? 3 : 9;
     s16x8 ring[D];
     auto a_addr = [&](int step) -> const s16x8* {  // step in [0, 2*NSTEP): second half = next 32 input channels
       const int cadd = step >= NSTEP ? 64 : 0;
@@ -411,7 +379,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
   }
   const int strips = a.B * C::NS / NIMG;
   hipLaunchKernelGGL((conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, NSPL, PRO, NIMG, KSPL>),
-                     dim3((strips < C::MAXGRID ? strips : C::MAXGRID) * NSPL), dim3(C::NTH), C::LDS, st, a);
+                     dim3(strips * NSPL), dim3(C::NTH), C::LDS, st, a);
   FR_LAUNCH_CHECK();
 }
 
