@@ -136,6 +136,12 @@ int fr_stem_im2col(const float* x, const float* avg, void* out, int B, int H, in
  * Replace the GEMM half of input_layer Conv2d(3|6,64,3,1,1) (model_irse.py:140) forward and its weight gradient. */
 int fr_stem_gemm(const void* X, const void* Wp, void* out, float* part, long long M, int K, int nblocks, void* stream);
 int fr_stem_wgrad(const void* G, const void* X, float* slab, long long M, int K, int nblocks, void* stream);
+/* As fr_stem_wgrad, with the backward of BatchNorm2d(64) -> PReLU(64) (model_irse.py:141-142) applied to the rows of G
+ * while they are staged: G = gradient at the PReLU output, Y = BN input (the stem GEMM output), s0/s1 = the reduced
+ * sums of fr_bn_bwd_reduce; equals fr_bn_bwd_apply followed by fr_stem_wgrad bit for bit without the 3-pass round trip. */
+int fr_stem_wgrad_bn(const void* G, const void* Y, const void* X, const float* mean, const float* invstd,
+                     const float* scale, const float* shift, const float* slope, const float* gamma, const float* s0,
+                     const float* s1, float inv_count, float* slab, long long M, int K, int nblocks, void* stream);
 
 /* ---- BatchNorm statistics (train mode; torch defaults eps 1e-5, momentum 0.1 -- SURVEY App. B 13)
  * part: [nparts][2][C] partial (sum, sum of squares) rows; count = elements per channel.

@@ -118,9 +118,19 @@ __device__ __forceinline__ s16x8 tr_frag2(const char* p0, const char* p1) {
   return (s16x8){ai[0], ai[1], ai[2], ai[3], bi[0], bi[1], bi[2], bi[3]};
 }
 
-template <int K>
+// BN: G is the gradient at the OUTPUT of BatchNorm -> PReLU (model_irse.py:141-142) and the BN backward is applied
+// while the rows are staged: g_y = gamma*invstd * (g*prelu'(u) - s0/n - xhat*s1/n), u = y*scale + shift -- the same
+// fp32 expression as bn_bwd_apply_kernel, rounded to bf16 once, so the result equals the unfused path bit for bit,
+// but the 411 MB gradient tensor at the stem output is never written or re-read.
+struct StemBn {
+  const bf16_t* y;  // BN input = stem GEMM output [M][64]
+  const float *mean, *invstd, *scale, *shift, *slope, *gamma, *s0, *s1;
+  float inv_count;
+};
+
+template <int K, bool BN>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
-                                                         float* __restrict__ slab, int M) {
+                                                         float* __restrict__ slab, int M, const StemBn bn) {
   constexpr int RB = 64;                     // rows staged per trip (two 32-deep MFMA steps)
   constexpr int GSTR = SN * 2 + 32;          // conflict-free row strides for the transposing reads
   constexpr int XSTR = K * 2 + 32;
@@ -135,6 +145,22 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16_t* __restric
   f32x4 acc[KT];
 #pragma unroll
   for (int k = 0; k < KT; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // BN: per-channel coefficients of this thread's 8-channel chunk (256 % 8 == 0: the chunk never changes)
+  float bsc[8], bsh[8], bsl[8], bco[8], ba[8], bmu[8], bis[8], bbb[8];
+  if (BN) {
+    const int c0 = (tid & 7) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bsc[j] = bn.scale[c0 + j];
+      bsh[j] = bn.shift[c0 + j];
+      bsl[j] = bn.slope[c0 + j];
+      bmu[j] = bn.mean[c0 + j];
+      bis[j] = bn.invstd[c0 + j];
+      bco[j] = bn.gamma[c0 + j] * bis[j];
+      ba[j] = bn.s0[c0 + j] * bn.inv_count;
+      bbb[j] = bn.s1[c0 + j] * bn.inv_count;
+    }
+  }
   const int nchunks = (M + RB - 1) / RB;
   for (int cblk = blockIdx.x; cblk < nchunks; cblk += gridDim.x) {
     const int row0 = cblk * RB;
@@ -145,7 +171,21 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16_t* __restric
       v[u] = zero16();
       if (idx < GCH) {
         const int r = idx >> 3, c = idx & 7;
-        if (row0 + r < M) v[u] = ld16(G + (size_t)(row0 + r) * SN + c * 8);
+        if (row0 + r < M) {
+          v[u] = ld16(G + (size_t)(row0 + r) * SN + c * 8);
+          if (BN) {
+            float g[8], y[8];
+            unpack16<bf16_t>(v[u], g);
+            unpack16<bf16_t>(ld16(bn.y + (size_t)(row0 + r) * SN + c * 8), y);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float uu = fmaf(y[j], bsc[j], bsh[j]);
+              const float gp = uu > 0.f ? g[j] : g[j] * bsl[j];
+              g[j] = bco[j] * (gp - ba[j] - (y[j] - bmu[j]) * bis[j] * bbb[j]);
+            }
+            v[u] = pack16<bf16_t>(g);
+          }
+        }
       } else if (idx < NCH) {
         const int a = idx - GCH, r = a / (K / 8), c = a - r * (K / 8);
         if (row0 + r < M) v[u] = ld16(X + (size_t)(row0 + r) * K + c * 8);
@@ -201,11 +241,31 @@ extern "C" int fr_stem_wgrad(const void* G, const void* X, float* slab, long lon
   if ((K != 32 && K != 64) || M < 1 || M >= (1ll << 31) - 64 || nblocks < 1)
     FR_UNSUPPORTED("fr_stem_wgrad: K must be 32 or 64, 0 < M < 2^31, nblocks >= 1");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const StemBn none = {};
   if (K == 32)
-    hipLaunchKernelGGL(stem_wgrad_kernel<32>, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X, slab,
-                       (int)M);
+    hipLaunchKernelGGL((stem_wgrad_kernel<32, false>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X,
+                       slab, (int)M, none);
   else
-    hipLaunchKernelGGL(stem_wgrad_kernel<64>, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X, slab,
-                       (int)M);
+    hipLaunchKernelGGL((stem_wgrad_kernel<64, false>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X,
+                       slab, (int)M, none);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_stem_wgrad_bn(const void* G, const void* Y, const void* X, const float* mean, const float* invstd,
+                                const float* scale, const float* shift, const float* slope, const float* gamma,
+                                const float* s0, const float* s1, float inv_count, float* slab, long long M, int K,
+                                int nblocks, void* stream) {
+  if ((K != 32 && K != 64) || M < 1 || M >= (1ll << 31) - 64 || nblocks < 1)
+    FR_UNSUPPORTED("fr_stem_wgrad_bn: K must be 32 or 64, 0 < M < 2^31, nblocks >= 1");
+  if (!Y || !mean || !invstd || !scale || !shift || !slope || !gamma || !s0 || !s1)
+    FR_UNSUPPORTED("fr_stem_wgrad_bn: every BatchNorm / PReLU coefficient vector is required");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const StemBn bn = {(const bf16_t*)Y, mean, invstd, scale, shift, slope, gamma, s0, s1, inv_count};
+  if (K == 32)
+    hipLaunchKernelGGL((stem_wgrad_kernel<32, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X,
+                       slab, (int)M, bn);
+  else
+    hipLaunchKernelGGL((stem_wgrad_kernel<64, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X,
+                       slab, (int)M, bn);
   FR_LAUNCH_CHECK();
 }

@@ -743,12 +743,22 @@ class BackbonePlan(object):
         g_y0 = self.g_y1s[-1][:self.M0 * 64]  # unit 0's wgrads (side stream) still read set 0
         if self.dual and 1 in unit_done:
             L.append(_EvWait(self.stream1_t, unit_done[1]))  # set 1 was last read by unit 1's weight gradients
-        L.append(ops.bn_bwd_apply(st, fr, gx=g_y0, gamma=sb.weight, s0=s0, s1=s1, inv_count=1.0 / self.M0, **common))
         gw0 = self.grad_of(sc.weight)
+        fuse = self.use_stem_gemm and os.environ.get("FRHIP_NO_STEM_BNFUSE", "0") != "1"
+        if gw0 is not None and not fuse:
+            L.append(ops.bn_bwd_apply(st, fr, gx=g_y0, gamma=sb.weight, s0=s0, s1=s1, inv_count=1.0 / self.M0,
+                                      **common))
         if gw0 is not None:
-            if self.use_stem_gemm:
-                nsl = int(min(1024 if self.K0 == 32 else 512, (self.M0 + 63) // 64))  # partials live in self.part
+            if self.use_stem_gemm and not fuse:
+                nsl = int(min(1024 if self.K0 == 32 else 512, (self.M0 + 63) // 64))
                 L.append(ops.call("fr_stem_wgrad", g_y0, self.X0, self.part, self.M0, self.K0, nsl, st))
+                L.append(ops.call("fr_reduce_parts", self.part, nsl, 1, 64 * self.K0, self.gW0p, None, None, st))
+            elif fuse:
+                # BN0 backward is applied while the gradient rows are staged: g_y0 is never materialised
+                nsl = int(min(1024 if self.K0 == 32 else 512, (self.M0 + 63) // 64))  # partials live in self.part
+                L.append(ops.call("fr_stem_wgrad_bn", g_out, self.y0, self.X0, self.bn0.mean, self.bn0.invstd,
+                                  self.bn0.scale, self.bn0.shift, sp.weight, sb.weight, s0, s1, 1.0 / self.M0,
+                                  self.part, self.M0, self.K0, nsl, st))
                 L.append(ops.call("fr_reduce_parts", self.part, nsl, 1, 64 * self.K0, self.gW0p, None, None, st))
             else:
                 L.append(ops.call("fr_fill_rows", self.gW0p, None, 64, self.K0, st))

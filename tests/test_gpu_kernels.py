@@ -795,3 +795,32 @@ def test_bn_prelu_backward(K, name, dtype, tol):
     np.testing.assert_allclose(s1.cpu(), gg, rtol=tol * 5, atol=tol * 20)
     np.testing.assert_allclose(s2.cpu(), gs, rtol=tol * 5, atol=tol * 20)
     assert relerr(from_nhwc(gxd), gx) < tol * 2
+
+
+@pytest.mark.parametrize("Kp", [32, 64])
+def test_stem_wgrad_bn_equals_unfused(K, Kp):
+    """fr_stem_wgrad_bn == fr_bn_bwd_apply (BN -> PReLU backward) followed by fr_stem_wgrad, bit for bit."""
+    dtype = torch.bfloat16
+    M, C = 4099, 64
+    st = K.current_stream_ptr()
+    fr = K.fr_dtype(torch.empty(0, dtype=dtype))
+    g = synth.normal(91, "fg", (M, C)).to("cuda", dtype)
+    y = synth.normal(91, "fy", (M, C)).to("cuda", dtype)
+    x = synth.normal(91, "fx", (M, Kp)).to("cuda", dtype)
+    vec = lambda n, lo, hi: synth.uniform(91, n, (C,), lo, hi).cuda()  # noqa: E731
+    mean, invstd, gamma, slope = vec("m", -0.3, 0.3), vec("i", 0.5, 2.0), vec("g", 0.8, 1.2), vec("s", 0.1, 0.4)
+    s0, s1 = vec("s0", -50.0, 50.0), vec("s1", -50.0, 50.0)
+    scale = gamma * invstd
+    shift = vec("b", -0.2, 0.2) - mean * scale
+    gy = torch.zeros(M, C, device="cuda", dtype=dtype)
+    K.bn_bwd_apply(st, fr, g=g, x=y, gx=gy, mean=mean, invstd=invstd, scale=scale, shift=shift, slope=slope, gamma=gamma,
+                   s0=s0, s1=s1, rows=M, inv_count=1.0 / M, C=C, rows_per_image=M, nblocks=8)()
+    ns = 9
+    slab_a = torch.zeros(ns, 64, Kp, device="cuda")
+    slab_b = torch.zeros(ns, 64, Kp, device="cuda")
+    K.call("fr_stem_wgrad", gy, x, slab_a, M, Kp, ns, st)()
+    K.call("fr_stem_wgrad_bn", g, y, x, mean, invstd, scale, shift, slope, gamma, s0, s1, 1.0 / M, slab_b, M, Kp, ns,
+           st)()
+    torch.cuda.synchronize()
+    assert torch.equal(slab_a, slab_b)
+    assert float(slab_a.abs().max()) > 0
