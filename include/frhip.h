@@ -36,7 +36,9 @@ enum {
   FR_EPI_PRELU_BWD = 2, /* out = acc * (aux>0 ? 1 : epi_a[n]); part[mtile][0][n] = sum acc*aux*[aux<=0] */
   FR_EPI_BNBWD = 3,     /* out = acc; part[.][0] = sum acc; part[.][1] = sum acc*(aux-epi_a[n])*epi_b[n] */
   FR_EPI_MARGIN = 4,    /* out = scale*(n==label[m] ? phi(acc) : acc); cos_t[m] = acc[label] */
-  FR_EPI_ATOMIC = 5     /* atomicAdd(out, acc) fp32; used with splitk > 1 */
+  FR_EPI_ATOMIC = 5,    /* atomicAdd(out, acc) fp32; used with splitk > 1 (summation order not reproducible) */
+  FR_EPI_SLAB = 6       /* split-K slice z stores its fp32 partial (+bias in slice 0) to out[z][rows][ldc]: the caller
+                           adds the splitk slabs with fr_reduce_parts(out, splitk, 1, rows*ldc, ...) -- reproducible */
 };
 
 typedef struct FrConvArgs {
@@ -108,7 +110,9 @@ typedef struct FrWgradArgs {
   int32_t nsplit; /* pixel slices (gridDim.y) / strip groups */
   const float* pro_a;
   const float* pro_b;
-  float* slab;     /* fr_conv_wgrad_strip only: [nsplit][Cout][9][SC] fp32 partial gradients */
+  float* slab;     /* [nsplit][Cout][taps][SC] fp32 partial gradients: required by fr_conv_wgrad_strip; optional for
+                      fr_conv_wgrad (NULL: pixel slices are combined with fp32 atomics onto a zeroed dw; non-NULL: each
+                      slice stores its slab and a second launch adds them in a fixed order -- reproducible) */
 } FrWgradArgs;
 
 /* Weight gradient  dw[co][tap][ci] += sum_p g[p][co] * pro(src[pixel(p,tap)][ci]).

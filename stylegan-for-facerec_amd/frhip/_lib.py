@@ -84,7 +84,7 @@ FrPackTensor = structs["FrPackTensor"]
 # enums of the header
 FR_F32, FR_BF16 = 0, 1
 PRO_NONE, PRO_BN, PRO_PRELU = 0, 1, 2
-EPI_STORE, EPI_STATS, EPI_PRELU_BWD, EPI_BNBWD, EPI_MARGIN, EPI_ATOMIC = range(6)
+EPI_STORE, EPI_STATS, EPI_PRELU_BWD, EPI_BNBWD, EPI_MARGIN, EPI_ATOMIC, EPI_SLAB = range(7)
 
 
 class FrhipError(RuntimeError):

@@ -319,6 +319,17 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
           if (full || n + j < p.N) atomicAdd(o + j, v[j]);
         continue;
       }
+      if (epi == FR_EPI_SLAB) {  // this split-K slice's partial sums, plain stores into its own slab
+        float* o = reinterpret_cast<float*>(p.out) + (size_t)blockIdx.z * (size_t)M * (size_t)p.ldc + ooff;
+        if (p.bias && blockIdx.z == 0) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[j] += eb[j];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          if (full || n + j < p.N) o[j] = v[j];
+        continue;
+      }
       if (p.bias && epi != FR_EPI_BNBWD) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) v[j] += eb[j];
@@ -480,8 +491,9 @@ extern "C" int fr_conv_igemm(const FrConvArgs* args, int dtype, void* stream) {
   if (a.mode == 2 && ((a.par_h < 0) != (a.par_w < 0) || a.par_h > 1 || a.par_w > 1))
     FR_UNSUPPORTED("fr_conv_igemm: parity class must be (0|1, 0|1) or (-1, -1) for all four in one launch");
   if ((long long)a.B * a.RH * a.RW >= (1ll << 31) / 4) FR_UNSUPPORTED("fr_conv_igemm: too many rows");
-  if (a.splitk > 1 && (a.epi != FR_EPI_ATOMIC || !a.out_f32))
-    FR_UNSUPPORTED("fr_conv_igemm: split-K needs the fp32 atomic epilogue");
+  if (a.splitk > 1 && ((a.epi != FR_EPI_ATOMIC && a.epi != FR_EPI_SLAB) || !a.out_f32))
+    FR_UNSUPPORTED("fr_conv_igemm: split-K needs the fp32 atomic or slab epilogue");
+  if (a.epi == FR_EPI_SLAB && (!a.out_f32 || a.mode == 2)) FR_UNSUPPORTED("fr_conv_igemm: slab epilogue is fp32, modes 0/1");
   const int esz = dtype == FR_F32 ? 4 : 2;
   if ((a.lda * esz) % 16 || (a.ldc * (a.out_f32 ? 4 : esz)) % 16 || (a.aux && (a.ldaux * esz) % 16))
     FR_UNSUPPORTED("fr_conv_igemm: row strides must be 16-byte multiples");

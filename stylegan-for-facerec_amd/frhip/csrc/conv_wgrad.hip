@@ -190,7 +190,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const FrWgradArgs p) {
     if (more) lstore(stage ^ 1);
     __syncthreads();
   }
-  if (nsteps == 0) return;
+  if (nsteps == 0 && !p.slab) return;  // (an empty pixel slice still has to zero its slab)
 
   // ---- epilogue: accumulators -> LDS (half of the co rows at a time) -> row-contiguous fp32 atomics
   constexpr int CROW = BCI + 4;
@@ -212,8 +212,11 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const FrWgradArgs p) {
     for (int e = tid; e < WM * BCI; e += NT) {
       const int r = e / BCI, c = e - r * BCI;
       const int co = co0 + h * WM + r, ci = ci0 + c;
-      if (co < p.Cout && ci < p.SC)
-        atomicAdd(p.dw + ((size_t)co * taps + tap) * (size_t)p.SC + ci, Cs[r * CROW + c]);
+      if (co < p.Cout && ci < p.SC) {
+        const size_t o = ((size_t)co * taps + tap) * (size_t)p.SC + ci;
+        if (p.slab) p.slab[(size_t)blockIdx.y * ((size_t)p.Cout * taps * p.SC) + o] = Cs[r * CROW + c];  // own slab
+        else atomicAdd(p.dw + o, Cs[r * CROW + c]);
+      }
     }
   }
 }
@@ -237,6 +240,14 @@ int launch(const FrWgradArgs& a, hipStream_t st) {
     attr_done = true;
   }
   hipLaunchKernelGGL((conv_wgrad_kernel<T, BCO, BCI, PRO>), grid, dim3(NT), LDS, st, a);
+  if (a.slab) {  // reproducible mode: every pixel slice wrote its own slab; add them in a fixed order into dw
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      fr_set_error(hipGetErrorString(e));
+      return (int)e;
+    }
+    return fr_launch_reduce_slabs(a.slab, a.nsplit, (long long)a.Cout * a.KH * a.KW * a.SC, a.dw, st);
+  }
   FR_LAUNCH_CHECK();
 }
 
@@ -270,6 +281,7 @@ extern "C" int fr_conv_wgrad(const FrWgradArgs* args, int dtype, void* stream) {
   if ((a.ldg * esz) % 16 || (a.lda * esz) % 16) FR_UNSUPPORTED("fr_conv_wgrad: row strides must be 16-byte multiples");
   if ((long long)a.B * a.GH * a.GW >= (1ll << 24)) FR_UNSUPPORTED("fr_conv_wgrad: more than 2^24 pixels");
   if (a.nsplit < 1 || a.nsplit > 65535) FR_UNSUPPORTED("fr_conv_wgrad: bad nsplit");
+  if (a.slab && ((long long)a.Cout * a.KH * a.KW * a.SC) % 4) FR_UNSUPPORTED("fr_conv_wgrad: slab mode needs Cout*taps*Cin % 4 == 0");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == FR_F32) return dispatch<float>(a, st);
   if (dtype == FR_BF16) return dispatch<bf16_t>(a, st);

@@ -315,6 +315,19 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slab, int groups, 
   }
 }
 
+}  // namespace
+
+int fr_launch_reduce_slabs(const float* slab, int groups, long long n, float* out, hipStream_t st) {
+  const long long n4 = n / 4;
+  long long g = (n4 + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)g), dim3(256), 0, st, slab, groups, n4, out);
+  FR_LAUNCH_CHECK();
+}
+
+namespace {
+
 template <int W, int ROWS, int NIMG, int NW, int PRO, bool S2 = false>
 int launch(const FrWgradArgs& a, hipStream_t st) {
   using C = WC<W, ROWS, NIMG, NW, S2>;
@@ -332,11 +345,7 @@ int launch(const FrWgradArgs& a, hipStream_t st) {
     fr_set_error(hipGetErrorString(e));
     return (int)e;
   }
-  const long long n4 = (long long)a.Cout * 9 * a.SC / 4;
-  long long g = (n4 + 255) / 256;
-  if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)g), dim3(256), 0, st, a.slab, a.nsplit, n4, a.dw);
-  FR_LAUNCH_CHECK();
+  return fr_launch_reduce_slabs(a.slab, a.nsplit, (long long)a.Cout * 9 * a.SC, a.dw, st);
 }
 
 template <int W, int ROWS, int NIMG, int NW, bool S2 = false>

@@ -390,16 +390,20 @@ class BackbonePlan(object):
             groups = int(max(1, min(fills, 256 // tiles if tiles <= 256 else 1)))
             self._slab_launch(L, dict(kw, nsplit=groups), groups * kw["Cout"] * 9 * kw["SC"])
             return
+        if kw.get("nsplit", 1) > 1:  # pixel slices go to slabs and are added in a fixed order (no float atomics)
+            self._slab_launch(L, kw, kw["nsplit"] * kw["Cout"] * kw["KH"] * kw["KW"] * kw["SC"], strip=False)
+            return
         l = ops.wgrad(self.stream2, self.fr, **kw)
         l.tstream = self.stream2_t
         L.append(l)
 
-    def _slab_launch(self, L, kw, need):
+    def _slab_launch(self, L, kw, need, strip=True):
         if self.slab is None or self.slab.numel() < need:
             self.slab = torch.empty(need, device=self.device)
             for l in self._slab_users:  # re-point earlier launches at the grown buffer
                 l.keep[0].slab = ops.ptr(self.slab)
-        l = ops.wgrad_strip(self.stream2, **dict(kw, slab=self.slab))
+        kw = dict(kw, slab=self.slab)
+        l = ops.wgrad_strip(self.stream2, **kw) if strip else ops.wgrad(self.stream2, self.fr, **kw)
         l.tstream = self.stream2_t
         self._slab_users.append(l)
         L.append(l)
@@ -507,12 +511,15 @@ class BackbonePlan(object):
                         0.0, 0, fr, st)
         L.append(drop)
         self.l_drop_fwd = drop
-        L.append(ops.call("fr_fill_rows", self.f, ol.bias, B, 512, st))
+        # split-K over 25088: every K slice stores its [B][512] partial (+ bias in slice 0) to its own slab and the
+        # slabs are added in a fixed order -- reproducible, unlike atomics, and the sums are formed in double
         nk = self.feat_in // 32
         self.lin_splitk = max(1, min(64, nk // 16))
-        L.append(ops.conv(st, fr, src=self.a, w=self.Wlin, out=self.f, B=B, RH=1, RW=1, SH=1, SW=1, SC=self.feat_in,
-                          N=512, KH=1, KW=1, stride=1, pad=0, mode=0, lda=self.feat_in, ldc=512, pro=0,
-                          epi=ops.EPI_ATOMIC, out_f32=1, splitk=self.lin_splitk))
+        self.lin_slab = torch.empty(self.lin_splitk * B * 512, device=self.device)
+        L.append(ops.conv(st, fr, src=self.a, w=self.Wlin, out=self.lin_slab, B=B, RH=1, RW=1, SH=1, SW=1,
+                          SC=self.feat_in, N=512, KH=1, KW=1, stride=1, pad=0, mode=0, lda=self.feat_in, ldc=512, pro=0,
+                          epi=ops.EPI_SLAB, out_f32=1, splitk=self.lin_splitk, bias=ol.bias))
+        L.append(ops.call("fr_reduce_parts", self.lin_slab, self.lin_splitk, 1, B * 512, self.f, None, None, st))
         nbf = ops.grid_blocks(B, 512, FR_F32)
         L.append(ops.call("fr_channel_stats", self.f, B, 512, self.part, nbf, FR_F32, st))
         self._bn_train_launches(L, self.bn1d, self.part, nbf, B)
@@ -761,10 +768,12 @@ class BackbonePlan(object):
                                   self.part, self.M0, self.K0, nsl, st))
                 L.append(ops.call("fr_reduce_parts", self.part, nsl, 1, 64 * self.K0, self.gW0p, None, None, st))
             else:
-                L.append(ops.call("fr_fill_rows", self.gW0p, None, 64, self.K0, st))
+                nsl = int(min(_wgrad_slices(self.M0, 1), self.part.numel() // (64 * self.K0)))
+                if nsl == 1:  # a single slice adds onto the buffer: clear it first
+                    L.append(ops.call("fr_fill_rows", self.gW0p, None, 64, self.K0, st))
                 L.append(ops.wgrad(st, fr, g=g_y0, src=self.X0, dw=self.gW0p, B=self.M0, GH=1, GW=1, Cout=64, SH=1,
                                    SW=1, SC=self.K0, KH=1, KW=1, stride=1, pad=0, ldg=64, lda=self.K0, pro=0,
-                                   nsplit=_wgrad_slices(self.M0, 1)))
+                                   nsplit=nsl, slab=self.part if nsl > 1 else None))
             L.append(ops.call("fr_unpack_stem_grad", self.gW0p, gw0, gw0.stride(0), gw0.stride(1), gw0.stride(2),
                               gw0.stride(3), 64, sc.weight.shape[1], self.K0, st))
         if self.dual and unit_done:

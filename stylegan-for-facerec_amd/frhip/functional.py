@@ -70,11 +70,13 @@ class MarginHeadFn(torch.autograd.Function):
         ops.call("fr_margin_bwd", g, label, cos_t, gcos, B, N, Np, kind, easy, cos_m, sin_m, th, s, FR_F32, st)()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            Gx = torch.zeros(B, D, device=dev)
+            Gx = torch.empty(B, D, device=dev)
             nk = Np // 32
             splitk = max(1, min(nk, 64, nk // 8))
-            ops.conv(st, FR_F32, src=gcos, w=wt, out=Gx, B=B, RH=1, RW=1, SH=1, SW=1, SC=Np, N=D, KH=1, KW=1,
-                     stride=1, pad=0, mode=0, lda=Np, ldc=D, pro=0, epi=ops.EPI_ATOMIC, out_f32=1, splitk=splitk)()
+            slab = torch.empty(splitk, B, D, device=dev)  # K slices to slabs, added in a fixed order (reproducible)
+            ops.conv(st, FR_F32, src=gcos, w=wt, out=slab, B=B, RH=1, RW=1, SH=1, SW=1, SC=Np, N=D, KH=1, KW=1,
+                     stride=1, pad=0, mode=0, lda=Np, ldc=D, pro=0, epi=ops.EPI_SLAB, out_f32=1, splitk=splitk)()
+            ops.call("fr_reduce_parts", slab, splitk, 1, B * D, Gx, None, None, st)()
             gx = torch.empty(B, D, device=dev)
             ops.call("fr_normalize_bwd", Gx, x, inv_x, gx, B, D, st)()
         if ctx.needs_input_grad[1]:

@@ -271,3 +271,52 @@ def test_bench_runs_through_rccl_with_one_rank(tmp_path):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["unit"] == "images/sec" and rec["scaling"] == "weak"
+
+
+def test_step_is_reproducible_and_side_stream_is_bit_identical():
+    """Every reduction on the IR-50 path has a fixed order (partial rows / slabs added by a second launch, no float
+    atomics), so two runs of three bf16 training steps give bit-identical parameters.  The weight gradients run on a
+    side stream behind event edges with double-buffered scratch: the same three steps with FRHIP_SINGLE_STREAM=1 must
+    ALSO be bit-identical -- any missing dependency edge (a buffer reused too early) shows up as a difference."""
+    _need_gpu()
+    import os
+    from backbone.model_irse import IR_50
+    from frhip import synth
+    from frhip.optim import SGD
+    from head.metrics import ArcFace
+    from loss.focal import FocalLoss
+    from util.utils import separate_irse_bn_paras
+
+    def run(single):
+        os.environ["FRHIP_SINGLE_STREAM"] = single
+        try:
+            m = IR_50([112, 112])
+            synth.fill_state_dict(m.state_dict(), 15)
+            m.output_layer[1].p = 0.0
+            m.compute_dtype = torch.bfloat16
+            m = m.cuda().train()
+            head = ArcFace(512, 100, None).cuda()
+            with torch.no_grad():
+                head.weight.copy_(synth.uniform(16, "full.head", (100, 512), -0.1, 0.1))
+            bn, wo = separate_irse_bn_paras(m)
+            opt = SGD([{"params": wo + list(head.parameters()), "weight_decay": 2e-3}, {"params": bn}], lr=0.03,
+                      momentum=0.9)
+            x = synth.uniform(16, "full.x", (6, 3, 112, 112)).cuda()
+            y = synth.labels(16, "full.label", 6, 100).cuda()
+            for _ in range(3):
+                loss, _ = FocalLoss()(head(m(x), y), y)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            torch.cuda.synchronize()
+            out = {n: p.detach().clone() for n, p in m.named_parameters()}
+            out["head.weight"] = head.weight.detach().clone()
+            return out
+        finally:
+            os.environ.pop("FRHIP_SINGLE_STREAM")
+
+    a, a2, b = run("0"), run("0"), run("1")
+    rerun = [n for n in a if not torch.equal(a[n], a2[n])]
+    assert not rerun, "two identical runs differ (a reduction without a fixed order?): %s" % rerun[:5]
+    sched = [n for n in a if not torch.equal(a[n], b[n])]
+    assert not sched, "side-stream and single-stream schedules differ (missing dependency edge?): %s" % sched[:5]
