@@ -30,8 +30,8 @@ from frhip.optim import SGD
 from frhip.parallel import DataParallel
 from head.metrics import Am_softmax, ArcFace, CosFace, SphereFace
 from loss.focal import FocalLoss
-from util.utils import (AverageMeter, accuracy, collate_fn_ignore_none, get_time, get_val_data, schedule_lr,
-                        separate_irse_bn_paras, warm_up_lr)
+from util.utils import (AverageMeter, accuracy, buffer_val, collate_fn_ignore_none, get_time, get_val_data, perform_val,
+                        schedule_lr, separate_irse_bn_paras, warm_up_lr)
 
 IRSE = {"IR_50": IR_50, "IR_101": IR_101, "IR_152": IR_152, "IR_SE_50": IR_SE_50, "IR_SE_101": IR_SE_101,
         "IR_SE_152": IR_SE_152}
@@ -103,7 +103,7 @@ def main():
                                          num_workers=cfg["NUM_WORKERS"], drop_last=cfg["DROP_LAST"],
                                          collate_fn=collate_fn_ignore_none)
     print("Number of Training Classes: {}".format(num_class))
-    val = get_val_data(cfg["DATA_ROOT"]) if not args.synthetic else None  # noqa: F841  (evaluation: SURVEY 8f)
+    val = get_val_data(cfg["DATA_ROOT"]) if not args.synthetic else None
 
     backbone = build_backbone(cfg)
     emb, s = cfg["EMBEDDING_SIZE"], cfg.get("ARCFACE_S", 64.0)
@@ -181,6 +181,21 @@ def main():
             batch += 1
             if args.max_steps and batch >= args.max_steps:
                 break
+        if rank == 0 and val is not None and val[-2] is not None:
+            # per-epoch verification on the RFW subsets (reference train.py:403-410); flip-TTA, k-fold accuracy
+            rfw, rfw_issame = val[-2], val[-1]
+            print("=" * 60)
+            for eth in ("African", "Asian", "Caucasian", "Indian"):
+                if eth not in rfw:
+                    continue
+                acc, thr, roc = perform_val(True, device, cfg["EMBEDDING_SIZE"], cfg["BATCH_SIZE"], BACKBONE, rfw[eth],
+                                            rfw_issame[eth], dset_name="RFW_" + eth,
+                                            ccrop=cfg.get("CCROP_AT_VAL", True))
+                if logger is not None:
+                    buffer_val(logger, "RFW_" + eth, acc, thr, roc, epoch + 1, batch * cfg["BATCH_SIZE"])
+                print("Evaluation: RFW {} Acc: {}".format(eth, acc))
+            print("=" * 60)
+            BACKBONE.module.train()
         if rank == 0:
             tag = "Epoch_{}_Batch_{}_Time_{}_checkpoint.pth".format(epoch + 1, batch, get_time())
             root = cfg["MODEL_ROOT"]

@@ -149,10 +149,97 @@ def get_val_data(data_path):
     return (None,) * _VAL_SLOTS + (rfw, rfw_issame)
 
 
+def de_preprocess(tensor):
+    return tensor * 0.5 + 0.5
+
+
+def _to_uint8(batch):
+    """torchvision ToPILImage on a float CHW tensor: ``pic.mul(255).byte()`` (truncation) -- utils.py:204-228."""
+    return de_preprocess(batch).mul(255).to(torch.uint8)
+
+
+def _from_uint8(u8):
+    """ToTensor + Normalize(0.5, 0.5): byte / 255, then (v - 0.5) / 0.5."""
+    return u8.to(torch.float32).div(255).sub_(0.5).div_(0.5)
+
+
+def hflip_batch(imgs_tensor):
+    """Horizontal flip through the reference's uint8 round trip (utils.py:204-218): the flipped copy is quantised
+    to 1/255 steps exactly as ToPILImage / ToTensor do, without leaving torch (works on device tensors)."""
+    return _from_uint8(torch.flip(_to_uint8(imgs_tensor), dims=[-1]))
+
+
+def ccrop_batch(imgs_tensor):
+    """Resize([128, 128]) + CenterCrop([112, 112]) through PIL (utils.py:221-236).  torchvision is not a dependency
+    here: the same PIL calls it makes are issued directly (``Image.resize(size, BILINEAR)``, centre crop box with
+    ``int(round((h - th) / 2.))``).  Host side, per image, like the reference."""
+    import numpy as np
+    from PIL import Image
+    u8 = _to_uint8(imgs_tensor.detach().cpu()).permute(0, 2, 3, 1).contiguous().numpy()
+    out = torch.empty(u8.shape[0], u8.shape[3], 112, 112, dtype=torch.float32)
+    for i in range(u8.shape[0]):
+        img = Image.fromarray(u8[i]).resize((128, 128), Image.BILINEAR)
+        top = int(round((128 - 112) / 2.0))
+        img = img.crop((top, top, top + 112, top + 112))
+        out[i] = torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1)
+    return _from_uint8(out.to(torch.uint8))
+
+
+def gen_plot(fpr, tpr):
+    """ROC curve as a JPEG in memory (utils.py:239-251); None when matplotlib is unavailable."""
+    try:
+        import io
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except Exception:  # noqa: BLE001
+        return None
+    plt.figure()
+    plt.xlabel("FPR", fontsize=14)
+    plt.ylabel("TPR", fontsize=14)
+    plt.title("ROC Curve", fontsize=14)
+    plt.plot(fpr, tpr, linewidth=2)
+    buf = io.BytesIO()
+    plt.savefig(buf, format="jpeg")
+    buf.seek(0)
+    plt.close()
+    return buf
+
+
 def perform_val(multi_gpu, device, embedding_size, batch_size, backbone, carray, issame, nrof_folds=10, tta=True,
-                dset_name="", ccrop=True):
-    raise NotImplementedError("perform_val (flip-TTA verification, reference util/utils.py:254-307) is the next "
-                              "scope row (SURVEY.md 8f rank 2) and is not part of this build")
+                dset_name=None, ccrop=True):
+    """Flip-TTA verification of ``backbone`` on interleaved image pairs (reference util/utils.py:254-307; SURVEY 8f
+    rank 2).  Same protocol: eval mode, batches of ``batch_size`` plus the remainder, optional centre-crop, embedding =
+    f(img) + f(hflip(img)) summed on the host, ``l2_norm``, then the k-fold metrics of util/verification.py.  Returns
+    (mean accuracy, mean best threshold, ROC-curve image tensor or None).  ``carray``: [2P, 3, 112, 112] (or NHWC)
+    float array in [-1, 1] (bcolz carray or numpy)."""
+    import numpy as np
+    from util.verification import evaluate
+    if multi_gpu:
+        backbone = backbone.module
+    backbone = backbone.to(device)
+    backbone.eval()
+    n = len(carray)
+    embeddings = np.zeros([n, embedding_size])
+    with torch.no_grad():
+        for idx in range(0, n, batch_size):
+            batch = torch.tensor(np.asarray(carray[idx:idx + batch_size])).float()
+            if batch.shape[-1] == 3:
+                batch = batch.permute(0, 3, 1, 2).contiguous()
+            cropped = ccrop_batch(batch) if ccrop else batch
+            if tta:
+                emb = backbone(cropped.to(device)).cpu() + backbone(hflip_batch(cropped).to(device)).cpu()
+            else:
+                emb = backbone(cropped.to(device)).cpu()
+            embeddings[idx:idx + batch.shape[0]] = l2_norm(emb).numpy()
+    tpr, fpr, acc, best_thresholds = evaluate(embeddings, issame, nrof_folds)
+    roc = None
+    buf = gen_plot(fpr, tpr)
+    if buf is not None:
+        from PIL import Image
+        img = np.asarray(Image.open(buf).convert("RGB"), dtype=np.float32) / 255.0
+        roc = torch.from_numpy(img).permute(2, 0, 1).contiguous()
+    return acc.mean(), best_thresholds.mean(), roc
 
 
 def buffer_val(writer, db_name, acc, best_threshold, roc_curve_tensor, epoch, n_samples_passed=None):

@@ -9,7 +9,7 @@ repo's own counter-based generator (stylegan-for-facerec_amd/frhip/synth.py) and
     python tests/golden/make_golden.py            # writes next to this file
 
 Fixtures: g1_head, g2_focal, g3_blocks, g4_se, g5_ir50, g6_psp, g7_sgd, g8_structure.json,
-g9_stage2.
+g9_stage2, g10_verification (8f rank 2: the k-fold verification metrics of util/verification.py).
 """
 import importlib.util
 import json
@@ -408,8 +408,33 @@ def g9_stage2():
     print("wrote g9_stage2.json")
 
 
+def verification_inputs(n_pairs, dim, seed, tag):
+    """Seeded pair embeddings with a real same/different signal: l2-normalised rows, pairs interleaved (2i, 2i+1)."""
+    base = synth.normal(seed, tag + ".a", (n_pairs, dim))
+    noise = synth.normal(seed, tag + ".n", (n_pairs, dim))
+    other = synth.normal(seed, tag + ".o", (n_pairs, dim))
+    same = (synth.uniform(seed, tag + ".s", (n_pairs,), 0.0, 1.0) < 0.5)
+    second = torch.where(same.view(-1, 1), base + 0.9 * noise, other)
+    emb = torch.stack([base, second], 1).reshape(2 * n_pairs, dim)
+    emb = emb / emb.norm(dim=1, keepdim=True)
+    return emb.double().numpy(), same.numpy()
+
+
+def g10_verification():
+    """util/verification.py evaluate(): k-fold ROC / accuracy / best threshold on seeded embeddings."""
+    from util import verification as V
+    out = {}
+    for tag, n_pairs, folds in (("a", 600, 10), ("b", 203, 10), ("c", 57, 5)):
+        emb, same = verification_inputs(n_pairs, 32, 77, "ver." + tag)
+        tpr, fpr, acc, best = V.evaluate(emb, same, nrof_folds=folds)
+        # (calculate_val is dead code in the reference -- commented out of evaluate() -- and its interp1d call
+        #  rejects the duplicate FAR values with the scipy of this container: not captured)
+        out.update({tag + "_tpr": tpr, tag + "_fpr": fpr, tag + "_acc": acc, tag + "_best": best})
+    save("g10_verification", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g9", "g10"]
     if "g1" in which:
         g1_head()
     if "g2" in which:
@@ -430,3 +455,5 @@ if __name__ == "__main__":
         g8_structure()
     if "g9" in which:
         g9_stage2()
+    if "g10" in which:
+        g10_verification()

@@ -369,3 +369,39 @@ def test_full_size_step_strip_and_generic_paths_agree():
         c = float(torch.nn.functional.cosine_similarity(g0[n].reshape(1, -1).float(), g1[n].reshape(1, -1).float()))
         d = float((g0[n] - g1[n]).norm() / (g1[n].norm() + 1e-20))
         assert c > 0.98 and d < 0.2, (n, c, d)
+
+
+def test_perform_val_matches_oracle_protocol():
+    """``perform_val`` (eval-mode forward on the HIP path, flip-TTA, l2_norm, k-fold verification)
+    against the same protocol carried out with the CPU oracle's eval forward and a literal threshold-by-threshold
+    fold loop (reference util/utils.py:254-307, util/verification.py:37-92)."""
+    _need_gpu()
+    from oracle import irse_ref as O
+    from util.utils import hflip_batch, l2_norm, perform_val
+    model, _ = build("IR_50")
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    pairs = 20
+    imgs = synth.uniform(41, "val.x", (2 * pairs, 3, 112, 112), -1.0, 1.0)
+    imgs[1::2][::2] = imgs[0::2][::2] + 0.05 * synth.normal(41, "val.n", (pairs // 2, 3, 112, 112))  # "same" pairs
+    imgs.clamp_(-1.0, 1.0)
+    issame = np.array([(i % 2) == 0 for i in range(pairs)])
+    acc, thr, _roc = perform_val(False, torch.device("cuda"), 512, 16, model, imgs.numpy(), issame, nrof_folds=5,
+                                 tta=True, ccrop=False)
+    assert not model.training
+    with torch.no_grad():
+        e = O.backbone_forward(sd, imgs, 50, False, bn_train=False) + \
+            O.backbone_forward(sd, hflip_batch(imgs), 50, False, bn_train=False)
+    e = l2_norm(e).double().numpy()
+    d = ((e[0::2] - e[1::2]) ** 2).sum(1)
+    thresholds = np.arange(0, 4, 0.01)
+    bounds = np.cumsum([0] + [pairs // 5] * 5)
+    accs, best = [], []
+    for f in range(5):
+        test = np.arange(bounds[f], bounds[f + 1])
+        train = np.setdiff1d(np.arange(pairs), test)
+        tr = [np.mean((d[train] < t) == issame[train]) for t in thresholds]
+        b = int(np.argmax(tr))
+        best.append(thresholds[b])
+        accs.append(np.mean((d[test] < thresholds[b]) == issame[test]))
+    assert abs(float(acc) - float(np.mean(accs))) <= 1.0 / pairs + 1e-9, (acc, np.mean(accs))
+    assert abs(float(thr) - float(np.mean(best))) <= 0.021, (thr, np.mean(best))

@@ -139,3 +139,62 @@ def test_synth_is_deterministic():
     assert abs(float(synth.normal(1, "n", (20000,)).std()) - 1.0) < 0.03
     lab = synth.labels(1, "l", 1000, 7)
     assert int(lab.min()) >= 0 and int(lab.max()) == 6
+
+
+# ------------------------------------------------------------------------------------------------ evaluation (8f rank 2)
+
+
+def _verification_inputs(n_pairs, dim, seed, tag):
+    from frhip import synth
+    base = synth.normal(seed, tag + ".a", (n_pairs, dim))
+    noise = synth.normal(seed, tag + ".n", (n_pairs, dim))
+    other = synth.normal(seed, tag + ".o", (n_pairs, dim))
+    same = (synth.uniform(seed, tag + ".s", (n_pairs,), 0.0, 1.0) < 0.5)
+    second = torch.where(same.view(-1, 1), base + 0.9 * noise, other)
+    emb = torch.stack([base, second], 1).reshape(2 * n_pairs, dim)
+    emb = emb / emb.norm(dim=1, keepdim=True)
+    return emb.double().numpy(), same.numpy()
+
+
+def test_verification_matches_reference_golden(golden_dir):
+    """util/verification.evaluate == the reference's (tests/golden/g10_verification.npz): ROC curves, per-fold
+    accuracy and best thresholds, incl. pair counts that do not divide into the folds."""
+    from util import verification as V
+    g = np.load(os.path.join(golden_dir, "g10_verification.npz"))
+    for tag, n_pairs, folds in (("a", 600, 10), ("b", 203, 10), ("c", 57, 5)):
+        emb, same = _verification_inputs(n_pairs, 32, 77, "ver." + tag)
+        tpr, fpr, acc, best = V.evaluate(emb, same, nrof_folds=folds)
+        np.testing.assert_array_equal(tpr, g[tag + "_tpr"])
+        np.testing.assert_array_equal(fpr, g[tag + "_fpr"])
+        np.testing.assert_array_equal(acc, g[tag + "_acc"])
+        np.testing.assert_array_equal(best, g[tag + "_best"])
+    # single-threshold helper agrees with the curves
+    emb, same = _verification_inputs(57, 32, 77, "ver.c")
+    d = ((emb[0::2] - emb[1::2]) ** 2).sum(1)
+    tpr1, fpr1, acc1 = V.calculate_accuracy(1.0, d, same)
+    assert abs(acc1 - ((d < 1.0) == same).mean()) < 1e-12 and 0.0 <= fpr1 <= tpr1 <= 1.0
+    with pytest.raises(NotImplementedError):
+        V.evaluate(emb, same, nrof_folds=5, pca=8)
+
+
+def test_tta_transforms_follow_the_uint8_round_trip():
+    """hflip_batch / ccrop_batch reproduce the reference's ToPILImage -> (flip | resize+crop) -> ToTensor -> Normalize
+    pipeline (util/utils.py:204-236): values land on the 1/255 grid, a double flip stays within one grid step of the
+    quantised image, the crop is the centre of the 128x128 bilinear up-sampling."""
+    from frhip import synth
+    from util.utils import ccrop_batch, hflip_batch
+    x = synth.uniform(5, "tta.x", (3, 3, 112, 112), -1.0, 1.0)
+    u8 = (x * 0.5 + 0.5).mul(255).to(torch.uint8)          # what ToPILImage stores (truncation)
+    quant = (u8.float() / 255 - 0.5) / 0.5                   # what ToTensor + Normalize give back
+    f = hflip_batch(x)
+    assert torch.equal(f, torch.flip(quant, dims=[-1]))
+    # (the truncating round trip is NOT idempotent -- v/255 can come back as v-1 -- which the reference shares)
+    assert float((hflip_batch(f) - quant).abs().max()) <= 2.0 / 255 + 1e-6
+    c = ccrop_batch(x)
+    assert c.shape == (3, 3, 112, 112)
+    grid = (c * 0.5 + 0.5) * 255
+    assert float((grid - grid.round()).abs().max()) < 1e-3
+    # a constant image stays constant through resize + crop
+    k = torch.full((1, 3, 112, 112), 0.25)
+    ck = ccrop_batch(k)
+    assert float((ck - ck[0, 0, 0, 0]).abs().max()) == 0.0 and abs(float(ck[0, 0, 0, 0]) - 0.25) < 1.0 / 255
