@@ -92,6 +92,22 @@ class BucketedAllReduce(object):
         self.reset()
 
 
+def _dense_flat(t):
+    """1-D view of a dense tensor's memory in storage order.  The conv weights are channels-last behind an OIHW shape
+    (not ``is_contiguous()``); collectives want contiguous tensors, and every rank has the same layout, so the flat
+    memory is what gets exchanged."""
+    if t.is_contiguous():
+        return t.view(-1)
+    sizes_strides = sorted((st, sz) for sz, st in zip(t.shape, t.stride()) if sz > 1)
+    expect = 1
+    for st, sz in sizes_strides:
+        if st != expect:
+            raise ValueError("frhip.parallel: cannot broadcast a non-dense tensor (shape %s, strides %s)"
+                             % (tuple(t.shape), t.stride()))
+        expect *= sz
+    return torch.as_strided(t, (t.numel(),), (1,), t.storage_offset())
+
+
 class DataParallel(object):
     """Glue between a frhip backbone (+ head) and ``BucketedAllReduce``.
 
@@ -120,7 +136,7 @@ class DataParallel(object):
         mods = [self.module] + ([self.head] if self.head is not None else [])
         for m in mods:
             for t in list(m.parameters()) + list(m.buffers()):
-                dist.broadcast(t.data, src, group=self.group)
+                dist.broadcast(_dense_flat(t.data), src, group=self.group)
 
     def _on_ready(self, params):
         plan = self.runner.plan

@@ -95,3 +95,51 @@ def test_single_process_is_a_noop():
     red.on_ready([p])
     red.synchronize()
     assert torch.equal(arena, torch.arange(10.0))
+
+
+def _bcast_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path.insert(0, os.path.join(os.path.dirname(here), "stylegan-for-facerec_amd"))
+        from backbone.model_irse import IR_50
+        from frhip.parallel import DataParallel, _dense_flat
+        torch.manual_seed(100 + rank)  # DIFFERENT initial weights per rank: the broadcast has to fix that
+        m = IR_50([112, 112])
+        w = m.body[0].res_layer[1].weight
+        assert not w.is_contiguous() and w.shape == (64, 64, 3, 3)  # channels-last memory behind the OIHW shape
+        assert _dense_flat(w.data).data_ptr() == w.data_ptr() and _dense_flat(w.data).numel() == w.numel()
+        head = torch.nn.Linear(512, 10, bias=False)
+        dp = DataParallel(m, head)  # broadcasts parameters and buffers from rank 0
+        assert dp.module is m
+        for t in list(m.parameters()) + list(m.buffers()) + list(head.parameters()):
+            got = [torch.zeros_like(t.data) for _ in range(world)]
+            dist.all_gather(got, t.data.contiguous())
+            assert torch.equal(got[0], got[1]), "ranks differ after broadcast"
+        with pytest.raises(ValueError):
+            _dense_flat(torch.zeros(4, 6)[:, ::2])
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_parameter_broadcast_handles_channels_last_weights_world2():
+    """DataParallel.broadcast_parameters: the conv weights are dense but not ``is_contiguous()``; they are exchanged
+    as flat storage-order views (this path only runs with world_size > 1)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
