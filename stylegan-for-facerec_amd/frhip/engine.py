@@ -206,6 +206,7 @@ class BackbonePlan(object):
         self.use_stem_gemm = self.fr == FR_BF16 and os.environ.get("FRHIP_NO_STEM_GEMM", "0") != "1"
         self.use_s2 = os.environ.get("FRHIP_NO_S2_STRIP", "0") != "1"  # stride-2 strip kernels (A/B switch)
         self.slab, self._slab_users = None, []
+        self.comm_stream_t, self.comm_events = None, None  # readiness callbacks (run_backward)
         self._normalize_params()
         self._alloc()
         self._bind_params()
@@ -813,14 +814,27 @@ class BackbonePlan(object):
         if on_ready is None:
             ops.run(self.bwd_list)
             return
+        # Readiness callbacks (gradient all-reduce) run on their own stream, ordered behind the main stream up to this
+        # point and behind the unit's side-stream weight gradients -- the main stream itself never waits for the side
+        # stream here, so the two-stream overlap survives data-parallel runs.  The callee enqueues collectives on the
+        # current stream (ProcessGroupNCCL orders its own stream behind it).
+        if self.comm_stream_t is None:
+            self.comm_stream_t = torch.cuda.Stream(device=self.device)
+            self.comm_events = [torch.cuda.Event() for _ in self.ready_marks]
+        comm = self.comm_stream_t
         pos = 0
-        for end, params, done in self.ready_marks:
+        for k, (end, params, done) in enumerate(self.ready_marks):
             ops.run(self.bwd_list[pos:end])
             pos = end
+            ev = self.comm_events[k]
+            ev.record(self.stream1_t)
+            comm.wait_event(ev)
             if done is not None:
-                self.stream1_t.wait_event(done)  # the collective is ordered behind the main stream only
-            on_ready([p for p in params if p.requires_grad])
+                comm.wait_event(done)
+            with torch.cuda.stream(comm):
+                on_ready([p for p in params if p.requires_grad])
         ops.run(self.bwd_list[pos:])
+        self.stream1_t.wait_stream(comm)  # whatever the callbacks enqueued themselves (not the async collectives)
 
 
 # ------------------------------------------------------------------------------------------------ autograd glue

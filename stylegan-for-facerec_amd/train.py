@@ -17,9 +17,11 @@ import importlib
 import os
 import sys
 
-import numpy as np
-import torch
-import torch.distributed as dist
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # main / side / RCCL streams on separate hardware queues (frhip/__init__.py)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 from backbone.model_irse import IR_50, IR_101, IR_152, IR_SE_50, IR_SE_101, IR_SE_152
 from backbone.model_resnet import ResNet_50, ResNet_101, ResNet_152  # noqa: F401  (import parity with the reference)

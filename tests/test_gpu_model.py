@@ -405,3 +405,44 @@ def test_perform_val_matches_oracle_protocol():
         accs.append(np.mean((d[test] < thresholds[b]) == issame[test]))
     assert abs(float(acc) - float(np.mean(accs))) <= 1.0 / pairs + 1e-9, (acc, np.mean(accs))
     assert abs(float(thr) - float(np.mean(best))) <= 0.021, (thr, np.mean(best))
+
+
+def test_readiness_callbacks_see_final_gradients():
+    """Data-parallel hook contract: ``on_grads_ready(params)`` runs on a communication stream that is ordered behind
+    the main stream and the unit's side-stream weight gradients.  A callback that copies the announced gradients on
+    its current stream must capture exactly the final values (a collective launched there would read the same bytes),
+    every trainable backbone parameter must be announced exactly once, and announcements follow the arena order."""
+    _need_gpu()
+    from backbone.model_irse import IR_50
+    from head.metrics import ArcFace
+    from loss.focal import FocalLoss
+    m = IR_50([112, 112])
+    synth.fill_state_dict(m.state_dict(), 15)
+    m.output_layer[1].p = 0.0
+    m.compute_dtype = torch.bfloat16
+    m = m.cuda().train()
+    head = ArcFace(512, 100, None).cuda()
+    x = synth.uniform(16, "full.x", (8, 3, 112, 112)).cuda()
+    y = synth.labels(16, "full.label", 8, 100).cuda()
+    seen, order = {}, []
+
+    def on_ready(params):
+        assert torch.cuda.current_stream() != torch.cuda.default_stream()
+        for p in params:
+            assert id(p) not in seen
+            seen[id(p)] = p.grad.clone()  # enqueued on the communication stream
+            order.append(p.grad.data_ptr())
+
+    m._runner[0].on_grads_ready = on_ready
+    for _ in range(2):  # second step: the plan (and its events) are reused
+        seen.clear()
+        order.clear()
+        loss, _ = FocalLoss()(head(m(x), y), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        trainable = [p for p in m.parameters() if p.requires_grad]
+        assert len(seen) == len(trainable)
+        assert order == sorted(order)
+        bad = [n for n, p in m.named_parameters() if not torch.equal(seen[id(p)], p.grad)]
+        assert not bad, "callback saw unfinished gradients for %s" % bad[:5]
+        assert all(float(p.grad.abs().max()) > 0 for p in trainable if p.dim() >= 2)
