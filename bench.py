@@ -41,6 +41,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_F32_TFLOPS = 157.3     # f32-input MFMA == vector peak
 IR50_FLOPS_PER_IMG = 37.7356e9   # conv + Linear, fwd+bwd, 2 flop/MAC (measured on the reference)
+FLOPS_PER_IMG = {"IR_50": IR50_FLOPS_PER_IMG, "IR_SE_50": 37.7356e9, "IR_SE_101": 72.4194e9, "IR_101": 72.4194e9}
 
 
 def parse():
@@ -51,6 +52,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--classes", type=int, default=7000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--model", default="IR_50", choices=["IR_50", "IR_101", "IR_152", "IR_SE_50", "IR_SE_101", "IR_SE_152"],
+                    help="IR_50 is the BASELINE.json workload; the others are for kernel tables of the SE / deep variants")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", default="", help="write the per-launch timing table of the instrumented step")
@@ -58,14 +61,14 @@ def parse():
 
 
 def build_job(args, device, rank):
-    from backbone.model_irse import IR_50
+    import backbone.model_irse as irse
     from frhip import synth
     from frhip.optim import SGD
     from head.metrics import ArcFace
     from loss.focal import FocalLoss
     from util.utils import separate_irse_bn_paras
     torch.manual_seed(900)
-    model = IR_50([112, 112])
+    model = getattr(irse, args.model)([112, 112])  # BASELINE metric: IR_50 (other factories: kernel tables only)
     synth.fill_state_dict(model.state_dict(), 15)   # identical "trained-looking" weights on every rank
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = model.to(device).train()
@@ -290,8 +293,8 @@ def main():
         "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "IR-50 + ArcFace(%d ids) + Focal + SGD train step, synthetic 112x112x3, bs=%d/GPU"
-                               % (args.classes, args.batch),
+        "config": {"workload": "%s + ArcFace(%d ids) + Focal + SGD train step, synthetic 112x112x3, bs=%d/GPU"
+                               % (args.model.replace("IR_", "IR-"), args.classes, args.batch),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                    "images_per_sec_per_gpu": round(ips / world, 1), "final_loss": float("%.3e" % loss_val)},
     }
@@ -309,7 +312,7 @@ def main():
             torch.cuda.synchronize()
     if rank == 0:
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        flops_img = IR50_FLOPS_PER_IMG + 6.0 * 512 * args.classes
+        flops_img = FLOPS_PER_IMG.get(args.model, IR50_FLOPS_PER_IMG) + 6.0 * 512 * args.classes
         step_tflops = flops_img * ips / world / 1e12
         if fams is not None:
             table = sorted(fams.items(), key=lambda kv: -kv[1][1])

@@ -233,10 +233,11 @@ int fr_se_mlp_fwd(const float* pooled, const float* w1, const float* w2, float* 
 /* gs[b][c] = sum_hw g * (x*scale+shift)  (gradient wrt the excite scale) */
 int fr_se_gscale(const void* g, const void* x, const float* scale, const float* shift, float* gs, int B, int HW,
                  int C, int dtype, void* stream);
-/* backward of the MLP: gpooled [B][C] (already divided by HW), dW1, dW2 accumulated (+=) */
+/* backward of the MLP: gpooled [B][C] (already divided by HW); dW1 [R][C], dW2 [C][R] OVERWRITTEN with the sums over
+ * the batch in image order (reproducible, no atomics); gz [B][C], gh [B][R]: scratch the two launches hand over */
 int fr_se_mlp_bwd(const float* gs, const float* s, const float* hidden, const float* pooled, const float* w1,
-                  const float* w2, float* gpooled, float* dw1, float* dw2, int B, int C, int R, int HW,
-                  void* stream);
+                  const float* w2, float* gpooled, float* dw1, float* dw2, float* gz, float* gh, int B, int C, int R,
+                  int HW, void* stream);
 
 /* ---- output layer pieces (model_irse.py:144-148) */
 /* a[b][(h*7+w)*C + c] = dropout(x*scale+shift): mask from a counter hash of (seed, element index in the

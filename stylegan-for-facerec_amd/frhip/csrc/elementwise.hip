@@ -496,8 +496,20 @@ __global__ __launch_bounds__(NT, 6) void bn_apply_lean_kernel(const FrApplyArgs 
 }
 
 // SLOPE: BN followed by PReLU (the stem, model_irse.py:141-142): g' = g * prelu'(u), u = x*scale + shift, and the third
-// partial row collects the slope gradient sum g*u*[u <= 0]
-template <bool SLOPE>
+// partial row collects the slope gradient sum g*u*[u <= 0].  SE: BN followed by the SE excite (bottleneck_IR_SE,
+// model_irse.py:86-87): g' = g * se[b][c] + gse[b][c], both [B][C] fp32 (a few KB per image, L2 hits).
+__device__ __forceinline__ void se_gprime(const FrBnBwdArgs& p, int r, int c0, float* v) {
+  const int b = r / p.rows_per_image;
+  const float4 s4 = *reinterpret_cast<const float4*>(p.se + (size_t)b * p.C + c0);
+  float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.gse) g4 = *reinterpret_cast<const float4*>(p.gse + (size_t)b * p.C + c0);
+  v[0] = fmaf(v[0], s4.x, g4.x);
+  v[1] = fmaf(v[1], s4.y, g4.y);
+  v[2] = fmaf(v[2], s4.z, g4.z);
+  v[3] = fmaf(v[3], s4.w, g4.w);
+}
+
+template <bool SLOPE, bool SE = false>
 __global__ __launch_bounds__(NT, 6) void bn_bwd_reduce_lean_kernel(const FrBnBwdArgs p) {
   __shared__ float red[NT * 3 * LV];
   const int C = p.C, cpr = C / LV, tid = threadIdx.x;
@@ -533,6 +545,7 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_reduce_lean_kernel(const FrBnBwd
         float gv[LV], xv[LV];
         unpack4bf(gr[u], gv);
         unpack4bf(xr[u], xv);
+        if (SE) se_gprime(p, r0 + u * rtc, c0, gv);  // same expression as bn_bwd_gprime
 #pragma unroll
         for (int j = 0; j < LV; ++j) {
           float v = gv[j];
@@ -551,7 +564,7 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_reduce_lean_kernel(const FrBnBwd
   block_col_reduce<3, LV>(acc, red, p.part + (size_t)blockIdx.x * 3 * C, C, cpr, tid);
 }
 
-template <bool ADD>
+template <bool ADD, bool SE = false>
 __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdArgs p) {
   const int C = p.C, cpr = C / LV, tid = threadIdx.x;
   const int cc = tid % cpr, rt = tid / cpr, rtc = NT / cpr, c0 = cc * LV;
@@ -588,6 +601,7 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdA
         unpack4bf(gr[u], gv);
         unpack4bf(xr[u], xv);
         if (ADD) unpack4bf(er[u], e);
+        if (SE) se_gprime(p, r, c0, gv);
 #pragma unroll
         for (int j = 0; j < LV; ++j) {
           o[j] = coef[j] * (gv[j] - a[j] - (xv[j] - mu[j]) * is[j] * bb[j]);
@@ -675,18 +689,22 @@ __global__ void se_mlp_fwd_kernel(const float* __restrict__ pooled, const float*
   }
 }
 
-// backward of the MLP for one image per block; dW1/dW2 accumulated with atomics (tiny tensors)
+// backward of the MLP, image part: one block per image.  gz (gradient at the fc2 output) and gh (at the fc1 output)
+// are written out for the weight-gradient kernel below -- accumulating dW1/dW2 with atomics from 256 blocks onto the
+// same few thousand addresses took 110 us per SE module (and an unordered sum); gz and gh are [B][C] / [B][R] floats.
 __global__ void se_mlp_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ s,
-                                  const float* __restrict__ hidden, const float* __restrict__ pooled,
-                                  const float* __restrict__ w1, const float* __restrict__ w2,
-                                  float* __restrict__ gpooled, float* dw1, float* dw2, int C, int R, float inv_hw) {
+                                  const float* __restrict__ hidden, const float* __restrict__ w1,
+                                  const float* __restrict__ w2, float* __restrict__ gpooled, float* __restrict__ gz_out,
+                                  float* __restrict__ gh_out, int C, int R, float inv_hw) {
   extern __shared__ float sm[];  // [C] gz (grad at fc2 output), [R] gh
   float* gz = sm;
   float* gh = sm + C;
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int c = tid; c < C; c += blockDim.x) {
     const float sv = s[(size_t)b * C + c];
-    gz[c] = gs[(size_t)b * C + c] * sv * (1.f - sv);
+    const float v = gs[(size_t)b * C + c] * sv * (1.f - sv);
+    gz[c] = v;
+    gz_out[(size_t)b * C + c] = v;
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
@@ -694,18 +712,60 @@ __global__ void se_mlp_bwd_kernel(const float* __restrict__ gs, const float* __r
     float acc = 0.f;
     for (int c = lane; c < C; c += 64) acc = fmaf(w2[(size_t)c * R + r], gz[c], acc);
     acc = wave_sum(acc);
-    if (lane == 0) gh[r] = hidden[(size_t)b * R + r] > 0.f ? acc : 0.f;
+    if (lane == 0) {
+      const float v = hidden[(size_t)b * R + r] > 0.f ? acc : 0.f;
+      gh[r] = v;
+      gh_out[(size_t)b * R + r] = v;
+    }
   }
   __syncthreads();
   for (int c = tid; c < C; c += blockDim.x) {
     float acc = 0.f;
-    const float pc = pooled[(size_t)b * C + c];
-    for (int r = 0; r < R; ++r) {
-      acc = fmaf(w1[(size_t)r * C + c], gh[r], acc);
-      atomicAdd(dw1 + (size_t)r * C + c, gh[r] * pc);
-      atomicAdd(dw2 + (size_t)c * R + r, gz[c] * hidden[(size_t)b * R + r]);
-    }
+    for (int r = 0; r < R; ++r) acc = fmaf(w1[(size_t)r * C + c], gh[r], acc);
     gpooled[(size_t)b * C + c] = acc * inv_hw;
+  }
+}
+
+// weight part: dW1[r][c] = sum_b gh[b][r] * pooled[b][c],  dW2[c][r] = sum_b gz[b][c] * hidden[b][r].  Block = 64
+// channels x 4 batch quarters of one r; each thread walks its quarter with 8 independent loads in flight, the four
+// partial sums are added in quarter order through LDS (reproducible); overwrites.
+__global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* __restrict__ gz, const float* __restrict__ gh,
+                                                           const float* __restrict__ hidden,
+                                                           const float* __restrict__ pooled, float* __restrict__ dw1,
+                                                           float* __restrict__ dw2, int B, int C, int R) {
+  __shared__ float part[2][4][64];
+  const int r = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  const int per = (B + 3) / 4, b0 = q * per, b1 = b0 + per < B ? b0 + per : B;
+  float a1 = 0.f, a2 = 0.f;
+  if (c < C) {
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      float g_[8], p_[8], z_[8], h_[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        g_[u] = gh[(size_t)(b + u) * R + r];
+        p_[u] = pooled[(size_t)(b + u) * C + c];
+        z_[u] = gz[(size_t)(b + u) * C + c];
+        h_[u] = hidden[(size_t)(b + u) * R + r];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a1 = fmaf(g_[u], p_[u], a1);
+        a2 = fmaf(z_[u], h_[u], a2);
+      }
+    }
+    for (; b < b1; ++b) {
+      a1 = fmaf(gh[(size_t)b * R + r], pooled[(size_t)b * C + c], a1);
+      a2 = fmaf(gz[(size_t)b * C + c], hidden[(size_t)b * R + r], a2);
+    }
+  }
+  part[0][q][threadIdx.x & 63] = a1;
+  part[1][q][threadIdx.x & 63] = a2;
+  __syncthreads();
+  if (q == 0 && c < C) {
+    const int t = threadIdx.x;
+    dw1[(size_t)r * C + c] = ((part[0][0][t] + part[0][1][t]) + part[0][2][t]) + part[0][3][t];
+    dw2[(size_t)c * R + r] = ((part[1][0][t] + part[1][1][t]) + part[1][2][t]) + part[1][3][t];
   }
 }
 
@@ -1012,10 +1072,12 @@ extern "C" int fr_bn_apply(const FrApplyArgs* args, int dtype, void* stream) {
 extern "C" int fr_bn_bwd_reduce(const FrBnBwdArgs* args, int dtype, void* stream) {
   if (!chan_ok(args->C, dtype)) FR_UNSUPPORTED("fr_bn_bwd_reduce: unsupported channel count");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == FR_BF16 && lean_ok(args->C) && !args->se && args->rows < (1ll << 31) &&
+  if (dtype == FR_BF16 && lean_ok(args->C) && args->rows < (1ll << 31) && !(args->se && args->slope) &&
       (!args->slope || (args->scale && args->shift))) {
-    if (args->slope) hipLaunchKernelGGL(bn_bwd_reduce_lean_kernel<true>, dim3(args->nblocks), dim3(NT), 0, st, *args);
-    else hipLaunchKernelGGL(bn_bwd_reduce_lean_kernel<false>, dim3(args->nblocks), dim3(NT), 0, st, *args);
+    const dim3 grid(args->nblocks), blk(NT);
+    if (args->se) hipLaunchKernelGGL((bn_bwd_reduce_lean_kernel<false, true>), grid, blk, 0, st, *args);
+    else if (args->slope) hipLaunchKernelGGL((bn_bwd_reduce_lean_kernel<true, false>), grid, blk, 0, st, *args);
+    else hipLaunchKernelGGL((bn_bwd_reduce_lean_kernel<false, false>), grid, blk, 0, st, *args);
     FR_LAUNCH_CHECK();
   }
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(args->nblocks), dim3(NT), 0, st, *args),
@@ -1027,10 +1089,15 @@ extern "C" int fr_bn_bwd_reduce(const FrBnBwdArgs* args, int dtype, void* stream
 extern "C" int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream) {
   if (!chan_ok(args->C, dtype)) FR_UNSUPPORTED("fr_bn_bwd_apply: unsupported channel count");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == FR_BF16 && lean_ok(args->C) && !args->se && !args->slope && args->add_kind != 2 &&
-      args->rows < (1ll << 31)) {
-    if (args->add_kind == 1) hipLaunchKernelGGL(bn_bwd_apply_lean_kernel<true>, dim3(args->nblocks), dim3(NT), 0, st, *args);
-    else hipLaunchKernelGGL(bn_bwd_apply_lean_kernel<false>, dim3(args->nblocks), dim3(NT), 0, st, *args);
+  if (dtype == FR_BF16 && lean_ok(args->C) && !args->slope && args->add_kind != 2 && args->rows < (1ll << 31)) {
+    const dim3 grid(args->nblocks), blk(NT);
+    if (args->se) {
+      if (args->add_kind == 1) hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<true, true>), grid, blk, 0, st, *args);
+      else hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<false, true>), grid, blk, 0, st, *args);
+    } else {
+      if (args->add_kind == 1) hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<true, false>), grid, blk, 0, st, *args);
+      else hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<false, false>), grid, blk, 0, st, *args);
+    }
     FR_LAUNCH_CHECK();
   }
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(args->nblocks), dim3(NT), 0, st, *args),
@@ -1073,10 +1140,14 @@ extern "C" int fr_se_mlp_fwd(const float* pooled, const float* w1, const float* 
 }
 
 extern "C" int fr_se_mlp_bwd(const float* gs, const float* s, const float* hidden, const float* pooled,
-                             const float* w1, const float* w2, float* gpooled, float* dw1, float* dw2, int B, int C,
-                             int R, int HW, void* stream) {
-  hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), (hipStream_t)stream, gs, s,
-                     hidden, pooled, w1, w2, gpooled, dw1, dw2, C, R, 1.0f / (float)HW);
+                             const float* w1, const float* w2, float* gpooled, float* dw1, float* dw2, float* gz,
+                             float* gh, int B, int C, int R, int HW, void* stream) {
+  if (!gz || !gh) FR_UNSUPPORTED("fr_se_mlp_bwd: gz [B][C] and gh [B][R] scratch are required");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), st, gs, s, hidden, w1, w2, gpooled,
+                     gz, gh, C, R, 1.0f / (float)HW);
+  hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, gz, gh, hidden, pooled, dw1, dw2, B,
+                     C, R);
   FR_LAUNCH_CHECK();
 }
 

@@ -255,7 +255,8 @@ class BackbonePlan(object):
                 max_xs = max(max_xs, rin * u.cin)
             if u.se is not None:
                 R = u.se.fc1.out_channels
-                for k, n in (("pooled", u.depth), ("s", u.depth), ("gs", u.depth), ("gpooled", u.depth), ("hidden", R)):
+                for k, n in (("pooled", u.depth), ("s", u.depth), ("gs", u.depth), ("gpooled", u.depth), ("hidden", R),
+                             ("gz", u.depth), ("gh", R)):
                     d[k] = torch.zeros(B, n, device=dev)
             self.ubuf.append(d)
             max_in = max(max_in, rin * u.cin)
@@ -643,7 +644,7 @@ class BackbonePlan(object):
                 if g2 is None:
                     g2 = self.se_scratch[1, :R * u.depth]
                 L.append(ops.call("fr_se_mlp_bwd", d["gs"], d["s"], d["hidden"], d["pooled"], u.se.fc1.weight,
-                                  u.se.fc2.weight, d["gpooled"], g1, g2, B, u.depth, R, HWo, st))
+                                  u.se.fc2.weight, d["gpooled"], g1, g2, d["gz"], d["gh"], B, u.depth, R, HWo, st))
                 se_kw = dict(se=d["s"], gse=d["gpooled"])
                 ready += [u.se.fc1.weight, u.se.fc2.weight]
             db, dg = self._bn_grads(bn2)

@@ -824,3 +824,41 @@ def test_stem_wgrad_bn_equals_unfused(K, Kp):
     torch.cuda.synchronize()
     assert torch.equal(slab_a, slab_b)
     assert float(slab_a.abs().max()) > 0
+
+
+@pytest.mark.parametrize("name,dtype,tol", DT)
+@pytest.mark.parametrize("with_add", [False, True])
+def test_bn_backward_with_se_gate(K, name, dtype, tol, with_add):
+    """BN followed by the SE excite (bottleneck_IR_SE, model_irse.py:86-87): g' = g * s[b][c] + gs[b][c] feeds the BN
+    backward sums and input gradient (the bf16 case takes the lean SE kernels), vs the same algebra in fp32 on the CPU."""
+    B, H, C = 5, 7, 128   # 49 rows per image: a thread's rows in flight straddle image boundaries
+    HW, rows = H * H, B * H * H
+    x = q(synth.normal(83, "sx", (B, C, H, H)), dtype)
+    g = q(synth.normal(83, "sg", (B, C, H, H)), dtype)
+    add = q(synth.normal(83, "sa", (B, C, H, H)), dtype)
+    se = synth.uniform(83, "ss", (B, C), 0.1, 0.9)
+    gse = synth.uniform(83, "sq", (B, C), -0.05, 0.05)
+    gamma = synth.uniform(83, "sw", (C,), 0.8, 1.2)
+    mean = x.mean((0, 2, 3))
+    invstd = 1.0 / torch.sqrt(x.var((0, 2, 3), unbiased=False) + 1e-5)
+    gp = g * se.view(B, C, 1, 1) + gse.view(B, C, 1, 1)
+    xhat = (x - mean.view(1, C, 1, 1)) * invstd.view(1, C, 1, 1)
+    r0, r1 = gp.sum((0, 2, 3)), (gp * xhat).sum((0, 2, 3))
+    want = (gamma * invstd).view(1, C, 1, 1) * (gp - (r0 / rows).view(1, C, 1, 1) - xhat * (r1 / rows).view(1, C, 1, 1))
+    if with_add:
+        want = want + add
+    fr, st = K.fr_dtype(torch.empty(0, dtype=dtype)), K.current_stream_ptr()
+    nb = 6
+    common = dict(g=nhwc(g, dtype), x=nhwc(x, dtype), mean=mean.cuda(), invstd=invstd.cuda(), se=se.cuda(),
+                  gse=gse.cuda(), rows=rows, C=C, rows_per_image=HW, nblocks=nb)
+    part = torch.zeros(nb, 3, C, device="cuda")
+    K.bn_bwd_reduce(st, fr, part=part, **common)()
+    s0, s1 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    K.call("fr_reduce_parts", part, nb, 3, C, s0, s1, None, st)()
+    gx = torch.zeros(B, H, H, C, device="cuda", dtype=dtype)
+    extra = dict(add=nhwc(add, dtype), add_kind=1) if with_add else {}
+    K.bn_bwd_apply(st, fr, gx=gx, gamma=gamma.cuda(), s0=s0, s1=s1, inv_count=1.0 / rows, **common, **extra)()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(s0.cpu(), r0, rtol=tol * 5, atol=tol * 20)
+    np.testing.assert_allclose(s1.cpu(), r1, rtol=tol * 5, atol=tol * 20)
+    assert relerr(from_nhwc(gx), want) < tol * 2
