@@ -227,6 +227,10 @@ int fr_bn_eval_coeffs(const float* running_mean, const float* running_var, const
 /* pooled[b][c] = mean_hw (x*scale+shift)  */
 int fr_se_pool(const void* x, const float* scale, const float* shift, float* pooled, int B, int HW, int C,
                int dtype, void* stream);
+/* the same from the per-strip column sums of a strip convolution's STATS epilogue (part[strip][2][C], the strips of
+ * image b at rows b*rows_per_image ..): pooled[b][c] = scale[c] * (sum of those rows' [0][c]) / HW + shift[c] */
+int fr_se_pool_parts(const float* part, int rows_per_image, const float* scale, const float* shift, float* pooled,
+                     int B, int HW, int C, void* stream);
 /* s = sigmoid(W2 relu(W1 pooled)); W1 [R][C], W2 [C][R]; saves hidden [B][R] */
 int fr_se_mlp_fwd(const float* pooled, const float* w1, const float* w2, float* hidden, float* s, int B, int C,
                   int R, void* stream);

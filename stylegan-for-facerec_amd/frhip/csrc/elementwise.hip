@@ -660,6 +660,18 @@ __global__ __launch_bounds__(NT) void se_pool_kernel(const T* __restrict__ x, co
   }
 }
 
+// The same squeeze from per-strip column sums a strip convolution's STATS epilogue already produced: part rows are
+// [strip][2][C] with the strips of image b at rows b*NS .. b*NS+NS-1, so the activation is not read again.
+__global__ void se_pool_parts_kernel(const float* __restrict__ part, int NS, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, float* __restrict__ out, int C, float inv_hw) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < NS; ++k) s += part[((size_t)(b * NS + k) * 2) * C + c];
+    out[(size_t)b * C + c] = fmaf(s * inv_hw, scale[c], shift[c]);
+  }
+}
+
 // s = sigmoid(W2 relu(W1 pooled)); one block per image
 __global__ void se_mlp_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
                                   const float* __restrict__ w2, float* __restrict__ hidden, float* __restrict__ s,
@@ -1116,6 +1128,14 @@ extern "C" int fr_se_pool(const void* x, const float* scale, const float* shift,
              hipLaunchKernelGGL((se_pool_kernel<bf16_t, false>), dim3(B), dim3(NT), 0, st, (const bf16_t*)x,
                                 (const bf16_t*)nullptr, scale, shift, pooled, HW, C),
              "fr_se_pool");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_se_pool_parts(const float* part, int rows_per_image, const float* scale, const float* shift,
+                                float* pooled, int B, int HW, int C, void* stream) {
+  if (rows_per_image < 1 || B < 1 || C < 1) FR_UNSUPPORTED("fr_se_pool_parts: bad geometry");
+  hipLaunchKernelGGL(se_pool_parts_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, part, rows_per_image, scale, shift,
+                     pooled, C, 1.0f / (float)HW);
   FR_LAUNCH_CHECK();
 }
 

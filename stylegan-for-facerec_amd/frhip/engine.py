@@ -353,6 +353,7 @@ class BackbonePlan(object):
             n = ops.strip_parts(kw["B"], kw["SC"], kw["N"], kw["SW"], kw.get("epi", 0))
             if n:
                 L.append(ops.conv_strip(self.stream, **kw))
+                self._last_conv_strips = n  # partial rows = strips, image-major
                 return n
         if (self.fr == FR_BF16 and self.use_strip and self.use_s2 and kw["KH"] == 3 and kw["stride"] == 2 and
                 kw.get("mode", 0) in (0, 2)):
@@ -360,7 +361,9 @@ class BackbonePlan(object):
             n = ops.s2_strip_parts(kw["B"], kw["SC"], kw["N"], kw["RW"] if mode == 0 else kw["SW"], mode)
             if n:
                 L.append(ops.conv_s2_strip(self.stream, **kw))
+                self._last_conv_strips = n if mode == 0 else 0
                 return n
+        self._last_conv_strips = 0
         L.append(ops.conv(self.stream, self.fr, **kw))
         if kw.get("mode", 0) == 2:  # all four parity classes in one launch: [class][M tile] partial rows
             return 4 * ((kw["B"] * (kw["RH"] // 2) * (kw["RW"] // 2) + 127) // 128)
@@ -473,6 +476,7 @@ class BackbonePlan(object):
                              ldc=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight, epi=ops.EPI_STATS,
                              part=self.part)
             self._bn_train_launches(L, bn2, self.part, np2, rout)
+            strips2 = self._last_conv_strips  # conv2's partial rows, if they are whole strips of single images
             if u.sc_conv is not None:
                 ws = self._conv_master(u.sc_conv)
                 if fr == FR_BF16:
@@ -487,8 +491,13 @@ class BackbonePlan(object):
                 self._bn_train_launches(L, d["bnS"], self.part, (rout + 127) // 128, rout)
             if u.se is not None:
                 R = u.se.fc1.out_channels
-                L.append(ops.call("fr_se_pool", d["y2"], bn2.scale, bn2.shift, d["pooled"], B, u.Ho * u.Ho, u.depth,
-                                  fr, st))
+                if strips2 and strips2 % B == 0 and u.sc_conv is None:
+                    # the squeeze from conv2's per-strip column sums (still in self.part): no pass over y2
+                    L.append(ops.call("fr_se_pool_parts", self.part, strips2 // B, bn2.scale, bn2.shift, d["pooled"], B,
+                                      u.Ho * u.Ho, u.depth, st))
+                else:
+                    L.append(ops.call("fr_se_pool", d["y2"], bn2.scale, bn2.shift, d["pooled"], B, u.Ho * u.Ho,
+                                      u.depth, fr, st))
                 L.append(ops.call("fr_se_mlp_fwd", d["pooled"], u.se.fc1.weight, u.se.fc2.weight, d["hidden"],
                                   d["s"], B, u.depth, R, st))
             nb = ops.grid_blocks(rout, u.depth, fr)
