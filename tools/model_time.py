@@ -24,3 +24,22 @@ for name, ctor, B in (("IR_50", IR_50, 256), ("IR_SE_50", IR_SE_50, 256), ("IR_S
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
     print("%s B=%d: %.2f ms/step, %.0f img/s" % (name, B, dt * 1e3, B / dt), flush=True)
     del m, head, opt; torch.cuda.empty_cache()
+
+# pSp (IR-SE-50 trunk, 6-channel stem with the average image): BASELINE configs 1 and 5
+from backbone.restyle_psp import pSp
+B = 256
+avg = synth.uniform(2, "avg", (3, 112, 112))
+m = pSp(size=112, encoder_type="BackboneEncoder", avg_image=avg)
+m.encoder.compute_dtype = torch.bfloat16
+m = m.cuda().train()
+head = ArcFace(512, 7000, None).cuda()
+bn, wo = separate_irse_bn_paras(m)
+opt = SGD([{"params": wo + list(head.parameters()), "weight_decay": 2e-3}, {"params": bn}], lr=0.03, momentum=0.9)
+x = synth.uniform(1, "x", (B, 3, 112, 112)).cuda(); y = synth.labels(1, "y", B, 7000).cuda()
+def step():
+    loss, _ = FocalLoss()(head(m(x), y), y); opt.zero_grad(); loss.backward(); opt.step()
+for _ in range(5): step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20): step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+print("pSp(IR_SE_50, 6ch) B=%d: %.2f ms/step, %.0f img/s" % (B, dt * 1e3, B / dt), flush=True)
