@@ -5,7 +5,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "stylegan-for-facerec_amd"))
 import torch
 import bench
-class A: batch=256; classes=7000; dtype="bf16"
+class A: batch=256; classes=7000; dtype="bf16"; model="IR_50"
 dev = torch.device("cuda", 0)
 model, head, loss_fn, opt, x, y = bench.build_job(A, dev, 0)
 step = bench.make_step(model, head, loss_fn, opt, None)
