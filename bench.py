@@ -47,8 +47,8 @@ FLOPS_PER_IMG = {"IR_50": IR50_FLOPS_PER_IMG, "IR_SE_50": 37.7356e9, "IR_SE_101"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--classes", type=int, default=7000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
