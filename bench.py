@@ -252,6 +252,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FRHIP_BENCH_ONE_DEVICE") == "1":
+        local = 0  # test hook: several ranks share GPU 0 (with FRHIP_DIST_BACKEND=gloo; RCCL refuses duplicate devices)
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback for the product path)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -259,7 +261,11 @@ def main():
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("FRHIP_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; gloo only for the shared-GPU test
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     model, head, loss_fn, opt, x, y = build_job(args, device, rank)
     dp = None
     if world > 1 or force_dp:

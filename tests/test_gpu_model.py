@@ -446,3 +446,26 @@ def test_readiness_callbacks_see_final_gradients():
         bad = [n for n, p in m.named_parameters() if not torch.equal(seen[id(p)], p.grad)]
         assert not bad, "callback saw unfinished gradients for %s" % bad[:5]
         assert all(float(p.grad.abs().max()) > 0 for p in trainable if p.dim() >= 2)
+
+
+def test_bench_two_ranks_sharing_one_gpu(tmp_path):
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, two processes), except that both
+    ranks use GPU 0 and the collectives go through gloo (RCCL refuses two ranks on one device).  Exercises what one
+    rank cannot: the parameter broadcast, the non-zero rank's side of the barriers / MAX-reduction / extra roofline
+    steps (a rank-0-only step with a collective inside would hang here), and the averaged gradients."""
+    _need_gpu()
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FRHIP_BENCH_ONE_DEVICE="1", FRHIP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "16", "--classes", "1000", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0) expected, got %d" % len(lines)
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 32 and rec["value"] > 0
+    assert rec["config"]["parallelism"] == "dp2" and "roofline" in rec
