@@ -469,3 +469,18 @@ def test_bench_two_ranks_sharing_one_gpu(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 32 and rec["value"] > 0
     assert rec["config"]["parallelism"] == "dp2" and "roofline" in rec
+
+
+def test_two_rank_gradients_are_the_rank_average():
+    """Two ranks on one GPU (gloo collectives): the gradients frhip.parallel.DataParallel leaves in ``.grad`` are
+    bit-for-bit the mean of the two single-rank gradients, different initial weights are overwritten by rank 0's, and
+    the replicas stay identical through optimizer steps (tests/dp_worker.py)."""
+    _need_gpu()
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", os.path.join(here, "dp_worker.py")]
+    out = subprocess.run(cmd, cwd=os.path.dirname(here), env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "DP_WORKER_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
