@@ -219,6 +219,7 @@ class BackbonePlan(object):
         self.use_stem_gemm = self.fr == FR_BF16 and os.environ.get("FRHIP_NO_STEM_GEMM", "0") != "1"
         self.use_s2 = os.environ.get("FRHIP_NO_S2_STRIP", "0") != "1"  # stride-2 strip kernels (A/B switch)
         self.slab, self._slab_users = None, []
+        self.part_slope = None  # per-buffer-set partial rows of the PReLU slope gradient (side-stream reduction)
         self.comm_stream_t, self.comm_events = None, None  # readiness callbacks (run_backward)
         self._normalize_params()
         self._alloc()
@@ -301,6 +302,9 @@ class BackbonePlan(object):
         self.g_fT = self._act(B, 512)
         self.part = torch.zeros(max(4 * 1024 * 1024, ((M0 + 127) // 128) * 2 * 64 + 4096, B * 28 * 2 * 64 + 4096),
                                 device=dev)
+        self.side_slope = self.dual and os.environ.get("FRHIP_SLOPE_ON_MAIN", "0") != "1"  # A/B switch
+        if self.side_slope:
+            self.part_slope = [torch.zeros_like(self.part), torch.zeros_like(self.part)]
         self.se_scratch = torch.zeros(2, 512 * 64, device=dev)  # dW1/dW2 sink while the SE weights are frozen
         self.zeros_c = torch.zeros(512, device=dev)
         self.sums = torch.zeros(3, 512, device=dev)      # scratch reduce target for frozen parameters
@@ -708,18 +712,29 @@ class BackbonePlan(object):
             c2 = dict(src=g_y2, w=d["wt2"], out=g_y1, B=B, RH=u.H, RW=u.H, SH=u.Ho, SW=u.Ho, SC=u.depth, N=u.depth,
                       KH=3, KW=3, stride=u.stride, pad=1, lda=u.depth, ldc=u.depth, ldaux=u.depth, pro=0,
                       epi=ops.EPI_PRELU_BWD, aux=d["y1"], epi_a=u.prelu.weight)
+            # The PReLU-slope partial sums of this data gradient feed nothing downstream (a parameter gradient): with the
+            # side stream they go to a buffer of their own (one per buffer set) and are added there, off the main chain.
+            part2 = self.part_slope[par] if self.side_slope else self.part
             if u.stride == 2 and u.H % 2 == 0:
                 # one launch per output-pixel parity class: 9/4 taps per pixel instead of 9 (3/4 of them misses)
                 # (all four classes in one launch: par = -1; partial rows come back as [class][M tile])
-                mt = self._conv(L, mode=2, par_h=-1, par_w=-1, part=self.part, **c2)
+                mt = self._conv(L, mode=2, par_h=-1, par_w=-1, part=part2, **c2)
             else:
-                mt = self._conv(L, mode=1, part=self.part, **c2)
+                mt = self._conv(L, mode=1, part=part2, **c2)
             gsl = self.grad_of(u.prelu.weight)
-            self._reduce(L, mt, 2, u.depth, gsl if gsl is not None else self.sums[2, :u.depth], None)
+            gsl = gsl if gsl is not None else self.sums[2, :u.depth]
             gw2 = self.grad_of(u.conv2.weight)
+            if self.side_slope:
+                self._side_after_main(L)  # g_y1 / the slope partials, g_y2 (BN2 backward) and y1 are final
+                r = ops.call("fr_reduce_parts", part2, mt, 2, u.depth, gsl, None, None, self.stream2)
+                r.tstream = self.stream2_t
+                L.append(r)
+            else:
+                self._reduce(L, mt, 2, u.depth, gsl, None)
             if gw2 is not None:
                 tiles = ((u.depth + 127) // 128) ** 2 * 9
-                self._side_after_main(L)  # g_y2 (BN2 backward) and y1 are final on the main stream
+                if not self.side_slope:
+                    self._side_after_main(L)
                 self._wgrad(L, g=g_y2, src=d["y1"], dw=gw2, B=B, GH=u.Ho, GW=u.Ho, Cout=u.depth, SH=u.H,
                             SW=u.H, SC=u.depth, KH=3, KW=3, stride=u.stride, pad=1, ldg=u.depth, lda=u.depth,
                             pro=ops.PRO_PRELU, pro_a=u.prelu.weight, nsplit=_wgrad_slices(rout, tiles))
