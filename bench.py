@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--model", default="IR_50", choices=["IR_50", "IR_101", "IR_152", "IR_SE_50", "IR_SE_101", "IR_SE_152"],
                     help="IR_50 is the BASELINE.json workload; the others are for kernel tables of the SE / deep variants")
+    ap.add_argument("--sharded-head", action="store_true",
+                    help="class-sharded ArcFace + focal loss over the ranks (frhip/sharded_head.py) instead of the "
+                         "replicated head; off by default: the BASELINE configs replicate the head")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", default="", help="write the per-launch timing table of the instrumented step")
@@ -76,6 +79,9 @@ def build_job(args, device, rank):
     with torch.no_grad():
         head.weight.copy_(synth.uniform(16, "bench.head", (args.classes, 512), -0.05, 0.05))
     head = head.to(device).train()
+    if getattr(args, "sharded_head", False):
+        from frhip.sharded_head import ShardedMarginLoss
+        head = ShardedMarginLoss.from_head(head, gamma=2.0).to(device)  # this rank's class range of the same weight
     bn, wo = separate_irse_bn_paras(model)
     _, hwo = separate_irse_bn_paras(head)
     opt = SGD([{"params": wo + hwo, "weight_decay": 2e-3}, {"params": bn}], lr=0.03, momentum=0.9)
@@ -88,6 +94,18 @@ def make_step(model, head, loss_fn, opt, dp):
     from frhip import functional as FRF
     from util.utils import accuracy
     FRF.CHECK_LABELS = False  # synthetic labels are in range by construction; the check is a host sync
+
+    def sharded_step(x, y):
+        loss, p1, p5 = head(model(x), y)  # global-batch loss / accuracy; the weight-shard gradient needs no exchange
+        opt.zero_grad(set_to_none=False)
+        loss.backward()
+        if dp is not None:
+            dp.synchronize()
+        opt.step()
+        return loss, (p1, p5)
+
+    if head.__class__.__name__ == "ShardedMarginLoss":
+        return sharded_step
 
     def step(x, y):
         feats = model(x)
@@ -270,7 +288,7 @@ def main():
     dp = None
     if world > 1 or force_dp:
         from frhip.parallel import DataParallel
-        dp = DataParallel(model, head)
+        dp = DataParallel(model, None if args.sharded_head else head)  # a weight shard is complete on its owner
     step = make_step(model, head, loss_fn, opt, dp)
 
     for _ in range(args.warmup):
@@ -301,7 +319,7 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%s + ArcFace(%d ids) + Focal + SGD train step, synthetic 112x112x3, bs=%d/GPU"
                                % (args.model.replace("IR_", "IR-"), args.classes, args.batch),
-                   "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                   "global_batch": args.batch * world, "parallelism": "dp%d" % world + ("+class-sharded head" if args.sharded_head else ""),
                    "images_per_sec_per_gpu": round(ips / world, 1), "final_loss": float("%.3e" % loss_val)},
     }
     fams = None

@@ -298,6 +298,20 @@ int fr_focal_finalize(const float* ce, const int32_t* rank, int rows, float gamm
 int fr_focal_bwd(const float* logits, const int64_t* label, const float* lse, const float* scalars,
                  const float* gup, float* grad, int rows, int N, int ld, void* stream);
 
+/* ---- class-sharded softmax (the process-per-GPU form of the class-dimension split of
+ *      head/metrics.py:104-113,170-179): every rank holds the logits of a contiguous class range [lo, hi) for ALL rows of
+ *      the global batch; label_local = label - lo, or any value outside [0, N) where another rank owns the label.
+ *   fr_shard_row_stats : stats[0][m] = max_n z[m][n], stats[1][m] = sum_n exp(z - max), stats[2][m] = z[m][label_local]
+ *                        (0 if not owned); stats is [3][rows] fp32
+ *   fr_shard_combine   : stats_all = the ranks' stats in rank order, [world][3][rows]; lse[m] = log sum_n exp z over all
+ *                        classes, tlogit[m] = the label's logit, ce[m] = lse - tlogit (fixed summation order: every
+ *                        rank gets identical bits)
+ *   fr_shard_rank_rows : rank[m] = #{n in this shard: z[m][n] > tlogit[m]} (sum over ranks = top-k rank of the label) */
+int fr_shard_row_stats(const float* logits, const int64_t* label_local, float* stats, int rows, int N, int ld,
+                       void* stream);
+int fr_shard_combine(const float* stats_all, int world, int rows, float* lse, float* ce, float* tlogit, void* stream);
+int fr_shard_rank_rows(const float* logits, const float* tlogit, int32_t* rank, int rows, int N, int ld, void* stream);
+
 /* ---- multi-tensor SGD with momentum (torch.optim.SGD defaults; train.py:196)
  *   d = g + wd*p ; buf = momentum*buf + d ; p -= lr*buf      (buf starts at 0, so the first step gives buf = d)
  * table_dev: device array of tensor records; chunks_dev: device array of (tensor index, chunk index) pairs,

@@ -184,6 +184,69 @@ __global__ __launch_bounds__(256) void rank_rows_kernel(const float* __restrict_
   if (tid == 0) rank[m] = ired[0] + ired[1] + ired[2] + ired[3];
 }
 
+// ------------------------------------------------------------------------------------------ class-sharded softmax
+// One rank holds the logits of its own contiguous class range only.  Per row it contributes (max, sum exp(z - max),
+// label logit or 0); the ranks' triples are gathered and combined in rank order (shard_combine_kernel), which gives every
+// rank the same log-sum-exp / cross entropy bit for bit.
+__global__ __launch_bounds__(256) void shard_row_stats_kernel(const float* __restrict__ z,
+                                                              const long long* __restrict__ label,
+                                                              float* __restrict__ stats, int rows, int N, int ld) {
+  __shared__ float sred[4];
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = z + (size_t)m * ld;
+  float mx = -INFINITY;
+  for (int n = tid; n < N; n += 256) mx = fmaxf(mx, row[n]);
+  mx = wave_max(mx);
+  if (lane == 0) sred[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int n = tid; n < N; n += 256) se += __expf(row[n] - mx);
+  se = wave_sum(se);
+  if (lane == 0) sred[wave] = se;
+  __syncthreads();
+  if (tid == 0) {
+    const long long lab = label[m];
+    stats[m] = mx;
+    stats[rows + m] = sred[0] + sred[1] + sred[2] + sred[3];
+    stats[2 * rows + m] = (lab >= 0 && lab < N) ? row[lab] : 0.f;
+  }
+}
+
+__global__ void shard_combine_kernel(const float* __restrict__ stats_all, int world, int rows, float* __restrict__ lse,
+                                     float* __restrict__ ce, float* __restrict__ tlogit) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= rows) return;
+  float gmax = -INFINITY;
+  for (int w = 0; w < world; ++w) gmax = fmaxf(gmax, stats_all[(size_t)w * 3 * rows + m]);
+  float sum = 0.f, t = 0.f;
+  for (int w = 0; w < world; ++w) {
+    const float* s = stats_all + (size_t)w * 3 * rows;
+    sum += s[rows + m] * expf(s[m] - gmax);
+    t += s[2 * rows + m];  // exactly one rank owns the label, the others contribute 0
+  }
+  const float l = gmax + logf(sum);
+  lse[m] = l;
+  ce[m] = l - t;
+  tlogit[m] = t;
+}
+
+// rank[m] = #{n in this shard: z[m][n] > t[m]}; the ranks' counts add up to the global rank of the label
+__global__ __launch_bounds__(256) void shard_rank_rows_kernel(const float* __restrict__ z, const float* __restrict__ t,
+                                                              int* __restrict__ rank, int N, int ld) {
+  __shared__ int ired[4];
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = z + (size_t)m * ld;
+  const float zl = t[m];
+  int cnt = 0;
+  for (int n = tid; n < N; n += 256) cnt += row[n] > zl ? 1 : 0;
+  const float fc = wave_sum((float)cnt);
+  if (lane == 0) ired[wave] = (int)fc;
+  __syncthreads();
+  if (tid == 0) rank[m] = ired[0] + ired[1] + ired[2] + ired[3];
+}
+
 // ------------------------------------------------------------------------------------------ SGD
 constexpr int SGD_CHUNK = 4096;
 __global__ __launch_bounds__(256) void sgd_kernel(const FrSgdTensor* __restrict__ table,
@@ -268,6 +331,30 @@ extern "C" int fr_focal_bwd(const float* logits, const int64_t* label, const flo
   dim3 grid((N + 1023) / 1024, rows);
   hipLaunchKernelGGL(focal_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, logits, (const long long*)label,
                      lse, scalars, gup, grad, rows, N, ld);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_shard_row_stats(const float* logits, const int64_t* label_local, float* stats, int rows, int N, int ld,
+                                  void* stream) {
+  if (rows <= 0 || N <= 0) FR_UNSUPPORTED("fr_shard_row_stats: empty shard");
+  hipLaunchKernelGGL(shard_row_stats_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
+                     (const long long*)label_local, stats, rows, N, ld);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_shard_combine(const float* stats_all, int world, int rows, float* lse, float* ce, float* tlogit,
+                                void* stream) {
+  if (rows <= 0 || world <= 0) FR_UNSUPPORTED("fr_shard_combine: empty");
+  hipLaunchKernelGGL(shard_combine_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats_all,
+                     world, rows, lse, ce, tlogit);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_shard_rank_rows(const float* logits, const float* tlogit, int32_t* rank, int rows, int N, int ld,
+                                  void* stream) {
+  if (rows <= 0 || N <= 0) FR_UNSUPPORTED("fr_shard_rank_rows: empty shard");
+  hipLaunchKernelGGL(shard_rank_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, tlogit, rank, N,
+                     ld);
   FR_LAUNCH_CHECK();
 }
 

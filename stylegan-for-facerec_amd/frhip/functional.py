@@ -17,6 +17,79 @@ def _pad(n, m):
     return (n + m - 1) // m * m
 
 
+def margin_forward(x, weight, label, kind, s, m, easy_margin):
+    """logits = s * where(j == label, phi(cos), cos) for fp32 device tensors.  Returns (logits, saved, cfg) for
+    ``margin_backward``.  A label outside [0, N) selects nothing in its row (the class-sharded head passes -1 for rows
+    whose label lives on another rank)."""
+    B, D = x.shape
+    N = weight.shape[0]
+    dev = x.device
+    st = ops.current_stream_ptr()
+    x = x.contiguous().float()
+    w = weight.contiguous().float()
+    label = label.contiguous().long()
+    Np = _pad(N, 32)
+    xn = torch.empty(B, D, device=dev)
+    inv_x = torch.empty(B, device=dev)
+    wn = torch.empty(Np, D, device=dev)
+    wt = torch.empty(D, Np, device=dev)
+    inv_w = torch.empty(N, device=dev)
+    ops.call("fr_row_normalize", x, xn, None, inv_x, B, B, D, 0, FR_F32, st)()
+    ops.call("fr_row_normalize", w, wn, wt, inv_w, N, Np, D, Np, FR_F32, st)()
+    ld = _pad(N, 4)  # 16-byte row pitch for the GEMM's vector stores; [B, N] is a view when N is not a multiple of 4
+    store = torch.empty(B, ld, device=dev)
+    logits = store if ld == N else store[:, :N]
+    cos_t = torch.zeros(B, device=dev)
+    if kind == 0:
+        cos_m, sin_m = math.cos(m), math.sin(m)
+        th, mm = math.cos(math.pi - m), math.sin(math.pi - m) * m
+    else:
+        cos_m, sin_m, th, mm = m, 0.0, 0.0, 0.0
+    ops.conv(st, FR_F32, src=xn, w=wn, out=logits, B=B, RH=1, RW=1, SH=1, SW=1, SC=D, N=N, KH=1, KW=1, stride=1,
+             pad=0, mode=0, lda=D, ldc=ld, pro=0, epi=ops.EPI_MARGIN, out_f32=1, margin_kind=kind,
+             easy_margin=int(bool(easy_margin)), cos_m=cos_m, sin_m=sin_m, th=th, mm=mm, scale=float(s),
+             label=label, cos_t=cos_t)()
+    saved = (x, w, label, xn, wt, inv_x, inv_w, cos_t)
+    cfg = (kind, float(s), cos_m, sin_m, th, int(bool(easy_margin)), Np)
+    return logits, saved, cfg
+
+
+def margin_backward(saved, cfg, g, need_x, need_w, raw_x_grad=False):
+    """(gx, gw) of ``margin_forward``.  ``raw_x_grad``: return G = d loss / d normalize(x) instead of gx (the
+    class-sharded head sums G over ranks before it goes through the normalisation backward, which is linear in G)."""
+    x, w, label, xn, wt, inv_x, inv_w, cos_t = saved
+    kind, s, cos_m, sin_m, th, easy, Np = cfg
+    B, D = x.shape
+    N = w.shape[0]
+    dev = x.device
+    st = ops.current_stream_ptr()
+    g = g.contiguous().float()
+    gcos = torch.empty(B, Np, device=dev)
+    ops.call("fr_margin_bwd", g, label, cos_t, gcos, B, N, Np, kind, easy, cos_m, sin_m, th, s, FR_F32, st)()
+    gx = gw = None
+    if need_x:
+        Gx = torch.empty(B, D, device=dev)
+        nk = Np // 32
+        splitk = max(1, min(nk, 64, nk // 8))
+        slab = torch.empty(splitk, B, D, device=dev)  # K slices to slabs, added in a fixed order (reproducible)
+        ops.conv(st, FR_F32, src=gcos, w=wt, out=slab, B=B, RH=1, RW=1, SH=1, SW=1, SC=Np, N=D, KH=1, KW=1,
+                 stride=1, pad=0, mode=0, lda=Np, ldc=D, pro=0, epi=ops.EPI_SLAB, out_f32=1, splitk=splitk)()
+        ops.call("fr_reduce_parts", slab, splitk, 1, B * D, Gx, None, None, st)()
+        if raw_x_grad:
+            gx = Gx
+        else:
+            gx = torch.empty(B, D, device=dev)
+            ops.call("fr_normalize_bwd", Gx, x, inv_x, gx, B, D, st)()
+    if need_w:
+        N4 = _pad(N, 4)  # the weight-gradient GEMM wants 16-byte channel counts; gcos columns >= N are zero
+        GW = torch.zeros(N4, D, device=dev)
+        ops.wgrad(st, FR_F32, g=gcos, src=xn, dw=GW, B=B, GH=1, GW=1, Cout=N4, SH=1, SW=1, SC=D, KH=1, KW=1,
+                  stride=1, pad=0, ldg=Np, lda=D, pro=0, nsplit=1)()
+        gw = torch.empty(N, D, device=dev)
+        ops.call("fr_normalize_bwd", GW, w, inv_w, gw, N, D, st)()
+    return gx, gw
+
+
 class MarginHeadFn(torch.autograd.Function):
     """logits = s * where(j == label, phi(cos), cos),  cos = normalize(x) . normalize(W)^T
 
@@ -26,65 +99,15 @@ class MarginHeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, label, kind, s, m, easy_margin):
-        B, D = x.shape
-        N = weight.shape[0]
-        dev = x.device
-        st = ops.current_stream_ptr()
-        x = x.contiguous().float()
-        w = weight.contiguous().float()
-        label = label.contiguous().long()
-        Np = _pad(N, 32)
-        xn = torch.empty(B, D, device=dev)
-        inv_x = torch.empty(B, device=dev)
-        wn = torch.empty(Np, D, device=dev)
-        wt = torch.empty(D, Np, device=dev)
-        inv_w = torch.empty(N, device=dev)
-        ops.call("fr_row_normalize", x, xn, None, inv_x, B, B, D, 0, FR_F32, st)()
-        ops.call("fr_row_normalize", w, wn, wt, inv_w, N, Np, D, Np, FR_F32, st)()
-        logits = torch.empty(B, N, device=dev)
-        cos_t = torch.zeros(B, device=dev)
-        if kind == 0:
-            cos_m, sin_m = math.cos(m), math.sin(m)
-            th, mm = math.cos(math.pi - m), math.sin(math.pi - m) * m
-        else:
-            cos_m, sin_m, th, mm = m, 0.0, 0.0, 0.0
-        ops.conv(st, FR_F32, src=xn, w=wn, out=logits, B=B, RH=1, RW=1, SH=1, SW=1, SC=D, N=N, KH=1, KW=1, stride=1,
-                 pad=0, mode=0, lda=D, ldc=N, pro=0, epi=ops.EPI_MARGIN, out_f32=1, margin_kind=kind,
-                 easy_margin=int(bool(easy_margin)), cos_m=cos_m, sin_m=sin_m, th=th, mm=mm, scale=float(s),
-                 label=label, cos_t=cos_t)()
-        ctx.save_for_backward(x, w, label, xn, wt, inv_x, inv_w, cos_t)
-        ctx.cfg = (kind, float(s), cos_m, sin_m, th, int(bool(easy_margin)), Np)
+        logits, saved, cfg = margin_forward(x, weight, label, kind, s, m, easy_margin)
+        ctx.save_for_backward(*saved)
+        ctx.cfg = cfg
         ctx.mark_non_differentiable(label)
         return logits
 
     @staticmethod
     def backward(ctx, g):
-        x, w, label, xn, wt, inv_x, inv_w, cos_t = ctx.saved_tensors
-        kind, s, cos_m, sin_m, th, easy, Np = ctx.cfg
-        B, D = x.shape
-        N = w.shape[0]
-        dev = x.device
-        st = ops.current_stream_ptr()
-        g = g.contiguous().float()
-        gcos = torch.empty(B, Np, device=dev)
-        ops.call("fr_margin_bwd", g, label, cos_t, gcos, B, N, Np, kind, easy, cos_m, sin_m, th, s, FR_F32, st)()
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            Gx = torch.empty(B, D, device=dev)
-            nk = Np // 32
-            splitk = max(1, min(nk, 64, nk // 8))
-            slab = torch.empty(splitk, B, D, device=dev)  # K slices to slabs, added in a fixed order (reproducible)
-            ops.conv(st, FR_F32, src=gcos, w=wt, out=slab, B=B, RH=1, RW=1, SH=1, SW=1, SC=Np, N=D, KH=1, KW=1,
-                     stride=1, pad=0, mode=0, lda=Np, ldc=D, pro=0, epi=ops.EPI_SLAB, out_f32=1, splitk=splitk)()
-            ops.call("fr_reduce_parts", slab, splitk, 1, B * D, Gx, None, None, st)()
-            gx = torch.empty(B, D, device=dev)
-            ops.call("fr_normalize_bwd", Gx, x, inv_x, gx, B, D, st)()
-        if ctx.needs_input_grad[1]:
-            GW = torch.zeros(N, D, device=dev)
-            ops.wgrad(st, FR_F32, g=gcos, src=xn, dw=GW, B=B, GH=1, GW=1, Cout=N, SH=1, SW=1, SC=D, KH=1, KW=1,
-                      stride=1, pad=0, ldg=Np, lda=D, pro=0, nsplit=1)()
-            gw = torch.empty(N, D, device=dev)
-            ops.call("fr_normalize_bwd", GW, w, inv_w, gw, N, D, st)()
+        gx, gw = margin_backward(ctx.saved_tensors, ctx.cfg, g, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return gx, gw, None, None, None, None, None
 
 

@@ -127,8 +127,20 @@ def main():
     optimizer = SGD([{"params": other_params + head_params, "weight_decay": cfg["WEIGHT_DECAY"]},
                      {"params": bn_params}], lr=cfg["LR"], momentum=cfg["MOMENTUM"])
     opt_resume = cfg.get("OPTIMIZER_RESUME_ROOT")
-    BACKBONE = DataParallel(backbone, head)  # exposes .module like nn.DataParallel; all-reduce only when world > 1
     loss_fn = FocalLoss() if cfg["LOSS_NAME"] == "Focal" else None
+    crit = None
+    if cfg.get("SHARDED_HEAD", False):
+        # class-sharded head + focal loss over the ranks (frhip/sharded_head.py): the N x 512 weight, its momentum and the
+        # [B, N] logits are split by class range; the loss is the focal loss of the GLOBAL batch, as under the
+        # reference's nn.DataParallel.  Checkpoints keep the reference's layout (gathered ``weight``).
+        if cfg["HEAD_NAME"] not in ("ArcFace", "CosFace") or loss_fn is None:
+            raise NotImplementedError("SHARDED_HEAD needs HEAD_NAME ArcFace/CosFace and LOSS_NAME 'Focal'")
+        from frhip.sharded_head import ShardedMarginLoss
+        crit = ShardedMarginLoss.from_head(head, gamma=loss_fn.gamma).to(device)
+        optimizer = SGD([{"params": other_params + [crit.weight], "weight_decay": cfg["WEIGHT_DECAY"]},
+                         {"params": bn_params}], lr=cfg["LR"], momentum=cfg["MOMENTUM"])
+    # exposes .module like nn.DataParallel; all-reduce only when world > 1 (a weight shard is complete on its owner)
+    BACKBONE = DataParallel(backbone, None if crit is not None else head)
     ce = torch.nn.CrossEntropyLoss()
 
     disp_freq = max(1, len(loader) // 10)  # the reference divides by zero below 10 batches/epoch
@@ -158,9 +170,12 @@ def main():
             labels = labels.to(device, non_blocking=True).long()
             if batch == 0 and opt_resume and os.path.isfile(opt_resume):
                 pass  # momentum buffers are created lazily; loaded right after the first step below
-            outputs = head(BACKBONE(inputs), labels)
-            loss = loss_fn(outputs, labels)[0] if loss_fn is not None else ce(outputs, labels)
-            prec1, prec5 = accuracy(outputs.data, labels, topk=(1, 5))
+            if crit is not None:
+                loss, prec1, prec5 = crit(BACKBONE(inputs), labels)
+            else:
+                outputs = head(BACKBONE(inputs), labels)
+                loss = loss_fn(outputs, labels)[0] if loss_fn is not None else ce(outputs, labels)
+                prec1, prec5 = accuracy(outputs.data, labels, topk=(1, 5))
             pending.append((loss.detach(), prec1, prec5, inputs.size(0)))
             optimizer.zero_grad()
             loss.backward()
@@ -198,6 +213,9 @@ def main():
                 print("Evaluation: RFW {} Acc: {}".format(eth, acc))
             print("=" * 60)
             BACKBONE.module.train()
+        if crit is not None:
+            with torch.no_grad():
+                head.weight.copy_(crit.gather_weight())  # collective: every rank takes part, rank 0 writes the file
         if rank == 0:
             tag = "Epoch_{}_Batch_{}_Time_{}_checkpoint.pth".format(epoch + 1, batch, get_time())
             root = cfg["MODEL_ROOT"]
