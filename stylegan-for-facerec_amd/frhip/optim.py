@@ -52,6 +52,14 @@ class SGD(torch.optim.Optimizer):
                 if "momentum_buffer" not in st:
                     st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 buf, g = st["momentum_buffer"], p.grad
+                if buf is None:  # torch.optim.SGD writes None before its first step
+                    buf = st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if buf.shape == p.shape and not _dense_same(p, buf):
+                    # a buffer loaded from a checkpoint written with another memory layout (the reference's
+                    # torch.optim.SGD keeps OIHW-contiguous buffers; the conv weights here are channels-last)
+                    relaid = torch.empty_like(p, memory_format=torch.preserve_format)
+                    relaid.copy_(buf)
+                    buf = st["momentum_buffer"] = relaid
                 if not (_dense_same(p, g) and _dense_same(p, buf)):
                     raise _lib.FrhipError("frhip.optim.SGD: param / grad / momentum buffer must share one dense layout")
                 n = p.numel()
@@ -69,6 +77,12 @@ class SGD(torch.optim.Optimizer):
             ch = torch.tensor(chunks, dtype=torch.int32).reshape(-1).to(dev)
             self._tables.append((raw, ch, len(chunks)))
             keep.append(arr)
+
+    def load_state_dict(self, state_dict):
+        """As torch.optim.Optimizer.load_state_dict (works before the first step, like the reference's resume at
+        train.py:227-230); the launch tables are rebuilt because the momentum buffers are new tensors."""
+        super().load_state_dict(state_dict)
+        self._sig = None
 
     def _signature(self):
         return tuple((p.data_ptr(), 0 if p.grad is None else p.grad.data_ptr(), float(g["weight_decay"]))

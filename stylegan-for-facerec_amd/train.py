@@ -10,7 +10,11 @@ eagerly), the BN / non-BN parameter groups, LR stages (/1.5), optional warm-up, 
 ``.module.encoder.body``, per-step top-1/5, per-epoch checkpoint file names.  Changed on purpose (SURVEY.md section 7,
 hard parts): one process per GPU with RCCL gradient all-reduce instead of nn.DataParallel (BATCH_SIZE is per GPU),
 the head lives on the GPU, metrics are read back every DISP_FREQ steps instead of three ``.item()`` syncs per step,
-wandb / bcolz validation are optional.
+wandb / bcolz validation are optional.  Resume: the reference restores weights and optimizer state
+but restarts the batch counter (warm-up, logging), the shuffle and the dropout stream; here a ``State_*`` file written
+next to every checkpoint carries epoch, batch counter and dropout stream, the per-epoch shuffle is a function of
+(SEED, epoch), and ``STATE_RESUME_ROOT`` restores them -- training resumed at an epoch boundary continues bit for bit
+(tests/test_gpu_model.py::test_resume_continues_bit_for_bit).
 """
 import argparse
 import importlib
@@ -99,9 +103,10 @@ def main():
         dataset = FacesDataset(os.path.join(cfg["DATA_ROOT"], cfg["TRAIN_IMAGES_FOLDER"]),
                                TrainTransform(cfg["INPUT_SIZE"][0], cfg["RGB_MEAN"], cfg["RGB_STD"]))
     num_class = len(dataset.classes)
-    sampler = torch.utils.data.distributed.DistributedSampler(dataset, world, rank, shuffle=True) if world > 1 else None
+    # shuffle = f(SEED, epoch) on every world size (set_epoch below), so a resumed run sees the epochs it would have seen
+    sampler = torch.utils.data.distributed.DistributedSampler(dataset, world, rank, shuffle=True, seed=cfg["SEED"])
     loader = torch.utils.data.DataLoader(dataset, batch_size=cfg["BATCH_SIZE"], sampler=sampler,
-                                         shuffle=sampler is None, pin_memory=cfg["PIN_MEMORY"],
+                                         shuffle=False, pin_memory=cfg["PIN_MEMORY"],
                                          num_workers=cfg["NUM_WORKERS"], drop_last=cfg["DROP_LAST"],
                                          collate_fn=collate_fn_ignore_none)
     print("Number of Training Classes: {}".format(num_class))
@@ -143,13 +148,26 @@ def main():
     BACKBONE = DataParallel(backbone, None if crit is not None else head)
     ce = torch.nn.CrossEntropyLoss()
 
+    if opt_resume:  # reference train.py:227-232: before the first step (momentum buffers and the groups' LR come back)
+        if os.path.isfile(opt_resume):
+            print("Loading Optimizer Checkpoint '{}'".format(opt_resume))
+            optimizer.load_state_dict(torch.load(opt_resume, map_location=device))
+        else:
+            print("No Checkpoint Found at '{}'. Please Have a Check or Continue to Train from Scratch".format(opt_resume))
+    runner = (backbone.encoder if hasattr(backbone, "encoder") else backbone)._runner[0]
+    start_epoch, batch = cfg.get("START_EPOCH", 0), 0
+    state_resume = cfg.get("STATE_RESUME_ROOT")
+    if state_resume and os.path.isfile(state_resume):
+        state = torch.load(state_resume, map_location="cpu")
+        start_epoch, batch, runner.step_seed = int(state["epoch"]), int(state["batch"]), int(state["dropout_stream"])
+        print("Resuming at epoch {} batch {}".format(start_epoch, batch))
+
     disp_freq = max(1, len(loader) // 10)  # the reference divides by zero below 10 batches/epoch
     warm_epochs = cfg["NUM_EPOCH"] // 25
     warm_batches = len(loader) * warm_epochs
     freeze = cfg.get("FREEZE_BACKBONE_EPOCHS")
-    batch = 0
     FRF.CHECK_LABELS = False  # labels come from the dataset's own class index
-    for epoch in range(cfg.get("START_EPOCH", 0), cfg["NUM_EPOCH"]):
+    for epoch in range(start_epoch, cfg["NUM_EPOCH"]):
         if epoch in cfg["STAGES"]:
             schedule_lr(optimizer)
         backbone.train()
@@ -159,8 +177,7 @@ def main():
             enc.input_layer.requires_grad_(True)
             enc.body.requires_grad_(epoch > freeze)
             enc.output_layer.requires_grad_(True)
-        if sampler is not None:
-            sampler.set_epoch(epoch)
+        sampler.set_epoch(epoch)
         losses, top1, top5 = AverageMeter(), AverageMeter(), AverageMeter()
         pending = []
         for inputs, labels in loader:
@@ -168,8 +185,6 @@ def main():
                 warm_up_lr(batch, warm_batches, cfg["LR"], optimizer)
             inputs = inputs.to(device, non_blocking=True)
             labels = labels.to(device, non_blocking=True).long()
-            if batch == 0 and opt_resume and os.path.isfile(opt_resume):
-                pass  # momentum buffers are created lazily; loaded right after the first step below
             if crit is not None:
                 loss, prec1, prec5 = crit(BACKBONE(inputs), labels)
             else:
@@ -181,8 +196,6 @@ def main():
             loss.backward()
             BACKBONE.synchronize()
             optimizer.step()
-            if batch == 0 and opt_resume and os.path.isfile(opt_resume):
-                optimizer.load_state_dict(torch.load(opt_resume, map_location=device))
             if (batch + 1) % disp_freq == 0 or (args.max_steps and batch + 1 >= args.max_steps):
                 for l, p1, p5, n in pending:  # one host sync per display interval
                     losses.update(float(l), n)
@@ -222,6 +235,8 @@ def main():
             torch.save(BACKBONE.module.state_dict(), os.path.join(root, "Backbone_{}_{}".format(cfg["BACKBONE_NAME"], tag)))
             torch.save(head.state_dict(), os.path.join(root, "Head_{}_{}".format(cfg["HEAD_NAME"], tag)))
             torch.save(optimizer.state_dict(), os.path.join(root, "Optimizer_{}_{}".format(cfg["HEAD_NAME"], tag)))
+            torch.save({"epoch": epoch + 1, "batch": batch, "dropout_stream": runner.step_seed},
+                       os.path.join(root, "State_{}_{}".format(cfg["HEAD_NAME"], tag)))
         if args.max_steps and batch >= args.max_steps:
             break
     if world > 1:

@@ -484,3 +484,83 @@ def test_two_rank_gradients_are_the_rank_average():
            "127.0.0.1", "--master-port", "29547", os.path.join(here, "dp_worker.py")]
     out = subprocess.run(cmd, cwd=os.path.dirname(here), env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "DP_WORKER_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def _run_train(tmp, tag, extra_cfg, max_steps=0):
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stylegan-for-facerec_amd")
+    env = dict(os.environ, PYTHONPATH=root)
+    argv = ["train.py", "--config", "configs/config_synthetic_smoke.py", "--synthetic", "12x10"]
+    if max_steps:
+        argv += ["--max-steps", str(max_steps)]
+    model_dir = tmp / tag
+    cfg_patch = ("import configs.config_synthetic_smoke as c; c.configurations[1].update(BATCH_SIZE=20, NUM_EPOCH=2, "
+                 "MODEL_ROOT=r'%s', LOG_ROOT=r'%s', **%r)" % (model_dir, tmp / "log", extra_cfg))
+    code = "import sys, runpy; sys.argv=%r; %s; runpy.run_path('train.py', run_name='__main__')" % (argv, cfg_patch)
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    return model_dir, out.stdout
+
+
+def _ckpt(model_dir, prefix):
+    hits = sorted(f for f in os.listdir(model_dir) if f.startswith(prefix))
+    assert len(hits) == 1, (prefix, os.listdir(model_dir))
+    return os.path.join(model_dir, hits[0])
+
+
+def test_resume_continues_bit_for_bit(tmp_path):
+    """SURVEY 8f rank 4 (resume fidelity).  Two epochs in one run == one epoch, stop, resume from the Backbone_/Head_/
+    Optimizer_/State_ files for the second epoch: weights, BN running statistics, head and momentum buffers are equal
+    BIT FOR BIT (deterministic kernels + restored batch counter, dropout stream and per-epoch shuffle).  The reference
+    restores weights and optimizer only (train.py:206-232)."""
+    _need_gpu()
+    a_dir, _ = _run_train(tmp_path, "straight", {})
+    b1_dir, _ = _run_train(tmp_path, "first", {}, max_steps=6)
+    resume = dict(BACKBONE_RESUME_ROOT=_ckpt(b1_dir, "Backbone_IR_50_ReStyle_Epoch_1_Batch_6_"),
+                  HEAD_RESUME_ROOT=_ckpt(b1_dir, "Head_ArcFace_Epoch_1_Batch_6_"),
+                  OPTIMIZER_RESUME_ROOT=_ckpt(b1_dir, "Optimizer_ArcFace_Epoch_1_Batch_6_"),
+                  STATE_RESUME_ROOT=_ckpt(b1_dir, "State_ArcFace_Epoch_1_Batch_6_"))
+    b2_dir, log = _run_train(tmp_path, "second", resume)
+    assert "Resuming at epoch 1 batch 6" in log and "Loading Optimizer Checkpoint" in log
+    for prefix in ("Backbone_IR_50_ReStyle_Epoch_2_Batch_12_", "Head_ArcFace_Epoch_2_Batch_12_"):
+        sa = torch.load(_ckpt(a_dir, prefix), map_location="cpu")
+        sb = torch.load(_ckpt(b2_dir, prefix), map_location="cpu")
+        assert list(sa.keys()) == list(sb.keys())
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), (prefix, k, float((sa[k].float() - sb[k].float()).abs().max()))
+    oa = torch.load(_ckpt(a_dir, "Optimizer_ArcFace_Epoch_2_Batch_12_"), map_location="cpu")
+    ob = torch.load(_ckpt(b2_dir, "Optimizer_ArcFace_Epoch_2_Batch_12_"), map_location="cpu")
+    assert oa["param_groups"] == ob["param_groups"] and oa["state"].keys() == ob["state"].keys()
+    for k in oa["state"]:
+        assert torch.equal(oa["state"][k]["momentum_buffer"], ob["state"][k]["momentum_buffer"]), k
+    sa = torch.load(_ckpt(a_dir, "State_ArcFace_Epoch_2_Batch_12_"))
+    sb = torch.load(_ckpt(b2_dir, "State_ArcFace_Epoch_2_Batch_12_"))
+    assert sa == sb and sa["epoch"] == 2 and sa["batch"] == 12
+
+
+def test_optimizer_loads_reference_layout_momentum():
+    """A torch.optim.SGD state dict (OIHW-contiguous momentum buffers, as the reference writes them) loads into
+    frhip.optim.SGD before the first step and the next update equals torch's."""
+    _need_gpu()
+    from frhip.optim import SGD
+    torch.manual_seed(3)
+    w0 = torch.randn(8, 4, 3, 3).cuda()
+    g1, g2 = torch.randn(8, 4, 3, 3).cuda(), torch.randn(8, 4, 3, 3).cuda()
+    ref_p = torch.nn.Parameter(w0.clone())
+    ref = torch.optim.SGD([ref_p], lr=0.1, momentum=0.9, weight_decay=2e-3)
+    ref_p.grad = g1.clone()
+    ref.step()
+    import copy
+    saved = copy.deepcopy(ref.state_dict())  # as read back from a file (state_dict() itself shares the live buffers)
+    assert saved["state"][0]["momentum_buffer"].is_contiguous()
+    mine_p = torch.nn.Parameter(ref_p.detach().clone().contiguous(memory_format=torch.channels_last))
+    mine = SGD([mine_p], lr=0.1, momentum=0.9, weight_decay=2e-3)
+    mine.load_state_dict(saved)
+    mine_p.grad = g2.clone().contiguous(memory_format=torch.channels_last)
+    ref_p.grad = g2.clone()
+    ref.step()
+    mine.step()
+    torch.testing.assert_close(mine_p.detach(), ref_p.detach(), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(mine.state[mine_p]["momentum_buffer"], ref.state[ref_p]["momentum_buffer"], rtol=1e-6,
+                               atol=1e-7)
