@@ -312,6 +312,18 @@ int fr_shard_row_stats(const float* logits, const int64_t* label_local, float* s
 int fr_shard_combine(const float* stats_all, int world, int rows, float* lse, float* ce, float* tlogit, void* stream);
 int fr_shard_rank_rows(const float* logits, const float* tlogit, int32_t* rank, int rows, int N, int ld, void* stream);
 
+/* ---- GPU-side training-input transform (replaces the per-sample host transform of train.py:108-116
+ *      applied in dataset.py:85-88): Resize(Hr x Wr, Pillow 8-bit bilinear, bit-exact) -> crop S x S at crop[b] = (x0, y0)
+ *      -> horizontal flip where flip[b] -> ToTensor -> Normalize, for a batch of staged uint8 images.
+ *   src  uint8 [B][Hin][Win][3] (HWC, as decoded)          out  float32 [B][3][S][S] (NCHW, what the reference collates)
+ *   xtab int32 [Wr][kx+2], ytab int32 [Hr][ky+2]: per resized column / row (first input index, tap count, kx / ky integer
+ *        weights with 22 fractional bits) -- Pillow's precompute_coeffs + normalize_coeffs_8bpc (frhip/input_pipeline.py)
+ *   lut  float32 [256][3]: ((v / 255) - mean[c]) / std[c], every step rounded to float32
+ *   crop offsets must satisfy 0 <= x0 <= Wr - S, 0 <= y0 <= Hr - S (checked by the caller: they live in device memory) */
+int fr_augment_u8(const uint8_t* src, const int32_t* xtab, const int32_t* ytab, const int32_t* crop, const uint8_t* flip,
+                  const float* lut, float* out, int B, int Hin, int Win, int Hr, int Wr, int S, int kx, int ky,
+                  void* stream);
+
 /* ---- multi-tensor SGD with momentum (torch.optim.SGD defaults; train.py:196)
  *   d = g + wd*p ; buf = momentum*buf + d ; p -= lr*buf      (buf starts at 0, so the first step gives buf = d)
  * table_dev: device array of tensor records; chunks_dev: device array of (tensor index, chunk index) pairs,

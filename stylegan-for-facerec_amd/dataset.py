@@ -1,9 +1,11 @@
 """``from dataset import FacesDataset`` (reference train.py:13, dataset.py:17-91) plus a synthetic stand-in.
 
 ``FacesDataset`` reads ``<root>/<identity>/*.jpg|png``; label = index of the identity in sorted order; a sample that
-fails to load returns ``None`` (dropped by ``collate_fn_ignore_none``).  JPEG decode and augmentation stay on host
-workers (SURVEY.md 8f rank 3 lists a GPU-side input pipeline as a later row).  torchvision is not required: the
-default train transform (resize 128 -> random crop 112 -> h-flip -> [-1,1] CHW float) is implemented with PIL+numpy.
+fails to load returns ``None`` (dropped by ``collate_fn_ignore_none``).  torchvision is not required: the default
+train transform (resize 128 -> random crop 112 -> h-flip -> [-1,1] CHW float) is implemented with PIL+numpy on the host
+worker, as in the reference.  With ``StageTransform`` the worker only decodes and hands over the uint8 HWC image; resize,
+crop, flip and normalisation then run on the GPU for the whole batch (frhip/input_pipeline.py, SURVEY.md 8f rank 3;
+``GPU_INPUT_PIPELINE=True`` in a train config).
 """
 import glob
 import os
@@ -32,6 +34,14 @@ class TrainTransform(object):
         return torch.from_numpy((arr.transpose(2, 0, 1) - self.mean) / self.std)
 
 
+class StageTransform(object):
+    """Decode only: PIL image -> uint8 [H, W, 3] tensor for frhip.input_pipeline.GpuTrainTransform.  All images of a
+    batch must share one size (the aligned training crops do: dataset.py:62 ``dims = (112, 112, 3)``)."""
+
+    def __call__(self, img):
+        return torch.from_numpy(np.array(img.convert("RGB"), dtype=np.uint8))
+
+
 class FacesDataset(Dataset):
     def __init__(self, root, transform=None, extensions=(".jpg", ".jpeg", ".png")):
         self.root, self.transform = root, transform or TrainTransform()
@@ -58,13 +68,16 @@ class FacesDataset(Dataset):
 class SyntheticFaces(Dataset):
     """``identities`` x ``per_identity`` seeded 112x112 tensors in [-1, 1]; exposes ``.classes`` like FacesDataset."""
 
-    def __init__(self, identities=100, per_identity=12, size=112, seed=900):
+    def __init__(self, identities=100, per_identity=12, size=112, seed=900, staged=False):
         self.classes = ["id_%05d" % i for i in range(identities)]
-        self.per, self.size, self.seed = per_identity, size, seed
+        self.per, self.size, self.seed, self.staged = per_identity, size, seed, staged
 
     def __len__(self):
         return len(self.classes) * self.per
 
     def __getitem__(self, idx):
         from frhip import synth
+        if self.staged:  # uint8 HWC, as StageTransform delivers decoded files
+            img = synth.uniform(self.seed, "face%d" % idx, (self.size, self.size, 3), 0.0, 256.0)
+            return img.clamp_(0, 255).to(torch.uint8), idx // self.per
         return synth.uniform(self.seed, "face%d" % idx, (3, self.size, self.size)), idx // self.per

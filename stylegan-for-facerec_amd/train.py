@@ -30,7 +30,7 @@ import torch.distributed as dist  # noqa: E402
 from backbone.model_irse import IR_50, IR_101, IR_152, IR_SE_50, IR_SE_101, IR_SE_152
 from backbone.model_resnet import ResNet_50, ResNet_101, ResNet_152  # noqa: F401  (import parity with the reference)
 from backbone.restyle_psp import pSp
-from dataset import FacesDataset, SyntheticFaces, TrainTransform
+from dataset import FacesDataset, StageTransform, SyntheticFaces, TrainTransform
 from frhip import functional as FRF
 from frhip.optim import SGD
 from frhip.parallel import DataParallel
@@ -96,11 +96,18 @@ def main():
     os.makedirs(cfg["LOG_ROOT"], exist_ok=True)
     logger = make_logger(cfg, rank)
 
+    gpu_tf = None
+    if cfg.get("GPU_INPUT_PIPELINE", False):
+        # workers decode only; resize / crop / flip / normalise run on the GPU per batch (frhip/input_pipeline.py)
+        from frhip.input_pipeline import GpuTrainTransform
+        gpu_tf = GpuTrainTransform(cfg["INPUT_SIZE"][0], cfg["RGB_MEAN"], cfg["RGB_STD"])
+        aug_rng = torch.Generator().manual_seed(cfg["SEED"] + 7919 * rank)
     if args.synthetic:
         ids, per = (int(v) for v in args.synthetic.split("x"))
-        dataset = SyntheticFaces(ids, per, cfg["INPUT_SIZE"][0], cfg["SEED"])
+        dataset = SyntheticFaces(ids, per, cfg["INPUT_SIZE"][0], cfg["SEED"], staged=gpu_tf is not None)
     else:
         dataset = FacesDataset(os.path.join(cfg["DATA_ROOT"], cfg["TRAIN_IMAGES_FOLDER"]),
+                               StageTransform() if gpu_tf is not None else
                                TrainTransform(cfg["INPUT_SIZE"][0], cfg["RGB_MEAN"], cfg["RGB_STD"]))
     num_class = len(dataset.classes)
     # shuffle = f(SEED, epoch) on every world size (set_epoch below), so a resumed run sees the epochs it would have seen
@@ -185,6 +192,8 @@ def main():
                 warm_up_lr(batch, warm_batches, cfg["LR"], optimizer)
             inputs = inputs.to(device, non_blocking=True)
             labels = labels.to(device, non_blocking=True).long()
+            if gpu_tf is not None:
+                inputs = gpu_tf(inputs, generator=aug_rng)
             if crit is not None:
                 loss, prec1, prec5 = crit(BACKBONE(inputs), labels)
             else:
