@@ -158,9 +158,19 @@ def _to_uint8(batch):
     return de_preprocess(batch).mul(255).to(torch.uint8)
 
 
+_U8_LUT = {}
+
+
 def _from_uint8(u8):
-    """ToTensor + Normalize(0.5, 0.5): byte / 255, then (v - 0.5) / 0.5."""
-    return u8.to(torch.float32).div(255).sub_(0.5).div_(0.5)
+    """ToTensor + Normalize(0.5, 0.5): byte / 255, then (v - 0.5) / 0.5, in float32 on the host.  Device tensors go
+    through the 256-entry table of those host results (the device's float division is not correctly rounded: 1 ulp
+    off for a third of the byte values), so both paths give the same bits."""
+    if not u8.is_cuda:
+        return u8.to(torch.float32).div(255).sub_(0.5).div_(0.5)
+    lut = _U8_LUT.get(u8.device)
+    if lut is None:
+        lut = _U8_LUT[u8.device] = torch.arange(256, dtype=torch.float32).div(255).sub_(0.5).div_(0.5).to(u8.device)
+    return lut[u8.long()]
 
 
 def hflip_batch(imgs_tensor):
@@ -169,17 +179,31 @@ def hflip_batch(imgs_tensor):
     return _from_uint8(torch.flip(_to_uint8(imgs_tensor), dims=[-1]))
 
 
+_CCROP_GPU = {}
+
+
 def ccrop_batch(imgs_tensor):
-    """Resize([128, 128]) + CenterCrop([112, 112]) through PIL (utils.py:221-236).  torchvision is not a dependency
-    here: the same PIL calls it makes are issued directly (``Image.resize(size, BILINEAR)``, centre crop box with
-    ``int(round((h - th) / 2.))``).  Host side, per image, like the reference."""
+    """Resize([128, 128]) + CenterCrop([112, 112]) through the reference's uint8 round trip (utils.py:221-236).
+
+    Device tensors: ONE launch of the input-transform kernel for the whole batch (frhip/input_pipeline.py; Pillow's 8-bit
+    bilinear resample restated bit-exactly, crop offset ``int(round((128 - 112) / 2.))`` = 8, no flip).  Host tensors: the
+    PIL calls torchvision makes (``Image.resize(size, BILINEAR)``, centre crop box), per image, like the reference."""
+    top = int(round((128 - 112) / 2.0))
+    if imgs_tensor.is_cuda:
+        from frhip.input_pipeline import GpuTrainTransform
+        tf = _CCROP_GPU.get("tf")
+        if tf is None:
+            tf = _CCROP_GPU["tf"] = GpuTrainTransform(112, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+        n = imgs_tensor.shape[0]
+        u8 = _to_uint8(imgs_tensor.detach()).permute(0, 2, 3, 1).contiguous()
+        crop = torch.full((n, 2), top, dtype=torch.int32)
+        return tf(u8, crop, torch.zeros(n, dtype=torch.uint8))
     import numpy as np
     from PIL import Image
     u8 = _to_uint8(imgs_tensor.detach().cpu()).permute(0, 2, 3, 1).contiguous().numpy()
     out = torch.empty(u8.shape[0], u8.shape[3], 112, 112, dtype=torch.float32)
     for i in range(u8.shape[0]):
         img = Image.fromarray(u8[i]).resize((128, 128), Image.BILINEAR)
-        top = int(round((128 - 112) / 2.0))
         img = img.crop((top, top, top + 112, top + 112))
         out[i] = torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1)
     return _from_uint8(out.to(torch.uint8))
@@ -226,11 +250,12 @@ def perform_val(multi_gpu, device, embedding_size, batch_size, backbone, carray,
             batch = torch.tensor(np.asarray(carray[idx:idx + batch_size])).float()
             if batch.shape[-1] == 3:
                 batch = batch.permute(0, 3, 1, 2).contiguous()
+            batch = batch.to(device)  # crop and flip run on the device (one launch each per batch)
             cropped = ccrop_batch(batch) if ccrop else batch
             if tta:
-                emb = backbone(cropped.to(device)).cpu() + backbone(hflip_batch(cropped).to(device)).cpu()
+                emb = backbone(cropped).cpu() + backbone(hflip_batch(cropped)).cpu()
             else:
-                emb = backbone(cropped.to(device)).cpu()
+                emb = backbone(cropped).cpu()
             embeddings[idx:idx + batch.shape[0]] = l2_norm(emb).numpy()
     tpr, fpr, acc, best_thresholds = evaluate(embeddings, issame, nrof_folds)
     roc = None

@@ -169,3 +169,22 @@ def test_train_driver_with_gpu_input_pipeline(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "Training Loss" in out.stdout and "nan" not in out.stdout.lower()
+
+
+@pytest.mark.gpu
+def test_eval_transforms_on_device_equal_the_host_pil_path():
+    """perform_val's centre crop (Resize 128 -> CenterCrop 112) and flip on device tensors == the host PIL round trip of
+    the reference (util/utils.py:204-236), bit for bit; also at the uint8 quantisation edges (-1, 1, k/255 steps)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from frhip import synth
+    from util.utils import ccrop_batch, hflip_batch
+    x = synth.uniform(77, "tta.x", (5, 3, 112, 112), -1.0, 1.0)
+    x[0] = 1.0
+    x[1] = -1.0
+    x[2, :, :, :56] = (torch.arange(56) / 127.5 - 1.0)  # exact k/255 grid values
+    for fn in (ccrop_batch, hflip_batch):
+        host = fn(x)
+        dev = fn(x.cuda())
+        assert dev.is_cuda and dev.shape == host.shape
+        assert torch.equal(dev.cpu(), host), (fn.__name__, float((dev.cpu() - host).abs().max()))
