@@ -253,7 +253,7 @@ def perform_val(multi_gpu, device, embedding_size, batch_size, backbone, carray,
             batch = batch.to(device)  # crop and flip run on the device (one launch each per batch)
             cropped = ccrop_batch(batch) if ccrop else batch
             if tta:
-                emb = backbone(cropped).cpu() + backbone(hflip_batch(cropped)).cpu()
+                emb = (backbone(cropped) + backbone(hflip_batch(cropped))).cpu()  # fp32 add: same bits as on the host
             else:
                 emb = backbone(cropped).cpu()
             embeddings[idx:idx + batch.shape[0]] = l2_norm(emb).numpy()
