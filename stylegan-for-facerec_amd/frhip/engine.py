@@ -300,7 +300,10 @@ class BackbonePlan(object):
         self.g_xS = self._act(max_xs, 1).view(-1) if max_xs else None
         self.g_f32 = torch.empty(B, 512, device=dev)     # BN1d backward output (fp32)
         self.g_fT = self._act(B, 512)
-        self.part = torch.zeros(max(4 * 1024 * 1024, ((M0 + 127) // 128) * 2 * 64 + 4096, B * 28 * 2 * 64 + 4096),
+        # partial rows of every epilogue / channel-wise reduction.  Largest users: the stride-2 data gradient at 56x56
+        # ([4 classes][B * 28 strips][2][64] floats), the stem ([M0/128][2][64]), 64-channel strips at 112 ([B * 56][2][64]);
+        # _check_part() verifies every launch against the allocation when the plan is built.
+        self.part = torch.zeros(max(4 * 1024 * 1024, ((M0 + 127) // 128) * 2 * 64 + 4096, B * 4 * 28 * 2 * 64 + 4096),
                                 device=dev)
         self.side_slope = self.dual and os.environ.get("FRHIP_SLOPE_ON_MAIN", "0") != "1"  # A/B switch
         if self.side_slope:
@@ -363,9 +366,20 @@ class BackbonePlan(object):
         return conv.weight
 
     # ---- conv dispatch ----------------------------------------------------------------------------
+    def _check_part(self, n, kw):
+        """Fail loudly (instead of a GPU memory fault) if an epilogue's partial rows would not fit their buffer."""
+        part = kw.get("part")
+        if part is not None and n * 2 * kw["N"] > part.numel():
+            raise _lib.FrhipError("frhip: %d partial rows x 2 x %d channels exceed the %d-float partial-sum buffer "
+                                  "(batch %d)" % (n, kw["N"], part.numel(), kw["B"]))
+        return n
+
     def _conv(self, L, **kw):
         """Append a convolution launch; returns the number of partial rows its epilogue writes.  bf16 stride-1
         3x3 layers whose shape is in the strip table run with the input strip resident in LDS."""
+        return self._check_part(self._conv_launch(L, **kw), kw)
+
+    def _conv_launch(self, L, **kw):
         if (self.fr == FR_BF16 and self.use_strip and kw["KH"] == 3 and kw["stride"] == 1 and kw["RH"] == kw["SH"]):
             n = ops.strip_parts(kw["B"], kw["SC"], kw["N"], kw["SW"], kw.get("epi", 0))
             if n:

@@ -564,3 +564,30 @@ def test_optimizer_loads_reference_layout_momentum():
     torch.testing.assert_close(mine_p.detach(), ref_p.detach(), rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(mine.state[mine_p]["momentum_buffer"], ref.state[ref_p]["momentum_buffer"], rtol=1e-6,
                                atol=1e-7)
+
+
+def test_batch_512_step_and_partial_buffer_guard():
+    """Maximum-size case: one bf16 training step at twice the BASELINE batch (the stride-2 data gradient at 56x56 writes
+    4 x B x 28 partial rows: a buffer sized for B = 256 faulted here), and the guard that turns an undersized
+    partial-sum buffer into an error instead of a GPU memory fault."""
+    _need_gpu()
+    from frhip._lib import FrhipError
+    from head.metrics import ArcFace
+    from loss.focal import FocalLoss
+    model, _ = build("IR_50")
+    model.train()
+    model.compute_dtype = torch.bfloat16
+    B = 512
+    x = synth.uniform(17, "big.x", (B, 3, 112, 112)).cuda()
+    y = synth.labels(17, "big.y", B, 100).cuda()
+    head = ArcFace(512, 100, None).cuda()
+    loss, _ = FocalLoss()(head(model(x), y), y)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    for n, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    plan = model._runner[0].plan
+    assert plan.part.numel() >= 4 * B * 28 * 2 * 64
+    with pytest.raises(FrhipError):
+        plan._check_part(plan.part.numel() // 128 + 1, dict(part=plan.part, N=64, B=B))
