@@ -72,6 +72,45 @@ def build_backbone(cfg):
     raise ValueError("unsupported BACKBONE_NAME %r" % name)
 
 
+def _head_state_index(optimizer, crit):
+    """Index of the sharded head weight in the optimizer's flat parameter numbering (state_dict keys)."""
+    i = 0
+    for group in optimizer.param_groups:
+        for p in group["params"]:
+            if p is crit.weight:
+                return i
+            i += 1
+    raise RuntimeError("the sharded head weight is not in the optimizer")
+
+
+def optimizer_state_for_checkpoint(optimizer, crit):
+    """``optimizer.state_dict()`` in the reference's layout.  With a class-sharded head the momentum buffer of the head
+    weight is gathered to [classes, 512] (collective: every rank calls this), so optimizer checkpoints are
+    interchangeable between replicated and sharded runs and between world sizes."""
+    sd = optimizer.state_dict()
+    if crit is None:
+        return sd
+    idx = _head_state_index(optimizer, crit)
+    st = sd["state"].get(idx)
+    if st is not None and st.get("momentum_buffer") is not None:
+        full = crit.comm.gather_ragged_rows(st["momentum_buffer"], crit.shard_sizes())
+        sd = dict(sd, state=dict(sd["state"]))
+        sd["state"][idx] = dict(st, momentum_buffer=full)
+    return sd
+
+
+def load_optimizer_checkpoint(optimizer, crit, sd):
+    """Inverse of ``optimizer_state_for_checkpoint``: this rank keeps its class range of the head momentum."""
+    if crit is not None:
+        idx = _head_state_index(optimizer, crit)
+        st = sd["state"].get(idx)
+        if st is not None and st.get("momentum_buffer") is not None and \
+                st["momentum_buffer"].shape[0] == crit.out_features:
+            sd = dict(sd, state=dict(sd["state"]))
+            sd["state"][idx] = dict(st, momentum_buffer=st["momentum_buffer"][crit.lo:crit.hi].clone())
+    optimizer.load_state_dict(sd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=str, default="config.py")
@@ -84,11 +123,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("train.py: the frhip engine needs a ROCm GPU; the CPU restatement in oracle/ is for tests only")
+    if os.environ.get("FRHIP_TRAIN_ONE_DEVICE") == "1":
+        local = 0  # test hook: several ranks share GPU 0 (with FRHIP_DIST_BACKEND=gloo; RCCL refuses duplicate devices)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("FRHIP_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     np.random.seed(cfg["SEED"])
     torch.manual_seed(cfg["SEED"])  # identical initial weights on every rank (and broadcast below)
@@ -158,7 +203,7 @@ def main():
     if opt_resume:  # reference train.py:227-232: before the first step (momentum buffers and the groups' LR come back)
         if os.path.isfile(opt_resume):
             print("Loading Optimizer Checkpoint '{}'".format(opt_resume))
-            optimizer.load_state_dict(torch.load(opt_resume, map_location=device))
+            load_optimizer_checkpoint(optimizer, crit, torch.load(opt_resume, map_location=device))
         else:
             print("No Checkpoint Found at '{}'. Please Have a Check or Continue to Train from Scratch".format(opt_resume))
     runner = (backbone.encoder if hasattr(backbone, "encoder") else backbone)._runner[0]
@@ -238,12 +283,13 @@ def main():
         if crit is not None:
             with torch.no_grad():
                 head.weight.copy_(crit.gather_weight())  # collective: every rank takes part, rank 0 writes the file
+        opt_state = optimizer_state_for_checkpoint(optimizer, crit)  # collective with a sharded head
         if rank == 0:
             tag = "Epoch_{}_Batch_{}_Time_{}_checkpoint.pth".format(epoch + 1, batch, get_time())
             root = cfg["MODEL_ROOT"]
             torch.save(BACKBONE.module.state_dict(), os.path.join(root, "Backbone_{}_{}".format(cfg["BACKBONE_NAME"], tag)))
             torch.save(head.state_dict(), os.path.join(root, "Head_{}_{}".format(cfg["HEAD_NAME"], tag)))
-            torch.save(optimizer.state_dict(), os.path.join(root, "Optimizer_{}_{}".format(cfg["HEAD_NAME"], tag)))
+            torch.save(opt_state, os.path.join(root, "Optimizer_{}_{}".format(cfg["HEAD_NAME"], tag)))
             torch.save({"epoch": epoch + 1, "batch": batch, "dropout_stream": runner.step_seed},
                        os.path.join(root, "State_{}_{}".format(cfg["HEAD_NAME"], tag)))
         if args.max_steps and batch >= args.max_steps:

@@ -173,3 +173,58 @@ def test_train_driver_with_sharded_head(tmp_path):
     assert list(sd.keys()) == ["weight"] and tuple(sd["weight"].shape) == (12, 512)
     # three SGD steps moved the weight away from its xavier draw (bound sqrt(6/(12+512)) ~ 0.107)
     assert torch.isfinite(sd["weight"]).all() and float(sd["weight"].abs().max()) > 0
+
+
+def test_train_driver_two_ranks_sharded_head_and_gpu_input(tmp_path):
+    """train.py as launched for two GPUs (torch.distributed.run), both ranks on GPU 0 with gloo: DistributedSampler,
+    parameter broadcast, averaged backbone gradients, class-sharded head (12 classes over 2 ranks), GPU-side input
+    transform, the collective weight gather before rank 0 writes the reference-layout head checkpoint."""
+    _need_gpu()
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stylegan-for-facerec_amd")
+    env = dict(os.environ, PYTHONPATH=root, FRHIP_TRAIN_ONE_DEVICE="1", FRHIP_DIST_BACKEND="gloo",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    patch = tmp_path / "run_train.py"
+    patch.write_text(
+        "import sys, runpy\n"
+        "import configs.config_synthetic_smoke as c\n"
+        "c.configurations[1].update(BATCH_SIZE=10, SHARDED_HEAD=True, GPU_INPUT_PIPELINE=True, MODEL_ROOT=r'%s', "
+        "LOG_ROOT=r'%s')\n"
+        "sys.argv = ['train.py', '--config', 'configs/config_synthetic_smoke.py', '--synthetic', '12x10', "
+        "'--max-steps', '3']\n"
+        "runpy.run_path('train.py', run_name='__main__')\n" % (tmp_path / "model", tmp_path / "log"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29571", str(patch)]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2500:] + out.stderr[-2500:]
+    assert "Training Loss" in out.stdout
+    files = sorted(os.listdir(tmp_path / "model"))
+    heads = [f for f in files if f.startswith("Head_ArcFace_Epoch_1_")]
+    assert len(heads) == 1, files  # rank 0 only
+    sd = torch.load(os.path.join(tmp_path / "model", heads[0]), map_location="cpu")
+    assert tuple(sd["weight"].shape) == (12, 512) and torch.isfinite(sd["weight"]).all()
+    # the optimizer checkpoint keeps the reference layout too: the head momentum is gathered to [classes, 512]
+    opts = [f for f in files if f.startswith("Optimizer_ArcFace_Epoch_1_")]
+    osd = torch.load(os.path.join(tmp_path / "model", opts[0]), map_location="cpu")
+    shapes = [tuple(v["momentum_buffer"].shape) for v in osd["state"].values()]
+    assert (12, 512) in shapes and (6, 512) not in shapes
+    # ... and both ranks resume from those files, each taking its class range of weight and momentum back
+    state = [f for f in files if f.startswith("State_ArcFace_Epoch_1_")][0]
+    bb = [f for f in files if f.startswith("Backbone_")][0]
+    patch2 = tmp_path / "resume_train.py"
+    m = tmp_path / "model"
+    patch2.write_text(
+        "import sys, runpy\n"
+        "import configs.config_synthetic_smoke as c\n"
+        "c.configurations[1].update(BATCH_SIZE=10, NUM_EPOCH=2, SHARDED_HEAD=True, GPU_INPUT_PIPELINE=True, "
+        "MODEL_ROOT=r'%s', LOG_ROOT=r'%s', BACKBONE_RESUME_ROOT=r'%s', HEAD_RESUME_ROOT=r'%s', "
+        "OPTIMIZER_RESUME_ROOT=r'%s', STATE_RESUME_ROOT=r'%s')\n"
+        "sys.argv = ['train.py', '--config', 'configs/config_synthetic_smoke.py', '--synthetic', '12x10', "
+        "'--max-steps', '5']\n"
+        "runpy.run_path('train.py', run_name='__main__')\n"
+        % (tmp_path / "model2", tmp_path / "log", m / bb, m / heads[0], m / opts[0], m / state))
+    cmd[-1] = str(patch2)
+    cmd[cmd.index("--master-port") + 1] = "29573"
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2500:] + out.stderr[-2500:]
+    assert "Resuming at epoch 1 batch 3" in out.stdout and "Loading Optimizer Checkpoint" in out.stdout
+    assert any(f.startswith("Head_ArcFace_Epoch_2_Batch_5_") for f in os.listdir(tmp_path / "model2"))
