@@ -340,13 +340,29 @@ int fr_sgd_chunk_elems(void);
 int fr_sgd_step(const FrSgdTensor* table_dev, const int32_t* chunks_dev, int nchunks, float lr, float momentum,
                 void* stream);
 
+/* ---- multi-tensor Adam (torch.optim.Adam defaults: no weight decay, no amsgrad; the reference's OPTIMIZER_NAME ==
+ *      'Adam' branch, train.py:197-198), same table / chunk scheme as fr_sgd_step:
+ *   m += (g - m) * w1 ; v = v * beta2 + (w2 * g) * g ; p += (-step_size * m) / (sqrt(v) / bc2_sqrt + eps)
+ * with the scalars torch derives in double precision on the host and rounds to float: w1 = 1 - beta1, w2 = 1 - beta2,
+ * step_size = lr / (1 - beta1^step), bc2_sqrt = sqrt(1 - beta2^step).  Operation order = ATen's CPU kernels (lerp,
+ * addcmul, addcdiv), so the update matches torch.optim.Adam to the last bits. */
+typedef struct FrAdamTensor {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  long long n;
+} FrAdamTensor;
+int fr_adam_step(const FrAdamTensor* table_dev, const int32_t* chunks_dev, int nchunks, float step_size, float w1,
+                 float beta2, float w2, float eps, float bc2_sqrt, void* stream);
+
 /* out[r][c] = bias ? bias[c] : 0  (fp32 [rows][C]); seeds the split-K accumulation of Linear(25088,512) */
 int fr_fill_rows(float* out, const float* bias, long long rows, int C, void* stream);
 
 /* ---- misc */
 int fr_abi_version(void);
 /* sizeof() of the argument structs as compiled, for binding self-checks: 0 FrConvArgs, 1 FrWgradArgs,
- * 2 FrApplyArgs, 3 FrBnBwdArgs, 4 FrSgdTensor, 5 FrPackTensor */
+ * 2 FrApplyArgs, 3 FrBnBwdArgs, 4 FrSgdTensor, 5 FrPackTensor, 6 FrAdamTensor */
 int fr_struct_size(int which);
 const char* fr_last_error_string(void);
 

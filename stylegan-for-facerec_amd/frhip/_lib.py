@@ -80,6 +80,7 @@ FrApplyArgs = structs["FrApplyArgs"]
 FrBnBwdArgs = structs["FrBnBwdArgs"]
 FrSgdTensor = structs["FrSgdTensor"]
 FrPackTensor = structs["FrPackTensor"]
+FrAdamTensor = structs["FrAdamTensor"]
 
 # enums of the header
 FR_F32, FR_BF16 = 0, 1
@@ -109,7 +110,7 @@ lib = _load()
 
 def self_check():
     assert lib.fr_abi_version() == 1
-    for i, s in enumerate((FrConvArgs, FrWgradArgs, FrApplyArgs, FrBnBwdArgs, FrSgdTensor, FrPackTensor)):
+    for i, s in enumerate((FrConvArgs, FrWgradArgs, FrApplyArgs, FrBnBwdArgs, FrSgdTensor, FrPackTensor, FrAdamTensor)):
         got = lib.fr_struct_size(i)
         if got != ctypes.sizeof(s):
             raise FrhipError("frhip: struct %s is %d bytes in libfrhip.so but %d in the ctypes binding"

@@ -20,6 +20,7 @@ extern "C" int fr_struct_size(int which) {
     case 3: return (int)sizeof(FrBnBwdArgs);
     case 4: return (int)sizeof(FrSgdTensor);
     case 5: return (int)sizeof(FrPackTensor);
+    case 6: return (int)sizeof(FrAdamTensor);
   }
   return -1;
 }

@@ -265,6 +265,29 @@ __global__ __launch_bounds__(256) void sgd_kernel(const FrSgdTensor* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------ Adam
+// Operation order of torch.optim.Adam's single-tensor path (lerp, mul + addcmul, sqrt / sqrt(bc2) + eps, addcdiv); the
+// explicit _rn intrinsics keep the compiler from contracting them into different roundings.
+__global__ __launch_bounds__(256) void adam_kernel(const FrAdamTensor* __restrict__ table,
+                                                   const int2* __restrict__ chunks, float step_size, float w1,
+                                                   float beta2, float w2, float eps, float bc2_sqrt) {
+  const int2 ch = chunks[blockIdx.x];
+  const FrAdamTensor t = table[ch.x];
+  const long long base = (long long)ch.y * SGD_CHUNK;
+  long long end = base + SGD_CHUNK;
+  if (end > t.n) end = t.n;
+  const float neg_step = -step_size;
+  for (long long i = base + threadIdx.x; i < end; i += 256) {
+    const float g = t.g[i];
+    const float m = __fadd_rn(t.m[i], __fmul_rn(w1, __fsub_rn(g, t.m[i])));
+    const float v = __fadd_rn(__fmul_rn(t.v[i], beta2), __fmul_rn(__fmul_rn(w2, g), g));
+    t.m[i] = m;
+    t.v[i] = v;
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);
+    t.p[i] = __fadd_rn(t.p[i], __fdiv_rn(__fmul_rn(neg_step, m), denom));  // addcdiv: self + (value * t1) / t2
+  }
+}
+
 }  // namespace
 
 extern "C" int fr_row_normalize(const float* x, void* xn, void* xt, float* inv, int rows, int rows_pad, int D,
@@ -355,6 +378,14 @@ extern "C" int fr_shard_rank_rows(const float* logits, const float* tlogit, int3
   if (rows <= 0 || N <= 0) FR_UNSUPPORTED("fr_shard_rank_rows: empty shard");
   hipLaunchKernelGGL(shard_rank_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, tlogit, rank, N,
                      ld);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_adam_step(const FrAdamTensor* table_dev, const int32_t* chunks_dev, int nchunks, float step_size,
+                            float w1, float beta2, float w2, float eps, float bc2_sqrt, void* stream) {
+  if (nchunks <= 0) return 0;
+  hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table_dev, (const int2*)chunks_dev,
+                     step_size, w1, beta2, w2, eps, bc2_sqrt);
   FR_LAUNCH_CHECK();
 }
 

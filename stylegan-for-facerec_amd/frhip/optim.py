@@ -106,6 +106,92 @@ class SGD(torch.optim.Optimizer):
         return loss
 
 
+class Adam(torch.optim.Optimizer):
+    """``torch.optim.Adam(params, lr)`` with its defaults (betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad) as one
+    multi-tensor HIP launch per parameter group -- the reference's ``OPTIMIZER_NAME == 'Adam'`` branch (train.py:197-198).
+    State keys and layout follow torch (``step`` as a host float tensor, ``exp_avg``, ``exp_avg_sq``), so state dicts
+    are interchangeable with ``torch.optim.Adam``.  Parameters whose ``.grad`` is None are skipped and keep their step."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._sig = None
+        self._tables = []  # (group index, step value before this update, table_dev, chunks_dev, nchunks, params)
+
+    zero_grad = SGD.zero_grad
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._sig = None
+
+    def _relaid(self, p, t):
+        if t.shape == p.shape and not _dense_same(p, t):
+            r = torch.empty_like(p, memory_format=torch.preserve_format)
+            r.copy_(t)
+            return r
+        return t
+
+    def _build(self):
+        chunk = _lib.lib.fr_sgd_chunk_elems()
+        self._tables = []
+        for gi, group in enumerate(self.param_groups):
+            by_step = {}
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise _lib.FrhipError("frhip.optim.Adam: parameter on %s -- the HIP optimizer needs ROCm tensors"
+                                          % p.device)
+                st = self.state[p]
+                if "step" not in st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg"], st["exp_avg_sq"] = self._relaid(p, st["exp_avg"]), self._relaid(p, st["exp_avg_sq"])
+                if not (_dense_same(p, p.grad) and _dense_same(p, st["exp_avg"]) and _dense_same(p, st["exp_avg_sq"])):
+                    raise _lib.FrhipError("frhip.optim.Adam: param / grad / moments must share one dense layout")
+                by_step.setdefault(float(st["step"]), []).append(p)
+            for step0, plist in by_step.items():
+                arr = (_lib.FrAdamTensor * len(plist))()
+                chunks = []
+                for i, p in enumerate(plist):
+                    st = self.state[p]
+                    arr[i].p, arr[i].g = p.data_ptr(), p.grad.data_ptr()
+                    arr[i].m, arr[i].v, arr[i].n = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+                    chunks.extend((i, c) for c in range((p.numel() + chunk - 1) // chunk))
+                dev = plist[0].device
+                raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+                ch = torch.tensor(chunks, dtype=torch.int32).reshape(-1).to(dev)
+                self._tables.append([gi, step0, raw, ch, len(chunks), plist])
+
+    def _signature(self):
+        return tuple((p.data_ptr(), 0 if p.grad is None else p.grad.data_ptr())
+                     for g in self.param_groups for p in g["params"])
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        sig = self._signature()
+        if sig != self._sig:
+            self._build()
+            self._sig = sig
+        st = ops.current_stream_ptr()
+        for rec in self._tables:
+            gi, step0, raw, ch, n, plist = rec
+            group = self.param_groups[gi]
+            b1, b2 = group["betas"]
+            step = step0 + 1.0
+            # the scalars torch computes in double on the host (torch/optim/adam.py, _single_tensor_adam)
+            step_size = group["lr"] / (1.0 - b1 ** step)
+            bc2_sqrt = (1.0 - b2 ** step) ** 0.5
+            table = ctypes.cast(ctypes.c_void_p(raw.data_ptr()), ctypes.POINTER(_lib.FrAdamTensor))
+            ops.Launch("fr_adam_step", [table, ctypes.c_void_p(ch.data_ptr()), n, float(step_size), float(1.0 - b1),
+                                        float(b2), float(1.0 - b2), float(group["eps"]), float(bc2_sqrt), st])()
+            for p in plist:
+                self.state[p]["step"] += 1.0
+            rec[1] = step
+        return loss
+
+
 def _dense_same(a, b):
     return a.shape == b.shape and a.stride() == b.stride() and _is_dense(a)
 

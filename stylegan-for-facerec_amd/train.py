@@ -32,7 +32,7 @@ from backbone.model_resnet import ResNet_50, ResNet_101, ResNet_152  # noqa: F40
 from backbone.restyle_psp import pSp
 from dataset import FacesDataset, StageTransform, SyntheticFaces, TrainTransform
 from frhip import functional as FRF
-from frhip.optim import SGD
+from frhip.optim import SGD, Adam
 from frhip.parallel import DataParallel
 from head.metrics import Am_softmax, ArcFace, CosFace, SphereFace
 from loss.focal import FocalLoss
@@ -92,22 +92,24 @@ def optimizer_state_for_checkpoint(optimizer, crit):
         return sd
     idx = _head_state_index(optimizer, crit)
     st = sd["state"].get(idx)
-    if st is not None and st.get("momentum_buffer") is not None:
-        full = crit.comm.gather_ragged_rows(st["momentum_buffer"], crit.shard_sizes())
+    if st is not None:
+        full = {k: crit.comm.gather_ragged_rows(v, crit.shard_sizes()) for k, v in st.items()
+                if torch.is_tensor(v) and v.shape == crit.weight.shape}  # momentum_buffer / exp_avg / exp_avg_sq
         sd = dict(sd, state=dict(sd["state"]))
-        sd["state"][idx] = dict(st, momentum_buffer=full)
+        sd["state"][idx] = dict(st, **full)
     return sd
 
 
 def load_optimizer_checkpoint(optimizer, crit, sd):
-    """Inverse of ``optimizer_state_for_checkpoint``: this rank keeps its class range of the head momentum."""
+    """Inverse of ``optimizer_state_for_checkpoint``: this rank keeps its class range of the head's optimizer state."""
     if crit is not None:
         idx = _head_state_index(optimizer, crit)
         st = sd["state"].get(idx)
-        if st is not None and st.get("momentum_buffer") is not None and \
-                st["momentum_buffer"].shape[0] == crit.out_features:
+        if st is not None:
+            part = {k: v[crit.lo:crit.hi].clone() for k, v in st.items()
+                    if torch.is_tensor(v) and v.dim() == 2 and v.shape[0] == crit.out_features}
             sd = dict(sd, state=dict(sd["state"]))
-            sd["state"][idx] = dict(st, momentum_buffer=st["momentum_buffer"][crit.lo:crit.hi].clone())
+            sd["state"][idx] = dict(st, **part)
     optimizer.load_state_dict(sd)
 
 
@@ -179,10 +181,16 @@ def main():
         else:
             print("No Checkpoint Found at '{}' and '{}'".format(cfg["BACKBONE_RESUME_ROOT"], cfg["HEAD_RESUME_ROOT"]))
     backbone, head = backbone.to(device), head.to(device)
-    if cfg.get("OPTIMIZER_NAME", "SGD") != "SGD":
-        raise NotImplementedError("only OPTIMIZER_NAME='SGD' is on the accelerated path")
-    optimizer = SGD([{"params": other_params + head_params, "weight_decay": cfg["WEIGHT_DECAY"]},
-                     {"params": bn_params}], lr=cfg["LR"], momentum=cfg["MOMENTUM"])
+    def make_optimizer(head_weights):
+        name = cfg.get("OPTIMIZER_NAME", "SGD")
+        if name == "SGD":  # reference train.py:195-196
+            return SGD([{"params": other_params + head_weights, "weight_decay": cfg["WEIGHT_DECAY"]},
+                        {"params": bn_params}], lr=cfg["LR"], momentum=cfg["MOMENTUM"])
+        if name == "Adam":  # reference train.py:197-198: one group, torch defaults, no weight decay
+            return Adam([{"params": bn_params + other_params + head_weights}], lr=cfg["LR"])
+        raise NotImplementedError("OPTIMIZER_NAME %r: the reference builds 'SGD' or 'Adam'" % (name,))
+
+    optimizer = make_optimizer(head_params)
     opt_resume = cfg.get("OPTIMIZER_RESUME_ROOT")
     loss_fn = FocalLoss() if cfg["LOSS_NAME"] == "Focal" else None
     crit = None
@@ -194,8 +202,7 @@ def main():
             raise NotImplementedError("SHARDED_HEAD needs HEAD_NAME ArcFace/CosFace and LOSS_NAME 'Focal'")
         from frhip.sharded_head import ShardedMarginLoss
         crit = ShardedMarginLoss.from_head(head, gamma=loss_fn.gamma).to(device)
-        optimizer = SGD([{"params": other_params + [crit.weight], "weight_decay": cfg["WEIGHT_DECAY"]},
-                         {"params": bn_params}], lr=cfg["LR"], momentum=cfg["MOMENTUM"])
+        optimizer = make_optimizer([crit.weight])
     # exposes .module like nn.DataParallel; all-reduce only when world > 1 (a weight shard is complete on its owner)
     BACKBONE = DataParallel(backbone, None if crit is not None else head)
     ce = torch.nn.CrossEntropyLoss()

@@ -591,3 +591,57 @@ def test_batch_512_step_and_partial_buffer_guard():
     assert plan.part.numel() >= 4 * B * 28 * 2 * 64
     with pytest.raises(FrhipError):
         plan._check_part(plan.part.numel() // 128 + 1, dict(part=plan.part, N=64, B=B))
+
+
+def test_adam_matches_torch_adam():
+    """frhip.optim.Adam (one multi-tensor launch per group) against torch.optim.Adam on the host, five steps with random
+    gradients: a channels-last conv weight, a large flat tensor (several 4096-element chunks), a parameter that is frozen
+    for two steps (its step count must lag), LR changes between steps; then a torch state dict loads into it."""
+    _need_gpu()
+    import copy
+    from frhip.optim import Adam
+    g = torch.Generator().manual_seed(5)
+    shapes = [(16, 8, 3, 3), (10000,), (7,), (33, 5)]
+    ref_p = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    mine_p = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref_p]
+    mine_p[0] = torch.nn.Parameter(mine_p[0].detach().contiguous(memory_format=torch.channels_last))
+    ref = torch.optim.Adam([{"params": ref_p}], lr=0.01)
+    mine = Adam([{"params": mine_p}], lr=0.01)
+    for step in range(5):
+        for i, (a, b) in enumerate(zip(ref_p, mine_p)):
+            if i == 2 and step in (1, 2):
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(a.shape, generator=g) * (10.0 ** (step - 2))
+            a.grad = gr.clone()
+            b.grad = gr.cuda().contiguous(memory_format=torch.channels_last) if i == 0 else gr.cuda()
+        if step == 3:
+            for o in (ref, mine):
+                o.param_groups[0]["lr"] = 0.003
+        ref.step()
+        mine.step()
+        for a, b in zip(ref_p, mine_p):
+            torch.testing.assert_close(b.detach().cpu(), a.detach(), rtol=2e-6, atol=1e-7)
+    assert float(mine.state[mine_p[2]]["step"]) == 3.0 and float(mine.state[mine_p[0]]["step"]) == 5.0
+    for a, b in zip(ref_p, mine_p):
+        torch.testing.assert_close(mine.state[b]["exp_avg_sq"].cpu(), ref.state[a]["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+    # a torch state dict (as read from a file) loads, and the next update agrees
+    other = Adam([{"params": [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref_p]}], lr=0.003)
+    other.load_state_dict(copy.deepcopy(ref.state_dict()))
+    gr = [torch.randn(s, generator=g) for s in shapes]
+    for a, b, x in zip(ref_p, other.param_groups[0]["params"], gr):
+        a.grad, b.grad = x.clone(), x.cuda()
+    ref.step()
+    other.step()
+    for a, b in zip(ref_p, other.param_groups[0]["params"]):
+        torch.testing.assert_close(b.detach().cpu(), a.detach(), rtol=2e-6, atol=1e-7)
+
+
+def test_train_driver_with_adam(tmp_path):
+    """OPTIMIZER_NAME='Adam' (reference train.py:197-198) through train.py: runs, writes an Adam-layout checkpoint."""
+    _need_gpu()
+    model_dir, out = _run_train(tmp_path, "adam", dict(OPTIMIZER_NAME="Adam", LR=1e-4), max_steps=3)
+    assert "Training Loss" in out and "nan" not in out.lower()
+    osd = torch.load(_ckpt(model_dir, "Optimizer_ArcFace_Epoch_1_Batch_3_"), map_location="cpu")
+    assert all(set(v.keys()) == {"step", "exp_avg", "exp_avg_sq"} for v in osd["state"].values())
+    assert len(osd["param_groups"]) == 1
