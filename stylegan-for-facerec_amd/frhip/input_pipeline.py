@@ -102,7 +102,9 @@ class GpuTrainTransform(object):
         flip = (torch.rand(batch, generator=generator) < self.flip_p).to(torch.uint8)
         return crop, flip
 
-    def __call__(self, u8, crop=None, flip=None, generator=None):
+    def __call__(self, u8, crop=None, flip=None, generator=None, validate=True):
+        """``validate=False``: the caller guarantees 0 <= crop <= big - size (skips the host-side range check, which is a
+        device synchronisation when ``crop`` already lives on the device)."""
         if u8.dtype != torch.uint8 or u8.dim() != 4 or u8.shape[3] != 3:
             raise ValueError("GpuTrainTransform: expected uint8 [B, H, W, 3], got %s %s" % (u8.dtype, tuple(u8.shape)))
         b, h, w, _ = u8.shape
@@ -111,7 +113,7 @@ class GpuTrainTransform(object):
         if crop is None or flip is None:
             crop, flip = self.draw(b, generator)
         span = self.big - self.size
-        if b and (int(crop.min()) < 0 or int(crop.max()) > span):
+        if b and validate and (int(crop.min()) < 0 or int(crop.max()) > span):
             raise ValueError("GpuTrainTransform: crop offsets must lie in [0, %d]" % span)
         dev = u8.device
         xtab, ytab, lut, kx, ky = self.tables(dev, h, w)

@@ -196,8 +196,12 @@ def ccrop_batch(imgs_tensor):
             tf = _CCROP_GPU["tf"] = GpuTrainTransform(112, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
         n = imgs_tensor.shape[0]
         u8 = _to_uint8(imgs_tensor.detach()).permute(0, 2, 3, 1).contiguous()
-        crop = torch.full((n, 2), top, dtype=torch.int32)
-        return tf(u8, crop, torch.zeros(n, dtype=torch.uint8))
+        key = (imgs_tensor.device, n)
+        if key not in _CCROP_GPU:  # constant offsets, kept on the device: no per-batch host-to-device copy / sync
+            _CCROP_GPU[key] = (torch.full((n, 2), top, dtype=torch.int32, device=imgs_tensor.device),
+                               torch.zeros(n, dtype=torch.uint8, device=imgs_tensor.device))
+        crop, flip = _CCROP_GPU[key]
+        return tf(u8, crop, flip, validate=False)
     import numpy as np
     from PIL import Image
     u8 = _to_uint8(imgs_tensor.detach().cpu()).permute(0, 2, 3, 1).contiguous().numpy()
@@ -244,19 +248,35 @@ def perform_val(multi_gpu, device, embedding_size, batch_size, backbone, carray,
     backbone = backbone.to(device)
     backbone.eval()
     n = len(carray)
-    embeddings = np.zeros([n, embedding_size])
+    is_dev = torch.device(device).type == "cuda"
+    sums = torch.empty(n, embedding_size, device=device, dtype=torch.float32)  # f(img) [+ f(hflip(img))], on the device
+    # two pinned staging buffers: the host prepares batch i+1 while the GPU works on batch i, and nothing in the loop waits
+    # for the device (the reference copies every batch's embeddings back before it reads the next batch)
+    stage, free = [None, None], [None, None]
     with torch.no_grad():
-        for idx in range(0, n, batch_size):
-            batch = torch.tensor(np.asarray(carray[idx:idx + batch_size])).float()
-            if batch.shape[-1] == 3:
-                batch = batch.permute(0, 3, 1, 2).contiguous()
-            batch = batch.to(device)  # crop and flip run on the device (one launch each per batch)
-            cropped = ccrop_batch(batch) if ccrop else batch
-            if tta:
-                emb = (backbone(cropped) + backbone(hflip_batch(cropped))).cpu()  # fp32 add: same bits as on the host
+        for k, idx in enumerate(range(0, n, batch_size)):
+            host = torch.from_numpy(np.ascontiguousarray(carray[idx:idx + batch_size], dtype=np.float32))
+            if host.shape[-1] == 3:
+                host = host.permute(0, 3, 1, 2)
+            if is_dev:
+                slot = k & 1
+                if stage[slot] is None or stage[slot].shape != host.shape:
+                    stage[slot] = torch.empty(host.shape, dtype=torch.float32).pin_memory()
+                if free[slot] is not None:
+                    free[slot].synchronize()  # the copy that last read this buffer is done
+                stage[slot].copy_(host)
+                batch = stage[slot].to(device, non_blocking=True)
+                free[slot] = torch.cuda.Event()
+                free[slot].record()
             else:
-                emb = backbone(cropped).cpu()
-            embeddings[idx:idx + batch.shape[0]] = l2_norm(emb).numpy()
+                batch = host.contiguous().to(device)
+            cropped = ccrop_batch(batch) if ccrop else batch  # crop and flip run on the device (one launch each)
+            emb = backbone(cropped)
+            if tta:
+                emb = emb + backbone(hflip_batch(cropped))  # fp32 add: same bits as on the host
+            sums[idx:idx + batch.shape[0]] = emb
+    embeddings = np.zeros([n, embedding_size])
+    embeddings[:] = l2_norm(sums.cpu()).numpy()  # one copy back; normalisation on the host, as in the reference
     tpr, fpr, acc, best_thresholds = evaluate(embeddings, issame, nrof_folds)
     roc = None
     buf = gen_plot(fpr, tpr)
