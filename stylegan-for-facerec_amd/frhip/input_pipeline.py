@@ -102,6 +102,15 @@ class GpuTrainTransform(object):
         flip = (torch.rand(batch, generator=generator) < self.flip_p).to(torch.uint8)
         return crop, flip
 
+    @staticmethod
+    def _to_device(t, dtype, dev):
+        """Host draws go through pinned memory with an asynchronous copy: a pageable host-to-device copy would make the
+        host wait for everything already queued on the stream, i.e. for the previous training step."""
+        t = t.to(dtype).contiguous()
+        if t.is_cuda:
+            return t
+        return t.pin_memory().to(dev, non_blocking=True)
+
     def __call__(self, u8, crop=None, flip=None, generator=None, validate=True):
         """``validate=False``: the caller guarantees 0 <= crop <= big - size (skips the host-side range check, which is a
         device synchronisation when ``crop`` already lives on the device)."""
@@ -117,8 +126,7 @@ class GpuTrainTransform(object):
             raise ValueError("GpuTrainTransform: crop offsets must lie in [0, %d]" % span)
         dev = u8.device
         xtab, ytab, lut, kx, ky = self.tables(dev, h, w)
-        crop = crop.to(device=dev, dtype=torch.int32).contiguous()
-        flip = flip.to(device=dev, dtype=torch.uint8).contiguous()
+        crop, flip = self._to_device(crop, torch.int32, dev), self._to_device(flip, torch.uint8, dev)
         out = torch.empty(b, 3, self.size, self.size, device=dev, dtype=torch.float32)
         ops.call("fr_augment_u8", u8.contiguous(), xtab, ytab, crop, flip, lut, out, b, h, w, self.big, self.big,
                  self.size, kx, ky, ops.current_stream_ptr())()
