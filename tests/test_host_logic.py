@@ -198,3 +198,45 @@ def test_tta_transforms_follow_the_uint8_round_trip():
     k = torch.full((1, 3, 112, 112), 0.25)
     ck = ccrop_batch(k)
     assert float((ck - ck[0, 0, 0, 0]).abs().max()) == 0.0 and abs(float(ck[0, 0, 0, 0]) - 0.25) < 1.0 / 255
+
+
+def test_initial_weight_distributions_follow_the_reference():
+    """``Backbone`` draws xavier-uniform Conv2d / Linear weights (bound sqrt(6 / (fan_in + fan_out)),
+    model_irse.py:174-189); ``pSp`` re-initialises its encoder with kaiming-normal(fan_out) (std sqrt(2 / (Cout * kh * kw)),
+    Linear std sqrt(2 / 512), util/utils.py:24-44, incl. the SE 1x1 convolutions); biases 0, BatchNorm (1, 0)."""
+    import math
+    import torch.nn as nn
+    from backbone.model_irse import IR_50
+    from backbone.restyle_psp import pSp
+    torch.manual_seed(3)
+    m = IR_50([112, 112])
+    for name, mod in m.named_modules():
+        if isinstance(mod, (nn.Conv2d, nn.Linear)):
+            w = mod.weight.detach()
+            rf = w[0][0].numel() if w.dim() > 2 else 1
+            bound = math.sqrt(6.0 / (w.shape[1] * rf + w.shape[0] * rf))
+            assert float(w.abs().max()) <= bound + 1e-7, name
+            if w.numel() >= 4096:
+                assert abs(float(w.std()) / (bound / math.sqrt(3.0)) - 1.0) < 0.05, name  # uniform: std = bound / sqrt(3)
+                assert float(w.abs().max()) > 0.98 * bound, name
+            if mod.bias is not None:
+                assert float(mod.bias.detach().abs().max()) == 0.0
+        elif isinstance(mod, (nn.BatchNorm2d, nn.BatchNorm1d)):
+            assert bool((mod.weight == 1).all()) and bool((mod.bias == 0).all()), name
+    p = pSp(size=112, encoder_type="BackboneEncoder", avg_image=None)
+    seen_se = False
+    for name, mod in p.encoder.named_modules():
+        if isinstance(mod, (nn.Conv2d, nn.Linear)):
+            w = mod.weight.detach()
+            rf = w[0][0].numel() if w.dim() > 2 else 1
+            std = math.sqrt(2.0 / (w.shape[0] * rf))  # fan_out
+            if w.numel() >= 4096:
+                assert abs(float(w.std()) / std - 1.0) < 0.05, (name, float(w.std()), std)
+                assert abs(float(w.mean())) < 0.05 * std, name
+                assert float(w.abs().max()) > 3.0 * std, name  # a normal draw has tails a uniform one has not
+            seen_se = seen_se or (w.dim() == 4 and rf == 1 and "fc" in name)
+            if mod.bias is not None:
+                assert float(mod.bias.detach().abs().max()) == 0.0
+        elif isinstance(mod, nn.BatchNorm2d):
+            assert bool((mod.weight == 1).all()) and bool((mod.bias == 0).all()), name
+    assert seen_se  # the SE squeeze / excite 1x1 convolutions are re-initialised too
