@@ -1,5 +1,5 @@
 import os, sys, time
-REPO = "/root/repo"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "stylegan-for-facerec_amd")); sys.path.insert(0, REPO)
 import torch
 from backbone.model_irse import IR_50, IR_SE_50, IR_SE_101
