@@ -78,6 +78,12 @@ class SyntheticFaces(Dataset):
     def __getitem__(self, idx):
         from frhip import synth
         if self.staged:  # uint8 HWC, as StageTransform delivers decoded files
-            img = synth.uniform(self.seed, "face%d" % idx, (self.size, self.size, 3), 0.0, 256.0)
-            return img.clamp_(0, 255).to(torch.uint8), idx // self.per
+            # an identity is a coarse 8x8 colour pattern, a sample adds noise to it: unlike white noise this survives the
+            # resize / random crop / flip of the input pipeline, so a network can actually learn the identities
+            ident = idx // self.per
+            cell = (self.size + 7) // 8
+            base = synth.uniform(self.seed, "identity%d" % ident, (8, 8, 3), 32.0, 224.0)
+            base = base.repeat_interleave(cell, 0).repeat_interleave(cell, 1)[:self.size, :self.size]
+            img = base + synth.uniform(self.seed, "face%d" % idx, (self.size, self.size, 3), -24.0, 24.0)
+            return img.clamp_(0, 255).to(torch.uint8), ident
         return synth.uniform(self.seed, "face%d" % idx, (3, self.size, self.size)), idx // self.per
