@@ -962,6 +962,13 @@ class BackboneRunner(object):
         S = self.module.input_size if isinstance(self.module.input_size, int) else self.module.input_size[0]
         if x.shape[2] != S or x.shape[3] != S:
             raise _lib.FrhipError("frhip: expected %dx%d inputs, got %s" % (S, S, tuple(x.shape)))
+        if x.shape[0] == 0:  # the reference fails in Flatten (model_irse.py:146) in both modes
+            raise RuntimeError("cannot reshape tensor of 0 elements into shape [0, -1] because the unspecified dimension "
+                               "size -1 can be any value and is ambiguous")
+        bn1d = self.module.output_layer[-1]
+        if x.shape[0] == 1 and bn1d.training:  # BatchNorm1d(512) on one row (model_irse.py:148), as torch raises it
+            raise ValueError("Expected more than 1 value per channel when training, got input size "
+                             "torch.Size([1, %d])" % bn1d.num_features)
         self._avg = None if avg_image is None else self._device_avg(avg_image, x.device)
         have = x.shape[1] + (0 if self._avg is None else self._avg.shape[0])
         if have != self.in_channels:

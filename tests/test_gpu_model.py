@@ -645,3 +645,24 @@ def test_train_driver_with_adam(tmp_path):
     osd = torch.load(_ckpt(model_dir, "Optimizer_ArcFace_Epoch_1_Batch_3_"), map_location="cpu")
     assert all(set(v.keys()) == {"step", "exp_avg", "exp_avg_sq"} for v in osd["state"].values())
     assert len(osd["param_groups"]) == 1
+
+
+def test_degenerate_batches_raise_like_the_reference():
+    """One image in train mode: torch's BatchNorm1d error (the reference's output_layer, model_irse.py:148); an empty batch:
+    the Flatten error, in both modes; one image in eval mode runs."""
+    _need_gpu()
+    model, _ = build("IR_50")
+    model.train()
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        model(torch.zeros(1, 3, 112, 112).cuda())
+    for mode in (True, False):
+        model.train(mode)
+        with pytest.raises(RuntimeError, match="cannot reshape tensor of 0 elements"):
+            model(torch.zeros(0, 3, 112, 112).cuda())
+    model.eval()
+    with torch.no_grad():
+        assert tuple(model(torch.zeros(1, 3, 112, 112).cuda()).shape) == (1, 512)
+    psp, _ = build("pSp")
+    psp.train()
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        psp(torch.zeros(1, 3, 112, 112).cuda())
