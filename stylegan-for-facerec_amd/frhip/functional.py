@@ -115,6 +115,9 @@ CHECK_LABELS = True  # host-side range check of the labels (one device sync per 
 
 
 def margin_head(x, weight, label, kind, s, m, easy_margin=False):
+    if x.shape[0] == 0:  # the reference returns empty logits (F.linear / scatter_ on zero rows); nothing to launch
+        ops.ptr(x)  # host tensors still fail loudly
+        return x.new_zeros((0, weight.shape[0]), dtype=torch.float32) + 0.0 * (x.sum() + weight.sum())
     if CHECK_LABELS and (label.min() < 0 or label.max() >= weight.shape[0]):  # reference: RuntimeError from scatter_ (metrics.py:134)
         raise RuntimeError("index %d is out of bounds for dimension 1 with size %d"
                            % (int(label.max()), weight.shape[0]))
@@ -152,12 +155,18 @@ class FocalLossFn(torch.autograd.Function):
 
 
 def focal_loss(logits, target, gamma=2.0):
+    if logits.shape[0] == 0:  # mean cross entropy of no rows is NaN in the reference (loss/focal.py:18)
+        ops.ptr(logits)
+        return logits.sum() * float("nan")
     return FocalLossFn.apply(logits, target, gamma)
 
 
 def topk_ranks(logits, target):
     """rank[m] = number of classes scoring strictly above the label's logit (device int32 [B])."""
     B, N = logits.shape
+    if B == 0:
+        ops.ptr(logits)
+        return torch.empty(0, device=logits.device, dtype=torch.int32)
     st = ops.current_stream_ptr()
     logits = logits.contiguous().float()
     rank = torch.empty(B, device=logits.device, dtype=torch.int32)

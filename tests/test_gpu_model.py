@@ -666,3 +666,26 @@ def test_degenerate_batches_raise_like_the_reference():
     psp.train()
     with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
         psp(torch.zeros(1, 3, 112, 112).cuda())
+
+
+def test_empty_batch_through_head_loss_and_accuracy():
+    """Zero rows: the reference's heads return empty logits, the focal loss of no rows is NaN, ``accuracy`` divides by the
+    batch size (head/metrics.py, loss/focal.py:17-21, util/utils.py:343-358) -- same here, without launching anything."""
+    _need_gpu()
+    from head.metrics import ArcFace, CosFace
+    from loss.focal import FocalLoss
+    from util.utils import accuracy
+    x = torch.zeros(0, 512, device="cuda", requires_grad=True)
+    y = torch.zeros(0, dtype=torch.long, device="cuda")
+    for cls in (ArcFace, CosFace):
+        head = cls(512, 10, None).cuda()
+        out = head(x, y)
+        assert tuple(out.shape) == (0, 10) and out.dtype == torch.float32
+        loss, extra = FocalLoss()(out, y)
+        assert extra is None and bool(torch.isnan(loss))
+        loss.backward()  # gradients of nothing: zeros / NaNs, but no error
+        assert x.grad is not None and tuple(x.grad.shape) == (0, 512)
+        with pytest.raises(ZeroDivisionError):
+            accuracy(out.detach(), y, topk=(1, 5))
+    with pytest.raises(Exception):
+        ArcFace(512, 10, None)(torch.zeros(0, 512), torch.zeros(0, dtype=torch.long))  # host tensors: no CPU path
