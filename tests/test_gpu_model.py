@@ -689,3 +689,34 @@ def test_empty_batch_through_head_loss_and_accuracy():
             accuracy(out.detach(), y, topk=(1, 5))
     with pytest.raises(Exception):
         ArcFace(512, 10, None)(torch.zeros(0, 512), torch.zeros(0, dtype=torch.long))  # host tensors: no CPU path
+
+
+def test_input_size_224_matches_oracle():
+    """The reference's other allowed input size (model_irse.py:132: 112 or 224 -> Linear(512*14*14, 512)): the fp32 path
+    against the oracle's forward, and a bf16 step with finite gradients (generic kernels where a 224 / 14x14-final shape
+    is not in the strip tables)."""
+    _need_gpu()
+    from backbone.model_irse import IR_50
+    from head.metrics import ArcFace
+    from loss.focal import FocalLoss
+    from oracle import irse_ref as O
+    x = synth.uniform(5, "x224", (3, 3, 224, 224))
+    y = synth.labels(5, "y224", 3, 50)
+    for dt in (torch.float32, torch.bfloat16):
+        m = IR_50([224, 224])
+        synth.fill_state_dict(m.state_dict(), 15)
+        m.output_layer[1].p = 0.0
+        m.compute_dtype = dt
+        m = m.cuda().train()
+        head = ArcFace(512, 50, None).cuda()
+        f = m(x.cuda())
+        loss, _ = FocalLoss()(head(f, y.cuda()), y.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        assert tuple(f.shape) == (3, 512) and bool(torch.isfinite(loss))
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+        if dt == torch.float32:
+            sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+            fo = O.backbone_forward(sd, x, 50, False, bn_train=True)
+            fo = fo[0] if isinstance(fo, tuple) else fo
+            assert float((f.detach().cpu() - fo).abs().max()) < 1e-3
