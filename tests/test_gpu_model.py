@@ -720,3 +720,28 @@ def test_input_size_224_matches_oracle():
             fo = O.backbone_forward(sd, x, 50, False, bn_train=True)
             fo = fo[0] if isinstance(fo, tuple) else fo
             assert float((f.detach().cpu() - fo).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("name,layers,se", [("IR_101", 100, False), ("IR_152", 152, False), ("IR_SE_152", 152, True)])
+def test_other_factories_match_oracle_forward(name, layers, se):
+    """The factories no golden fixture covers (model_irse.py:200-237; ``IR_101`` builds the 100-layer table): fp32
+    train-mode forward against the oracle on the same seeded weights, and one backward with finite gradients."""
+    _need_gpu()
+    import backbone.model_irse as irse
+    from oracle import irse_ref as O
+    m = getattr(irse, name)([112, 112])
+    synth.fill_state_dict(m.state_dict(), 21)
+    m.output_layer[1].p = 0.0
+    m.compute_dtype = torch.float32
+    m = m.cuda().train()
+    # six images: with two, the final BatchNorm1d maps every feature to +-gamma and amplifies 1e-4 differences wherever
+    # the two rows nearly tie
+    x = synth.uniform(6, "fx", (6, 3, 112, 112))
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    f = m(x.cuda())
+    f.square().sum().backward()
+    torch.cuda.synchronize()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    fo = O.backbone_forward(sd, x, layers, se, bn_train=True)
+    fo = fo[0] if isinstance(fo, tuple) else fo
+    assert float((f.detach().cpu() - fo).abs().max()) < 1e-3, float((f.detach().cpu() - fo).abs().max())
