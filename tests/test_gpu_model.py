@@ -745,3 +745,29 @@ def test_other_factories_match_oracle_forward(name, layers, se):
     fo = O.backbone_forward(sd, x, layers, se, bn_train=True)
     fo = fo[0] if isinstance(fo, tuple) else fo
     assert float((f.detach().cpu() - fo).abs().max()) < 1e-3, float((f.detach().cpu() - fo).abs().max())
+
+
+@pytest.mark.parametrize("encoder_type,layers", [("BackboneEncoder34", 34), ("BackboneEncoder100", 100)])
+def test_other_psp_encoders_match_oracle_forward(encoder_type, layers):
+    """The IR_34_ReStyle / IR_100_ReStyle trunks (restyle_psp.py:407-415, restyle_psp_helpers.py:33-64; IR-SE units,
+    6-channel stem with the average image): fp32 train-mode forward against the oracle, one backward."""
+    _need_gpu()
+    from backbone.restyle_psp import pSp
+    from oracle import irse_ref as O
+    avg = synth.uniform(15, "avg_image", (3, 112, 112))
+    m = pSp(size=112, encoder_type=encoder_type, checkpoint_path=None, avg_image=avg, include_dropout=False)
+    synth.fill_state_dict(m.state_dict(), 23)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.encoder.compute_dtype = torch.float32
+    m = m.cuda().train()
+    x = synth.uniform(7, "px", (6, 3, 112, 112))
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    f = m(x.cuda())
+    f.square().sum().backward()
+    torch.cuda.synchronize()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    fo = O.backbone_forward(sd, x, layers, True, bn_train=True, prefix="encoder.", avg_image=avg)
+    fo = fo[0] if isinstance(fo, tuple) else fo
+    assert float((f.detach().cpu() - fo).abs().max()) < 1e-3, float((f.detach().cpu() - fo).abs().max())
