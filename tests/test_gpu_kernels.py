@@ -278,6 +278,49 @@ def test_margin_head_backward_vs_oracle(K):
         assert relerr(head.weight.grad.cpu(), gwr) < 1e-3
 
 
+def test_margin_head_easy_margin_and_custom_scale(K, golden_dir):
+    """ArcFace(s=30, m=0.35, easy_margin=True) (head/metrics.py:120-121: phi where cos > 0, cos elsewhere) and
+    CosFace(s=30, m=0.35): logits against the reference's own vector where the fixture has one, gradients against the
+    oracle; includes rows on both sides of the easy-margin switch."""
+    import os
+    from oracle import irse_ref as O
+    from head.metrics import ArcFace, CosFace
+    g = np.load(os.path.join(golden_dir, "g1_head.npz"))
+    head = ArcFace(512, 100, None, s=30.0, m=0.35, easy_margin=True).cuda()
+    with torch.no_grad():
+        head.weight.copy_(torch.from_numpy(g["w"]))
+    x = torch.from_numpy(g["x"]).cuda()
+    label = torch.from_numpy(g["label"]).cuda()
+    got = head(x, label).cpu()
+    ref = torch.from_numpy(g["ArcFace.easy.logits"])
+    loose = torch.zeros_like(ref, dtype=torch.bool)
+    loose[4, 13] = True  # cos = +1: sqrt of a clamped difference, ill-conditioned in the reference itself
+    assert float((got - ref).abs()[~loose].max()) < 1e-3 and float((got - ref).abs()[4, 13]) < 0.1
+    # random case with negative label cosines too (easy margin leaves those rows untouched)
+    B, N = 29, 203
+    x0 = synth.normal(31, "ex", (B, 512))
+    w0 = synth.uniform(31, "ew", (N, 512), -0.1, 0.1)
+    lab = synth.labels(31, "el", B, N)
+    with torch.no_grad():
+        cos = O.cosine_logits(x0, w0)
+    sel = cos[torch.arange(B), lab]
+    assert bool((sel > 0).any()) and bool((sel < 0).any())
+    gout = synth.normal(31, "eg", (B, N))
+    for cls, f, kw in ((ArcFace, O.arcface_forward, dict(s=30.0, m=0.35, easy_margin=True)),
+                       (CosFace, O.cosface_forward, dict(s=30.0, m=0.35))):
+        xr, wr = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        yr = f(xr, wr, lab, **kw)
+        gxr, gwr = torch.autograd.grad(yr, [xr, wr], gout)
+        h = cls(512, N, None, **kw).cuda()
+        with torch.no_grad():
+            h.weight.copy_(w0)
+        xg = x0.cuda().requires_grad_(True)
+        y = h(xg, lab.cuda())
+        assert float((y.detach().cpu() - yr.detach()).abs().max()) < 1e-3
+        y.backward(gout.cuda())
+        assert relerr(xg.grad.cpu(), gxr) < 1e-3 and relerr(h.weight.grad.cpu(), gwr) < 1e-3
+
+
 def test_focal_and_accuracy_match_golden(K, golden_dir):
     import os
     g = np.load(os.path.join(golden_dir, "g2_focal.npz"))
