@@ -321,6 +321,27 @@ def test_margin_head_easy_margin_and_custom_scale(K, golden_dir):
         assert relerr(xg.grad.cpu(), gxr) < 1e-3 and relerr(h.weight.grad.cpu(), gwr) < 1e-3
 
 
+@pytest.mark.parametrize("gamma", [0.0, 1.0, 2.0, 3.5])
+def test_focal_loss_other_gammas(K, gamma):
+    """FocalLoss(gamma) for gamma != 2 (loss/focal.py:9-21; gamma = 0 is plain mean cross entropy): value and gradient
+    against the oracle, N not a multiple of the vector width, a row whose label has the largest logit."""
+    from oracle import irse_ref as O
+    from loss.focal import FocalLoss
+    B, N = 19, 333
+    z0 = synth.normal(41, "fz", (B, N)) * 3.0
+    y = synth.labels(41, "fy", B, N)
+    z0[0, y[0]] = 50.0
+    zr = z0.clone().requires_grad_(True)
+    lr = O.focal_loss(zr, y, gamma)
+    gr, = torch.autograd.grad(lr, [zr])
+    z = z0.cuda().requires_grad_(True)
+    loss, extra = FocalLoss(gamma=gamma)(z, y.cuda())
+    loss.backward()
+    assert extra is None
+    assert abs(float(loss) - float(lr)) < 1e-5 * max(1.0, abs(float(lr)))
+    assert relerr(z.grad.cpu(), gr) < 1e-4
+
+
 def test_focal_and_accuracy_match_golden(K, golden_dir):
     import os
     g = np.load(os.path.join(golden_dir, "g2_focal.npz"))
