@@ -41,6 +41,20 @@ __global__ void row_normalize_kernel(const float* __restrict__ x, T* __restrict_
   }
 }
 
+// xt[d][r] = xn[r][d] through 64 x 64 LDS tiles (both sides coalesced).  The per-row kernel above writes the transposed
+// copy as 4-byte stores with a stride of a whole row per lane; for the head weight (N x 512) this second pass is 3x cheaper.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_rows_kernel(const T* __restrict__ in, T* __restrict__ out, int R, int D,
+                                                             int ldt) {
+  __shared__ T tt[64][66];
+  const int d0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int j = ty; j < 64; j += 4)
+    if (r0 + j < R && d0 + tx < D) tt[j][tx] = in[(size_t)(r0 + j) * D + d0 + tx];
+  __syncthreads();
+  for (int j = ty; j < 64; j += 4)
+    if (d0 + j < D && r0 + tx < R) out[(size_t)(d0 + j) * ldt + r0 + tx] = tt[tx][j];
+}
+
 __global__ void normalize_bwd_kernel(const float* __restrict__ G, const float* __restrict__ x,
                                      const float* __restrict__ inv, float* __restrict__ gx, int rows, int D) {
   const int lane = threadIdx.x & 63;
@@ -294,14 +308,23 @@ extern "C" int fr_row_normalize(const float* x, void* xn, void* xt, float* inv, 
                                 int ldt, int dtype, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int grid = (rows_pad + 3) / 4;
-  if (dtype == FR_F32)
-    hipLaunchKernelGGL(row_normalize_kernel<float>, dim3(grid), dim3(256), 0, st, x, (float*)xn, (float*)xt, inv,
-                       rows, rows_pad, D, ldt);
-  else if (dtype == FR_BF16)
-    hipLaunchKernelGGL(row_normalize_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, x, (bf16_t*)xn, (bf16_t*)xt, inv,
-                       rows, rows_pad, D, ldt);
-  else
+  const bool tiled = xt && rows_pad >= 256;  // transposed copy by a second, coalesced pass
+  const dim3 tgrid((D + 63) / 64, (rows_pad + 63) / 64);
+  if (dtype == FR_F32) {
+    hipLaunchKernelGGL(row_normalize_kernel<float>, dim3(grid), dim3(256), 0, st, x, (float*)xn,
+                       tiled ? (float*)nullptr : (float*)xt, inv, rows, rows_pad, D, ldt);
+    if (tiled)
+      hipLaunchKernelGGL(transpose_rows_kernel<float>, tgrid, dim3(256), 0, st, (const float*)xn, (float*)xt, rows_pad, D,
+                         ldt);
+  } else if (dtype == FR_BF16) {
+    hipLaunchKernelGGL(row_normalize_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, x, (bf16_t*)xn,
+                       tiled ? (bf16_t*)nullptr : (bf16_t*)xt, inv, rows, rows_pad, D, ldt);
+    if (tiled)
+      hipLaunchKernelGGL(transpose_rows_kernel<bf16_t>, tgrid, dim3(256), 0, st, (const bf16_t*)xn, (bf16_t*)xt, rows_pad,
+                         D, ldt);
+  } else {
     FR_UNSUPPORTED("fr_row_normalize: dtype");
+  }
   FR_LAUNCH_CHECK();
 }
 

@@ -278,6 +278,31 @@ def test_margin_head_backward_vs_oracle(K):
         assert relerr(head.weight.grad.cpu(), gwr) < 1e-3
 
 
+@pytest.mark.parametrize("rows,dt", [(100, "f32"), (1000, "f32"), (7000, "f32"), (28000, "f32"), (1000, "bf16"), (333, "bf16")])
+def test_row_normalize_and_transposed_copy(K, rows, dt):
+    """F.normalize rows (eps 1e-12, head/metrics.py:103) + the zero-padded transposed copy the head GEMMs read; padded
+    row counts below / above the tiled-transpose threshold, both dtypes."""
+    from frhip._lib import FR_BF16, FR_F32
+    ops = K
+    D = 512
+    pad = (rows + 31) // 32 * 32
+    x = synth.normal(51, "rn", (rows, D))
+    x[3] = 0.0  # a zero row: 0 / max(0, eps) = 0
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    xn = torch.full((pad, D), 7.0, device="cuda", dtype=tdt)
+    xt = torch.full((D, pad), 7.0, device="cuda", dtype=tdt)
+    inv = torch.empty(rows, device="cuda")
+    ops.call("fr_row_normalize", x.cuda(), xn, xt, inv, rows, pad, D, pad, FR_F32 if dt == "f32" else FR_BF16,
+             ops.current_stream_ptr())()
+    ref = torch.nn.functional.normalize(x)
+    tol = 1e-6 if dt == "f32" else 4e-3
+    assert float((xn[:rows].float().cpu() - ref).abs().max()) <= tol
+    assert bool((xn[rows:] == 0).all()) and bool((xt[:, rows:] == 0).all())
+    assert torch.equal(xt, xn.t().contiguous())
+    nrm = x.norm(dim=1).clamp_min(1e-12)
+    torch.testing.assert_close(inv.cpu(), 1.0 / nrm, rtol=1e-6, atol=0)
+
+
 def test_margin_head_easy_margin_and_custom_scale(K, golden_dir):
     """ArcFace(s=30, m=0.35, easy_margin=True) (head/metrics.py:120-121: phi where cos > 0, cos elsewhere) and
     CosFace(s=30, m=0.35): logits against the reference's own vector where the fixture has one, gradients against the
