@@ -409,7 +409,17 @@ static int strip_variant() {
 }
 
 // fewer whole-image workgroups than ~3/4 of the CUs: prefer the instances that split an image over two workgroups
-static bool small_batch(int B) { return B <= 160 && strip_variant() >= 2; }
+// FRHIP_SPLIT_STRIPS=1 forces them at any batch: 2 x B workgroups of half the output channels instead of B whole-image
+// ones, so that CUs taken by another resident kernel (RCCL's all-reduce under data parallelism) cost a proportional
+// share instead of a whole second round of workgroups (A/B switch for multi-GPU runs; slower stand-alone).
+static bool small_batch(int B) {
+  static int force = -1;
+  if (force < 0) {
+    const char* e = getenv("FRHIP_SPLIT_STRIPS");
+    force = (e && e[0] == '1') ? 1 : 0;
+  }
+  return (B <= 160 || force) && strip_variant() >= 2;
+}
 
 // rows per strip for a shape (0 = not served)
 static int strip_rows(int Cin, int Cout, int W) {
