@@ -240,3 +240,33 @@ def test_initial_weight_distributions_follow_the_reference():
         elif isinstance(mod, nn.BatchNorm2d):
             assert bool((mod.weight == 1).all()) and bool((mod.bias == 0).all()), name
     assert seen_se  # the SE squeeze / excite 1x1 convolutions are re-initialised too
+
+
+def test_get_val_data_layout_and_buffer_val(tmp_path):
+    """``get_val_data`` returns the reference's 16-tuple (util/utils.py:89-114: seven benchmark sets, their issame lists,
+    then the RFW dicts) with the RFW subsets read from the .npy fallback; ``buffer_val`` logs the reference's keys
+    (:310-321)."""
+    from util.utils import buffer_val, get_val_data
+    out = get_val_data(str(tmp_path))
+    assert len(out) == 16 and all(v is None for v in out)
+    pairs = np.zeros((6, 3, 112, 112), np.float32)
+    np.save(tmp_path / "RFW_Asian.npy", pairs)
+    np.save(tmp_path / "RFW_Asian_list.npy", np.array([True, False, True]))
+    np.save(tmp_path / "RFW_Indian.npy", pairs)  # no list file: ignored
+    out = get_val_data(str(tmp_path))
+    assert all(v is None for v in out[:14])
+    rfw, rfw_issame = out[14], out[15]
+    assert list(rfw) == ["Asian"] and rfw["Asian"].shape == (6, 3, 112, 112) and rfw_issame["Asian"].tolist() == [True, False, True]
+
+    class Log(object):
+        def __init__(self):
+            self.rows = []
+
+        def log(self, stats):
+            self.rows.append(stats)
+
+    w = Log()
+    buffer_val(w, "RFW_Asian", 0.9, 1.25, None, 3)
+    buffer_val(w, "RFW_Asian", 0.91, 1.2, None, 4, n_samples_passed=1000)
+    assert w.rows[0] == {"RFW_Asian_Accuracy": 0.9, "RFW_Asian_Best_Threshold": 1.25, "epoch": 3}
+    assert w.rows[1]["step"] == 1000 and w.rows[1]["epoch"] == 4
