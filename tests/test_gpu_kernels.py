@@ -2,8 +2,11 @@
 
 Sizes are tiny (the CPU side finishes in seconds) but chosen to hit the edges: row counts that are not a
 multiple of the 128-row tile, stride-2 gathers, class counts that are not a multiple of the vector width.
-Tolerances: fp32 path 1e-4 relative to the output scale; bf16 path 3e-2 (8-bit mantissa operands, fp32
-accumulate) -- the 1e-3 logits bar of BASELINE.json applies to the fp32 path only.
+Tolerances: fp32 path 2e-4 relative to the output scale.  bf16 path 8e-3 of max|ref|: the reference inputs are
+quantised to bf16 first (``q()``), accumulation is fp32 on both sides, so the only legitimate difference is the ONE
+rounding of the output to bf16 (2^-9 = 2e-3 of the value) plus a rare 1-ulp flip of a prologue result; a dropped
+32-channel chunk of one tap at K = 2304 is ~2.6e-2 of max and fails.  The 1e-3 logits bar of BASELINE.json applies
+to the fp32 path only.
 """
 import math
 
@@ -26,7 +29,8 @@ def K():
     return ops
 
 
-DT = [("f32", torch.float32, 2e-4), ("bf16", torch.bfloat16, 4e-2)]
+BF16_TOL = 8e-3
+DT = [("f32", torch.float32, 2e-4), ("bf16", torch.bfloat16, BF16_TOL)]
 
 
 def nhwc(t, dtype):
@@ -456,7 +460,7 @@ def test_bn_apply_and_backward(K, name, dtype, tol):
 def test_bn_lean_bf16_variants(K, C, H, res_kind):
     """The 4-channel x 4-row bf16 kernels (same-geometry shortcut, folded shortcut BN, add in the backward) on row
     counts that are not a multiple of the rows in flight, against the same arithmetic in fp32 on the CPU."""
-    dtype, tol = torch.bfloat16, 4e-2
+    dtype, tol = torch.bfloat16, BF16_TOL
     B = 3
     rows = B * H * H
     x = q(synth.normal(21, "lx", (B, C, H, H)), dtype)
@@ -561,7 +565,11 @@ STRIP_SHAPES = [(64, 64, 112), (64, 64, 56), (64, 128, 56), (128, 64, 56), (128,
                 (256, 128, 28), (256, 256, 14), (256, 512, 14), (512, 256, 14), (512, 512, 7)]
 
 
-STRIP_CASES = [s + (3,) for s in STRIP_SHAPES] + [(512, 512, 7, 4)]  # even batch: two images per workgroup at 7x7
+# B = 3: every shape of the dispatch table; (512, 512, 7, 4): even batch = two images per workgroup at 7x7;
+# B = 162 (> 160, even): the instances bench.py's B = 256 step runs -- conv3x3_strip_kernel<256,256,14,14,8,8,1,...>
+# (NSPL = 1, the kernel ``roofline.kernel`` names; B <= 160 takes the split-channel NSPL = 2 instance) and the
+# 256 -> 512 two-pass path built on it -- against CPU F.conv2d / autograd (~40 GFLOP on the host)
+STRIP_CASES = [s + (3,) for s in STRIP_SHAPES] + [(512, 512, 7, 4), (256, 256, 14, 162), (256, 512, 14, 162)]
 
 
 @pytest.mark.parametrize("cin,cout,W,B", STRIP_CASES, ids=["%d_%d_%d_b%d" % s for s in STRIP_CASES])
@@ -569,14 +577,15 @@ def test_conv3x3_strip(K, cin, cout, W, B):
     """LDS-resident-strip 3x3 s1 conv (bf16): forward with BN prologue + statistics, and the mirrored-tap data
     gradient with the PReLU-backward and BN-backward epilogues, every shape of its dispatch table (B = 3; the 7x7
     stage also with an even batch, which takes the two-images-per-workgroup / split-channel instance)."""
-    dtype, tol = torch.bfloat16, 4e-2
+    dtype, tol = torch.bfloat16, BF16_TOL
     assert K.strip_parts(B, cin, cout, W) > 0
     st = K.current_stream_ptr()
     x = q(synth.normal(31, "sx", (B, cin, W, W)), dtype)
     w = q(synth.normal(31, "sw", (cout, cin, 3, 3), std=0.05), dtype)
     pa = synth.uniform(31, "spa", (cin,), 0.5, 1.5)
     pb = synth.uniform(31, "spb", (cin,), -0.5, 0.5)
-    xin = q(x * pa.view(1, -1, 1, 1) + pb.view(1, -1, 1, 1), dtype)
+    # the kernel's prologue is one fmaf: form the reference product-sum in double so that it is rounded once, too
+    xin = q((x.double() * pa.double().view(1, -1, 1, 1) + pb.double().view(1, -1, 1, 1)).float(), dtype)
     ref = F.conv2d(xin, w, padding=1)
     xd = nhwc(x, dtype)
     out = torch.zeros(B, W, W, cout, device="cuda", dtype=dtype)
@@ -591,8 +600,8 @@ def test_conv3x3_strip(K, cin, cout, W, B):
     assert relerr(from_nhwc(out), ref) < tol
     if not store_only:
         s = part.sum(0).cpu()
-        np.testing.assert_allclose(s[0], ref.sum((0, 2, 3)), rtol=5e-2, atol=5e-2 * float(ref.abs().sum() / cout))
-        np.testing.assert_allclose(s[1], (ref * ref).sum((0, 2, 3)), rtol=5e-2)
+        np.testing.assert_allclose(s[0], ref.sum((0, 2, 3)), rtol=1e-2, atol=1e-2 * float(ref.abs().sum() / cout))
+        np.testing.assert_allclose(s[1], (ref * ref).sum((0, 2, 3)), rtol=1e-2)
     # data gradient: g [B, cout, W, W] -> gx [B, cin, W, W] with weights given as [cin][tap][cout]
     g = q(synth.normal(31, "sg", (B, cout, W, W)), dtype)
     xg = synth.normal(31, "sxx", (B, cin, W, W)).requires_grad_(True)
@@ -616,17 +625,17 @@ def test_conv3x3_strip(K, cin, cout, W, B):
             torch.cuda.synchronize()
             want = torch.where(aux > 0, gx, gx * slope.view(1, -1, 1, 1))
             assert relerr(from_nhwc(o), want) < tol
-            np.testing.assert_allclose(part.sum(0)[0].cpu(), (gx * aux * (aux <= 0)).sum((0, 2, 3)), rtol=5e-2,
-                                       atol=5e-2 * float((gx * aux).abs().sum() / cin))
+            np.testing.assert_allclose(part.sum(0)[0].cpu(), (gx * aux * (aux <= 0)).sum((0, 2, 3)), rtol=1e-2,
+                                       atol=1e-2 * float((gx * aux).abs().sum() / cin))
         else:
             K.conv_strip(st, epi=K.EPI_BNBWD, epi_a=mean.cuda(), epi_b=invstd.cuda(), **kw)()
             torch.cuda.synchronize()
             xh = (aux - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
             assert relerr(from_nhwc(o), gx) < tol
-            np.testing.assert_allclose(part.sum(0)[0].cpu(), gx.sum((0, 2, 3)), rtol=5e-2,
-                                       atol=5e-2 * float(gx.abs().sum() / cin))
-            np.testing.assert_allclose(part.sum(0)[1].cpu(), (gx * xh).sum((0, 2, 3)), rtol=5e-2,
-                                       atol=5e-2 * float((gx * xh).abs().sum() / cin))
+            np.testing.assert_allclose(part.sum(0)[0].cpu(), gx.sum((0, 2, 3)), rtol=1e-2,
+                                       atol=1e-2 * float(gx.abs().sum() / cin))
+            np.testing.assert_allclose(part.sum(0)[1].cpu(), (gx * xh).sum((0, 2, 3)), rtol=1e-2,
+                                       atol=1e-2 * float((gx * xh).abs().sum() / cin))
 
 
 def test_bf16_engine_with_and_without_strip_agree():
@@ -671,17 +680,25 @@ WGS_SHAPES = [(64, 64, 112, "bn"), (64, 64, 56, "prelu"), (128, 64, 56, "bn"), (
               (128, 128, 28, "none")]
 
 
-@pytest.mark.parametrize("cout,cin,W,pro", WGS_SHAPES, ids=["%d_%d_%d_%s" % s for s in WGS_SHAPES])
-@pytest.mark.parametrize("groups", [1, 3])
-def test_conv_wgrad_strip(K, cout, cin, W, pro, groups):
-    """LDS-strip weight gradient (bf16) vs CPU autograd; B = 5 exercises the ragged last fill of the 7x7 case."""
-    B, dtype, tol = 5 if W <= 14 else 2, torch.bfloat16, 4e-2
+# (cout, cin, W, prologue, B, strip groups).  Small cases: B = 5 exercises the ragged last fill of the 7x7 kernel.
+# "bench" cases: the group counts engine._wgrad computes for the B = 256 step (min(fills, 256 / tiles)) with batches
+# large enough to reach them, and B = 162 for the two 14x14 / 7x7 instances that carry most of the weight-gradient time.
+WGS_CASES = [s + (5 if s[2] <= 14 else 2, g) for s in WGS_SHAPES for g in (1, 3)] + [
+    (256, 256, 14, "prelu", 162, 16), (256, 256, 14, "bn", 162, 16), (512, 512, 7, "prelu", 162, 4),
+    (512, 256, 14, "bn", 40, 8), (128, 128, 28, "prelu", 18, 64), (64, 64, 56, "prelu", 20, 256),
+    (64, 64, 112, "bn", 6, 256)]
+
+
+@pytest.mark.parametrize("cout,cin,W,pro,B,groups", WGS_CASES, ids=["%d_%d_%d_%s_b%d_g%d" % s for s in WGS_CASES])
+def test_conv_wgrad_strip(K, cout, cin, W, pro, B, groups):
+    """LDS-strip weight gradient (bf16) vs CPU autograd."""
+    dtype, tol = torch.bfloat16, BF16_TOL
     assert K.wgrad_strip_supported(cout, cin, W)
     x = q(synth.normal(41, "wsx", (B, cin, W, W)), dtype)
     pa = synth.uniform(41, "wspa", (cin,), 0.5, 1.5)
     pb = synth.uniform(41, "wspb", (cin,), -0.5, 0.5)
     if pro == "bn":
-        xin = x * pa.view(1, -1, 1, 1) + pb.view(1, -1, 1, 1)
+        xin = (x.double() * pa.double().view(1, -1, 1, 1) + pb.double().view(1, -1, 1, 1)).float()  # one rounding (fmaf)
     elif pro == "prelu":
         xin = F.prelu(x, pa * 0.25)
     else:
@@ -740,7 +757,7 @@ S2_SHAPES = [(64, 56), (128, 28), (256, 14), (512, 7)]
 def test_conv3x3_s2_strip_forward(K, C, WL, pro):
     """fr_conv3x3_s2_strip mode 0: stride-2 3x3 forward on LDS parity planes (+ prologue, + BN statistics) vs
     F.conv2d on the CPU, and vs the generic implicit-GEMM kernel's partial-sum contract (column totals)."""
-    dtype, tol = torch.bfloat16, 4e-2
+    dtype, tol = torch.bfloat16, BF16_TOL
     B, H = 3, 2 * WL
     x = q(synth.normal(61, "sx", (B, C, H, H)), dtype)
     w = q(synth.normal(61, "sw", (C, C, 3, 3), std=0.05), dtype)
@@ -774,7 +791,7 @@ def test_conv3x3_s2_strip_forward(K, C, WL, pro):
 def test_conv3x3_s2_strip_dgrad(K, C, WL):
     """fr_conv3x3_s2_strip mode 2: all four parity classes of the stride-2 data gradient with the PReLU-backward
     epilogue, vs autograd through F.conv2d(stride=2)."""
-    dtype, tol = torch.bfloat16, 4e-2
+    dtype, tol = torch.bfloat16, BF16_TOL
     B, H = 2, 2 * WL
     x = synth.normal(63, "dx", (B, C, H, H)).requires_grad_(True)
     w = q(synth.normal(63, "dw", (C, C, 3, 3), std=0.05), dtype)
@@ -803,7 +820,7 @@ def test_conv3x3_s2_strip_dgrad(K, C, WL):
 def test_stem_gemm_and_wgrad(K, Kp, M):
     """fr_stem_gemm / fr_stem_wgrad: the 64-column input-layer GEMMs over im2col rows (row counts that are not a
     multiple of the 16-row tile or the 64-row staging chunk), forward + column statistics + weight gradient."""
-    dtype, tol = torch.bfloat16, 4e-2
+    dtype, tol = torch.bfloat16, BF16_TOL
     x = q(synth.normal(71, "gx%d" % M, (M, Kp)), dtype)
     w = q(synth.normal(71, "gw", (64, Kp), std=0.2), dtype)
     y = x @ w.t()
@@ -832,7 +849,7 @@ def test_stem_gemm_and_wgrad(K, Kp, M):
 @pytest.mark.parametrize("groups", [1, 3])
 def test_conv_wgrad_strip_stride2(K, C, WL, groups):
     """fr_conv_wgrad_strip on a stride-2 layer (input tile = four parity planes) with the PReLU prologue, vs autograd."""
-    dtype, tol = torch.bfloat16, 4e-2
+    dtype, tol = torch.bfloat16, BF16_TOL
     B, H = 3, 2 * WL
     x = q(synth.normal(65, "wx", (B, C, H, H)), dtype)
     slope = synth.uniform(65, "ws", (C,), 0.1, 0.4)

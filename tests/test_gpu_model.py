@@ -87,6 +87,65 @@ def test_full_step_matches_reference(golden_dir, fixture, kind, batch):
             np.testing.assert_allclose(bufs[k[4:]].cpu().numpy(), g[k], atol=1e-4, rtol=1e-4)
 
 
+# bf16 bars, set from measured runs on MI355X (printed by the test; `pytest -s` shows them).  The fixtures are random-init
+# networks at batch 8 / 4 where the final BatchNorm1d amplifies any perturbation, so these are far looser than the fp32
+# bars above, but a dropped tap, a wrong BN coefficient or a missing gradient term moves them by an order of magnitude.
+BF16_BARS = dict(loss_rel=5e-2, feat_cos=0.99, grad_cos=0.98, grad_norm_ratio=0.10, all_norms_median=0.05,
+                 all_norms_worst=0.35)
+
+
+@pytest.mark.parametrize("fixture,kind,batch", FULL, ids=[f[0] for f in FULL])
+def test_bf16_full_step_tracks_reference(golden_dir, fixture, kind, batch):
+    """The THROUGHPUT path (bf16 storage, fp32 accumulate: LDS-strip / stride-2 / stem / strip-wgrad kernels -- what
+    bench.py times) against the golden vectors captured from the reference: loss, features, every captured gradient
+    tensor (direction and norm) and all per-parameter gradient norms."""
+    _need_gpu()
+    from head.metrics import ArcFace
+    from loss.focal import FocalLoss
+    g = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    model, prefix = build(kind)
+    inner = model.encoder if kind == "pSp" else model
+    inner.compute_dtype = torch.bfloat16
+    model.train()
+    head = ArcFace(512, 100, None, s=64.0).cuda()
+    with torch.no_grad():
+        head.weight.copy_(synth.uniform(16, "full.head", (100, 512), -0.1, 0.1))
+    x = synth.uniform(16, "full.x", (batch, 3, 112, 112)).cuda()
+    label = synth.labels(16, "full.label", batch, 100).cuda()
+    feats = model(x)
+    logits = head(feats, label)
+    loss, _ = FocalLoss()(logits, label)
+    loss.backward()
+    torch.cuda.synchronize()
+    plan = inner._runner[0].plan
+    assert plan.tdtype == torch.bfloat16 and plan.use_strip, "the test must run the bf16 strip path"
+    cosf = torch.nn.functional.cosine_similarity
+    m = {"loss_rel": abs(float(loss) - float(g["loss"])) / abs(float(g["loss"])),
+         "feat_cos_min": float(cosf(feats.detach().cpu(), torch.from_numpy(g["features"]), dim=1).min()),
+         "logit_max_abs": float((logits.detach().cpu() - torch.from_numpy(g["logits"])).abs().max())}
+    named = dict(model.named_parameters())
+    named["head.weight"] = head.weight
+    per = {}
+    for k in g.files:
+        if k.startswith("g."):
+            mine, ref = named[k[2:]].grad.detach().cpu().double().reshape(1, -1), torch.from_numpy(g[k]).double().reshape(1, -1)
+            per[k[2:]] = (float(cosf(mine, ref)), float(mine.norm() / ref.norm()))
+    names = list(g["grad_names"])
+    got = np.array([float(named[n].grad.double().norm()) for n in names])
+    ratio = np.abs(got / np.maximum(g["grad_norms"], 1e-30) - 1.0)
+    big = g["grad_norms"] > 1e-6 * g["grad_norms"].max()  # biases cancelled by a following BN have pure-noise gradients
+    m["all_norms_median"], m["all_norms_worst"] = float(np.median(ratio[big])), float(ratio[big].max())
+    m["worst_name"] = names[int(np.argmax(np.where(big, ratio, 0)))]
+    print("\nbf16 vs golden %s: %s" % (fixture, json.dumps(m)))
+    for n, (c, r) in per.items():
+        print("   grad %-40s cos %.5f  norm ratio %.4f" % (n, c, r))
+    b = BF16_BARS
+    assert m["loss_rel"] < b["loss_rel"] and m["feat_cos_min"] > b["feat_cos"], m
+    for n, (c, r) in per.items():
+        assert c > b["grad_cos"] and abs(r - 1) < b["grad_norm_ratio"], (n, c, r)
+    assert m["all_norms_median"] < b["all_norms_median"] and m["all_norms_worst"] < b["all_norms_worst"], m
+
+
 def test_two_sgd_steps_match_reference(golden_dir):
     """A0 / A15: param-group split + fused SGD over two steps (g7_sgd)."""
     _need_gpu()
@@ -131,6 +190,79 @@ def test_two_sgd_steps_match_reference(golden_dir):
     # step 2 runs on weights that already moved by lr*grad ~ 5e-2 per element with a random-init net: rounding
     # differences of step 1 are amplified chaotically, so only norms are compared, loosely
     np.testing.assert_allclose([float(named[n].double().norm()) for n in names], g["param_norms"], rtol=2e-3)
+
+
+@pytest.mark.parametrize("device_id", [[0], None], ids=["device_id_list", "device_id_none"])
+def test_reference_shaped_loop_runs_unchanged(golden_dir, device_id):
+    """The inner loop of the reference driver AS WRITTEN (/root/reference/train.py:178-222 setup, :287-316 loop) against
+    the drop-in modules: ``nn.DataParallel(BACKBONE, device_ids=[0])``, HEAD built with ``device_id = GPU_ID`` and never
+    moved by the caller, stock ``torch.optim.SGD`` over the ``separate_irse_bn_paras`` groups, ``accuracy(outputs.data,
+    ...)`` and three ``.data.item()`` reads before ``zero_grad / backward / step`` -- none of INTEGRATION.md's optional
+    edits applied.  Two steps compared with g7_sgd (captured from the reference with Dropout off, so p is set to 0 here)."""
+    _need_gpu()
+    import torch.nn as nn
+    import torch.optim as optim
+    from backbone.model_irse import IR_50
+    from head.metrics import ArcFace, CosFace, SphereFace, Am_softmax
+    from loss.focal import FocalLoss
+    from util.utils import AverageMeter, accuracy, separate_irse_bn_paras
+    g = np.load(os.path.join(golden_dir, "g7_sgd.npz"))
+    DEVICE, GPU_ID, INPUT_SIZE, EMBEDDING_SIZE, NUM_CLASS = torch.device("cuda:0"), device_id, [112, 112], 512, 100
+    LR, MOMENTUM, WEIGHT_DECAY = 0.03, 0.9, 2e-3
+    BACKBONE = IR_50(INPUT_SIZE)
+    synth.fill_state_dict(BACKBONE.state_dict(), 15)
+    BACKBONE.output_layer[1].p = 0.0
+    HEAD_DICT = {'ArcFace': ArcFace(in_features=EMBEDDING_SIZE, out_features=NUM_CLASS, device_id=GPU_ID, s=64.0),
+                 'CosFace': CosFace(in_features=EMBEDDING_SIZE, out_features=NUM_CLASS, device_id=GPU_ID),
+                 'SphereFace': SphereFace(in_features=EMBEDDING_SIZE, out_features=NUM_CLASS, device_id=GPU_ID),
+                 'Am_softmax': Am_softmax(in_features=EMBEDDING_SIZE, out_features=NUM_CLASS, device_id=GPU_ID)}
+    HEAD = HEAD_DICT['ArcFace']
+    with torch.no_grad():
+        HEAD.weight.copy_(synth.uniform(16, "full.head", (100, 512), -0.1, 0.1))
+    assert not HEAD.weight.is_cuda  # the reference never calls HEAD.to(DEVICE)
+    backbone_paras_only_bn, backbone_paras_wo_bn = separate_irse_bn_paras(BACKBONE)
+    _, head_paras_wo_bn = separate_irse_bn_paras(HEAD)
+    OPTIMIZER = optim.SGD([{'params': backbone_paras_wo_bn + head_paras_wo_bn, 'weight_decay': WEIGHT_DECAY},
+                           {'params': backbone_paras_only_bn}], lr=LR, momentum=MOMENTUM)
+    BACKBONE = nn.DataParallel(BACKBONE, device_ids=[0])
+    BACKBONE = BACKBONE.to(DEVICE)
+    LOSS = FocalLoss()
+    BACKBONE.train()
+    HEAD.train()
+    losses, top1, top5 = AverageMeter(), AverageMeter(), AverageMeter()
+    named = dict(BACKBONE.module.named_parameters())
+    named["head.weight"] = HEAD.weight
+    names = list(g["param_names"])
+    for step in range(2):
+        inputs = synth.uniform(17, "sgd.x%d" % step, (8, 3, 112, 112))
+        labels = synth.labels(17, "sgd.label%d" % step, 8, 100)
+        inputs = inputs.to(DEVICE)
+        labels = labels.to(DEVICE).long()
+        features = BACKBONE(inputs)
+        outputs = HEAD(features, labels)
+        loss, loss_components = LOSS(outputs, labels)
+        prec1, prec5 = accuracy(outputs.data, labels, topk=(1, 5))
+        losses.update(loss.data.item(), inputs.size(0))
+        top1.update(prec1.data.item(), inputs.size(0))
+        top5.update(prec5.data.item(), inputs.size(0))
+        OPTIMIZER.zero_grad()
+        loss.backward()
+        OPTIMIZER.step()
+        assert loss_components is None
+        assert abs(losses.val - g["loss"][step]) < 2e-3
+        assert top1.val == g["prec1"][step] and top5.val == g["prec5"][step]
+        if step == 0:
+            torch.cuda.synchronize()
+            np.testing.assert_allclose([float(named[n].double().norm()) for n in names], g["param_norms_step1"],
+                                       rtol=2e-5)
+            np.testing.assert_allclose(BACKBONE.module.input_layer[0].weight.detach().cpu().numpy(),
+                                       g["w1.input_layer.0.weight"], atol=3e-4)
+            np.testing.assert_allclose(HEAD.weight[:4].detach().cpu().numpy(), g["w1.head.weight.rows0_3"], atol=1e-5)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose([float(named[n].double().norm()) for n in names], g["param_norms"], rtol=2e-3)
+    # the optimizer still owns the live parameters: the head moved to the GPU in place, state sits next to it
+    assert HEAD.weight.is_cuda and OPTIMIZER.state[HEAD.weight]["momentum_buffer"].is_cuda
+    assert list(BACKBONE.state_dict().keys())[0].startswith("module.")  # train.py:415 saves BACKBONE.module.state_dict()
 
 
 def test_bf16_path_tracks_fp32():

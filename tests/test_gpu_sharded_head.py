@@ -68,7 +68,10 @@ def test_empty_shard_is_refused():
                  4, 0, 4, ops.current_stream_ptr())()
 
 
-@pytest.mark.parametrize("kind,N,B", [("ArcFace", 100, 8), ("CosFace", 1001, 16), ("ArcFace", 7000, 64), ("ArcFace", 875, 24)])
+# (ArcFace, 28000, 256) and (CosFace, 28000, 128): the BUPT-Balancedface head sizes of BASELINE.json configs[2] / configs[3]
+# (head/metrics.py:77-140 at N = 28 000), replicated and class-sharded at world size 1, against the oracle (~22 GFLOP on CPU)
+@pytest.mark.parametrize("kind,N,B", [("ArcFace", 100, 8), ("CosFace", 1001, 16), ("ArcFace", 7000, 64), ("ArcFace", 875, 24),
+                                      ("ArcFace", 28000, 256), ("CosFace", 28000, 128)])
 def test_one_rank_equals_replicated_head(kind, N, B):
     """Without a process group the sharded module is the whole head: loss, accuracy and both gradients equal the
     replicated HIP head + FocalLoss + accuracy, and the oracle within the north-star bar."""

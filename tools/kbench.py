@@ -89,6 +89,29 @@ def wgrad_case(kind, cout, cin, W, B, stride=1, pro=1, iters=20):
     return timeit(l, iters, flops)
 
 
+# The launches of one IR-50 training step that the round-2 profile work looks at (B = 256): (label, callable args).
+# conv1 of a unit: forward pro=BN epi=STORE, data gradient mode 1 epi=BNBWD; conv2: forward pro=PRELU epi=STATS,
+# data gradient epi=PRELU_BWD (engine.py _build_forward / _build_backward).
+def suite_cases(B):
+    return [
+        ("strip_64_64_112_fwd", lambda it: conv_case("strip", 64, 64, 112, B, pro=1, epi=0, iters=it)),
+        ("strip_64_64_112_dgrad", lambda it: conv_case("strip", 64, 64, 112, B, pro=0, epi=3, mode=1, iters=it)),
+        ("s2_64_56_fwd", lambda it: conv_case("s2", 64, 64, 112, B, stride=2, pro=2, epi=1, iters=it)),
+        ("s2_64_56_dgrad", lambda it: conv_case("s2", 64, 64, 112, B, stride=2, pro=0, epi=2, mode=2, iters=it)),
+        ("strip_64_64_56_fwd_bn", lambda it: conv_case("strip", 64, 64, 56, B, pro=1, epi=0, iters=it)),
+        ("strip_64_64_56_fwd_prelu", lambda it: conv_case("strip", 64, 64, 56, B, pro=2, epi=1, iters=it)),
+        ("strip_64_64_56_dgrad", lambda it: conv_case("strip", 64, 64, 56, B, pro=0, epi=2, mode=1, iters=it)),
+        ("wgs_64_64_112", lambda it: wgrad_case("wgs", 64, 64, 112, B, pro=1, iters=it)),
+        ("wgs_64_64_56", lambda it: wgrad_case("wgs", 64, 64, 56, B, pro=2, iters=it)),
+        ("strip_128_128_28_fwd", lambda it: conv_case("strip", 128, 128, 28, B, pro=1, epi=0, iters=it)),
+        ("strip_256_256_14_fwd_bn", lambda it: conv_case("strip", 256, 256, 14, B, pro=1, epi=0, iters=it)),
+        ("strip_256_256_14_fwd_prelu", lambda it: conv_case("strip", 256, 256, 14, B, pro=2, epi=1, iters=it)),
+        ("strip_256_256_14_dgrad", lambda it: conv_case("strip", 256, 256, 14, B, pro=0, epi=2, mode=1, iters=it)),
+        ("wgs_256_256_14", lambda it: wgrad_case("wgs", 256, 256, 14, B, pro=2, iters=it)),
+        ("strip_512_512_7_fwd", lambda it: conv_case("strip", 512, 512, 7, B, pro=1, epi=0, iters=it)),
+    ]
+
+
 LAYERS = [(64, 64, 112), (64, 64, 56), (64, 128, 56), (128, 128, 28), (128, 256, 28), (256, 256, 14), (256, 512, 14),
           (512, 512, 7)]
 
@@ -103,7 +126,20 @@ def main():
     ap.add_argument("--epi", type=int, default=1)
     ap.add_argument("--mode", type=int, default=0)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="", help="suite: comma-separated case labels")
     a = ap.parse_args()
+    if a.kind == "suite":  # one process, many kernels: what tools/pmc_round.sh profiles
+        import json
+        only = set(x for x in a.only.split(",") if x)
+        res = {}
+        for label, fn in suite_cases(a.batch):
+            if only and label not in only:
+                continue
+            ms, tf = fn(a.iters)
+            res[label] = {"ms": round(ms, 4), "tflops": round(tf, 1)}
+            print("%-28s %.4f ms  %7.1f TFLOP/s" % (label, ms, tf), flush=True)
+        print("KBENCH_SUITE " + json.dumps(res))
+        return
     if a.kind == "all":
         for cin, cout, W in LAYERS:
             r = ["%3d->%3d @%3d" % (cin, cout, W)]
