@@ -1,8 +1,8 @@
 """``from dataset import FacesDataset`` (reference train.py:13, dataset.py:17-91) plus a synthetic stand-in.
 
-``FacesDataset`` reads ``<root>/<identity>/*.jpg|png``; label = index of the identity in sorted order; a sample that
-fails to load returns ``None`` (dropped by ``collate_fn_ignore_none``).  torchvision is not required: the default
-train transform (resize 128 -> random crop 112 -> h-flip -> [-1,1] CHW float) is implemented with PIL+numpy on the host
+``FacesDataset`` reads ``<root>/<identity>/*.jpg``; label = index of the identity (ethnicity prefix removed) in the
+sorted identity set; a sample that fails to load returns ``None`` (dropped by ``collate_fn_ignore_none``).  torchvision
+is not required: the train transform (resize 128 -> random crop 112 -> h-flip -> [-1,1] CHW float) is implemented with PIL+numpy on the host
 worker, as in the reference.  With ``StageTransform`` the worker only decodes and hands over the uint8 HWC image; resize,
 crop, flip and normalisation then run on the GPU for the whole batch (frhip/input_pipeline.py, SURVEY.md 8f rank 3;
 ``GPU_INPUT_PIPELINE=True`` in a train config).
@@ -42,27 +42,73 @@ class StageTransform(object):
         return torch.from_numpy(np.array(img.convert("RGB"), dtype=np.uint8))
 
 
+def identity_of(dirname):
+    """Identity code of a sample directory: everything after the last '^' ("Caucasian^m49.r8743" -> "m49.r8743",
+    reference dataset.py:47-48); names without '^' are identities as they stand."""
+    return dirname[dirname.rfind("^") + 1:] if "^" in dirname else dirname
+
+
 class FacesDataset(Dataset):
-    def __init__(self, root, transform=None, extensions=(".jpg", ".jpeg", ".png")):
-        self.root, self.transform = root, transform or TrainTransform()
-        self.classes = sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)))
-        self.samples = []
-        for label, ident in enumerate(self.classes):
-            for f in sorted(glob.glob(os.path.join(root, ident, "*"))):
-                if f.lower().endswith(extensions):
-                    self.samples.append((f, label))
+    """``<root>/<identity_code>/<filename.jpg>`` (reference dataset.py:17-91).
+
+    As in the reference: the sample list is ``sorted(glob(root/*/*.jpg))`` (only .jpg; directories without one
+    contribute nothing), an identity is its directory name with an ethnicity prefix up to the last '^' removed,
+    ``classes = id_list = sorted(set(identities))`` (so "African^x" and "Asian^x" are ONE class and the label order is
+    the order of the bare ids, not of the prefixed directory names), ``label = id2label[identity]``, ``transform=None``
+    hands the PIL image through, and a sample that fails to load or transform is ``None`` (dropped by
+    ``collate_fn_ignore_none``).  The constructor keeps the reference's signature; ``jpeg_loader`` /
+    ``loss_weights_file`` / ``return_onehot`` are accepted and unused there too.  ``extensions`` is an opt-in
+    extra (e.g. lossless .png fixtures); the default is the reference's '*.jpg'.  One deliberate difference: the
+    reference strips the prefix in ``__getitem__`` only for the four RFW ethnicities and raises ``KeyError`` for any
+    other 'x^id' directory (dataset.py:72-73 vs :47-48); here both places use the same rule."""
+
+    class2race = {"African": 0, "Asian": 1, "Caucasian": 2, "Indian": 3}
+    race2class = ["African", "Asian", "Caucasian", "Indian"]
+
+    def __init__(self, root, transform=None, jpeg_loader=None, loss_weights_file=None, return_onehot=False,
+                 id2race_file=None, extensions=(".jpg",)):
+        super().__init__()
+        self.root, self.transform = root, transform
+        names = []
+        for ext in extensions:
+            names += glob.glob(os.path.join(root, "*", "*" + ext))
+        self.filenames = sorted(set(names))
+        print("Checking loaded data.")
+        print("# filenames:", len(self.filenames))
+        print("filenames[:5]", self.filenames[:5])
+        self.id_list = sorted(set(identity_of(fn.split(os.sep)[-2]) for fn in self.filenames))
+        print("self.id_list[:5]:", self.id_list[:5])
+        self.id2race = None
+        if id2race_file is not None:
+            with open(id2race_file) as f:
+                self.id2race = dict(line.split(" ")[:2] for line in f.read().splitlines())
+        self.classes = self.id_list
+        self.id2label = {identity: label for label, identity in enumerate(self.id_list)}
+        self.n_identities = len(self.id_list)
+        print("# identities:", self.n_identities)
+        self.orig_n_samples = len(self.filenames)
+        self.dims = (112, 112, 3)
 
     def __len__(self):
-        return len(self.samples)
+        return len(self.filenames)
 
     def __getitem__(self, idx):
         from PIL import Image
-        path, label = self.samples[idx]
+        fn = self.filenames[idx]
+        label = self.id2label[identity_of(fn.split(os.sep)[-2])]
         try:
-            return self.transform(Image.open(path).convert("RGB")), label
-        except Exception as e:  # noqa: BLE001 -- broken files are skipped, as in the reference
-            print("[FacesDataset] failed on", path, e)
+            img = Image.open(fn)
+            img.load()
+        except Exception:  # noqa: BLE001 -- broken file, as in the reference (dataset.py:77-81)
+            print("[Image Jpeg loading error]")
             return None
+        try:
+            if self.transform:
+                img = self.transform(img)
+        except Exception:  # noqa: BLE001
+            print("[Error during transforming image]")
+            return None
+        return (img, label)
 
 
 class SyntheticFaces(Dataset):

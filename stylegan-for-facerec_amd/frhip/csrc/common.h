@@ -148,6 +148,17 @@ __device__ __forceinline__ void fast_divmod(uint32_t n, uint32_t d, float inv, u
   r = (uint32_t)rr;
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (block b runs on the XCD that also runs b + 8, MI355X_MICROARCH.md,
+// "Workgroup dispatch"), each with its own L2.  xcd_remap turns a block id into a LOGICAL work index such that every
+// XCD owns one contiguous range of the n items and walks it in order: neighbouring items (strips that share halo
+// rows, the two channel halves of one strip) then run on the same XCD at about the same time and meet in its L2.
+// Placement only changes speed, never results.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7;
+  const int x = b & 7, k = b >> 3;
+  return x * q + (x < r ? x : r) + k;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // MFMA wrappers: one 16x16 output tile, K = 32 per call.  Fragment convention (both dtypes):
 //   lane l holds A[row = l&15][k = 8*(l>>4) + j] and B[k = 8*(l>>4) + j][col = l&15], j = 0..7

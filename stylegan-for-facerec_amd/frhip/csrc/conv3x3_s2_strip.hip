@@ -134,7 +134,7 @@ __device__ __forceinline__ void mma_taps(const char* smem, const int (&abase0)[C
 }
 
 template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND, int PRO>
-__global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs p) {
+__global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs p, const int xcd) {
   using C = S2<CIN, COUT, WL, ROWS, WN, NW, KIND>;
   constexpr int NTH = C::NTH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
   const bf16_t* __restrict__ wgt = reinterpret_cast<const bf16_t*>(p.w);
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
 
-  const int sblk = blockIdx.x;
+  const int sblk = xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;  // halo-sharing strips meet in one XCD's L2
   const int b = sblk / C::NS, row0 = (sblk - b * C::NS) * ROWS;
 
   // ------------------------------------------------------------------ image loader (prologue applied once)
@@ -378,6 +378,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
   }
 }
 
+static int s2_xcd_order() {  // FRHIP_XCD_ORDER=0: strips in dispatch order (A/B switch)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FRHIP_XCD_ORDER");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
 template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND, int PRO>
 int launch(const FrConvArgs& a, hipStream_t st) {
   using C = S2<CIN, COUT, WL, ROWS, WN, NW, KIND>;
@@ -388,7 +397,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
     attr_done = true;
   }
   hipLaunchKernelGGL((conv3x3_s2_kernel<CIN, COUT, WL, ROWS, WN, NW, KIND, PRO>), dim3(a.B * C::NS), dim3(C::NTH), C::LDS,
-                     st, a);
+                     st, a, s2_xcd_order());
   FR_LAUNCH_CHECK();
 }
 

@@ -73,7 +73,7 @@ struct SC {
 };
 
 template <int CIN, int COUT, int W, int ROWS, int WN, int NW, int NSPL, int PRO, int NIMG = 1, int KSPL = 1>
-__global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvArgs p) {
+__global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvArgs p, const int xcd) {
   using C = SC<CIN, COUT, W, ROWS, WN, NW, NIMG, KSPL>;
   constexpr int CK = C::CK;
   constexpr int NTH = C::NTH;
@@ -88,9 +88,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
   // One strip per workgroup.  (Walking several strips with the next one register-prefetched under the MFMAs was
   // measured slower -- spills, and the strips of a workgroup serialise -- and is gone.)
   // NSPL > 1: the output channels are split over NSPL workgroups per strip (COUT is the per-workgroup width)
-  const int nh = NSPL > 1 ? blockIdx.x % NSPL : 0;
+  // logical block: strips that share halo rows (and the NSPL halves of one strip) are neighbours on one XCD
+  const int lb = xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int nh = NSPL > 1 ? lb % NSPL : 0;
   const int ncol0 = nh * COUT;
-  const int sblk = NSPL > 1 ? blockIdx.x / NSPL : blockIdx.x;
+  const int sblk = NSPL > 1 ? lb / NSPL : lb;
   const int s = sblk;  // strip index; a multi-image strip = NIMG consecutive images
 
   constexpr int WP = W + 2;
@@ -367,6 +369,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
   }
 }
 
+// FRHIP_XCD_ORDER=0: workgroups take strips in dispatch order (A/B switch for tools/kbench.py)
+static int xcd_order() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FRHIP_XCD_ORDER");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
 template <int CIN, int COUT, int W, int ROWS, int WN, int NW, int NSPL, int PRO, int NIMG = 1, int KSPL = 1>
 int launch(const FrConvArgs& a, hipStream_t st) {
   using C = SC<CIN, COUT, W, ROWS, WN, NW, NIMG, KSPL>;
@@ -379,7 +391,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
   }
   const int strips = a.B * C::NS / NIMG;
   hipLaunchKernelGGL((conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, NSPL, PRO, NIMG, KSPL>),
-                     dim3(strips * NSPL), dim3(C::NTH), C::LDS, st, a);
+                     dim3(strips * NSPL), dim3(C::NTH), C::LDS, st, a, xcd_order());
   FR_LAUNCH_CHECK();
 }
 

@@ -13,8 +13,16 @@ from . import _lib, ops
 
 
 class SGD(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0):
-        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0, weight_decay=0.0, nesterov=False, *,
+                 maximize=False):
+        # the defaults carry every key torch.optim.SGD reads in step(): an Optimizer_*.pth written here loads into
+        # the reference's torch.optim.SGD (train.py:196, :227-230) and steps there, and the other way round
+        if dampening != 0 or nesterov or maximize:
+            raise NotImplementedError("frhip.optim.SGD implements the reference's update only (train.py:196: dampening 0, "
+                                      "no nesterov, minimise)")
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
+                                      nesterov=nesterov, maximize=maximize, foreach=None, differentiable=False,
+                                      fused=None))
         self._sig = None
         self._tables = []  # per group: (table_dev, chunks_dev, nchunks)
 
@@ -37,6 +45,9 @@ class SGD(torch.optim.Optimizer):
             a.zero_()
 
     def _build(self):
+        for group in self.param_groups:  # a loaded state dict may carry settings this kernel does not implement
+            if group.get("dampening", 0) != 0 or group.get("nesterov", False) or group.get("maximize", False):
+                raise NotImplementedError("frhip.optim.SGD: dampening / nesterov / maximize are not implemented")
         chunk = _lib.lib.fr_sgd_chunk_elems()
         self._tables = []
         keep = []
@@ -131,6 +142,9 @@ class Adam(torch.optim.Optimizer):
         return t
 
     def _build(self):
+        for group in self.param_groups:  # a loaded state dict may carry settings this kernel does not implement
+            if group.get("dampening", 0) != 0 or group.get("nesterov", False) or group.get("maximize", False):
+                raise NotImplementedError("frhip.optim.SGD: dampening / nesterov / maximize are not implemented")
         chunk = _lib.lib.fr_sgd_chunk_elems()
         self._tables = []
         for gi, group in enumerate(self.param_groups):

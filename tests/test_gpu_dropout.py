@@ -132,15 +132,28 @@ def test_full_step_with_dropout_matches_oracle():
     assert float((nodrop - rf.detach()).abs().max()) > 0.05
     dl = float((logits.detach().cpu() - rlogits.detach()).abs().max())
     df = float((feats.detach().cpu() - rf.detach()).abs().max())
-    print("\ndropout step: max|dfeat| %.2e  max|dlogit| %.2e  loss %.6f vs %.6f" % (df, dl, float(loss), float(rloss)))
+    print("\ndropout step: max|dfeat| %.2e  max|dlogit| %.2e  loss %.6f vs %.6f" % (df, dl, float(loss.detach()), float(rloss.detach())))
     assert df < 1e-3 and dl < 1e-3 and abs(float(loss) - float(rloss)) < 1e-4
     named = dict(model.named_parameters())
     named["head.weight"] = head.weight
+    # Gradients.  Bars as in the golden-fixture tests (tests/test_gpu_model.py): within 2.5e-3 of the oracle's fp32
+    # gradient, OR -- where fp32 summation noise is larger than that (BatchNorm bias gradients of the deep layers are sums
+    # of ~1600 cancelling terms) -- no further from the float64 truth than 4x the fp32 oracle itself.  Every
+    # ``res_layer.4.bias`` / ``shortcut_layer.1.bias`` / ``output_layer.3.bias`` is a per-channel shift that only ever
+    # reaches BatchNorms: its true gradient is exactly zero, both sides hold rounding noise; hence the 2e-5 floor.
+    sd64 = {k: (v.detach().double().requires_grad_(v.requires_grad) if v.is_floating_point() else v.detach().clone())
+            for k, v in ref_sd.items()}
+    _f, _l, _loss, g64 = O.train_step(sd64, x.double(), label, hw.double().requires_grad_(True), drop_mask=mask.double())
     worst = ("", 0.0)
     for k, gref in rgrads.items():
-        if gref.dim() == 1 and k.endswith("output_layer.3.bias"):
-            continue  # cancelled exactly by the following BatchNorm1d: pure rounding noise on both sides
-        d = float((named[k].grad.cpu() - gref).norm() / (gref.norm() + 1e-30))
-        worst = max(worst, (k, d), key=lambda t: t[1])
-    print("dropout step: worst relative gradient error %.2e at %s" % (worst[1], worst[0]))
-    assert worst[1] < 2.5e-3, worst
+        mine, t64 = named[k].grad.cpu().double(), g64[k]
+        e32 = float((mine - gref.double()).norm())
+        e64 = float((mine - t64).norm())
+        noise = float((gref.double() - t64).norm())
+        bar32 = 2.5e-3 * float(gref.norm()) + 2e-5
+        bar64 = 4.0 * noise + 2e-5
+        excess = min(e32 / bar32, e64 / bar64)
+        worst = max(worst, (k, excess, e32, e64, noise, float(gref.norm())), key=lambda t: t[1])
+    print("dropout step: worst gradient error / bar = %.3f at %s (|err32| %.2e, |err64| %.2e, oracle fp32 noise %.2e, "
+          "|ref| %.2e)" % ((worst[1], worst[0]) + tuple(worst[2:])))
+    assert worst[1] < 1.0, worst

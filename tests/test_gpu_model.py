@@ -90,8 +90,14 @@ def test_full_step_matches_reference(golden_dir, fixture, kind, batch):
 # bf16 bars, set from measured runs on MI355X (printed by the test; `pytest -s` shows them).  The fixtures are random-init
 # networks at batch 8 / 4 where the final BatchNorm1d amplifies any perturbation, so these are far looser than the fp32
 # bars above, but a dropped tap, a wrong BN coefficient or a missing gradient term moves them by an order of magnitude.
-BF16_BARS = dict(loss_rel=5e-2, feat_cos=0.99, grad_cos=0.98, grad_norm_ratio=0.10, all_norms_median=0.05,
-                 all_norms_worst=0.35)
+# Measured (round 2, MI355X; g5 / g6 / g6b): loss_rel 9e-4 / 3e-4 / 3e-4, feat_cos_min 0.99972 / 0.99977 / 0.99947,
+# captured gradient tensors cos 0.979 .. 0.9999 (lowest: the 64 PReLU slopes of unit 0 and the stem weight, which sit
+# behind the rounding of the whole backward pass), their norm ratios within 0.5 % (4.6 % for one slope vector), all
+# per-parameter gradient norms: median deviation 0.3 - 0.6 %, worst 5 - 9 %.
+BF16_BARS = dict(loss_rel=5e-3, feat_cos=0.999, grad_cos=0.97, grad_norm_ratio=0.07, all_norms_median=0.012,
+                 all_norms_worst=0.15)
+# per-channel shifts that only ever reach BatchNorms: their true gradient is exactly zero, both sides hold noise
+ZERO_GRAD_SUFFIXES = ("res_layer.4.bias", "shortcut_layer.1.bias", "output_layer.3.bias")
 
 
 @pytest.mark.parametrize("fixture,kind,batch", FULL, ids=[f[0] for f in FULL])
@@ -133,7 +139,7 @@ def test_bf16_full_step_tracks_reference(golden_dir, fixture, kind, batch):
     names = list(g["grad_names"])
     got = np.array([float(named[n].grad.double().norm()) for n in names])
     ratio = np.abs(got / np.maximum(g["grad_norms"], 1e-30) - 1.0)
-    big = g["grad_norms"] > 1e-6 * g["grad_norms"].max()  # biases cancelled by a following BN have pure-noise gradients
+    big = np.array([not n.endswith(ZERO_GRAD_SUFFIXES) for n in names])
     m["all_norms_median"], m["all_norms_worst"] = float(np.median(ratio[big])), float(ratio[big].max())
     m["worst_name"] = names[int(np.argmax(np.where(big, ratio, 0)))]
     print("\nbf16 vs golden %s: %s" % (fixture, json.dumps(m)))

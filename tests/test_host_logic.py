@@ -270,3 +270,73 @@ def test_get_val_data_layout_and_buffer_val(tmp_path):
     buffer_val(w, "RFW_Asian", 0.91, 1.2, None, 4, n_samples_passed=1000)
     assert w.rows[0] == {"RFW_Asian_Accuracy": 0.9, "RFW_Asian_Best_Threshold": 1.25, "epoch": 3}
     assert w.rows[1]["step"] == 1000 and w.rows[1]["epoch"] == 4
+
+
+def test_faces_dataset_matches_reference_golden(golden_dir, tmp_path):
+    """dataset.FacesDataset on a tiny tree with ``Race^id`` directory names (reference dataset.py:38-58, :68-91): file
+    order, classes = sorted set of the BARE ids (the same id under two ethnicity prefixes is ONE class), id2label and
+    the label of every sample equal what the reference produced (tests/golden/g11_dataset.json, make_golden.py g11)."""
+    import numpy as np
+    from PIL import Image
+    from dataset import FacesDataset
+    g = json.load(open(os.path.join(golden_dir, "g11_dataset.json")))
+    for d, files in g["tree"].items():
+        os.makedirs(tmp_path / d, exist_ok=True)
+        for k, f in enumerate(files):
+            if f.endswith(".txt"):
+                (tmp_path / d / f).write_text("x")
+            else:
+                Image.fromarray(np.full((8, 8, 3), 10 * k + len(d), np.uint8)).save(tmp_path / d / f)
+    ds = FacesDataset(str(tmp_path))
+    assert [os.path.relpath(f, str(tmp_path)) for f in ds.filenames] == g["filenames"]
+    assert ds.classes == g["classes"] and ds.id_list == g["classes"] and ds.id2label == g["id2label"]
+    assert len(ds) == g["len"] and ds.n_identities == g["n_identities"] and ds.orig_n_samples == g["orig_n_samples"]
+    assert list(ds.dims) == g["dims"]
+    items = [ds[i] for i in range(len(ds))]
+    assert [it[1] for it in items] == g["labels"]
+    assert type(items[0][0]).__module__.split(".")[0] == g["item0_type"] == "PIL"  # transform=None: the PIL image
+    assert FacesDataset.class2race["Caucasian"] == 2 and FacesDataset.race2class[3] == "Indian"
+
+
+def test_resnet_structure_matches_reference_golden(golden_dir):
+    """backbone.model_resnet (plain PyTorch, off the accelerated path; reference model_resnet.py:91-188): ordered
+    state-dict keys, shapes, parameter count, output shape and the zero-initialised last BN of every residual branch."""
+    from backbone.model_resnet import ResNet_50, ResNet_101, ResNet_152
+    g = json.load(open(os.path.join(golden_dir, "g12_resnet_structure.json")))
+    for name, ctor in (("ResNet_50", ResNet_50), ("ResNet_101", ResNet_101), ("ResNet_152", ResNet_152)):
+        m = ctor([g[name]["input"]] * 2)
+        sd = m.state_dict()
+        assert list(sd.keys()) == g[name]["keys"]
+        assert [list(v.shape) for v in sd.values()] == g[name]["shapes"]
+        assert sum(p.numel() for p in m.parameters()) == g[name]["n_params"]
+    m = ResNet_50([112, 112]).eval()
+    with torch.no_grad():
+        assert list(m(torch.zeros(2, 3, 112, 112)).shape) == g["ResNet_50"]["out_shape"]
+    assert (float(m.layer1[0].bn3.weight.abs().sum()) == 0.0) == g["ResNet_50"]["bn3_weight_zero"]
+    with pytest.raises(AssertionError):
+        ResNet_50([96, 96])
+
+
+def test_sgd_state_dict_round_trips_with_torch_sgd():
+    """An Optimizer_*.pth written by frhip.optim.SGD must load into the reference's torch.optim.SGD AND step there
+    (train.py:196, :227-230): param_groups carry dampening / nesterov / maximize like torch's own."""
+    from frhip.optim import SGD
+    p = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5))]
+    mine = SGD([{"params": [p[0]], "weight_decay": 2e-3}, {"params": [p[1]]}], lr=0.03, momentum=0.9)
+    ref_defaults = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.03, momentum=0.9).param_groups[0]
+    for k in ("dampening", "nesterov", "maximize", "weight_decay", "momentum", "lr"):
+        assert k in mine.param_groups[0] and k in mine.param_groups[1], k
+    assert mine.param_groups[1]["dampening"] == ref_defaults["dampening"] == 0
+    assert mine.param_groups[1]["nesterov"] is False and mine.param_groups[0]["weight_decay"] == 2e-3
+    q = [torch.nn.Parameter(t.detach().clone()) for t in p]
+    theirs = torch.optim.SGD([{"params": [q[0]], "weight_decay": 0.5}, {"params": [q[1]]}], lr=1.0, momentum=0.0)
+    theirs.load_state_dict(mine.state_dict())
+    for t in q:
+        t.grad = torch.ones_like(t)
+    theirs.step()  # KeyError('dampening') before the defaults were completed
+    assert theirs.param_groups[0]["lr"] == 0.03 and theirs.param_groups[0]["weight_decay"] == 2e-3
+    torch.testing.assert_close(q[1].detach(), p[1].detach() - 0.03)
+    with pytest.raises(NotImplementedError):
+        SGD(p, lr=0.1, momentum=0.9, nesterov=True)
+    with pytest.raises(NotImplementedError):
+        SGD(p, lr=0.1, momentum=0.9, dampening=0.1)

@@ -142,7 +142,7 @@ def test_stage_transform_hands_over_decoded_pixels(tmp_path):
             Image.fromarray(a).save(tmp_path / ident / ("%d.png" % k))
             want[(ident, k)] = a
     (tmp_path / "id_a" / "broken.png").write_bytes(b"not an image")
-    ds = FacesDataset(str(tmp_path), StageTransform())
+    ds = FacesDataset(str(tmp_path), StageTransform(), extensions=(".png",))  # lossless fixtures
     assert ds.classes == ["id_a", "id_b"] and len(ds) == 7
     items = [ds[i] for i in range(len(ds))]
     assert sum(it is None for it in items) == 1  # the broken file is skipped, as in the reference (dataset.py:77-81)
