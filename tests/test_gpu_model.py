@@ -97,7 +97,7 @@ def test_full_step_matches_reference(golden_dir, fixture, kind, batch):
 BF16_BARS = dict(loss_rel=5e-3, feat_cos=0.999, grad_cos=0.97, grad_norm_ratio=0.07, all_norms_median=0.012,
                  all_norms_worst=0.15)
 # per-channel shifts that only ever reach BatchNorms: their true gradient is exactly zero, both sides hold noise
-ZERO_GRAD_SUFFIXES = ("res_layer.4.bias", "shortcut_layer.1.bias", "output_layer.3.bias")
+ZERO_GRAD_SUFFIXES = ("res_layer.4.bias", "shortcut_layer.1.bias", "output_layer.0.bias", "output_layer.3.bias")
 
 
 @pytest.mark.parametrize("fixture,kind,batch", FULL, ids=[f[0] for f in FULL])
