@@ -26,6 +26,22 @@
 #include "common.h"
 #include "frhip_internal.h"
 
+#ifdef FRHIP_STAMPS
+// Diagnostic build only (make stamps -> libfrhip_stamps.so; never the product library): wave 0 of every workgroup
+// writes s_memrealtime (100 MHz) at its phase boundaries + its hardware id to a buffer of its own, read by
+// tools/stamps.py.  No output value depends on a stamp.
+__device__ unsigned long long* fr_stamp_buf = nullptr;
+extern "C" int fr_debug_set_stamp_buffer(unsigned long long* dev_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(fr_stamp_buf), &dev_ptr, sizeof(dev_ptr));
+}
+#define FR_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    if (tid == 0 && fr_stamp_buf) fr_stamp_buf[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define FR_STAMP(k)
+#endif
+
 namespace {
 
 
@@ -149,8 +165,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
       st16(smem + ioff + gh * C::RSTR + gw * C::PSTR + ch * 16, x);
     }
   };
-  auto load_now = [&](int s) {  // stream the strip through 8 registers at a time
-    constexpr int UNR = 8;
+  auto load_now = [&](int s) {  // stream the strip through UNR registers at a time
+    // 4-wave workgroups (two per CU): the whole strip in ONE batch of <= 18 loads per thread.  In-kernel stamps
+    // (tools/stamps.py) showed the two batches of 8 of a 58-KB strip taking 5.4 us -- two HBM round trips with too
+    // few bytes in flight per CU -- next to 5.6 us of MFMA loop.
+    constexpr int PER = (TOTAL + NTH - 1) / NTH;
+    constexpr int UNR = (NW == 4 && PER <= 18) ? PER : 8;
     load_pro();
     for (int base = 0; base < TOTAL; base += NTH * UNR) {
       U128 v[UNR];
@@ -187,8 +207,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
     for (kc = 0; kc < KSPL; ++kc) {
     // ---------------------------------------------------------------- strip -> LDS (prologue applied once)
     __syncthreads();  // the previous strip's output tile has left LDS / the previous channel stage has been consumed
+    FR_STAMP(0);
     load_now(s);
+    FR_STAMP(1);
     __syncthreads();
+    FR_STAMP(2);
 
     // ---------------------------------------------------------------- main loop: 9 taps x CK/32, no barriers
     int abase[C::TM];  // LDS byte address of this lane's fragment for tap (0,0), channel chunk c0 = 0
@@ -262,7 +285,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
     }  // channel stages
 
     // ---------------------------------------------------------------- epilogue
+    FR_STAMP(3);
     __syncthreads();  // every wave is done with the input strip; LDS is now the output tile
+    FR_STAMP(4);
     const size_t rowbase = (size_t)(b * C::H + row0) * W;
     if (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD) {
       const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
@@ -353,10 +378,21 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
       default: cells(std::integral_constant<int, FR_EPI_STORE>{}); break;
     }
     __syncthreads();
+    FR_STAMP(5);
     for (int idx = tid; idx < C::M * OCH; idx += NTH) {
       const int r = idx / OCH, c8 = idx - r * OCH;
       st16(out + (rowbase + r) * (size_t)p.ldc + ncol0 + c8 * 8, ld16(smem + r * C::OSTR + c8 * 16));
     }
+    FR_STAMP(6);
+#ifdef FRHIP_STAMPS
+    if (tid == 0 && fr_stamp_buf) {
+      unsigned hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      fr_stamp_buf[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
     if (stats) {
       for (int c = tid; c < 2 * COUT; c += NTH) {
         const int k = c / COUT, n = c - k * COUT;
@@ -456,6 +492,7 @@ static int strip_rows(int Cin, int Cout, int W) {
 // Number of partial rows the kernel writes into `part` (= workgroups) for a supported shape, 0 if unsupported.
 extern "C" int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi) {
   if (Cin == 256 && Cout == 512 && W == 14 && epi != FR_EPI_STORE) return 0;
+  if (Cin == 64 && Cout == 64 && (W == 112 || W == 56) && fr_roll64_enabled()) return fr_roll64_parts(B, W);
   const int rows = strip_rows(Cin, Cout, W);
   if (Cin == 512 && Cout == 512 && W == 7 && strip_variant() >= 2 && B % 2 == 0) return B / 2;  // two images per strip
   return rows ? B * (W / rows) : 0;
@@ -468,6 +505,7 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
       a.out_f32 || a.splitk > 1 || a.bias || a.epi == FR_EPI_MARGIN || a.epi == FR_EPI_ATOMIC)
     FR_UNSUPPORTED("fr_conv3x3_strip: only square stride-1 3x3 bf16 convolutions");
   if (a.lda % 8 || a.ldc % 8 || (a.aux && a.ldaux % 8)) FR_UNSUPPORTED("fr_conv3x3_strip: strides must be 16-byte multiples");
+  if (a.SC == 64 && a.N == 64 && (a.SW == 112 || a.SW == 56) && fr_roll64_enabled()) return fr_roll64_launch(a, st);
   const bool v1 = strip_variant() >= 1;
 #define SHAPE(ci, co, w, rows, wn, nw) \
   if (a.SC == ci && a.N == co && a.SW == w) return by_pro<ci, co, w, rows, wn, nw>(a, st);

@@ -6,3 +6,8 @@
 
 // out[i] = sum_g slab[g][i] in the fixed order g = 0, 1, ... (n elements, n % 4 == 0); conv_wgrad_strip.hip
 int fr_launch_reduce_slabs(const float* slab, int groups, long long n, float* out, hipStream_t st);
+
+// 64 -> 64 stride-1 3x3 layers on the rolling-window kernel (conv3x3_roll64.hip); dispatched from fr_conv3x3_strip
+bool fr_roll64_enabled();
+int fr_roll64_parts(int B, int W);
+int fr_roll64_launch(const FrConvArgs& a, hipStream_t st);

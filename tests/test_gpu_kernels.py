@@ -569,7 +569,11 @@ STRIP_SHAPES = [(64, 64, 112), (64, 64, 56), (64, 128, 56), (128, 64, 56), (128,
 # B = 162 (> 160, even): the instances bench.py's B = 256 step runs -- conv3x3_strip_kernel<256,256,14,14,8,8,1,...>
 # (NSPL = 1, the kernel ``roofline.kernel`` names; B <= 160 takes the split-channel NSPL = 2 instance) and the
 # 256 -> 512 two-pass path built on it -- against CPU F.conv2d / autograd (~40 GFLOP on the host)
-STRIP_CASES = [s + (3,) for s in STRIP_SHAPES] + [(512, 512, 7, 4), (256, 256, 14, 162), (256, 512, 14, 162)]
+# 64 -> 64 (rolling-window kernel, conv3x3_roll64.hip): B = 3 walks 2-iteration row segments (14 per band); B = 162 @56
+# and B = 130 @112 give more work items than the 256 persistent workgroups (item loop, one 14- / 28-iteration walk per
+# item); B = 40 @56 takes 7-iteration segments
+STRIP_CASES = [s + (3,) for s in STRIP_SHAPES] + [(512, 512, 7, 4), (256, 256, 14, 162), (256, 512, 14, 162),
+                                                  (64, 64, 56, 162), (64, 64, 112, 130), (64, 64, 56, 40)]
 
 
 @pytest.mark.parametrize("cin,cout,W,B", STRIP_CASES, ids=["%d_%d_%d_b%d" % s for s in STRIP_CASES])
