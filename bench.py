@@ -12,9 +12,12 @@ all-reduce (N > 1), optimizer step -- everything the reference loop does per ite
 its three host syncs.  Rank 0 prints ONE JSON line.
 
 Besides the contract fields the line carries
-  roofline      dominant kernel (by time) of one event-instrumented step after the timed region: algorithmic
-                FLOPs of its launches / their summed duration, against the dense bf16 MFMA peak (2.5 PFLOP/s,
-                MI355X_MICROARCH.md); plus the whole-step fraction
+  roofline      dominant kernel FAMILY (by time; prologue variants of one template counted together) of one
+                event-instrumented step after the timed region: algorithmic FLOPs of its launches / their summed
+                duration, against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md); ``all_mfma`` = the same
+                quotient over EVERY MFMA launch of the step (convolutions, weight gradients, GEMMs); ``step_frac`` =
+                the whole step incl. the HBM-bound channel-wise passes; ``traffic`` = HBM bytes per launch of the
+                dominant family from the committed rocprofv3 --pmc passes (profiles/r02_pmc_kernels.json)
   cpu_baseline  the CPU oracle (oracle/irse_ref.py, a port of the reference's PyTorch path) timed on the host
                 cores of this box on a bounded sample of the same workload (N = 1, rank 0 only)
 """
@@ -228,13 +231,13 @@ def host_cores():
 
 def cpu_baseline(classes, seconds_budget=15.0):
     """The oracle (CPU port of the reference path) on this box's host cores: IR-50 + ArcFace + focal + SGD, fp32,
-    batch 16: one warm-up step, then as many timed steps as fit the budget (at least 1)."""
+    batch 32: one warm-up step, then as many timed steps as fit the budget (at least 1)."""
     from frhip import synth
     from oracle import irse_ref as O
     from backbone.model_irse import IR_50
     cores = host_cores()
     torch.set_num_threads(cores)
-    B = 16
+    B = 32
     sd = {k: v.detach().clone() for k, v in IR_50([112, 112]).state_dict().items()}
     synth.fill_state_dict(sd, 15)
     names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
@@ -340,31 +343,62 @@ def main():
         step_tflops = flops_img * ips / world / 1e12
         if fams is not None:
             table = sorted(fams.items(), key=lambda kv: -kv[1][1])
-            dom = next(((k, v) for k, v in table if v[2] > 0), None)
             total_ms = sum(v[1] for v in fams.values())
             if args.kernel_table:
                 with open(args.kernel_table, "w") as f:
                     d = {k: {"launches": v[0], "ms": round(v[1], 4), "tflops": round(v[2] / 1e12, 4)} for k, v in table}
                     d["_launch_detail"] = getattr(instrumented_step, "detail", [])
                     json.dump(d, f, indent=1)
-            if dom is not None:
-                name, (cnt, kms, flops) = dom
+            # families: the prologue is a template argument of the same kernel -- count its variants together
+            import re
+            groups = {}
+            for k, v in fams.items():
+                if v[2] <= 0:
+                    continue
+                base = re.sub(r",PRO=\d", "", k)
+                g = groups.setdefault(base, [0, 0.0, 0.0, {}])
+                g[0] += v[0]
+                g[1] += v[1]
+                g[2] += v[2]
+                g[3][k] = v[0]
+            mf_ms = sum(g[1] for g in groups.values())
+            mf_flops = sum(g[2] for g in groups.values())
+            if groups:
+                name, (cnt, kms, flops, members) = max(groups.items(), key=lambda kv: kv[1][1])
                 ach = flops / (kms * 1e-3) / 1e12
+                all_ach = mf_flops / (mf_ms * 1e-3) / 1e12
                 out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                    "frac": round(ach / peak, 4), "traffic": None, "kernel": name, "launches": cnt,
                                    "avg_launch_ms": round(kms / cnt, 4),
                                    "share_of_step": round(kms / total_ms, 3),
+                                   "all_mfma": {"achieved": round(all_ach, 2), "frac": round(all_ach / peak, 4),
+                                                "ms": round(mf_ms, 3), "share_of_step": round(mf_ms / total_ms, 3),
+                                                "launches": sum(g[0] for g in groups.values())},
+                                   "channelwise_ms": round(sum(v[1] for k, v in fams.items() if k.startswith(
+                                       ("fr_bn_", "fr_reduce_parts", "fr_channel_stats", "fr_se_"))), 3),
+                                   "step_kernel_ms_single_stream": round(total_ms, 3),
                                    "step_achieved": round(step_tflops, 2), "step_frac": round(step_tflops / peak, 4)}
                 # HBM bytes per launch cannot be counted from inside this process; they come from the committed
-                # rocprofv3 --pmc passes on the same kernel instance (tools/pmc_traffic.py writes the summary)
-                pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_dominant_kernel.json")
-                if os.path.exists(pmc):
+                # rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections) over the same
+                # kernel instances (tools/pmc_round.sh + tools/pmc_summary.py), averaged over this family's launches
+                pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_kernels.json")
+                m = re.match(r"conv3x3_strip<(\d+),(\d+),(\d+)>", name)
+                if os.path.exists(pmc) and m:
                     with open(pmc) as f:
-                        rec = json.load(f)
-                    if rec.get("kernel") == name:
-                        out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
-                        out["roofline"]["traffic_algorithmic"] = rec["algorithmic_bytes_per_launch"]
-                        out["roofline"]["traffic_source"] = "profiles/r01_pmc_dominant_kernel.json"
+                        recs = {r["kernel"]: r for r in json.load(f)["kernels"]}
+                    pre = "strip_%s_%s_%s_" % m.groups()
+                    by_pro = {0: pre + "dgrad", 1: pre + "fwd_bn", 2: pre + "fwd_prelu"}
+                    num = den = alg = 0.0
+                    for member, n in members.items():
+                        r = recs.get(by_pro.get(int(member[-2]), ""))
+                        if r and "hbm_bytes" in r:
+                            num += n * r["hbm_bytes"]
+                            alg += n * r["algorithmic_bytes"]
+                            den += n
+                    if den:
+                        out["roofline"]["traffic"] = int(num / den)
+                        out["roofline"]["traffic_algorithmic"] = int(alg / den)
+                        out["roofline"]["traffic_source"] = "profiles/r02_pmc_kernels.json"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.classes)
         print(json.dumps(out))

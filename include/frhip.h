@@ -37,6 +37,9 @@ enum {
   FR_EPI_BNBWD = 3,     /* out = acc; part[.][0] = sum acc; part[.][1] = sum acc*(aux-epi_a[n])*epi_b[n] */
   FR_EPI_MARGIN = 4,    /* out = scale*(n==label[m] ? phi(acc) : acc); cos_t[m] = acc[label] */
   FR_EPI_ATOMIC = 5,    /* atomicAdd(out, acc) fp32; used with splitk > 1 (summation order not reproducible) */
+  FR_EPI_BIAS_RES = 7,  /* out = acc + epi_a[n] + epi_b[n] + aux[m][n]: inference with BatchNorm folded into the weights
+                           (util/utils.py:254-307 runs the backbone in eval mode): epi_a / epi_b = the folded BN shifts of
+                           the residual branch and of the conv shortcut (both required; pass zeros), aux = the shortcut */
   FR_EPI_SLAB = 6       /* split-K slice z stores its fp32 partial (+bias in slice 0) to out[z][rows][ldc]: the caller
                            adds the splitk slabs with fr_reduce_parts(out, splitk, 1, rows*ldc, ...) -- reproducible */
 };
@@ -222,6 +225,21 @@ int fr_reduce_parts(const float* part, int nparts, int K, int C, float* o0, floa
 /* eval-mode BatchNorm coefficients from the running statistics */
 int fr_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
                       float eps, int C, float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* the same for every BatchNorm of a network in one launch (inference: util/utils.py:254-307 evaluates the backbone in
+ * eval mode once per epoch on ~50 k images; 53 separate coefficient launches per forward were most of its launches) */
+typedef struct FrBnEvalEntry {
+  const float* rm;
+  const float* rv;
+  const float* gamma;
+  const float* beta;
+  float* mean;
+  float* invstd;
+  float* scale;
+  float* shift;
+  int32_t C;
+  float eps;
+} FrBnEvalEntry;
+int fr_bn_eval_coeffs_multi(const FrBnEvalEntry* table_dev, int n, void* stream);
 
 /* ---- SE block (model_irse.py:23-46 / restyle_psp_helpers.py:67-83) */
 /* pooled[b][c] = mean_hw (x*scale+shift)  */
@@ -260,6 +278,7 @@ typedef struct FrPackTensor {
   void* wp; /* may be NULL */
   void* wt; /* may be NULL */
   int32_t Cout, taps, Cin, pad_;
+  const float* oscale; /* [Cout] or NULL: wp = w * oscale[co] (BatchNorm scale folded into the output channels) */
 } FrPackTensor;
 int fr_pack_weights_multi(const FrPackTensor* table_dev, const int32_t* chunks_dev, int nchunks, int dtype,
                           void* stream);

@@ -81,11 +81,12 @@ FrBnBwdArgs = structs["FrBnBwdArgs"]
 FrSgdTensor = structs["FrSgdTensor"]
 FrPackTensor = structs["FrPackTensor"]
 FrAdamTensor = structs["FrAdamTensor"]
+FrBnEvalEntry = structs["FrBnEvalEntry"]
 
 # enums of the header
 FR_F32, FR_BF16 = 0, 1
 PRO_NONE, PRO_BN, PRO_PRELU = 0, 1, 2
-EPI_STORE, EPI_STATS, EPI_PRELU_BWD, EPI_BNBWD, EPI_MARGIN, EPI_ATOMIC, EPI_SLAB = range(7)
+EPI_STORE, EPI_STATS, EPI_PRELU_BWD, EPI_BNBWD, EPI_MARGIN, EPI_ATOMIC, EPI_SLAB, EPI_BIAS_RES = range(8)
 
 
 class FrhipError(RuntimeError):
@@ -110,7 +111,7 @@ lib = _load()
 
 def self_check():
     assert lib.fr_abi_version() == 1
-    for i, s in enumerate((FrConvArgs, FrWgradArgs, FrApplyArgs, FrBnBwdArgs, FrSgdTensor, FrPackTensor, FrAdamTensor)):
+    for i, s in enumerate((FrConvArgs, FrWgradArgs, FrApplyArgs, FrBnBwdArgs, FrSgdTensor, FrPackTensor, FrAdamTensor, FrBnEvalEntry)):
         got = lib.fr_struct_size(i)
         if got != ctypes.sizeof(s):
             raise FrhipError("frhip: struct %s is %d bytes in libfrhip.so but %d in the ctypes binding"

@@ -21,6 +21,7 @@ extern "C" int fr_struct_size(int which) {
     case 4: return (int)sizeof(FrSgdTensor);
     case 5: return (int)sizeof(FrPackTensor);
     case 6: return (int)sizeof(FrAdamTensor);
+    case 7: return (int)sizeof(FrBnEvalEntry);
   }
   return -1;
 }

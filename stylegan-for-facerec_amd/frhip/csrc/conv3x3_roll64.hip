@@ -89,7 +89,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_roll64_kernel(const FrConvArgs
     coef[tid] = PRO != FR_PRO_NONE ? p.pro_a[tid] : 0.f;
     coef[K::C + tid] = PRO == FR_PRO_BN ? p.pro_b[tid] : 0.f;
     coef[2 * K::C + tid] = AUX ? p.epi_a[tid] : 0.f;
-    coef[3 * K::C + tid] = (AUX && epi == FR_EPI_BNBWD) ? p.epi_b[tid] : 0.f;
+    coef[3 * K::C + tid] = (AUX && (epi == FR_EPI_BNBWD || epi == FR_EPI_BIAS_RES)) ? p.epi_b[tid] : 0.f;
   }
   __syncthreads();
 
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_roll64_kernel(const FrConvArgs
 #pragma unroll
         for (int j = 0; j < K::TN; ++j) {
           float ea[4], eb[4];  // from LDS per use rather than live across the MFMA loop
-          if (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD) {
+          if (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD || E == FR_EPI_BIAS_RES) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(coef + 2 * K::C + n0 + j * 16 + fq * 4);
             const f32x4 t2 = *reinterpret_cast<const f32x4*>(coef + 3 * K::C + n0 + j * 16 + fq * 4);
 #pragma unroll
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_roll64_kernel(const FrConvArgs
             float v[4], x[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-            if (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD) {
+            if (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD || E == FR_EPI_BIAS_RES) {
               const uint2 u = *cell;
               x[0] = __uint_as_float(u.x << 16);
               x[1] = __uint_as_float(u.x & 0xFFFF0000u);
@@ -407,6 +407,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_roll64_kernel(const FrConvArgs
               } else if (E == FR_EPI_BNBWD) {
                 s0[j][r] += v[r];
                 s1[j][r] = fmaf(v[r], (x[r] - ea[r]) * eb[r], s1[j][r]);
+              } else if (E == FR_EPI_BIAS_RES) {
+                v[r] += ea[r] + eb[r] + x[r];
               }
             }
             uint2 o;
@@ -418,7 +420,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_roll64_kernel(const FrConvArgs
       };
       if (AUX) {
         if (epi == FR_EPI_PRELU_BWD) cells(std::integral_constant<int, FR_EPI_PRELU_BWD>{});
-        else cells(std::integral_constant<int, FR_EPI_BNBWD>{});
+        else if (epi == FR_EPI_BNBWD) cells(std::integral_constant<int, FR_EPI_BNBWD>{});
+        else cells(std::integral_constant<int, FR_EPI_BIAS_RES>{});
       } else {
         if (epi == FR_EPI_STATS) cells(std::integral_constant<int, FR_EPI_STATS>{});
         else cells(std::integral_constant<int, FR_EPI_STORE>{});
@@ -437,7 +440,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_roll64_kernel(const FrConvArgs
 
     // ---------------------------------------------------------------- one partial row per work item
     float* red = reinterpret_cast<float*>(smem + K::RED_OFF);
-    if (epi != FR_EPI_STORE) {
+    const bool sums = epi != FR_EPI_STORE && epi != FR_EPI_BIAS_RES;
+    if (sums) {
 #pragma unroll
       for (int j = 0; j < K::TN; ++j)
 #pragma unroll
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_roll64_kernel(const FrConvArgs
         }
     }
     __syncthreads();  // end of item (matches the data-moving waves)
-    if (epi != FR_EPI_STORE && tid < 2 * K::C) {
+    if (sums && tid < 2 * K::C) {
       const int k = tid / K::C, n = tid - k * K::C;
       p.part[((size_t)item * 2 + k) * K::C + n] = red[(0 * 2 + k) * K::C + n] + red[(1 * 2 + k) * K::C + n];
     }
@@ -498,10 +502,14 @@ int launch(const FrConvArgs& a, hipStream_t st) {
 
 template <int W>
 int by_pro(const FrConvArgs& a, hipStream_t st) {
-  const bool aux = a.epi == FR_EPI_PRELU_BWD || a.epi == FR_EPI_BNBWD;
-  if (aux) {  // the fused backward epilogues come with the data gradients, which have no prologue
+  if (a.epi == FR_EPI_PRELU_BWD || a.epi == FR_EPI_BNBWD) {
+    // the fused backward epilogues come with the data gradients, which have no prologue
     if (a.pro != FR_PRO_NONE || !a.aux) return -1;
     return launch<W, FR_PRO_NONE, true>(a, st);
+  }
+  if (a.epi == FR_EPI_BIAS_RES) {  // inference conv2: PReLU prologue, folded shifts + shortcut epilogue
+    if (a.pro != FR_PRO_PRELU || !a.aux || !a.epi_a || !a.epi_b) return -1;
+    return launch<W, FR_PRO_PRELU, true>(a, st);
   }
   switch (a.pro) {
     case FR_PRO_NONE: return launch<W, FR_PRO_NONE, false>(a, st);

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
       if (KIND == 0) return (size_t)(b * C::HL + row0 + h) * WL + w;
       return (size_t)(b * 2 * C::HL + 2 * (row0 + h) + ph) * (2 * WL) + 2 * w + pw;
     };
-    if (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD) {
+    if (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD || epi == FR_EPI_BIAS_RES) {
       const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
       for (int idx = tid; idx < C::M * OCH; idx += NTH) {
         const int r = idx / OCH, c8 = idx - r * OCH;
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
   #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int n = n0 + j * 16 + fq * 4 + r;
-          ea[j][r] = (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD) ? p.epi_a[n] : 0.f;
-          eb[j][r] = (E == FR_EPI_BNBWD) ? p.epi_b[n] : 0.f;
+          ea[j][r] = (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD || E == FR_EPI_BIAS_RES) ? p.epi_a[n] : 0.f;
+          eb[j][r] = (E == FR_EPI_BNBWD || E == FR_EPI_BIAS_RES) ? p.epi_b[n] : 0.f;
           s0[j][r] = s1[j][r] = 0.f;
         }
   #pragma unroll
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
           float v[4], x[4];
   #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-          if (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD) {
+          if (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD || E == FR_EPI_BIAS_RES) {
             const uint2 u = *cell;
             x[0] = __uint_as_float(u.x << 16);
             x[1] = __uint_as_float(u.x & 0xFFFF0000u);
@@ -291,6 +291,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
             } else if (E == FR_EPI_BNBWD) {
               s0[j][r] += v[r];
               s1[j][r] = fmaf(v[r], (x[r] - ea[j][r]) * eb[j][r], s1[j][r]);
+            } else if (E == FR_EPI_BIAS_RES) {
+              v[r] += ea[j][r] + eb[j][r] + x[r];
             }
           }
           uint2 o;
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
           *cell = o;
         }
       }
-      if (E != FR_EPI_STORE) {
+      if (E != FR_EPI_STORE && E != FR_EPI_BIAS_RES) {
   #pragma unroll
         for (int j = 0; j < C::TN; ++j)
   #pragma unroll
@@ -321,6 +323,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
       case FR_EPI_STATS: cells(std::integral_constant<int, FR_EPI_STATS>{}); break;
       case FR_EPI_PRELU_BWD: cells(std::integral_constant<int, FR_EPI_PRELU_BWD>{}); break;
       case FR_EPI_BNBWD: cells(std::integral_constant<int, FR_EPI_BNBWD>{}); break;
+      case FR_EPI_BIAS_RES: cells(std::integral_constant<int, FR_EPI_BIAS_RES>{}); break;
       default: cells(std::integral_constant<int, FR_EPI_STORE>{}); break;
     }
     __syncthreads();

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
     __syncthreads();  // every wave is done with the input strip; LDS is now the output tile
     FR_STAMP(4);
     const size_t rowbase = (size_t)(b * C::H + row0) * W;
-    if (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD) {
+    if (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD || epi == FR_EPI_BIAS_RES) {
       const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
       for (int idx = tid; idx < C::M * OCH; idx += NTH) {
         const int r = idx / OCH, c8 = idx - r * OCH;
@@ -311,8 +311,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
   #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int n = ncol0 + n0 + j * 16 + fq * 4 + r;
-          ea[j][r] = (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD) ? p.epi_a[n] : 0.f;
-          eb[j][r] = (E == FR_EPI_BNBWD) ? p.epi_b[n] : 0.f;
+          ea[j][r] = (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD || E == FR_EPI_BIAS_RES) ? p.epi_a[n] : 0.f;
+          eb[j][r] = (E == FR_EPI_BNBWD || E == FR_EPI_BIAS_RES) ? p.epi_b[n] : 0.f;
           s0[j][r] = s1[j][r] = 0.f;
         }
   #pragma unroll
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
           float v[4], x[4];
   #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-          if (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD) {
+          if (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD || E == FR_EPI_BIAS_RES) {
             const uint2 u = *cell;
             x[0] = __uint_as_float(u.x << 16);
             x[1] = __uint_as_float(u.x & 0xFFFF0000u);
@@ -344,6 +344,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
             } else if (E == FR_EPI_BNBWD) {
               s0[j][r] += v[r];
               s1[j][r] = fmaf(v[r], (x[r] - ea[j][r]) * eb[j][r], s1[j][r]);
+            } else if (E == FR_EPI_BIAS_RES) {
+              v[r] += ea[j][r] + eb[j][r] + x[r];
             }
           }
           uint2 o;
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
         }
       }
       // column sums: fold the 16 pixel lanes (fr), then the WM row groups through LDS (behind the output tile)
-      if (E != FR_EPI_STORE) {
+      if (E != FR_EPI_STORE && E != FR_EPI_BIAS_RES) {
   #pragma unroll
         for (int j = 0; j < C::TN; ++j)
   #pragma unroll
@@ -375,6 +377,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
       case FR_EPI_STATS: cells(std::integral_constant<int, FR_EPI_STATS>{}); break;
       case FR_EPI_PRELU_BWD: cells(std::integral_constant<int, FR_EPI_PRELU_BWD>{}); break;
       case FR_EPI_BNBWD: cells(std::integral_constant<int, FR_EPI_BNBWD>{}); break;
+      case FR_EPI_BIAS_RES: cells(std::integral_constant<int, FR_EPI_BIAS_RES>{}); break;
       default: cells(std::integral_constant<int, FR_EPI_STORE>{}); break;
     }
     __syncthreads();

@@ -268,11 +268,11 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
     eb[j] = 0.f;
     if (n < p.N) {
       if (epi == FR_EPI_PRELU_BWD) ea[j] = p.epi_a[n];
-      if (epi == FR_EPI_BNBWD) {
+      if (epi == FR_EPI_BNBWD || epi == FR_EPI_BIAS_RES) {
         ea[j] = p.epi_a[n];
         eb[j] = p.epi_b[n];
       }
-      if (p.bias) eb[j] = (epi == FR_EPI_BNBWD) ? eb[j] : p.bias[n];
+      if (p.bias) eb[j] = (epi == FR_EPI_BNBWD || epi == FR_EPI_BIAS_RES) ? eb[j] : p.bias[n];
     }
   }
 
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
           if (full || n + j < p.N) o[j] = v[j];
         continue;
       }
-      if (p.bias && epi != FR_EPI_BNBWD) {
+      if (p.bias && epi != FR_EPI_BNBWD && epi != FR_EPI_BIAS_RES) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) v[j] += eb[j];
       }
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
           s0[j] += v[j];
           s1[j] = fmaf(v[j], v[j], s1[j]);
         }
-      } else if (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD) {
+      } else if (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD || epi == FR_EPI_BIAS_RES) {
         float x[VEC];
         const T* ap = reinterpret_cast<const T*>(p.aux) + mrow * (size_t)p.ldaux + n;
         if (full) {
@@ -349,7 +349,11 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) x[j] = (n + j < p.N) ? Elt<T>::ld(ap + j) : 0.f;
         }
-        if (epi == FR_EPI_PRELU_BWD) {
+        if (epi == FR_EPI_BIAS_RES) {
+          // inference, BatchNorm folded into the weights: + folded shifts + shortcut
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[j] += ea[j] + eb[j] + x[j];
+        } else if (epi == FR_EPI_PRELU_BWD) {
           // g_y = g_a * prelu'(y);  d slope += g_a * y  for y <= 0   
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {

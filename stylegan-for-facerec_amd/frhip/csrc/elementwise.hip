@@ -864,6 +864,7 @@ __global__ void pack_weights_multi_kernel(const FrPackTensor* __restrict__ table
     float v = 0.f;
     if (co < t.Cout && ci < t.Cin) {
       v = t.w[((size_t)co * t.taps + tap) * t.Cin + ci];
+      if (t.oscale) v *= t.oscale[co];  // inference: BatchNorm scale of the layer's output folded into the weights
       if (wp) Elt<T>::st(wp + ((size_t)co * t.taps + tap) * t.Cin + ci, v);
     }
     tile[r][tx] = v;
@@ -1024,6 +1025,25 @@ extern "C" int fr_bn_finalize(const float* part, int nparts, int C, double count
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(RT), 0, (hipStream_t)stream, part, nparts, C,
                      count, gamma, beta, eps, momentum, running_mean, running_var, (long long*)nbt, mean, invstd,
                      scale, shift);
+  FR_LAUNCH_CHECK();
+}
+
+namespace {
+__global__ void bn_eval_coeffs_multi_kernel(const FrBnEvalEntry* __restrict__ table) {
+  const FrBnEvalEntry e = table[blockIdx.x];
+  for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
+    const float is = 1.0f / sqrtf(e.rv[c] + e.eps);
+    e.mean[c] = e.rm[c];
+    e.invstd[c] = is;
+    e.scale[c] = e.gamma[c] * is;
+    e.shift[c] = e.beta[c] - e.rm[c] * e.gamma[c] * is;
+  }
+}
+}  // namespace
+
+extern "C" int fr_bn_eval_coeffs_multi(const FrBnEvalEntry* table_dev, int n, void* stream) {
+  if (n < 1) return 0;
+  hipLaunchKernelGGL(bn_eval_coeffs_multi_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, table_dev);
   FR_LAUNCH_CHECK();
 }
 

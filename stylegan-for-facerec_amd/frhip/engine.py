@@ -194,8 +194,15 @@ def _side_stream(device, priority):
 
 
 class BackbonePlan(object):
-    def __init__(self, module, B, dtype, device, in_channels, avg_channels, single_stream=False):
+    def __init__(self, module, B, dtype, device, in_channels, avg_channels, single_stream=False, infer=False):
         self.module, self.B, self.device = module, B, device
+        # infer: forward only (no gradient arena, no backward scratch, no backward list).  fold: additionally every
+        # BatchNorm runs on its running statistics, so BN2 / the shortcut BN are folded into the packed conv weights and
+        # the residual add moves into conv2's epilogue (reference: util/utils.py:254-307 evaluates in eval mode).
+        self.infer = infer
+        self.fold = infer and all(not m.training for m in module.modules()
+                                  if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d))) and \
+            os.environ.get("FRHIP_NO_FOLD", "0") != "1"
         self.tdtype = dtype
         self.fr = FR_F32 if dtype == torch.float32 else FR_BF16
         self.esz = 4 if dtype == torch.float32 else 2
@@ -225,7 +232,8 @@ class BackbonePlan(object):
         self._alloc()
         self._bind_params()
         self._build_forward()
-        self._build_backward()
+        if not self.infer:
+            self._build_backward()
 
     # ---- buffers -----------------------------------------------------------------------------------
     def _act(self, rows, C):
@@ -267,6 +275,10 @@ class BackbonePlan(object):
                 if self.fr == FR_BF16:
                     d["wpS"] = torch.empty(u.depth, 1, u.cin, device=dev, dtype=self.tdtype)
                 max_xs = max(max_xs, rin * u.cin)
+            if self.fold and u.se is None:
+                d["wf2"] = torch.empty(u.depth, 9, u.depth, device=dev, dtype=self.tdtype)
+                if u.sc_conv is not None:
+                    d["wfS"] = torch.empty(u.depth, 1, u.cin, device=dev, dtype=self.tdtype)
             if u.se is not None:
                 R = u.se.fc1.out_channels
                 for k, n in (("pooled", u.depth), ("s", u.depth), ("gs", u.depth), ("gpooled", u.depth), ("hidden", R),
@@ -287,6 +299,10 @@ class BackbonePlan(object):
         self.Wlin = torch.empty(512, self.feat_in, device=dev, dtype=self.tdtype)
         self.WlinT = torch.empty(self.feat_in, 512, device=dev, dtype=self.tdtype)
         self.gWlin = torch.zeros(512, self.feat_in, device=dev)
+        self.zeros_c = torch.zeros(512, device=dev)
+        if self.infer:
+            self.part = torch.zeros(max(4 * 1024 * 1024, ((M0 + 127) // 128) * 2 * 64 + 4096), device=dev)
+            return
         # backward scratch (sized for the largest unit)
         self.g_pp = [self._act(max_in, 1).view(-1), self._act(max_in, 1).view(-1)]   # unit input/output gradients
         # gradients consumed by the side-stream wgrads are double-buffered by unit parity (the next unit must not
@@ -309,7 +325,6 @@ class BackbonePlan(object):
         if self.side_slope:
             self.part_slope = [torch.zeros_like(self.part), torch.zeros_like(self.part)]
         self.se_scratch = torch.zeros(2, 512 * 64, device=dev)  # dW1/dW2 sink while the SE weights are frozen
-        self.zeros_c = torch.zeros(512, device=dev)
         self.sums = torch.zeros(3, 512, device=dev)      # scratch reduce target for frozen parameters
         self.nbt_dummy = None
 
@@ -336,6 +351,10 @@ class BackbonePlan(object):
     def _bind_params(self):
         """(Re)create the flat gradient arena and remember parameter storage addresses."""
         params = self._param_list()
+        if self.infer:
+            self.arena, self.gviews, self.arena_slices = None, {}, []
+            self.param_sig = self._signature()
+            return
         total = sum((p.numel() + 63) // 64 * 64 for p in params)
         self.arena = torch.zeros(total, device=self.device)
         self.arena._frhip_grad_arena = True  # lets frhip.optim.SGD.zero_grad clear all views with one fill
@@ -448,6 +467,9 @@ class BackbonePlan(object):
     def _bn_train_launches(self, L, bn, part, nparts, count):
         m = bn.mod
         st = self.stream
+        if self.fold:  # one fr_bn_eval_coeffs_multi launch in front of the weight packing covers every BatchNorm
+            self._fold_bns.append(bn)
+            return
         if m.training:
             L.append(ops.call("fr_bn_finalize", part, nparts, bn.C, float(count), m.weight, m.bias, float(m.eps),
                               float(m.momentum if m.momentum is not None else 0.1),
@@ -463,7 +485,11 @@ class BackbonePlan(object):
         B, S, st, fr = self.B, self.S, self.stream, self.fr
         P = []  # weight packing (runs every step: master weights change)
         L = []
-        self._pack_reqs = []  # (master, wp|None, wt|None, Cout, taps, Cin) -> one multi-tensor launch
+        self._pack_reqs = []  # (master, wp|None, wt|None, Cout, taps, Cin[, oscale]) -> one multi-tensor launch
+        self._fold_bns = []   # fold mode: every BatchNorm whose eval coefficients the multi launch computes
+        fold = self.fold
+        stats_epi = ops.EPI_STORE if fold else ops.EPI_STATS  # eval mode: nobody reads the partial sums
+        stats_part = None if fold else self.part
         sc, sb, sp = self.stem
         # ---- stem: im2col -> GEMM(+stats) -> BN+PReLU apply (+stats for unit 0's BN1)
         w0 = sc.weight
@@ -482,7 +508,7 @@ class BackbonePlan(object):
         nb = ops.grid_blocks(self.M0, 64, fr)
         first_bn = self.ubuf[0]["bn1"]
         L.append(ops.bn_apply(st, fr, x=self.y0, out=self.z0, scale=self.bn0.scale, shift=self.bn0.shift,
-                              slope=sp.weight, part=self.part, B=B, H=S, W=S, C=64, res_kind=0, res_stride=1,
+                              slope=sp.weight, part=stats_part, B=B, H=S, W=S, C=64, res_kind=0, res_stride=1,
                               nblocks=nb))
         self._bn_train_launches(L, first_bn, self.part, nb, self.M0)
         x = self.z0
@@ -502,12 +528,35 @@ class BackbonePlan(object):
             self._conv(L, src=x, w=wp1, out=d["y1"], B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H, SC=u.cin,
                        N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.cin, ldc=u.depth,
                        pro=ops.PRO_BN, pro_a=bn1.scale, pro_b=bn1.shift, epi=ops.EPI_STORE)
+            folded = fold and u.se is None and (u.sc_conv is not None or u.stride == 1)
+            if folded:
+                # inference with BN2 (and the shortcut BN) folded into the packed weights: out = conv2'(PReLU(y1)) +
+                # shift2 [+ shiftS] + shortcut straight from conv2's epilogue -- y2 is never written, no BN-apply pass
+                self._fold_bns += [bn2] + ([d["bnS"]] if u.sc_conv is not None else [])
+                self._pack_reqs.append((w2, d["wf2"], None, u.depth, 9, u.depth, bn2.scale))
+                if u.sc_conv is not None:
+                    ws = self._conv_master(u.sc_conv)
+                    self._pack_reqs.append((ws, d["wfS"], None, u.depth, 1, u.cin, d["bnS"].scale))
+                    L.append(ops.conv(st, fr, src=x, w=d["wfS"], out=d["yS"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H,
+                                      SC=u.cin, N=u.depth, KH=1, KW=1, stride=u.stride, pad=0, mode=0, lda=u.cin,
+                                      ldc=u.depth, pro=0, epi=ops.EPI_STORE))
+                    res, shift_s = d["yS"], d["bnS"].shift
+                else:
+                    res, shift_s = x, self.zeros_c[:u.depth]
+                self._conv(L, src=d["y1"], w=d["wf2"], out=d["out"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H, SC=u.depth,
+                           N=u.depth, KH=3, KW=3, stride=u.stride, pad=1, mode=0, lda=u.depth, ldc=u.depth,
+                           ldaux=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight, epi=ops.EPI_BIAS_RES, epi_a=bn2.shift,
+                           epi_b=shift_s, aux=res)
+                nxt = self.ubuf[i + 1]["bn1"] if i + 1 < len(self.units) else self.bn_out
+                self._bn_train_launches(L, nxt, None, 0, rout)
+                x = d["out"]
+                continue
             np2 = self._conv(L, src=d["y1"], w=wp2, out=d["y2"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H,
                              SC=u.depth, N=u.depth, KH=3, KW=3, stride=u.stride, pad=1, mode=0, lda=u.depth,
-                             ldc=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight, epi=ops.EPI_STATS,
-                             part=self.part)
+                             ldc=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight, epi=stats_epi,
+                             part=stats_part)
             self._bn_train_launches(L, bn2, self.part, np2, rout)
-            strips2 = self._last_conv_strips  # conv2's partial rows, if they are whole strips of single images
+            strips2 = self._last_conv_strips if not fold else 0  # conv2's partial rows, if they are whole strips of single images
             if u.sc_conv is not None:
                 ws = self._conv_master(u.sc_conv)
                 if fr == FR_BF16:
@@ -518,7 +567,7 @@ class BackbonePlan(object):
                     wps = ws
                 L.append(ops.conv(st, fr, src=x, w=wps, out=d["yS"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H, SC=u.cin,
                                   N=u.depth, KH=1, KW=1, stride=u.stride, pad=0, mode=0, lda=u.cin, ldc=u.depth,
-                                  pro=0, epi=ops.EPI_STATS, part=self.part))
+                                  pro=0, epi=stats_epi, part=stats_part))
                 self._bn_train_launches(L, d["bnS"], self.part, (rout + 127) // 128, rout)
             if u.se is not None:
                 R = u.se.fc1.out_channels
@@ -532,7 +581,7 @@ class BackbonePlan(object):
                 L.append(ops.call("fr_se_mlp_fwd", d["pooled"], u.se.fc1.weight, u.se.fc2.weight, d["hidden"],
                                   d["s"], B, u.depth, R, st))
             nb = ops.grid_blocks(rout, u.depth, fr)
-            kw = dict(x=d["y2"], out=d["out"], scale=bn2.scale, shift=bn2.shift, part=self.part, B=B, H=u.Ho, W=u.Ho,
+            kw = dict(x=d["y2"], out=d["out"], scale=bn2.scale, shift=bn2.shift, part=stats_part, B=B, H=u.Ho, W=u.Ho,
                       C=u.depth, nblocks=nb)
             if u.se is not None:
                 kw["se"] = d["s"]
@@ -563,11 +612,14 @@ class BackbonePlan(object):
                           epi=ops.EPI_SLAB, out_f32=1, splitk=self.lin_splitk, bias=ol.bias))
         L.append(ops.call("fr_reduce_parts", self.lin_slab, self.lin_splitk, 1, B * 512, self.f, None, None, st))
         nbf = ops.grid_blocks(B, 512, FR_F32)
-        L.append(ops.call("fr_channel_stats", self.f, B, 512, self.part, nbf, FR_F32, st))
+        if not fold:
+            L.append(ops.call("fr_channel_stats", self.f, B, 512, self.part, nbf, FR_F32, st))
         self._bn_train_launches(L, self.bn1d, self.part, nbf, B)
         L.append(ops.bn_apply(st, FR_F32, x=self.f, out=self.feat, scale=self.bn1d.scale, shift=self.bn1d.shift, B=B,
                               H=1, W=1, C=512, res_kind=0, res_stride=1, nblocks=nbf))
         P.append(self._pack_launch())
+        if fold:  # the coefficients feed the weight folding: first launch of the step
+            P.insert(0, self._eval_coeffs_launch())
         self.pack_list, self.fwd_list = P, L
 
     def _pack_launch(self):
@@ -575,8 +627,12 @@ class BackbonePlan(object):
         n = len(self._pack_reqs)
         arr = (_lib.FrPackTensor * n)()
         chunks = []
-        for i, (w, wp, wt, cout, taps, cin) in enumerate(self._pack_reqs):
-            arr[i].w, arr[i].wp, arr[i].wt = w.data_ptr(), (wp.data_ptr() if wp is not None else None), wt.data_ptr()
+        for i, req in enumerate(self._pack_reqs):
+            w, wp, wt, cout, taps, cin = req[:6]
+            arr[i].w = w.data_ptr()
+            arr[i].wp = wp.data_ptr() if wp is not None else None
+            arr[i].wt = wt.data_ptr() if wt is not None else None
+            arr[i].oscale = req[6].data_ptr() if len(req) > 6 else None
             arr[i].Cout, arr[i].taps, arr[i].Cin = cout, taps, cin
             tiles = taps * ((cout + 31) // 32) * ((cin + 31) // 32)
             chunks.extend((i, t) for t in range(tiles))
@@ -585,6 +641,25 @@ class BackbonePlan(object):
         table = ctypes.cast(ctypes.c_void_p(self._pack_table.data_ptr()), ctypes.POINTER(_lib.FrPackTensor))
         return ops.Launch("fr_pack_weights_multi", [table, ops.ptr(self._pack_chunks), len(chunks), self.fr,
                                                     self.stream], keep=(self._pack_reqs,))
+
+    def _eval_coeffs_launch(self):
+        """One launch that turns the running statistics of every BatchNorm into (mean, invstd, scale, shift)."""
+        seen, bns = set(), []
+        for bn in self._fold_bns:
+            if id(bn) not in seen:
+                seen.add(id(bn))
+                bns.append(bn)
+        arr = (_lib.FrBnEvalEntry * len(bns))()
+        for i, bn in enumerate(bns):
+            m = bn.mod
+            arr[i].rm, arr[i].rv = m.running_mean.data_ptr(), m.running_var.data_ptr()
+            arr[i].gamma, arr[i].beta = m.weight.data_ptr(), m.bias.data_ptr()
+            arr[i].mean, arr[i].invstd = bn.mean.data_ptr(), bn.invstd.data_ptr()
+            arr[i].scale, arr[i].shift = bn.scale.data_ptr(), bn.shift.data_ptr()
+            arr[i].C, arr[i].eps = bn.C, float(m.eps)
+        self._bn_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        table = ctypes.cast(ctypes.c_void_p(self._bn_table.data_ptr()), ctypes.POINTER(_lib.FrBnEvalEntry))
+        return ops.Launch("fr_bn_eval_coeffs_multi", [table, len(bns), self.stream], keep=(bns,))
 
     # ---- backward ----------------------------------------------------------------------------------
     def _reduce(self, L, nparts, K, C, o0, o1, o2=None):
@@ -849,8 +924,9 @@ class BackbonePlan(object):
         p = float(od.p) if od.training else 0.0
         self.l_drop_fwd.args[7] = p
         self.l_drop_fwd.args[8] = seed
-        self.l_drop_bwd.args[4] = p
-        self.l_drop_bwd.args[5] = seed
+        if not self.infer:
+            self.l_drop_bwd.args[4] = p
+            self.l_drop_bwd.args[5] = seed
         ops.run(self.pack_list)
         ops.run(self.fwd_list)
         self.generation += 1
@@ -924,19 +1000,19 @@ class BackboneRunner(object):
         self.single_stream = False  # True: weight gradients stay on the main stream (per-kernel profiling)
         self.step_seed = 0x5EED
 
-    def _get_plan(self, x, avg_channels):
+    def _get_plan(self, x, avg_channels, infer=False):
         dtype = self.compute_dtype or getattr(self.module, "compute_dtype", None) or compute_dtype_default()
-        key = (x.shape[0], dtype, x.device, avg_channels, self.single_stream)
+        key = (x.shape[0], dtype, x.device, avg_channels, self.single_stream, infer)
         plan = self.plans.get(key)
         if plan is None or not plan.check_current():
             plan = BackbonePlan(self.module, x.shape[0], dtype, x.device, self.in_channels - avg_channels,
-                                avg_channels, single_stream=self.single_stream)
+                                avg_channels, single_stream=self.single_stream, infer=infer)
             self.plans = {key: plan}  # one live plan: activations of a 256-batch are several GB
         return plan
 
-    def _forward_impl(self, x):
+    def _forward_impl(self, x, infer=False):
         avg = self._avg
-        self.plan = self._get_plan(x, 0 if avg is None else avg.shape[0])
+        self.plan = self._get_plan(x, 0 if avg is None else avg.shape[0], infer)
         self.step_seed = (self.step_seed * 6364136223846793005 + 1442695040888963407) % (1 << 64)
         return self.plan.run_forward(x, avg, self.step_seed)
 
@@ -977,4 +1053,4 @@ class BackboneRunner(object):
         params = [p for p in self.module.parameters()]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _BackboneFn.apply(self, x, *params)
-        return self._forward_impl(x).clone()
+        return self._forward_impl(x, infer=True).clone()  # forward-only plan (BatchNorm folded when in eval mode)

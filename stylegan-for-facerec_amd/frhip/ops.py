@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (EPI_ATOMIC, EPI_BNBWD, EPI_MARGIN, EPI_PRELU_BWD, EPI_SLAB, EPI_STATS, EPI_STORE, FR_BF16,  # noqa: F401
+from ._lib import (EPI_ATOMIC, EPI_BIAS_RES, EPI_BNBWD, EPI_MARGIN, EPI_PRELU_BWD, EPI_SLAB, EPI_STATS, EPI_STORE, FR_BF16,  # noqa: F401
                    FR_F32,
                    PRO_BN, PRO_NONE, PRO_PRELU, lib)
 

@@ -30,13 +30,13 @@ def table():
     w3 = lambda ci, co: ci * co * 9 * 2  # noqa: E731
     f3 = lambda W, ci, co: 2.0 * B * W * W * ci * co * 9  # noqa: E731
     return {
-        "strip_64_64_112_fwd": (r"conv3x3_strip_kernel<64, 64, 112, \d+, \d+, \d+, 1, 1,", 2 * act(112, 64) + w3(64, 64), f3(112, 64, 64)),
-        "strip_64_64_112_dgrad": (r"conv3x3_strip_kernel<64, 64, 112, \d+, \d+, \d+, 1, 0,", 3 * act(112, 64) + w3(64, 64), f3(112, 64, 64)),
+        "strip_64_64_112_fwd": (r"conv3x3_roll64_kernel<112, 1, false>|conv3x3_strip_kernel<64, 64, 112, \d+, \d+, \d+, 1, 1,", 2 * act(112, 64) + w3(64, 64), f3(112, 64, 64)),
+        "strip_64_64_112_dgrad": (r"conv3x3_roll64_kernel<112, 0, true>|conv3x3_strip_kernel<64, 64, 112, \d+, \d+, \d+, 1, 0,", 3 * act(112, 64) + w3(64, 64), f3(112, 64, 64)),
         "s2_64_56_fwd": (r"conv3x3_s2_kernel<64, 64, 56, .*, 0, 2>", act(112, 64) + act(56, 64) + w3(64, 64), f3(56, 64, 64)),
         "s2_64_56_dgrad": (r"conv3x3_s2_kernel<64, 64, 56, .*, 1, 0>", act(56, 64) + 2 * act(112, 64) + w3(64, 64), f3(56, 64, 64)),
-        "strip_64_64_56_fwd_bn": (r"conv3x3_strip_kernel<64, 64, 56, \d+, \d+, \d+, 1, 1,", 2 * act(56, 64) + w3(64, 64), f3(56, 64, 64)),
-        "strip_64_64_56_fwd_prelu": (r"conv3x3_strip_kernel<64, 64, 56, \d+, \d+, \d+, 1, 2,", 2 * act(56, 64) + w3(64, 64), f3(56, 64, 64)),
-        "strip_64_64_56_dgrad": (r"conv3x3_strip_kernel<64, 64, 56, \d+, \d+, \d+, 1, 0,", 3 * act(56, 64) + w3(64, 64), f3(56, 64, 64)),
+        "strip_64_64_56_fwd_bn": (r"conv3x3_roll64_kernel<56, 1, false>|conv3x3_strip_kernel<64, 64, 56, \d+, \d+, \d+, 1, 1,", 2 * act(56, 64) + w3(64, 64), f3(56, 64, 64)),
+        "strip_64_64_56_fwd_prelu": (r"conv3x3_roll64_kernel<56, 2, false>|conv3x3_strip_kernel<64, 64, 56, \d+, \d+, \d+, 1, 2,", 2 * act(56, 64) + w3(64, 64), f3(56, 64, 64)),
+        "strip_64_64_56_dgrad": (r"conv3x3_roll64_kernel<56, 0, true>|conv3x3_strip_kernel<64, 64, 56, \d+, \d+, \d+, 1, 0,", 3 * act(56, 64) + w3(64, 64), f3(56, 64, 64)),
         "wgs_64_64_112": (r"conv_wgrad_strip_kernel<112,", 2 * act(112, 64), f3(112, 64, 64)),
         "wgs_64_64_56": (r"conv_wgrad_strip_kernel<56, \d+, \d+, \d+, 2, false>", 2 * act(56, 64), f3(56, 64, 64)),
         "strip_128_128_28_fwd": (r"conv3x3_strip_kernel<128, 128, 28, \d+, \d+, \d+, 1, 1,", 2 * act(28, 128) + w3(128, 128), f3(28, 128, 128)),
