@@ -972,3 +972,41 @@ def test_bn_backward_with_se_gate(K, name, dtype, tol, with_add):
     np.testing.assert_allclose(s0.cpu(), r0, rtol=tol * 5, atol=tol * 20)
     np.testing.assert_allclose(s1.cpu(), r1, rtol=tol * 5, atol=tol * 20)
     assert relerr(from_nhwc(gx), want) < tol * 2
+
+
+BIAS_RES_CASES = [("igemm_f32", torch.float32, 64, 10, 1), ("igemm_bf16", torch.bfloat16, 64, 10, 1),
+                  ("igemm_f32_s2", torch.float32, 128, 12, 2), ("strip_256_14", torch.bfloat16, 256, 14, 1),
+                  ("strip_128_28", torch.bfloat16, 128, 28, 1), ("roll64_56", torch.bfloat16, 64, 56, 1),
+                  ("s2_128_56", torch.bfloat16, 128, 56, 2), ("s2_512_14", torch.bfloat16, 512, 14, 2)]
+
+
+@pytest.mark.parametrize("name,dtype,C,H,stride", BIAS_RES_CASES, ids=[c[0] for c in BIAS_RES_CASES])
+def test_conv_bias_residual_epilogue(K, name, dtype, C, H, stride):
+    """FR_EPI_BIAS_RES (inference, BatchNorm folded into the weights): out = conv(PReLU(y1)) + a[n] + b[n] + shortcut, on
+    every kernel that serves conv2 of a residual unit -- generic implicit GEMM (both dtypes), LDS strip, rolling 64-channel
+    kernel, stride-2 strip -- against CPU F.conv2d."""
+    B = 3
+    tol = 2e-4 if dtype == torch.float32 else BF16_TOL
+    Ho = H // stride
+    y1 = q(synth.normal(81, "br.y", (B, C, H, H)), dtype)
+    w = q(synth.normal(81, "br.w", (C, C, 3, 3), std=0.05), dtype)
+    slope = synth.uniform(81, "br.s", (C,), 0.1, 0.4)
+    a, b2 = synth.uniform(81, "br.a", (C,), -0.5, 0.5), synth.uniform(81, "br.b", (C,), -0.5, 0.5)
+    res = q(synth.normal(81, "br.r", (B, C, Ho, Ho)), dtype)
+    xin = q(torch.where(y1 > 0, y1, y1 * slope.view(1, -1, 1, 1)), dtype)
+    ref = F.conv2d(xin, w, stride=stride, padding=1) + (a + b2).view(1, -1, 1, 1) + res
+    out = torch.zeros(B, Ho, Ho, C, device="cuda", dtype=dtype)
+    kw = dict(src=nhwc(y1, dtype), w=pack_w(w, dtype), out=out, B=B, RH=Ho, RW=Ho, SH=H, SW=H, SC=C, N=C, KH=3, KW=3,
+              stride=stride, pad=1, mode=0, lda=C, ldc=C, ldaux=C, pro=K.PRO_PRELU, pro_a=slope.cuda(),
+              epi=K.EPI_BIAS_RES, epi_a=a.cuda(), epi_b=b2.cuda(), aux=nhwc(res, dtype))
+    st = K.current_stream_ptr()
+    if name.startswith("igemm"):
+        K.conv(st, K.fr_dtype(torch.empty(0, dtype=dtype)), **kw)()
+    elif name.startswith("s2"):
+        assert K.s2_strip_parts(B, C, C, Ho, 0) > 0
+        K.conv_s2_strip(st, **kw)()
+    else:
+        assert K.strip_parts(B, C, C, H, K.EPI_BIAS_RES) > 0
+        K.conv_strip(st, **kw)()
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(out), ref) < tol

@@ -413,10 +413,15 @@ def test_folded_eval_forward_matches_oracle_and_unfolded(kind, layers, se):
             inner._runner[0].plans = {}
         inner.compute_dtype = torch.bfloat16
         bf = model(x.cuda()).float().cpu()
+    # With made-up running statistics the activations grow along the network (IR-50: features up to ~260, the oracle's own
+    # fp32 run is 1.1e-3 away from its float64 run), so the bar is relative to the feature scale: 2e-5 ~ a hundred fp32
+    # ulps; a folding mistake (wrong scale vector, missing shift, residual added twice) is an O(1) relative error.
+    scale = max(1.0, float(ref.abs().max()))
     d_ref, d_unf = float((got - ref).abs().max()), float((got - unfolded).abs().max())
     cos = float(torch.nn.functional.cosine_similarity(bf, ref, dim=1).min())
-    print("\nfolded eval %s: max|d| vs oracle %.2e, vs unfolded %.2e; bf16 cos %.5f" % (kind, d_ref, d_unf, cos))
-    assert d_ref < 1e-3 and d_unf < 1e-3 and cos > 0.999
+    print("\nfolded eval %s: feature scale %.1f, max|d| vs oracle %.2e, vs unfolded %.2e; bf16 cos %.5f"
+          % (kind, scale, d_ref, d_unf, cos))
+    assert d_ref < 2e-5 * scale and d_unf < 2e-5 * scale and cos > 0.999
     # a training forward afterwards goes back to batch statistics (and a plan with a backward list)
     model.train()
     inner.compute_dtype = torch.float32
