@@ -12,9 +12,11 @@ hard parts): one process per GPU with RCCL gradient all-reduce instead of nn.Dat
 the head lives on the GPU, metrics are read back every DISP_FREQ steps instead of three ``.item()`` syncs per step,
 wandb / bcolz validation are optional.  Resume: the reference restores weights and optimizer state
 but restarts the batch counter (warm-up, logging), the shuffle and the dropout stream; here a ``State_*`` file written
-next to every checkpoint carries epoch, batch counter and dropout stream, the per-epoch shuffle is a function of
-(SEED, epoch), and ``STATE_RESUME_ROOT`` restores them -- training resumed at an epoch boundary continues bit for bit
-(tests/test_gpu_model.py::test_resume_continues_bit_for_bit).
+next to every checkpoint carries epoch, batch counter, dropout stream and the host RNG states, the per-epoch shuffle and
+the GPU crop / flip stream are functions of (SEED, epoch), and ``STATE_RESUME_ROOT`` restores them -- training resumed
+at an epoch boundary continues bit for bit (tests/test_gpu_model.py::test_resume_continues_bit_for_bit; with the HOST
+transform the workers' python ``random`` streams are re-seeded from the restored torch generator, which reproduces
+them only for the same NUM_WORKERS).  An epoch cut short by --max-steps is recorded as unfinished and repeated.
 """
 import argparse
 import importlib
@@ -132,10 +134,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("FRHIP_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
+        # Rank 0 alone runs the per-epoch RFW verification (4 x 12 k images with flip-TTA) while the others wait in the
+        # next collective: give them well more than the default 10-minute watchdog.
+        import datetime
+        patience = datetime.timedelta(hours=2)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=patience)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=patience)
 
     np.random.seed(cfg["SEED"])
     torch.manual_seed(cfg["SEED"])  # identical initial weights on every rank (and broadcast below)
@@ -219,14 +225,20 @@ def main():
     if state_resume and os.path.isfile(state_resume):
         state = torch.load(state_resume, map_location="cpu")
         start_epoch, batch, runner.step_seed = int(state["epoch"]), int(state["batch"]), int(state["dropout_stream"])
+        if "torch_rng" in state:
+            torch.set_rng_state(state["torch_rng"])
+            np.random.set_state(state["numpy_rng"])
         print("Resuming at epoch {} batch {}".format(start_epoch, batch))
 
     disp_freq = max(1, len(loader) // 10)  # the reference divides by zero below 10 batches/epoch
+    lts = cfg.get("LIMIT_TRAIN_SAMPLES", None)
+    limit_batches = None if lts is None else max(1, lts // cfg["BATCH_SIZE"])
     warm_epochs = cfg["NUM_EPOCH"] // 25
     warm_batches = len(loader) * warm_epochs
     freeze = cfg.get("FREEZE_BACKBONE_EPOCHS")
     FRF.CHECK_LABELS = False  # labels come from the dataset's own class index
     for epoch in range(start_epoch, cfg["NUM_EPOCH"]):
+        epoch_first_batch = batch
         if epoch in cfg["STAGES"]:
             schedule_lr(optimizer)
         backbone.train()
@@ -237,8 +249,18 @@ def main():
             enc.body.requires_grad_(epoch > freeze)
             enc.output_layer.requires_grad_(True)
         sampler.set_epoch(epoch)
+        if gpu_tf is not None:  # crops / flips are a function of (SEED, epoch, rank): a resumed run redraws the same ones
+            aug_rng.manual_seed(cfg["SEED"] + 7919 * rank + 104729 * (epoch + 1))
         losses, top1, top5 = AverageMeter(), AverageMeter(), AverageMeter()
         pending = []
+
+        def flush():  # one host sync per display interval; EVERY step reaches the meters (reference train.py:308-310)
+            for l, p1, p5, n in pending:
+                losses.update(float(l), n)
+                top1.update(float(p1), n)
+                top5.update(float(p5), n)
+            del pending[:]
+
         for inputs, labels in loader:
             if cfg.get("WARMUP", True) and epoch + 1 <= warm_epochs and batch + 1 <= warm_batches:
                 warm_up_lr(batch, warm_batches, cfg["LR"], optimizer)
@@ -258,11 +280,7 @@ def main():
             BACKBONE.synchronize()
             optimizer.step()
             if (batch + 1) % disp_freq == 0 or (args.max_steps and batch + 1 >= args.max_steps):
-                for l, p1, p5, n in pending:  # one host sync per display interval
-                    losses.update(float(l), n)
-                    top1.update(float(p1), n)
-                    top5.update(float(p5), n)
-                pending = []
+                flush()
                 if rank == 0:
                     print("Epoch {}/{} Batch {}\tTraining Loss {:.4f} ({:.4f})\tPrec@1 {:.3f} ({:.3f})\tPrec@5 {:.3f} "
                           "({:.3f})".format(epoch + 1, cfg["NUM_EPOCH"], batch + 1, losses.val, losses.avg, top1.val,
@@ -272,6 +290,18 @@ def main():
             batch += 1
             if args.max_steps and batch >= args.max_steps:
                 break
+            if limit_batches is not None and batch - epoch_first_batch >= limit_batches:
+                break  # LIMIT_TRAIN_SAMPLES: a shorter epoch, e.g. to validate more often (reference train.py:68-69,344)
+        flush()  # the trailing steps of the epoch
+        samples_seen = batch * cfg["BATCH_SIZE"] * world  # ONE x axis (global samples) for every log call
+        if rank == 0:  # per-epoch summary (reference train.py:347-357)
+            print("=" * 60)
+            print("Epoch: {}/{}\tTraining Loss {:.4f}\tTraining Prec@1 {:.3f}\tTraining Prec@5 {:.3f}".format(
+                epoch + 1, cfg["NUM_EPOCH"], losses.avg, top1.avg, top5.avg))
+            print("=" * 60)
+            if logger is not None:
+                logger.log({"train_loss_ep": losses.avg, "train_acc_ep": top1.avg, "train_acc_top5_ep": top5.avg,
+                            "epoch": epoch + 1, "step": samples_seen})
         if rank == 0 and val is not None and val[-2] is not None:
             # per-epoch verification on the RFW subsets (reference train.py:403-410); flip-TTA, k-fold accuracy
             rfw, rfw_issame = val[-2], val[-1]
@@ -283,7 +313,7 @@ def main():
                                             rfw_issame[eth], dset_name="RFW_" + eth,
                                             ccrop=cfg.get("CCROP_AT_VAL", True))
                 if logger is not None:
-                    buffer_val(logger, "RFW_" + eth, acc, thr, roc, epoch + 1, batch * cfg["BATCH_SIZE"])
+                    buffer_val(logger, "RFW_" + eth, acc, thr, roc, epoch + 1, samples_seen)
                 print("Evaluation: RFW {} Acc: {}".format(eth, acc))
             print("=" * 60)
             BACKBONE.module.train()
@@ -297,7 +327,16 @@ def main():
             torch.save(BACKBONE.module.state_dict(), os.path.join(root, "Backbone_{}_{}".format(cfg["BACKBONE_NAME"], tag)))
             torch.save(head.state_dict(), os.path.join(root, "Head_{}_{}".format(cfg["HEAD_NAME"], tag)))
             torch.save(opt_state, os.path.join(root, "Optimizer_{}_{}".format(cfg["HEAD_NAME"], tag)))
-            torch.save({"epoch": epoch + 1, "batch": batch, "dropout_stream": runner.step_seed},
+            # what the reference forgets on resume (train.py:206-232 restores weights and optimizer only): the batch
+            # counter (warm-up, logging), the dropout stream, the host RNG (DataLoader worker seeds -> python `random` of
+            # the host transform).  The per-epoch shuffle and the GPU crop / flip stream are functions of (SEED, epoch).
+            # An epoch cut short by --max-steps is recorded as NOT finished: resuming repeats it from its first batch
+            # with the weights of the checkpoint (mid-epoch positions are not restored).
+            epoch_len = len(loader) if limit_batches is None else min(len(loader), limit_batches)
+            finished = not (args.max_steps and batch >= args.max_steps and (batch - epoch_first_batch) < epoch_len)
+            torch.save({"epoch": epoch + 1 if finished else epoch, "batch": batch, "dropout_stream": runner.step_seed,
+                        "epoch_finished": finished, "torch_rng": torch.get_rng_state(),
+                        "numpy_rng": np.random.get_state()},
                        os.path.join(root, "State_{}_{}".format(cfg["HEAD_NAME"], tag)))
         if args.max_steps and batch >= args.max_steps:
             break

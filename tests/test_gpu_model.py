@@ -692,6 +692,22 @@ def test_two_rank_gradients_are_the_rank_average():
     assert out.returncode == 0 and "DP_WORKER_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
+def test_gradient_allreduce_overlaps_backward():
+    """The overlap claim of frhip.parallel on the GPU timeline (tests/overlap_worker.py, one rank through RCCL): the
+    gradient buckets are enqueued while the backward pass is still being enqueued, their inputs are final and their
+    all-reduces complete (HIP events) before the last backward kernel -- the collectives run under the backward pass."""
+    _need_gpu()
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29571", os.path.join(here, "overlap_worker.py")]
+    out = subprocess.run(cmd, cwd=os.path.dirname(here), env=env, capture_output=True, text=True, timeout=900)
+    print(out.stdout[-1500:])
+    assert out.returncode == 0 and "OVERLAP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def _run_train(tmp, tag, extra_cfg, max_steps=0):
     import subprocess
     import sys
