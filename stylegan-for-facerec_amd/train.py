@@ -102,6 +102,12 @@ def optimizer_state_for_checkpoint(optimizer, crit):
     return sd
 
 
+def _np_state_plain(st):
+    """numpy's RNG state with the key array as a plain list: State_* files stay loadable with torch.load's default
+    ``weights_only=True`` (no numpy globals in the pickle)."""
+    return (str(st[0]), [int(v) for v in st[1]], int(st[2]), int(st[3]), float(st[4]))
+
+
 def load_optimizer_checkpoint(optimizer, crit, sd):
     """Inverse of ``optimizer_state_for_checkpoint``: this rank keeps its class range of the head's optimizer state."""
     if crit is not None:
@@ -227,7 +233,8 @@ def main():
         start_epoch, batch, runner.step_seed = int(state["epoch"]), int(state["batch"]), int(state["dropout_stream"])
         if "torch_rng" in state:
             torch.set_rng_state(state["torch_rng"])
-            np.random.set_state(state["numpy_rng"])
+            n = state["numpy_rng"]
+            np.random.set_state((n[0], np.asarray(n[1], dtype=np.uint32), n[2], n[3], n[4]))
         print("Resuming at epoch {} batch {}".format(start_epoch, batch))
 
     disp_freq = max(1, len(loader) // 10)  # the reference divides by zero below 10 batches/epoch
@@ -336,7 +343,7 @@ def main():
             finished = not (args.max_steps and batch >= args.max_steps and (batch - epoch_first_batch) < epoch_len)
             torch.save({"epoch": epoch + 1 if finished else epoch, "batch": batch, "dropout_stream": runner.step_seed,
                         "epoch_finished": finished, "torch_rng": torch.get_rng_state(),
-                        "numpy_rng": np.random.get_state()},
+                        "numpy_rng": _np_state_plain(np.random.get_state())},
                        os.path.join(root, "State_{}_{}".format(cfg["HEAD_NAME"], tag)))
         if args.max_steps and batch >= args.max_steps:
             break
