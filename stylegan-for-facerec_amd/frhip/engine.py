@@ -370,6 +370,7 @@ class BackbonePlan(object):
             self.gviews[id(p)] = v
             self.arena_slices.append((p, off, n))
             off += (n + 63) // 64 * 64
+        self._grad_pairs = [(p, self.gviews[id(p)]) for p, _o, _n in self.arena_slices]
         self.param_sig = self._signature()
 
     def _signature(self):
@@ -934,11 +935,15 @@ class BackbonePlan(object):
 
     def run_backward(self, g_feat, on_ready=None):
         self.g_feat_in.copy_(g_feat)
-        self.arena.zero_()
-        for p, _off, _n in self.arena_slices:
-            if p.requires_grad:
-                if p.grad is None or p.grad.data_ptr() != self.gviews[id(p)].data_ptr():
-                    p.grad = self.gviews[id(p)]
+        # frhip.optim's zero_grad() has just cleared the arena with one fill and says so: do not fill 174 MB twice
+        if not getattr(self.arena, "_frhip_zeroed", False):
+            self.arena.zero_()
+        self.arena._frhip_zeroed = False
+        # (re)bind .grad to the arena views; an identity test per parameter -- this loop runs while the GPU drains the
+        # short head / loss kernels and was a visible idle gap in the trace when it called data_ptr() 188 times
+        for p, v in self._grad_pairs:
+            if p.grad is not v and p.requires_grad:
+                p.grad = v
         if on_ready is None:
             ops.run(self.bwd_list)
             return

@@ -43,6 +43,7 @@ class SGD(torch.optim.Optimizer):
                     g.zero_()
         for a in arenas.values():
             a.zero_()
+            a._frhip_zeroed = True  # the engine's next backward skips its own fill (engine.run_backward)
 
     def _build(self):
         for group in self.param_groups:  # a loaded state dict may carry settings this kernel does not implement

@@ -758,7 +758,10 @@ def test_resume_continues_bit_for_bit(tmp_path):
         assert torch.equal(oa["state"][k]["momentum_buffer"], ob["state"][k]["momentum_buffer"]), k
     sa = torch.load(_ckpt(a_dir, "State_ArcFace_Epoch_2_Batch_12_"))
     sb = torch.load(_ckpt(b2_dir, "State_ArcFace_Epoch_2_Batch_12_"))
-    assert sa == sb and sa["epoch"] == 2 and sa["batch"] == 12
+    assert sa["epoch"] == sb["epoch"] == 2 and sa["batch"] == sb["batch"] == 12
+    assert sa["dropout_stream"] == sb["dropout_stream"] and sa["epoch_finished"] and sb["epoch_finished"]
+    # the host generators (DataLoader worker seeds, host transforms) are restored too: same state after the same epochs
+    assert torch.equal(sa["torch_rng"], sb["torch_rng"]) and sa["numpy_rng"] == sb["numpy_rng"]
 
 
 def test_optimizer_loads_reference_layout_momentum():
