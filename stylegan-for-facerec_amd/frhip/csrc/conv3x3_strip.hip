@@ -271,7 +271,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
             nc += 32;
           }
           nc = nc < CK ? nc : CK - 32;  // clamp instead of branching: the count of loads in flight stays static
+#ifndef FRHIP_EXP_NOW  // timing ablation (tools/stamps.py): the loop without its weight stream (results are wrong)
           load_b(slot, nc, nt);
+#endif
         }
         __builtin_amdgcn_sched_group_barrier(0x008, C::TN, 0);  // MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read

@@ -307,7 +307,9 @@ class BackbonePlan(object):
         self.g_pp = [self._act(max_in, 1).view(-1), self._act(max_in, 1).view(-1)]   # unit input/output gradients
         # gradients consumed by the side-stream wgrads are double-buffered by unit parity (the next unit must not
         # overwrite what a still-running weight gradient reads)
-        nset = 2 if self.dual else 1
+        # FRHIP_WGRAD_SETS: how many units the main stream may run ahead of the side stream's weight gradients
+        nset = max(2, int(os.environ.get("FRHIP_WGRAD_SETS", "2"))) if self.dual else 1
+        self.nset = nset
         self.g_y2s = [self._act(max_out, 1).view(-1) for _ in range(nset)]
         self.g_ySs = [self._act(max_out, 1).view(-1) if max_xs else None for _ in range(nset)]
         self.g_y1s = [self._act(max(max_mid, M0 * 64), 1).view(-1) for _ in range(nset)]
@@ -323,7 +325,7 @@ class BackbonePlan(object):
                                 device=dev)
         self.side_slope = self.dual and os.environ.get("FRHIP_SLOPE_ON_MAIN", "0") != "1"  # A/B switch
         if self.side_slope:
-            self.part_slope = [torch.zeros_like(self.part), torch.zeros_like(self.part)]
+            self.part_slope = [torch.zeros_like(self.part) for _ in range(nset)]
         self.se_scratch = torch.zeros(2, 512 * 64, device=dev)  # dW1/dW2 sink while the SE weights are frozen
         self.sums = torch.zeros(3, 512, device=dev)      # scratch reduce target for frozen parameters
         self.nbt_dummy = None
@@ -743,10 +745,10 @@ class BackbonePlan(object):
             rin, rout = B * u.H * u.H, B * u.Ho * u.Ho
             HWo = u.Ho * u.Ho
             bn1, bn2 = d["bn1"], d["bn2"]
-            par = i & 1 if self.dual else 0
+            par = i % self.nset if self.dual else 0
             g_y2 = self.g_y2s[par][:rout * u.depth]
-            if self.dual and i + 2 in unit_done:
-                L.append(_EvWait(self.stream1_t, unit_done[i + 2]))  # that unit's wgrads read this buffer set
+            if self.dual and i + self.nset in unit_done:
+                L.append(_EvWait(self.stream1_t, unit_done[i + self.nset]))  # that unit's wgrads read this buffer set
             nb = ops.grid_blocks(rout, u.depth, fr)
             ready = [u.bn2.weight, u.bn2.bias]
             se_kw = {}
@@ -876,7 +878,7 @@ class BackbonePlan(object):
         L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
         self._reduce(L, nb, 3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64])
         s0, s1 = self._s01(self.bn0, db, dg)
-        g_y0 = self.g_y1s[-1][:self.M0 * 64]  # unit 0's wgrads (side stream) still read set 0
+        g_y0 = self.g_y1s[1 if self.dual else 0][:self.M0 * 64]  # unit 0's wgrads (side stream) still read set 0
         if self.dual and 1 in unit_done:
             L.append(_EvWait(self.stream1_t, unit_done[1]))  # set 1 was last read by unit 1's weight gradients
         gw0 = self.grad_of(sc.weight)
