@@ -379,6 +379,12 @@ int fr_adam_step(const FrAdamTensor* table_dev, const int32_t* chunks_dev, int n
 int fr_fill_rows(float* out, const float* bias, long long rows, int C, void* stream);
 
 /* ---- misc */
+/* Capability queries.  SURVEY.md 8(b)-ii sketched ONE `fr_supported(op, dtype, Cin, Cout, H, W, stride)`; the build answers
+ * the same question per kernel family instead, because the answer doubles as the launch geometry the caller must size
+ * buffers for: fr_conv3x3_strip_parts / fr_conv3x3_s2_strip_parts return the number of partial-sum rows a launch will
+ * write (0 = shape not served: the caller uses fr_conv_igemm, which serves every shape), fr_conv_wgrad_strip_supported
+ * answers yes / no.  Every entry point additionally returns < 0 for an unsupported argument (text in
+ * fr_last_error_string()), never silently computing something else. */
 int fr_abi_version(void);
 /* sizeof() of the argument structs as compiled, for binding self-checks: 0 FrConvArgs, 1 FrWgradArgs,
  * 2 FrApplyArgs, 3 FrBnBwdArgs, 4 FrSgdTensor, 5 FrPackTensor, 6 FrAdamTensor */
