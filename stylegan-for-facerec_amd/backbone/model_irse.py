@@ -10,14 +10,15 @@ logic of the training loop keep working.  It does not compute: ``Backbone.forwar
 MFMA implicit-GEMM convolutions with BatchNorm/PReLU folded into their gathers and epilogues).  Leaves are
 stock ``torch.nn`` layers on purpose: the weight-decay split is decided by their class names.
 
-Every leaf forward raises if it is ever called directly: there is no CPU / eager fallback in the product path
-(the CPU restatement used for parity lives in ``oracle/`` and is test-only).
+Leaf layers raise if they are ever called directly, and the residual units run through the engine on their own
+(``frhip.engine.UnitStackRunner``): there is no CPU / eager fallback in the product path (the CPU restatement used for
+parity lives in ``oracle/`` and is test-only).
 """
 import torch
 import torch.nn as nn
 from torch.nn import BatchNorm1d, BatchNorm2d, Conv2d, Dropout, Linear, MaxPool2d, Module, PReLU, Sequential
 
-from frhip.engine import BackboneRunner
+from frhip.engine import BackboneRunner, run_unit
 
 # stage plan: (width in, width out) and the number of units per stage for each depth
 _STAGE_WIDTHS = ((64, 64), (64, 128), (128, 256), (256, 512))
@@ -74,7 +75,10 @@ class bottleneck_IR(Module):
             layers.append(SEModule(depth, 16))
         self.res_layer = Sequential(*layers)
 
-    forward = _eager_forbidden
+    def forward(self, x):
+        """A unit called on its own (inside a Backbone the engine runs the whole network instead): the HIP launch lists
+        of this one unit, with gradients for x and the parameters."""
+        return run_unit(self, x)
 
 
 class bottleneck_IR_SE(bottleneck_IR):

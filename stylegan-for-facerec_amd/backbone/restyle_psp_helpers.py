@@ -34,7 +34,10 @@ class bottleneck_IR_SE(Module):
             print("[bottleneck_IR_SE] adding dropout layer")
             self.add_dropout(dropout)
 
-    forward = _eager_forbidden
+    def forward(self, x, race=None):
+        """A unit called on its own (reference :190-199; ``race`` feeds the experimental adaptive layers only)."""
+        from frhip.engine import run_unit
+        return run_unit(self, x)
 
     def add_dropout(self, p):
         """Dropout after the shortcut conv and after each residual conv (list indices 1 / 2 and 5)."""

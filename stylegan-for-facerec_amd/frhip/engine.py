@@ -52,7 +52,8 @@ def _children_of(container):
 def describe(module):
     """Walk the parameter-holding module tree (either Backbone of model_irse.py or BackboneEncoderDiffHead of
     restyle_psp.py -- Sequential or ModuleList children) and return (stem, units, out) layer handles."""
-    stem_conv, stem_bn, stem_prelu = _children_of(module.input_layer)[:3]
+    body_only = getattr(module, "input_layer", None) is None  # a bare stack of residual units (_UnitStack)
+    stem = None if body_only else tuple(_children_of(module.input_layer)[:3])
     units = []
     H = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
     for i, blk in enumerate(module.body):
@@ -83,18 +84,23 @@ def describe(module):
             u.sc_bn = [c for c in ch if isinstance(c, nn.BatchNorm2d)][0]
         units.append(u)
         H = u.Ho
+    if body_only:
+        return None, units, None
     out = _children_of(module.output_layer)
     out_bn = [c for c in out if isinstance(c, nn.BatchNorm2d)][0]
     out_drop = [c for c in out if isinstance(c, nn.Dropout)][0]
     out_lin = [c for c in out if isinstance(c, nn.Linear)][0]
     out_bn1d = [c for c in out if isinstance(c, nn.BatchNorm1d)][0]
-    return (stem_conv, stem_bn, stem_prelu), units, (out_bn, out_drop, out_lin, out_bn1d)
+    return stem, units, (out_bn, out_drop, out_lin, out_bn1d)
 
 
 def ready_order_params(module):
     """Parameters in the order their gradients complete during backward (for bucketing)."""
-    (sc, sb, sp), units, (ob, _od, ol, ob1) = describe(module)
-    order = [ob1.weight, ob1.bias, ol.weight, ol.bias, ob.weight, ob.bias]
+    stem, units, out = describe(module)
+    order = []
+    if out is not None:
+        ob, _od, ol, ob1 = out
+        order = [ob1.weight, ob1.bias, ol.weight, ol.bias, ob.weight, ob.bias]
     for u in reversed(units):
         order += [u.bn2.weight, u.bn2.bias]
         if u.se is not None:
@@ -102,7 +108,9 @@ def ready_order_params(module):
         if u.sc_conv is not None:
             order += [u.sc_bn.weight, u.sc_bn.bias, u.sc_conv.weight]
         order += [u.prelu.weight, u.conv2.weight, u.bn1.weight, u.bn1.bias, u.conv1.weight]
-    order += [sb.weight, sb.bias, sp.weight, sc.weight]
+    if stem is not None:
+        sc, sb, sp = stem
+        order += [sb.weight, sb.bias, sp.weight, sc.weight]
     return order
 
 
@@ -207,6 +215,7 @@ class BackbonePlan(object):
         self.fr = FR_F32 if dtype == torch.float32 else FR_BF16
         self.esz = 4 if dtype == torch.float32 else 2
         self.stem, self.units, self.out = describe(module)
+        self.body_only = self.stem is None  # residual units only: NHWC activation in, NHWC activation (and dL/dx) out
         self.in_channels, self.avg_channels = in_channels, avg_channels
         self.stream = ops.current_stream_ptr()
         self.stream1_t = torch.cuda.current_stream()
@@ -223,7 +232,8 @@ class BackbonePlan(object):
         self.S = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
         self.generation = 0
         self.use_strip = os.environ.get("FRHIP_NO_STRIP", "0") != "1"
-        self.use_stem_gemm = self.fr == FR_BF16 and os.environ.get("FRHIP_NO_STEM_GEMM", "0") != "1"
+        self.use_stem_gemm = (self.fr == FR_BF16 and os.environ.get("FRHIP_NO_STEM_GEMM", "0") != "1" and
+                              not self.body_only)
         self.use_s2 = os.environ.get("FRHIP_NO_S2_STRIP", "0") != "1"  # stride-2 strip kernels (A/B switch)
         self.slab, self._slab_users = None, []
         self.part_slope = None  # per-buffer-set partial rows of the PReLU slope gradient (side-stream reduction)
@@ -246,14 +256,16 @@ class BackbonePlan(object):
         self.K0 = 32 if 9 * ct <= 32 else 64
         M0 = B * S * S
         self.M0 = M0
-        self.X0 = self._act(M0, self.K0)
-        self.y0 = self._act(M0, 64)
-        self.z0 = self._act(M0, 64)
-        self.W0p = torch.empty(64, self.K0, device=dev, dtype=self.tdtype)
-        self.gW0p = torch.zeros(64, self.K0, device=dev)
-        self.bn0 = _BN(self.stem[1], self.pool)
+        C0 = self.units[0].cin if self.body_only else 64  # channels of the first unit's input
+        self.z0 = self._act(M0, C0)
+        if not self.body_only:
+            self.X0 = self._act(M0, self.K0)
+            self.y0 = self._act(M0, 64)
+            self.W0p = torch.empty(64, self.K0, device=dev, dtype=self.tdtype)
+            self.gW0p = torch.zeros(64, self.K0, device=dev)
+            self.bn0 = _BN(self.stem[1], self.pool)
         self.ubuf = []
-        max_in = M0 * 64
+        max_in = M0 * C0
         max_mid = 0
         max_out = 0
         max_xs = 0
@@ -291,14 +303,15 @@ class BackbonePlan(object):
         last = self.units[-1]
         self.HWo = last.Ho * last.Ho
         self.feat_in = last.depth * self.HWo
-        self.bn_out = _BN(self.out[0], self.pool)
-        self.bn1d = _BN(self.out[3], self.pool)
-        self.a = self._act(B, self.feat_in)
-        self.f = torch.empty(B, 512, device=dev)
-        self.feat = torch.empty(B, 512, device=dev)
-        self.Wlin = torch.empty(512, self.feat_in, device=dev, dtype=self.tdtype)
-        self.WlinT = torch.empty(self.feat_in, 512, device=dev, dtype=self.tdtype)
-        self.gWlin = torch.zeros(512, self.feat_in, device=dev)
+        if not self.body_only:
+            self.bn_out = _BN(self.out[0], self.pool)
+            self.bn1d = _BN(self.out[3], self.pool)
+            self.a = self._act(B, self.feat_in)
+            self.f = torch.empty(B, 512, device=dev)
+            self.feat = torch.empty(B, 512, device=dev)
+            self.Wlin = torch.empty(512, self.feat_in, device=dev, dtype=self.tdtype)
+            self.WlinT = torch.empty(self.feat_in, 512, device=dev, dtype=self.tdtype)
+            self.gWlin = torch.zeros(512, self.feat_in, device=dev)
         self.zeros_c = torch.zeros(512, device=dev)
         if self.infer:
             self.part = torch.zeros(max(4 * 1024 * 1024, ((M0 + 127) // 128) * 2 * 64 + 4096), device=dev)
@@ -312,12 +325,13 @@ class BackbonePlan(object):
         self.nset = nset
         self.g_y2s = [self._act(max_out, 1).view(-1) for _ in range(nset)]
         self.g_ySs = [self._act(max_out, 1).view(-1) if max_xs else None for _ in range(nset)]
-        self.g_y1s = [self._act(max(max_mid, M0 * 64), 1).view(-1) for _ in range(nset)]
+        self.g_y1s = [self._act(max(max_mid, M0 * C0), 1).view(-1) for _ in range(nset)]
         self.g_y1 = self.g_y1s[0]
         self.g_xh = self._act(max_in, 1).view(-1)
         self.g_xS = self._act(max_xs, 1).view(-1) if max_xs else None
-        self.g_f32 = torch.empty(B, 512, device=dev)     # BN1d backward output (fp32)
-        self.g_fT = self._act(B, 512)
+        if not self.body_only:
+            self.g_f32 = torch.empty(B, 512, device=dev)     # BN1d backward output (fp32)
+            self.g_fT = self._act(B, 512)
         # partial rows of every epilogue / channel-wise reduction.  Largest users: the stride-2 data gradient at 56x56
         # ([4 classes][B * 28 strips][2][64] floats), the stem ([M0/128][2][64]), 64-channel strips at 112 ([B * 56][2][64]);
         # _check_part() verifies every launch against the allocation when the plan is built.
@@ -493,27 +507,35 @@ class BackbonePlan(object):
         fold = self.fold
         stats_epi = ops.EPI_STORE if fold else ops.EPI_STATS  # eval mode: nobody reads the partial sums
         stats_part = None if fold else self.part
-        sc, sb, sp = self.stem
-        # ---- stem: im2col -> GEMM(+stats) -> BN+PReLU apply (+stats for unit 0's BN1)
-        w0 = sc.weight
-        P.append(ops.call("fr_pack_stem", w0, w0.stride(0), w0.stride(1), w0.stride(2), w0.stride(3), self.W0p, 64,
-                          w0.shape[1], self.K0, fr, st))
-        self.l_im2col = None  # bound per call (input pointer changes)
-        if self.use_stem_gemm:  # 3.2 M rows x 64 columns x K0: the row-streaming kernels of stem_gemm.hip
-            mt0 = int(min(2048, (self.M0 + 63) // 64))
-            L.append(ops.call("fr_stem_gemm", self.X0, self.W0p, self.y0, self.part, self.M0, self.K0, mt0, st))
-        else:
-            mt0 = (self.M0 + 127) // 128
-            L.append(ops.conv(st, fr, src=self.X0, w=self.W0p, out=self.y0, B=self.M0, RH=1, RW=1, SH=1, SW=1,
-                              SC=self.K0, N=64, KH=1, KW=1, stride=1, pad=0, mode=0, lda=self.K0, ldc=64, pro=0,
-                              epi=ops.EPI_STATS, part=self.part))
-        self._bn_train_launches(L, self.bn0, self.part, mt0, self.M0)
-        nb = ops.grid_blocks(self.M0, 64, fr)
         first_bn = self.ubuf[0]["bn1"]
-        L.append(ops.bn_apply(st, fr, x=self.y0, out=self.z0, scale=self.bn0.scale, shift=self.bn0.shift,
-                              slope=sp.weight, part=stats_part, B=B, H=S, W=S, C=64, res_kind=0, res_stride=1,
-                              nblocks=nb))
-        self._bn_train_launches(L, first_bn, self.part, nb, self.M0)
+        if self.body_only:
+            # a bare stack of residual units: the caller's activation sits in z0; its statistics for the first BN1
+            C0 = self.units[0].cin
+            nb = ops.grid_blocks(self.M0, C0, fr)
+            if not fold:
+                L.append(ops.call("fr_channel_stats", self.z0, self.M0, C0, self.part, nb, fr, st))
+            self._bn_train_launches(L, first_bn, self.part, nb, self.M0)
+        else:
+            sc, sb, sp = self.stem
+            # ---- stem: im2col -> GEMM(+stats) -> BN+PReLU apply (+stats for unit 0's BN1)
+            w0 = sc.weight
+            P.append(ops.call("fr_pack_stem", w0, w0.stride(0), w0.stride(1), w0.stride(2), w0.stride(3), self.W0p, 64,
+                              w0.shape[1], self.K0, fr, st))
+            self.l_im2col = None  # bound per call (input pointer changes)
+            if self.use_stem_gemm:  # 3.2 M rows x 64 columns x K0: the row-streaming kernels of stem_gemm.hip
+                mt0 = int(min(2048, (self.M0 + 63) // 64))
+                L.append(ops.call("fr_stem_gemm", self.X0, self.W0p, self.y0, self.part, self.M0, self.K0, mt0, st))
+            else:
+                mt0 = (self.M0 + 127) // 128
+                L.append(ops.conv(st, fr, src=self.X0, w=self.W0p, out=self.y0, B=self.M0, RH=1, RW=1, SH=1, SW=1,
+                                  SC=self.K0, N=64, KH=1, KW=1, stride=1, pad=0, mode=0, lda=self.K0, ldc=64, pro=0,
+                                  epi=ops.EPI_STATS, part=self.part))
+            self._bn_train_launches(L, self.bn0, self.part, mt0, self.M0)
+            nb = ops.grid_blocks(self.M0, 64, fr)
+            L.append(ops.bn_apply(st, fr, x=self.y0, out=self.z0, scale=self.bn0.scale, shift=self.bn0.shift,
+                                  slope=sp.weight, part=stats_part, B=B, H=S, W=S, C=64, res_kind=0, res_stride=1,
+                                  nblocks=nb))
+            self._bn_train_launches(L, first_bn, self.part, nb, self.M0)
         x = self.z0
         for i, u in enumerate(self.units):
             d = self.ubuf[i]
@@ -550,8 +572,9 @@ class BackbonePlan(object):
                            N=u.depth, KH=3, KW=3, stride=u.stride, pad=1, mode=0, lda=u.depth, ldc=u.depth,
                            ldaux=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight, epi=ops.EPI_BIAS_RES, epi_a=bn2.shift,
                            epi_b=shift_s, aux=res)
-                nxt = self.ubuf[i + 1]["bn1"] if i + 1 < len(self.units) else self.bn_out
-                self._bn_train_launches(L, nxt, None, 0, rout)
+                nxt = self.ubuf[i + 1]["bn1"] if i + 1 < len(self.units) else (None if self.body_only else self.bn_out)
+                if nxt is not None:
+                    self._bn_train_launches(L, nxt, None, 0, rout)
                 x = d["out"]
                 continue
             np2 = self._conv(L, src=d["y1"], w=wp2, out=d["y2"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H,
@@ -592,10 +615,20 @@ class BackbonePlan(object):
                 kw.update(res=x, res_kind=1, res_stride=u.stride)
             else:
                 kw.update(res=d["yS"], res_kind=2, res_stride=1, rscale=d["bnS"].scale, rshift=d["bnS"].shift)
+            nxt = self.ubuf[i + 1]["bn1"] if i + 1 < len(self.units) else (None if self.body_only else self.bn_out)
+            if nxt is None:
+                kw["part"] = None  # nobody consumes the statistics of a bare stack's output
             L.append(ops.bn_apply(st, fr, **kw))
-            nxt = self.ubuf[i + 1]["bn1"] if i + 1 < len(self.units) else self.bn_out
-            self._bn_train_launches(L, nxt, self.part, nb, rout)
+            if nxt is not None:
+                self._bn_train_launches(L, nxt, self.part, nb, rout)
             x = d["out"]
+        if self.body_only:
+            self.feat = x
+            P.append(self._pack_launch())
+            if fold:
+                P.insert(0, self._eval_coeffs_launch())
+            self.pack_list, self.fwd_list = P, L
+            return
         # ---- output layer: BN -> Dropout -> Flatten -> Linear(+bias) -> BN1d
         ob, od, ol, ob1 = self.out
         last = self.units[-1]
@@ -685,10 +718,12 @@ class BackbonePlan(object):
         B, st, fr = self.B, self.stream, self.fr
         L = []
         self.ready_marks = []  # (index into L after which a group of params is complete, [params])
-        ob, od, ol, ob1 = self.out
         last = self.units[-1]
         C = last.depth
         rows_o = B * self.HWo
+        if self.body_only:
+            return self._build_backward_units(L, self.g_pp[0][:rows_o * C], 0)
+        ob, od, ol, ob1 = self.out
         # ---- BN1d backward (fp32 tensors): g_in arrives in self.g_feat_in (bound per call)
         self.g_feat_in = torch.empty(B, 512, device=self.device)
         nbf = ops.grid_blocks(B, 512, FR_F32)
@@ -737,6 +772,10 @@ class BackbonePlan(object):
         g_out = self.g_pp[cur][:rows_o * C]
         L.append(ops.bn_bwd_apply(st, fr, gx=g_out, gamma=ob.weight, s0=s0, s1=s1, inv_count=1.0 / rows_o, **common))
         self.ready_marks.append((len(L), [ob1.weight, ob1.bias, ol.weight, ol.bias, ob.weight, ob.bias], None))
+        self._build_backward_units(L, g_out, cur)
+
+    def _build_backward_units(self, L, g_out, cur):
+        B, st, fr = self.B, self.stream, self.fr
         # ---- residual units in reverse
         unit_done = {}  # unit index -> event recorded on the side stream after its weight gradients
         for i in range(len(self.units) - 1, -1, -1):
@@ -867,6 +906,12 @@ class BackbonePlan(object):
                 unit_done[i] = done
             self.ready_marks.append((len(L), ready, done))
             g_out, cur = g_x, nxt
+        if self.body_only:  # the gradient with respect to the stack's input is the result
+            self.g_input = g_out
+            if self.dual and unit_done:
+                L.append(_EvWait(self.stream1_t, unit_done[min(unit_done)]))  # join: the side stream is FIFO
+            self.bwd_list = L
+            return
         # ---- stem: z0 = PReLU(BN0(y0)); y0 = X0 * W0p^T
         sc, sb, sp = self.stem
         nb = ops.grid_blocks(self.M0, 64, fr)
@@ -917,6 +962,29 @@ class BackbonePlan(object):
         if torch.cuda.current_stream().cuda_stream != self.stream_id:
             return False
         return self._signature() == self.param_sig
+
+    def run_body_forward(self, x):
+        """Bare stack of residual units: x [B, C, H, H] (any float dtype, NCHW) -> [B, depth, Ho, Ho] fp32 NCHW."""
+        B, S, C0 = self.B, self.S, self.units[0].cin
+        self.z0.view(B, S, S, C0).copy_(x.permute(0, 2, 3, 1))
+        ops.run(self.pack_list)
+        ops.run(self.fwd_list)
+        self.generation += 1
+        last = self.units[-1]
+        return self.feat.view(B, last.Ho, last.Ho, last.depth).permute(0, 3, 1, 2).float()
+
+    def run_body_backward(self, g):
+        """dL/d(output) [B, depth, Ho, Ho] -> dL/d(input) fp32 NCHW; parameter gradients land in the arena views."""
+        B, last, first = self.B, self.units[-1], self.units[0]
+        self.g_pp[0][:g.numel()].view(B, last.Ho, last.Ho, last.depth).copy_(g.permute(0, 2, 3, 1))
+        if not getattr(self.arena, "_frhip_zeroed", False):
+            self.arena.zero_()
+        self.arena._frhip_zeroed = False
+        for p, v in self._grad_pairs:
+            if p.grad is not v and p.requires_grad:
+                p.grad = v
+        ops.run(self.bwd_list)
+        return self.g_input.view(B, first.H, first.H, first.cin).permute(0, 3, 1, 2).float()
 
     def run_forward(self, x, avg_image, seed):
         B, S = self.B, self.S
@@ -1061,3 +1129,90 @@ class BackboneRunner(object):
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _BackboneFn.apply(self, x, *params)
         return self._forward_impl(x, infer=True).clone()  # forward-only plan (BatchNorm folded when in eval mode)
+
+
+# ------------------------------------------------------------------------------------------------ bare unit stacks
+
+
+class _UnitStack(object):
+    """What the plan needs from a module tree, for a bare list of residual units (no stem, no output layer)."""
+    input_layer = None
+
+    def __init__(self, blocks, size):
+        self.body, self.input_size = list(blocks), int(size)
+
+    def modules(self):
+        for b in self.body:
+            for m in b.modules():
+                yield m
+
+    def parameters(self):
+        for b in self.body:
+            for p in b.parameters():
+                yield p
+
+    def buffers(self):
+        for b in self.body:
+            for t in b.buffers():
+                yield t
+
+
+class _StackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, runner, x, *params):
+        y = runner._forward_impl(x, infer=False)
+        ctx.plan, ctx.generation = runner.plan, runner.plan.generation
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        if plan.generation != ctx.generation:
+            raise RuntimeError("frhip: the unit ran another forward before this backward; the activation buffers of the "
+                               "static plan hold one step at a time")
+        gx = plan.run_body_backward(g.contiguous().float())
+        return (None, gx) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class UnitStackRunner(object):
+    """Runs ``bottleneck_IR`` / ``bottleneck_IR_SE`` modules (reference backbone/model_irse.py:49-91,
+    restyle_psp_helpers.py:119-199) on their own: ``x [B, C, H, H] -> [B, depth, H/stride, H/stride]`` with gradients
+    for the input and every parameter, through the same launch lists a whole backbone uses (statistics of the input
+    for the first BatchNorm included).  This is what makes the reference's block classes callable outside a backbone,
+    and what the block-level golden fixtures (g3 / g4) run through on the GPU."""
+
+    def __init__(self, blocks):
+        self.blocks = list(blocks)
+        self.plan, self.plans, self.compute_dtype = None, {}, None
+        self.single_stream = False
+
+    def _forward_impl(self, x, infer):
+        dtype = self.compute_dtype or getattr(self.blocks[0], "compute_dtype", None) or compute_dtype_default()
+        key = (x.shape[0], x.shape[2], dtype, x.device, infer)
+        plan = self.plans.get(key)
+        if plan is None or not plan.check_current():
+            plan = BackbonePlan(_UnitStack(self.blocks, x.shape[2]), x.shape[0], dtype, x.device, 0, 0,
+                                single_stream=self.single_stream, infer=infer)
+            self.plans = {key: plan}
+        self.plan = plan
+        return plan.run_body_forward(x)
+
+    def __call__(self, x):
+        if not x.is_cuda:
+            raise _lib.FrhipError("frhip: residual units run on the HIP path only -- got a %s tensor (the CPU restatement "
+                                  "is oracle/, for tests)" % x.device)
+        cin = self.blocks[0].res_layer[0].num_features
+        if x.dim() != 4 or x.shape[1] != cin or x.shape[2] != x.shape[3]:
+            raise RuntimeError("frhip: expected a [B, %d, H, H] activation, got %s" % (cin, tuple(x.shape)))
+        params = [p for b in self.blocks for p in b.parameters()]
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+            return _StackFn.apply(self, x, *params)
+        return self._forward_impl(x, infer=True)
+
+
+def run_unit(block, x):
+    """forward() of a residual-unit module called on its own."""
+    r = block.__dict__.get("_frhip_runner")
+    if r is None:
+        r = block.__dict__["_frhip_runner"] = [UnitStackRunner([block])]
+    return r[0](x)

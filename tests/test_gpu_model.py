@@ -158,6 +158,60 @@ def test_bf16_full_step_tracks_reference(golden_dir, fixture, kind, batch):
     assert m["all_norms_p95"] < b["all_norms_p95"], m
 
 
+G3_BLOCKS = [("ir_64_64_1", False, 64, 64, 1, 16), ("ir_64_128_2", False, 64, 128, 2, 16),
+             ("irse_128_128_1", True, 128, 128, 1, 8), ("irse_256_512_2", True, 256, 512, 2, 8)]
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+@pytest.mark.parametrize("spec", G3_BLOCKS, ids=[b[0] for b in G3_BLOCKS])
+def test_residual_units_match_block_fixtures(golden_dir, spec, mode):
+    """SURVEY 8c G3 on the GPU: ``bottleneck_IR`` / ``bottleneck_IR_SE`` (reference backbone/model_irse.py:49-91) called
+    on their own run the unit's HIP launch lists (frhip.engine.UnitStackRunner; fp32 path) and are compared with the block
+    fixtures captured from the reference: output, gradient with respect to the input, every parameter gradient (first
+    2048 elements + norm), and the BatchNorm running statistics after one training forward.  The two IR-SE units carry
+    the squeeze-excite kernels (pool, MLP, gate, their backward) -- the GPU evidence for SEModule at block level."""
+    _need_gpu()
+    from backbone.model_irse import bottleneck_IR, bottleneck_IR_SE
+    from test_oracle_golden import block_state
+    tag, se, cin, depth, stride, hw = spec
+    g = np.load(os.path.join(golden_dir, "g3_blocks.npz"))
+    blk = (bottleneck_IR_SE if se else bottleneck_IR)(cin, depth, stride)
+    blk.load_state_dict(block_state(tag, se, cin, depth, stride))
+    blk.compute_dtype = torch.float32
+    blk = blk.cuda().train(mode == "train")
+    x = synth.normal(13, "g3.x." + tag, (4, cin, hw, hw)).cuda().requires_grad_(True)
+    gout = synth.normal(13, "g3.g." + tag, (4, depth, hw // stride, hw // stride)).cuda()
+    y = blk(x)
+    y.backward(gout)
+    torch.cuda.synchronize()
+    ref_y = g["%s.%s.y" % (tag, mode)]
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref_y, atol=2e-4 * max(1.0, float(np.abs(ref_y).max())), rtol=0)
+    ref_gx = g["%s.%s.gx" % (tag, mode)]
+    err = float(np.abs(x.grad.cpu().numpy() - ref_gx).max() / np.abs(ref_gx).max())
+    assert err < 1e-3, "input gradient: %g of max" % err
+    worst = ("", 0.0)
+    for n, p in blk.named_parameters():
+        ref = g["%s.%s.g.%s" % (tag, mode, n)]
+        got = p.grad.detach().cpu().reshape(-1)[:2048].numpy()
+        e = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6))
+        worst = max(worst, (n, e), key=lambda t: t[1])
+        nrm = float(g["%s.%s.gnorm.%s" % (tag, mode, n)])
+        assert abs(float(p.grad.double().norm()) - nrm) <= 2e-3 * max(1e-3, nrm), (n, float(p.grad.double().norm()), nrm)
+    print("\n%s %s: worst parameter-gradient error %.2e of max at %s; input gradient %.2e" % (tag, mode, worst[1], worst[0], err))
+    assert worst[1] < 2e-3, worst
+    if mode == "train":
+        for n, b in blk.named_buffers():
+            np.testing.assert_allclose(b.cpu().numpy(), g["%s.train.buf.%s" % (tag, n)], atol=1e-5, rtol=1e-5)
+    if not se:  # the bf16 path of the same unit (generic kernels at these sizes): direction only
+        blk.compute_dtype = torch.bfloat16
+        blk._frhip_runner[0].plans = {}
+        with torch.no_grad():
+            yb = blk(x.detach())
+        if mode == "eval":
+            c = float(torch.nn.functional.cosine_similarity(yb.reshape(1, -1).cpu(), torch.from_numpy(ref_y).reshape(1, -1)))
+            assert c > 0.999, c
+
+
 def test_two_sgd_steps_match_reference(golden_dir):
     """A0 / A15: param-group split + fused SGD over two steps (g7_sgd)."""
     _need_gpu()
