@@ -342,6 +342,9 @@ int fr_shard_rank_rows(const float* logits, const float* tlogit, int32_t* rank, 
 int fr_augment_u8(const uint8_t* src, const int32_t* xtab, const int32_t* ytab, const int32_t* crop, const uint8_t* flip,
                   const float* lut, float* out, int B, int Hin, int Win, int Hr, int Wr, int S, int kx, int ky,
                   void* stream);
+/* F.interpolate(x, size, mode='bilinear') of pSp.forward (backbone/restyle_psp.py:440-443: align_corners = False, no
+ * antialias) on fp32 NCHW planes: in [planes][Hin][Win] -> out [planes][Hout][Wout]; planes = B * C <= 65535. */
+int fr_resize_bilinear(const float* in, float* out, int planes, int Hin, int Win, int Hout, int Wout, void* stream);
 
 /* ---- multi-tensor SGD with momentum (torch.optim.SGD defaults; train.py:196)
  *   d = g + wd*p ; buf = momentum*buf + d ; p -= lr*buf      (buf starts at 0, so the first step gives buf = d)

@@ -118,7 +118,13 @@ class pSp(nn.Module):
 
     def forward(self, x, races=None, is_generated=None):
         if x.size(2) != self.size:
-            raise NotImplementedError("frhip: bilinear resize of %d -> %d inputs (reference restyle_psp.py:440-443) "
-                                      "is not on the accelerated path; feed %dx%d batches"
-                                      % (x.size(2), self.size, self.size, self.size))
+            # F.interpolate(x, self.size, mode='bilinear') of the reference (:440-443), one HIP launch
+            print('[interpolating ', x.size(2), ' to ', self.size, ']')
+            from frhip import _lib, ops
+            if not x.is_cuda:
+                raise _lib.FrhipError("frhip: pSp runs on the HIP path only -- got a %s tensor" % x.device)
+            xin = x.contiguous().float()
+            x = torch.empty(xin.shape[0], xin.shape[1], self.size, self.size, device=xin.device)
+            ops.call("fr_resize_bilinear", xin, x, xin.shape[0] * xin.shape[1], xin.shape[2], xin.shape[3], self.size,
+                     self.size, ops.current_stream_ptr())()
         return self.encoder(x, races=races, avg_image=self.avg_image)

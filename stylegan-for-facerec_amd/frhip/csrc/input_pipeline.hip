@@ -78,3 +78,39 @@ extern "C" int fr_augment_u8(const uint8_t* src, const int32_t* xtab, const int3
                      Hin, Win, S, kx, ky);
   FR_LAUNCH_CHECK();
 }
+
+
+// ------------------------------------------------------------------------------------------ bilinear resize (pSp)
+// pSp.forward resizes a batch whose side differs from the encoder's input size with
+// F.interpolate(x, size, mode='bilinear') (reference backbone/restyle_psp.py:440-443): align_corners = False, no
+// antialiasing -- ATen's upsample_bilinear2d restated: src = scale * (dst + 0.5) - 0.5 clamped at 0, scale = in / out in
+// float, the two taps weighted 1 - l and l in float32.  planes = B * C NCHW planes; one thread per output pixel.
+namespace {
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              int Hin, int Win, int Hout, int Wout, float sh, float sw) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= Hout * Wout) return;
+  const int oy = pix / Wout, ox = pix - oy * Wout;
+  float fy = sh * ((float)oy + 0.5f) - 0.5f, fx = sw * ((float)ox + 0.5f) - 0.5f;
+  fy = fy < 0.f ? 0.f : fy;
+  fx = fx < 0.f ? 0.f : fx;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float* pl = in + (size_t)blockIdx.y * Hin * Win;
+  const float v = hy * (hx * pl[(size_t)y0 * Win + x0] + lx * pl[(size_t)y0 * Win + x1]) +
+                  ly * (hx * pl[(size_t)y1 * Win + x0] + lx * pl[(size_t)y1 * Win + x1]);
+  out[(size_t)blockIdx.y * Hout * Wout + pix] = v;
+}
+}  // namespace
+
+extern "C" int fr_resize_bilinear(const float* in, float* out, int planes, int Hin, int Win, int Hout, int Wout,
+                                  void* stream) {
+  if (planes < 1 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1 || planes > 65535)
+    FR_UNSUPPORTED("fr_resize_bilinear: planes in 1..65535 and positive sizes");
+  const float sh = (float)Hin / (float)Hout, sw = (float)Win / (float)Wout;
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3((Hout * Wout + 255) / 256, planes), dim3(256), 0, (hipStream_t)stream, in,
+                     out, Hin, Win, Hout, Wout, sh, sw);
+  FR_LAUNCH_CHECK();
+}

@@ -484,6 +484,32 @@ def test_folded_eval_forward_matches_oracle_and_unfolded(kind, layers, se):
     assert not inner._runner[0].plan.infer and inner.input_layer[0].weight.grad is not None
 
 
+@pytest.mark.parametrize("hin", [128, 96, 224, 113])
+def test_psp_bilinear_resize_matches_torch(hin):
+    """pSp.forward on a batch whose side is not the encoder's (reference restyle_psp.py:440-443:
+    ``F.interpolate(x, self.size, mode='bilinear')``): the HIP resize equals ATen's CPU upsample (align_corners False, no
+    antialias; up- and down-scaling, odd sizes), and the features equal those of the pre-resized batch."""
+    _need_gpu()
+    from frhip import ops
+    x = synth.uniform(19, "rs.x%d" % hin, (3, 3, hin, hin))
+    ref = torch.nn.functional.interpolate(x, 112, mode="bilinear")
+    out = torch.empty(3, 3, 112, 112, device="cuda")
+    ops.call("fr_resize_bilinear", x.cuda(), out, 9, hin, hin, 112, 112, ops.current_stream_ptr())()
+    torch.cuda.synchronize()
+    assert float((out.cpu() - ref).abs().max()) < 2e-6
+    rect = synth.uniform(19, "rs.rect", (2, 1, 50, 77))  # non-square planes through the same entry point
+    o2 = torch.empty(2, 1, 31, 120, device="cuda")
+    ops.call("fr_resize_bilinear", rect.cuda(), o2, 2, 50, 77, 31, 120, ops.current_stream_ptr())()
+    torch.cuda.synchronize()
+    assert float((o2.cpu() - torch.nn.functional.interpolate(rect, (31, 120), mode="bilinear")).abs().max()) < 2e-6
+    model, _ = build("pSp")
+    model.eval()
+    with torch.no_grad():
+        a = model(x.cuda()).cpu()
+        b = model(ref.cuda()).cpu()
+    assert float((a - b).abs().max()) < 1e-4
+
+
 def test_wrong_channel_count_raises():
     _need_gpu()
     from backbone.restyle_psp import pSp
