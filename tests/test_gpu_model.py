@@ -59,6 +59,9 @@ def test_full_step_matches_reference(golden_dir, fixture, kind, batch):
     torch.cuda.synchronize()
     assert float((feats.detach().cpu() - torch.from_numpy(g["features"])).abs().max()) < 1e-3
     dl = float((logits.detach().cpu() - torch.from_numpy(g["logits"])).abs().max())
+    print("\nfp32 vs golden %s: max|dfeature| %.2e  max|dlogit| %.2e (bar 1e-3)  |dloss| %.2e" % (
+        fixture, float((feats.detach().cpu() - torch.from_numpy(g["features"])).abs().max()), dl,
+        abs(float(loss.detach()) - float(g["loss"]))))
     assert dl < 1e-3, "logits differ from the reference by %g" % dl
     assert abs(float(loss) - float(g["loss"])) < 1e-4
     named = dict(model.named_parameters())
@@ -77,6 +80,8 @@ def test_full_step_matches_reference(golden_dir, fixture, kind, batch):
             d32 = float((mine - ref32).norm() / ref32.norm())
             d64 = float((mine - ref64).norm() / ref64.norm())
             noise = float((ref32 - ref64).norm() / ref64.norm())
+            print("   %-44s vs ref fp32 %.2e (bar 2.5e-3)  vs float64 %.2e (reference's own fp32: %.2e, bar 4x)"
+                  % (k[2:], d32, d64, noise))
             assert d32 < 2.5e-3, "%s: relative gradient error vs reference fp32 %g" % (k, d32)
             assert d64 < max(4.0 * noise, 2e-5), "%s: error vs float64 truth %g (reference fp32: %g)" % (k, d64, noise)
     d64 = float((logits.detach().cpu().double() - torch.from_numpy(g["logits64"])).abs().max())
