@@ -27,7 +27,12 @@ constexpr int TSTR = CT * 2 + 32;    // LDS row stride (bytes) of both tiles: co
 // grid (= the gradient g); the input tile holds the four parity planes x[2i+ph][2j+pw] of the strip, each
 // (ROWS+1) x (W+1) pixels with one halo row / column (plane row -1, column -1), and tap (kh, kw) reads plane
 // (kh != 1, kw != 1) at row offset (kh > 0), column offset (kw > 0) -- still a compile-time address offset.
-template <int W, int ROWS, int NIMG, int NW, bool S2 = false>
+// RK ("row-aligned K"): the pixel (= K) axis of both tiles is laid out in rows of RW = 16 / 32 slots (W = 14 / 28; the
+// surplus slots of the g tile hold zeros), so that a tap's row shift kh is a shift by whole 16-pixel fragment halves: the
+// half-fragments of the input tile read for tap (0, kw) at K step s ARE the ones tap (kh, kw) needs at an earlier step, and
+// a step reads 6 new input half-fragments instead of 18 (10 instead of 22 LDS reads per 18 MFMAs: MFMA- instead of
+// LDS-bound: 8 waves x 22 x 512 B = 704 LDS clocks against 576 MFMA clocks per step before).
+template <int W, int ROWS, int NIMG, int NW, bool S2 = false, bool RK = false>
 struct WC {
   static constexpr int NTH = NW * 64;                 // 8 waves (2 co halves x 4 ci tiles) or 4 waves (4 ci tiles, all co)
   static constexpr int TCO = 4 / (NW / 4);            // co tiles (16 wide) per wave
@@ -36,11 +41,13 @@ struct WC {
   static constexpr int PLANE = GH * GW;               // S2: pixels of one parity plane
   static constexpr int MI = ROWS * W;                 // output pixels per image strip
   static constexpr int M = MI * NIMG;                 // pixels per fill
-  static constexpr int NKS = (M + 31) / 32;
+  static constexpr int RW = RK ? (W <= 14 ? 16 : 32) : GW;  // RK: K slots per image row
+  static constexpr int NKS = RK ? ROWS * RW / 32 : (M + 31) / 32;
   static constexpr int PXP = NKS * 32;
   static constexpr int G_BYTES = PXP * TSTR;
   static constexpr int APIX = NIMG * GH * GW * (S2 ? 4 : 1);
-  static constexpr int A_BYTES = APIX * TSTR;
+  static constexpr int APOS = RK ? GH * RW + 16 : APIX;  // RK: tile positions (+ the tail a kw-shifted read of the last row touches)
+  static constexpr int A_BYTES = APOS * TSTR;
   static constexpr int LDS = G_BYTES + A_BYTES;
   static constexpr int NS = H / ROWS;                 // strips per image
   static constexpr int GCH = M * 8, ACH = APIX * 8;   // 16-B chunks per fill
@@ -51,6 +58,7 @@ struct WC {
   static_assert(H % ROWS == 0, "strip rows must divide the image");
   static_assert(NIMG == 1 || ROWS == H, "several images per fill only for whole-image strips");
   static_assert(LDS <= 160 * 1024, "LDS budget");
+  static_assert(!RK || (!S2 && NIMG == 1 && W + 2 <= RW && (ROWS * RW) % 32 == 0), "row-aligned K: stride 1, one strip");
 };
 
 typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
@@ -64,6 +72,10 @@ __device__ __forceinline__ constexpr int tap_pix(int tap) {
   return plane * C::PLANE + (kh > 0 ? 1 : 0) * C::GW + (kw > 0 ? 1 : 0);
 }
 
+__device__ __forceinline__ s16x4 tr_half(const char* p0) {
+  return __builtin_bit_cast(s16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)p0));
+}
+
 __device__ __forceinline__ s16x8 tr_frag(const char* p0, const char* p1) {
   const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)p0);
   const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)p1);
@@ -71,9 +83,9 @@ __device__ __forceinline__ s16x8 tr_frag(const char* p0, const char* p1) {
   return (s16x8){ai[0], ai[1], ai[2], ai[3], bi[0], bi[1], bi[2], bi[3]};
 }
 
-template <int W, int ROWS, int NIMG, int NW, int PRO, bool S2 = false>
+template <int W, int ROWS, int NIMG, int NW, int PRO, bool S2 = false, bool RK = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_strip_kernel(const FrWgradArgs p) {
-  using C = WC<W, ROWS, NIMG, NW, S2>;
+  using C = WC<W, ROWS, NIMG, NW, S2, RK>;
   constexpr int NTH = C::NTH;
   constexpr int TCO = C::TCO;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,9 +114,17 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_strip_kernel(const FrWg
   const bf16_t* __restrict__ G = reinterpret_cast<const bf16_t*>(p.g);
   const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(p.src);
 
-  // zero the padded pixel rows of the g tile once (rows >= M never get written again)
-  for (int idx = tid; idx < (C::PXP - C::M) * 8; idx += NTH)
-    st16(Gs + (C::M + idx / 8) * TSTR + (idx & 7) * 16, zero16());
+  // zero the padded pixel rows of the g tile once (rows >= M never get written again); RK: the surplus slots are spread
+  // over both tiles (and must be finite in the input tile, where they meet the zeros of the g tile): clear everything
+  if (RK) {
+    for (int idx = tid; idx < (C::PXP + C::APOS) * 8; idx += NTH) st16(smem + (idx / 8) * TSTR + (idx & 7) * 16, zero16());
+  } else {
+    for (int idx = tid; idx < (C::PXP - C::M) * 8; idx += NTH)
+      st16(Gs + (C::M + idx / 8) * TSTR + (idx & 7) * 16, zero16());
+  }
+  // tile position of g pixel c / of input-tile pixel a
+  auto gpos = [](int c) -> int { return RK ? (c / W) * C::RW + c % W : c; };
+  auto apos = [](int a) -> int { return RK ? (a / C::GW) * C::RW + a % C::GW : a; };
 
   const int ch = tid & 7;  // NTH % 8 == 0: a thread always handles the same 8-channel chunk
   float pa[8], pb[8];
@@ -171,7 +191,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_strip_kernel(const FrWg
       const int idx = u * NTH + tid;
       const int c = idx >> 3;
       if (idx < C::GCH) {
-        st16(Gs + c * TSTR + ch * 16, ld[u]);
+        st16(Gs + gpos(c) * TSTR + ch * 16, ld[u]);
       } else if (idx < C::GCH + C::ACH) {
         U128 x = ld[u];
         if (PRO != FR_PRO_NONE && okv[u]) {
@@ -184,11 +204,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_strip_kernel(const FrWg
           }
           x = pack16<bf16_t>(f);
         }
-        st16(As + (c - C::M) * TSTR + ch * 16, x);
+        st16(As + apos(c - C::M) * TSTR + ch * 16, x);
       }
     }
   };
 
+  static_assert(!RK || C::PF, "row-aligned K rides on the register-prefetch loader");
   auto load_now = [&](int f) {  // !PF: stream the strip through 8 registers at a time
     const int img0 = NIMG > 1 ? f * NIMG : f / C::NS;
     const int row0 = NIMG > 1 ? 0 : (f - img0 * C::NS) * ROWS;
@@ -254,6 +275,38 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_strip_kernel(const FrWg
     else load_now(f);
     __syncthreads();
     if (C::PF && f + 1 < f_end) issue(f + 1);  // next strip's loads fly under this strip's MFMAs
+    if constexpr (RK) {
+      // half-fragment j = tile positions [16 j, 16 j + 16) shifted by kw; tap (kh, kw) of step ks pairs the halves
+      // 2 ks + kh RW / 16 and the next one.  Everything below is unrolled: hg[][] lives in registers, indices are static.
+      constexpr int R16 = C::RW / 16, NJ = 2 * C::NKS + 2 * R16;
+      const char* ab = As + (4 * lq + (li >> 2)) * TSTR + (wci * 16) * 2 + colb;
+      const char* gb = Gs + (4 * lq + (li >> 2)) * TSTR + (wco * 32) * 2 + colb;
+      s16x4 hg[NJ][3];
+#pragma unroll
+      for (int j = 0; j < 2 * R16; ++j)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) hg[j][kw] = tr_half(ab + (16 * j + kw) * TSTR);
+#pragma unroll
+      for (int ks = 0; ks < C::NKS; ++ks) {
+#pragma unroll
+        for (int j = 2 * ks + 2 * R16; j < 2 * ks + 2 * R16 + 2; ++j)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) hg[j][kw] = tr_half(ab + (16 * j + kw) * TSTR);
+        s16x8 gf[TCO];
+#pragma unroll
+        for (int t = 0; t < TCO; ++t) gf[t] = tr_frag(gb + (32 * ks) * TSTR + t * 32, gb + (32 * ks + 16) * TSTR + t * 32);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int j0 = 2 * ks + (tap / 3) * R16;
+          const s16x4 lo = hg[j0][tap % 3], hi = hg[j0 + 1][tap % 3];
+          const s16x8 af = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int t = 0; t < TCO; ++t)
+            acc[t][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[t], af, acc[t][tap], 0, 0, 0);
+        }
+      }
+      continue;
+    }
     // fully unrolled where registers allow (reads of step k+1 are then scheduled under the MFMAs of step k)
 #pragma unroll C::KUNR
     for (int ks = 0; ks < C::NKS; ++ks) {
@@ -328,18 +381,18 @@ int fr_launch_reduce_slabs(const float* slab, int groups, long long n, float* ou
 
 namespace {
 
-template <int W, int ROWS, int NIMG, int NW, int PRO, bool S2 = false>
+template <int W, int ROWS, int NIMG, int NW, int PRO, bool S2 = false, bool RK = false>
 int launch(const FrWgradArgs& a, hipStream_t st) {
-  using C = WC<W, ROWS, NIMG, NW, S2>;
+  using C = WC<W, ROWS, NIMG, NW, S2, RK>;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<W, ROWS, NIMG, NW, PRO, S2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<W, ROWS, NIMG, NW, PRO, S2, RK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     attr_done = true;
   }
   const int tiles = (a.Cout / CT) * (a.SC / CT);
-  hipLaunchKernelGGL((conv_wgrad_strip_kernel<W, ROWS, NIMG, NW, PRO, S2>), dim3(tiles * a.nsplit), dim3(C::NTH), C::LDS, st,
-                     a);
+  hipLaunchKernelGGL((conv_wgrad_strip_kernel<W, ROWS, NIMG, NW, PRO, S2, RK>), dim3(tiles * a.nsplit), dim3(C::NTH), C::LDS,
+                     st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     fr_set_error(hipGetErrorString(e));
@@ -348,14 +401,23 @@ int launch(const FrWgradArgs& a, hipStream_t st) {
   return fr_launch_reduce_slabs(a.slab, a.nsplit, (long long)a.Cout * 9 * a.SC, a.dw, st);
 }
 
-template <int W, int ROWS, int NIMG, int NW, bool S2 = false>
+template <int W, int ROWS, int NIMG, int NW, bool S2 = false, bool RK = false>
 int by_pro(const FrWgradArgs& a, hipStream_t st) {
   switch (a.pro) {
-    case FR_PRO_NONE: return launch<W, ROWS, NIMG, NW, FR_PRO_NONE, S2>(a, st);
-    case FR_PRO_BN: return launch<W, ROWS, NIMG, NW, FR_PRO_BN, S2>(a, st);
-    case FR_PRO_PRELU: return launch<W, ROWS, NIMG, NW, FR_PRO_PRELU, S2>(a, st);
+    case FR_PRO_NONE: return launch<W, ROWS, NIMG, NW, FR_PRO_NONE, S2, RK>(a, st);
+    case FR_PRO_BN: return launch<W, ROWS, NIMG, NW, FR_PRO_BN, S2, RK>(a, st);
+    case FR_PRO_PRELU: return launch<W, ROWS, NIMG, NW, FR_PRO_PRELU, S2, RK>(a, st);
   }
   return -1;
+}
+
+// FRHIP_WGRAD_ROWK=0: the 28x28 / 14x14 instances without the row-aligned K layout (A/B switch)
+bool row_k() {
+  static const bool on = [] {
+    const char* e = getenv("FRHIP_WGRAD_ROWK");
+    return !(e && e[0] == '0');
+  }();
+  return on;
 }
 
 }  // namespace
@@ -389,8 +451,8 @@ extern "C" int fr_conv_wgrad_strip(const FrWgradArgs* args, void* stream) {
   switch (a.SW) {
     case 112: return by_pro<112, 2, 1, 8>(a, st);
     case 56: return by_pro<56, 4, 1, 8>(a, st);
-    case 28: return by_pro<28, 7, 1, 8>(a, st);
-    case 14: return by_pro<14, 14, 1, 8>(a, st);
+    case 28: return row_k() ? by_pro<28, 7, 1, 8, false, true>(a, st) : by_pro<28, 7, 1, 8>(a, st);
+    case 14: return row_k() ? by_pro<14, 14, 1, 8, false, true>(a, st) : by_pro<14, 14, 1, 8>(a, st);
     case 7: return by_pro<7, 7, 4, 8>(a, st);
   }
   FR_UNSUPPORTED("fr_conv_wgrad_strip: width not in the strip table");
