@@ -429,6 +429,9 @@ int s2_rows(int C, int WL) {
 // mode 0: forward (one row per workgroup); mode 2: data gradient (4 classes x workgroups, ordered [class][workgroup]).
 extern "C" int fr_conv3x3_s2_strip_parts(int B, int Cin, int Cout, int WL, int mode) {
   if (Cin != Cout) return 0;
+  // 64 channels: one row per work item of the rolling-window kernel.  NOTE: the caller's epilogue decides whether that kernel
+  // serves the launch (forward STORE / STATS, gradient PReLU backward); the combinations it does not serve write no sums.
+  if (Cin == 64 && WL == 56 && fr_s2roll_enabled()) return fr_s2roll_parts(B);
   const int rows = s2_rows(Cin, WL);
   if (!rows) return 0;
   const int wgs = B * (WL / rows);
@@ -449,6 +452,7 @@ extern "C" int fr_conv3x3_s2_strip(const FrConvArgs* args, void* stream) {
   const int WHi = a.mode == 0 ? a.SW : a.RW, HHi = a.mode == 0 ? a.SH : a.RH;
   if (WLo != HLo || WHi != 2 * WLo || HHi != 2 * HLo || a.SC != a.N)
     FR_UNSUPPORTED("fr_conv3x3_s2_strip: square images, high-res side = 2 x low-res side, Cin == Cout");
+  if (fr_s2roll_serves(a)) return fr_s2roll_launch(a, st);
 #define SHAPE(c, wl, rows, wn, nw)                                   \
   if (a.SC == c && WLo == wl) {                                      \
     if (a.mode == 0) return by_pro<c, c, wl, rows, wn, nw, 0>(a, st); \

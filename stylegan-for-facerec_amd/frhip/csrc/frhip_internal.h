@@ -11,3 +11,10 @@ int fr_launch_reduce_slabs(const float* slab, int groups, long long n, float* ou
 bool fr_roll64_enabled();
 int fr_roll64_parts(int B, int W);
 int fr_roll64_launch(const FrConvArgs& a, hipStream_t st);
+
+// 64-channel stride-2 3x3 layer (112 -> 56) and its data gradient on the rolling-window kernel (conv3x3_s2_roll64.hip);
+// dispatched from fr_conv3x3_s2_strip
+bool fr_s2roll_serves(const FrConvArgs& a);
+int fr_s2roll_parts(int B);
+int fr_s2roll_launch(const FrConvArgs& a, hipStream_t st);
+bool fr_s2roll_enabled();

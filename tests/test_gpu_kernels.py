@@ -754,15 +754,30 @@ def test_conv_dgrad_stride2_by_parity(K, name, dtype, tol, fused):
 
 
 S2_SHAPES = [(64, 56), (128, 28), (256, 14), (512, 7)]
+# 64 channels run on the rolling-window kernel (conv3x3_s2_roll64.hip), whose walk depends on the batch: B = 3 / 2: 28 row
+# segments per image (2-row walks); B = 40: 7 segments, 280 work items on 256 persistent workgroups (item loop); B = 130: 2
+# segments; "whole": FRHIP_S2ROLL_NSEG=1 = the 56-row walk of the B >= 256 step, on three images
+S2_CASES = [s + (3, "") for s in S2_SHAPES] + [(64, 56, 40, ""), (64, 56, 130, ""), (64, 56, 3, "whole")]
 
 
-@pytest.mark.parametrize("C,WL", S2_SHAPES, ids=["%d_%d" % s for s in S2_SHAPES])
+@pytest.fixture
+def s2_walk(monkeypatch):
+    def set_walk(walk):
+        if walk == "whole":
+            monkeypatch.setenv("FRHIP_S2ROLL_NSEG", "1")
+    return set_walk
+
+
+@pytest.mark.parametrize("C,WL,B,walk", S2_CASES, ids=["%d_%d_b%d%s" % s for s in S2_CASES])
 @pytest.mark.parametrize("pro", ["none", "bn", "prelu"])
-def test_conv3x3_s2_strip_forward(K, C, WL, pro):
+def test_conv3x3_s2_strip_forward(K, s2_walk, C, WL, B, walk, pro):
     """fr_conv3x3_s2_strip mode 0: stride-2 3x3 forward on LDS parity planes (+ prologue, + BN statistics) vs
     F.conv2d on the CPU, and vs the generic implicit-GEMM kernel's partial-sum contract (column totals)."""
     dtype, tol = torch.bfloat16, BF16_TOL
-    B, H = 3, 2 * WL
+    s2_walk(walk)
+    H = 2 * WL
+    if B > 3 and pro != "prelu":
+        pytest.skip("large batches: the prologue the step uses")
     x = q(synth.normal(61, "sx", (B, C, H, H)), dtype)
     w = q(synth.normal(61, "sw", (C, C, 3, 3), std=0.05), dtype)
     pa = synth.uniform(61, "spa", (C,), 0.5, 1.5)
@@ -791,12 +806,13 @@ def test_conv3x3_s2_strip_forward(K, C, WL, pro):
     np.testing.assert_allclose(part.sum(0)[1].cpu(), (y * y).sum((0, 2, 3)), rtol=tol)
 
 
-@pytest.mark.parametrize("C,WL", S2_SHAPES, ids=["%d_%d" % s for s in S2_SHAPES])
-def test_conv3x3_s2_strip_dgrad(K, C, WL):
+@pytest.mark.parametrize("C,WL,B,walk", S2_CASES, ids=["%d_%d_b%d%s" % s for s in S2_CASES])
+def test_conv3x3_s2_strip_dgrad(K, s2_walk, C, WL, B, walk):
     """fr_conv3x3_s2_strip mode 2: all four parity classes of the stride-2 data gradient with the PReLU-backward
     epilogue, vs autograd through F.conv2d(stride=2)."""
     dtype, tol = torch.bfloat16, BF16_TOL
-    B, H = 2, 2 * WL
+    s2_walk(walk)
+    H = 2 * WL
     x = synth.normal(63, "dx", (B, C, H, H)).requires_grad_(True)
     w = q(synth.normal(63, "dw", (C, C, 3, 3), std=0.05), dtype)
     y = F.conv2d(x, w, stride=2, padding=1)
@@ -808,7 +824,7 @@ def test_conv3x3_s2_strip_dgrad(K, C, WL):
     wt = w.permute(1, 2, 3, 0).reshape(C, 9, C).contiguous().to("cuda", dtype)
     out = torch.zeros(B, H, H, C, device="cuda", dtype=dtype)
     n = K.s2_strip_parts(B, C, C, WL, 2)
-    assert n > 0 and n % 4 == 0
+    assert n > 0
     part = torch.zeros(n, 2, C, device="cuda")
     K.conv_s2_strip(K.current_stream_ptr(), src=nhwc(g, dtype), w=wt, out=out, B=B, RH=H, RW=H, SH=WL, SW=WL, SC=C, N=C,
                     KH=3, KW=3, stride=2, pad=1, mode=2, par_h=-1, par_w=-1, lda=C, ldc=C, ldaux=C, pro=0,
