@@ -92,6 +92,11 @@ constexpr Step step_of(int s) {
   return r;
 }
 
+// Pins the uses of a loaded chunk behind this point of the program.  The instruction scheduler otherwise hoists the unpacking
+// of the OTHER register set's chunks (committed after the next barrier) in front of the barrier, and with it their
+// s_waitcnt: the wait then covers loads that were meant to stay in flight for another iteration.
+__device__ __forceinline__ void pin(U128& a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)); }
+
 template <int S, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (S < N) {
@@ -191,10 +196,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_roll64_kernel(const FrConvA
           const unsigned okmask = rs.okmask;
           const int s0 = (first + 2 + 6 * K::F_NR) % K::F_NR;
 #pragma unroll
+          for (int u = 0; u < 7; ++u) pin(st[u]);
+          // no branch anywhere in the steady state of these waves: the compiler's vmcnt bookkeeping is exact only on
+          // straight-line code, and a conservative wait here would also wait for the loads of the OTHER register set
+#pragma unroll
           for (int u = 0; u < 7; ++u) {
-            const bool ok = (okmask >> u) & 1u;
-            U128 x = ok ? st[u] : zero16();
-            if (PRO != FR_PRO_NONE && ok) {
+            const unsigned keep = ((okmask >> u) & 1u) ? 0xFFFFFFFFu : 0u;
+            U128 x = st[u];
+            if (PRO != FR_PRO_NONE) {
               float f[8];
               unpack16<bf16_t>(x, f);
 #pragma unroll
@@ -204,6 +213,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_roll64_kernel(const FrConvA
               }
               x = pack16<bf16_t>(f);
             }
+            x.x &= keep;
+            x.y &= keep;
+            x.z &= keep;
+            x.w &= keep;
             st16(smem + (s0 + ((hrow >> u) & 1)) * K::F_RSTR + hlds[u], x);
           }
         };
@@ -213,13 +226,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_roll64_kernel(const FrConvA
           U128 o[2];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            const int m = u * 32 + t5;
-            o[u] = ld16(tile + (m < K::WL ? m : 0) * K::PSTR + ch * 16);
+            const int m = u * 32 + t5, mc = m < K::WL ? m : K::WL - 1;
+            o[u] = ld16(tile + mc * K::PSTR + ch * 16);
           }
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int m = u * 32 + t5;
-            if (m < K::WL) st16(rowb + (unsigned)(m * p.ldc + ch * 8) * 2u, o[u]);
+          for (int u = 0; u < 2; ++u) {  // lanes past the row store pixel 55 again (same bytes): no divergence
+            const int m = u * 32 + t5, mc = m < K::WL ? m : K::WL - 1;
+            st16(rowb + (unsigned)(mc * p.ldc + ch * 8) * 2u, o[u]);
           }
         };
         // prime: rows 2 r0 - 1 .. 2 r0 + 1 resident (as the pairs (2 r0 - 2, 2 r0 - 1), (2 r0, 2 r0 + 1)), the next pair requested
@@ -232,15 +245,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_roll64_kernel(const FrConvA
         __syncthreads();
         auto iteration = [&](RowSet& rs, int k) {  // rs: the rows of iteration k + 1, requested two iterations ago
           const int r = r0 + k;
-          if (k > 0) drain_tile(k - 1);
-          if (k + 1 < nit) commit_rows(rs, 2 * r + 2);
-          issue_rows(rs, 2 * r + 6);  // past the walk: clamped, never committed
-          __syncthreads();            // iteration k is computed, the rows of k + 1 are visible
+          commit_rows(rs, 2 * r + 2);  // (the last iteration commits rows nobody reads into slots nobody reads)
+          issue_rows(rs, 2 * r + 6);   // past the walk: clamped
+          __syncthreads();             // iteration k is computed, the rows of k + 1 are visible
         };
+        iteration(setA, 0);
+        drain_tile(0);
+        iteration(setB, 1);
 #pragma unroll 1
-        for (int k = 0; k < nit; k += 2) {
+        for (int k = 2; k < nit; k += 2) {  // nit is even
+          drain_tile(k - 1);
           iteration(setA, k);
-          if (k + 1 < nit) iteration(setB, k + 1);
+          drain_tile(k);
+          iteration(setB, k + 1);
         }
         drain_tile(nit - 1);
       } else {
@@ -252,18 +269,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_roll64_kernel(const FrConvA
           const int rc = row < K::WL ? row : K::WL - 1;
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            const int m = u * 32 + t5;
-            sg[u] = ld16(src_img + ((unsigned)(rc * lo_row_src) + (unsigned)((m < K::WL ? m : 0) * p.lda + ch * 8) * 2u));
+            const int m = u * 32 + t5, mc = m < K::WL ? m : K::WL - 1;  // lanes past the row repeat pixel 55
+            sg[u] = ld16(src_img + ((unsigned)(rc * lo_row_src) + (unsigned)(mc * p.lda + ch * 8) * 2u));
           }
         };
         auto commit_g = [&](GSet& gs, int row) {
           U128(&sg)[2] = gs.sg;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) pin(sg[u]);
           const bool ok = row < K::WL;
           char* slot = smem + (row % K::D_NR) * K::D_RSTR;
+          const unsigned keep = ok ? 0xFFFFFFFFu : 0u;
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            const int m = u * 32 + t5;
-            if (m < K::WL) st16(slot + m * K::PSTR + ch * 16, ok ? sg[u] : zero16());
+            const int m = u * 32 + t5, mc = m < K::WL ? m : K::WL - 1;
+            U128 x = sg[u];
+            x.x &= keep;
+            x.y &= keep;
+            x.z &= keep;
+            x.w &= keep;
+            st16(slot + mc * K::PSTR + ch * 16, x);
           }
         };
         auto issue_aux = [&](GSet& gs, int r) {  // aux rows 2r, 2r + 1 = 224 consecutive pixels (clamped past the image: never used)
@@ -275,6 +300,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_roll64_kernel(const FrConvA
         };
         auto stage_aux = [&](GSet& gs, int k) {  // gs -> the aux cells of the output tile of iteration k
           U128(&ax)[7] = gs.ax;
+#pragma unroll
+          for (int u = 0; u < 7; ++u) pin(ax[u]);
           char* tile = smem + LY::TILE_OFF + (k & 1) * LY::TILE;
 #pragma unroll
           for (int u = 0; u < 7; ++u) st16(tile + (u * 32 + t5) * K::PSTR + ch * 16, ax[u]);
@@ -302,19 +329,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_roll64_kernel(const FrConvA
         __syncthreads();
         auto iteration = [&](GSet& gs, int k) {  // gs: g row r + 2 and the aux cells of iteration k + 1
           const int r = r0 + k;
-          if (k > 0) drain_tile(k - 1);
-          if (k + 1 < nit) {
-            stage_aux(gs, k + 1);  // into the tile just drained
-            commit_g(gs, r + 2);
-          }
+          stage_aux(gs, k + 1);  // into the tile just drained (after the last iteration: cells nobody reads)
+          commit_g(gs, r + 2);
           issue_g(gs, r + 4);
           issue_aux(gs, r + 3);
           __syncthreads();
         };
+        iteration(setA, 0);
+        drain_tile(0);
+        iteration(setB, 1);
 #pragma unroll 1
-        for (int k = 0; k < nit; k += 2) {
+        for (int k = 2; k < nit; k += 2) {  // nit is even
+          drain_tile(k - 1);
           iteration(setA, k);
-          if (k + 1 < nit) iteration(setB, k + 1);
+          drain_tile(k);
+          iteration(setB, k + 1);
         }
         drain_tile(nit - 1);
       }
@@ -487,12 +516,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_roll64_kernel(const FrConvA
 
 int s2roll_nseg(int B) {
   // row segments per image: enough workgroups for one per CU on 256 CUs; 56 rows must divide evenly
-  static const int cand[7] = {1, 2, 4, 7, 8, 14, 28};
+  static const int cand[6] = {1, 2, 4, 7, 14, 28};  // rows per walk 56 / nseg: even (the data-moving loop is unrolled by two)
   const char* e = getenv("FRHIP_S2ROLL_NSEG");  // read per call: the tests walk whole images with small batches
   const int forced = e ? atoi(e) : -1;
-  for (int k = 0; k < 7; ++k)
+  for (int k = 0; k < 6; ++k)
     if (forced == cand[k]) return cand[k];
-  for (int k = 0; k < 7; ++k)
+  for (int k = 0; k < 6; ++k)
     if ((long long)B * cand[k] >= 256) return cand[k];
   return 28;
 }
