@@ -205,6 +205,51 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
     }
   };
 
+  // Forward: the NEXT plane is requested into registers before the taps of the current one run and committed after them
+  // (one workgroup per CU at 256 / 512 channels: nothing else hides the load latency of the four phases).
+  // Only where the register budget is spent anyway: at 64 / 128 channels the 20-32 extra registers cost a resident workgroup
+  // (128 -> 128 @28: 0.166 -> 0.196 ms with the prefetch).
+  constexpr bool PFP = KIND == 0 && CIN >= 256;
+  constexpr int NPF = (TOTAL + NTH - 1) / NTH;
+  U128 pf[PFP ? NPF : 1];
+  unsigned pfok = 0;
+  auto issue_plane = [&](int ph, int pw) {
+    pfok = 0;
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+      const int idx = u * NTH + tid;
+      const int pc = idx / C::CH;
+      const int gh = pc / C::GW, gw = pc - gh * C::GW;
+      const int i = row0 + gh - 1, j = gw - 1;
+      const bool ok = idx < TOTAL && i >= 0 && j >= 0;
+      const size_t pix = ((size_t)(b * 2 * C::HL + 2 * i + ph) * (2 * WL) + 2 * j + pw);
+      pf[PFP ? u : 0] = ok ? ld16(src + pix * (size_t)p.lda + ch * 8) : zero16();
+      pfok |= ok ? (1u << u) : 0u;
+    }
+  };
+  auto commit_plane = [&]() {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+      const int idx = u * NTH + tid;
+      if (idx < TOTAL) {
+        const int pc = idx / C::CH;
+        const int gh = pc / C::GW, gw = pc - gh * C::GW;
+        U128 x = pf[PFP ? u : 0];
+        if (PRO != FR_PRO_NONE && ((pfok >> u) & 1u)) {
+          float f[8];
+          unpack16<bf16_t>(x, f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (PRO == FR_PRO_BN) f[j] = fmaf(f[j], pa[j], pb[j]);
+            else f[j] = f[j] > 0.f ? f[j] : f[j] * pa[j];
+          }
+          x = pack16<bf16_t>(f);
+        }
+        st16(smem + gh * C::RSTR + gw * C::PSTR + ch * 16, x);
+      }
+    }
+  };
+
   const int fr = lane & 15, fq = lane >> 4;
   const int n0 = wn * C::TN * 16;
   const bf16_t* wrow[C::TN];
@@ -231,18 +276,39 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
 
   // ------------------------------------------------------------------ epilogue of one output class
   // cls < 0: forward (output pixel = low-res pixel); cls = 2*ph + pw: gradient class (output pixel (2i+ph, 2j+pw))
-  auto epilogue = [&](int cls) {
+  // aux cells of one output class: requested before the taps of that class run (data gradient), written into the output
+  // tile behind them
+  constexpr int NAX = (C::M * OCH + NTH - 1) / NTH;
+  U128 axr[NAX];
+  const bool has_aux = epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD || epi == FR_EPI_BIAS_RES;
+  auto out_pix = [&](int cls, int r) -> size_t {
     const int ph = cls < 0 ? 0 : cls >> 1, pw = cls < 0 ? 0 : cls & 1;
-    auto dst_pix = [&](int r) -> size_t {
-      const int h = r / WL, w = r - h * WL;
-      if (KIND == 0) return (size_t)(b * C::HL + row0 + h) * WL + w;
-      return (size_t)(b * 2 * C::HL + 2 * (row0 + h) + ph) * (2 * WL) + 2 * w + pw;
-    };
-    if (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD || epi == FR_EPI_BIAS_RES) {
+    const int h = r / WL, w = r - h * WL;
+    if (KIND == 0) return (size_t)(b * C::HL + row0 + h) * WL + w;
+    return (size_t)(b * 2 * C::HL + 2 * (row0 + h) + ph) * (2 * WL) + 2 * w + pw;
+  };
+  auto issue_aux = [&](int cls) {
+    if (has_aux) {
       const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
-      for (int idx = tid; idx < C::M * OCH; idx += NTH) {
+#pragma unroll
+      for (int u = 0; u < NAX; ++u) {
+        int idx = u * NTH + tid;
+        idx = idx < C::M * OCH ? idx : C::M * OCH - 1;
         const int r = idx / OCH, c8 = idx - r * OCH;
-        st16(otile + r * C::OSTR + c8 * 16, ld16(aux + dst_pix(r) * (size_t)p.ldaux + c8 * 8));
+        axr[u] = ld16(aux + out_pix(cls, r) * (size_t)p.ldaux + c8 * 8);
+      }
+    }
+  };
+  auto epilogue = [&](int cls) {
+    auto dst_pix = [&](int r) -> size_t { return out_pix(cls, r); };
+    if (has_aux) {
+#pragma unroll
+      for (int u = 0; u < NAX; ++u) {
+        const int idx = u * NTH + tid;
+        if (idx < C::M * OCH) {
+          const int r = idx / OCH, c8 = idx - r * OCH;
+          st16(otile + r * C::OSTR + c8 * 16, axr[u]);
+        }
       }
       __syncthreads();
     }
@@ -344,7 +410,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
     __syncthreads();  // the tile and the reduction scratch are free again
   };
 
-  if (KIND == 0) {
+  if (KIND == 0 && !PFP) {
     zero_acc();
     load_image(0, 0);
     __syncthreads();
@@ -360,6 +426,31 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
     __syncthreads();
     load_image(1, 1);
     __syncthreads();
+    issue_aux(-1);
+    mma_taps<C, CIN, 0, 3>(smem, abase, acc, wrow);
+    __syncthreads();  // LDS is now the output tile
+    epilogue(-1);
+  } else if (KIND == 0) {
+    zero_acc();
+    issue_plane(0, 0);
+    commit_plane();
+    __syncthreads();
+    issue_plane(0, 1);
+    mma_taps<C, CIN, 0, 0>(smem, abase, acc, wrow);
+    __syncthreads();  // every wave is done reading the plane
+    commit_plane();
+    __syncthreads();
+    issue_plane(1, 0);
+    mma_taps<C, CIN, 0, 1>(smem, abase, acc, wrow);
+    __syncthreads();
+    commit_plane();
+    __syncthreads();
+    issue_plane(1, 1);
+    mma_taps<C, CIN, 0, 2>(smem, abase, acc, wrow);
+    __syncthreads();
+    commit_plane();
+    __syncthreads();
+    issue_aux(-1);
     mma_taps<C, CIN, 0, 3>(smem, abase, acc, wrow);
     __syncthreads();  // LDS is now the output tile
     epilogue(-1);
@@ -367,15 +458,19 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
     load_image(0, 0);
     __syncthreads();
     zero_acc();
+    issue_aux(0);
     mma_taps<C, CIN, 1, 0>(smem, abase, acc, wrow);
     epilogue(0);
     zero_acc();
+    issue_aux(1);
     mma_taps<C, CIN, 1, 1>(smem, abase, acc, wrow);
     epilogue(1);
     zero_acc();
+    issue_aux(2);
     mma_taps<C, CIN, 1, 2>(smem, abase, acc, wrow);
     epilogue(2);
     zero_acc();
+    issue_aux(3);
     mma_taps<C, CIN, 1, 3>(smem, abase, acc, wrow);
     epilogue(3);
   }
