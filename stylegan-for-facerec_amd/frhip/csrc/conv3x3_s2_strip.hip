@@ -16,6 +16,8 @@
 // two tap-steps ahead), no barrier inside a tap list, bf16 results leave through an LDS tile as row-contiguous
 // 16-byte stores.  Same contracts as fr_conv_igemm (mode 0 stride 2 / mode 2): bit-compatible layouts of src, w,
 // out, aux and the column partial sums.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
   // aux cells of one output class: requested before the taps of that class run (data gradient), written into the output
   // tile behind them
   constexpr int NAX = (C::M * OCH + NTH - 1) / NTH;
-  U128 axr[NAX];
+  U128 axr[KIND == 1 ? NAX : 1];  // forward (inference epilogue only): loaded inside the epilogue, no registers held across the taps
   const bool has_aux = epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD || epi == FR_EPI_BIAS_RES;
   auto out_pix = [&](int cls, int r) -> size_t {
     const int ph = cls < 0 ? 0 : cls >> 1, pw = cls < 0 ? 0 : cls & 1;
@@ -288,26 +290,34 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
     return (size_t)(b * 2 * C::HL + 2 * (row0 + h) + ph) * (2 * WL) + 2 * w + pw;
   };
   auto issue_aux = [&](int cls) {
-    if (has_aux) {
+    if (KIND == 1 && has_aux) {
       const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
 #pragma unroll
       for (int u = 0; u < NAX; ++u) {
         int idx = u * NTH + tid;
         idx = idx < C::M * OCH ? idx : C::M * OCH - 1;
         const int r = idx / OCH, c8 = idx - r * OCH;
-        axr[u] = ld16(aux + out_pix(cls, r) * (size_t)p.ldaux + c8 * 8);
+        axr[KIND == 1 ? u : 0] = ld16(aux + out_pix(cls, r) * (size_t)p.ldaux + c8 * 8);
       }
     }
   };
   auto epilogue = [&](int cls) {
     auto dst_pix = [&](int r) -> size_t { return out_pix(cls, r); };
     if (has_aux) {
+      if (KIND == 1) {
 #pragma unroll
-      for (int u = 0; u < NAX; ++u) {
-        const int idx = u * NTH + tid;
-        if (idx < C::M * OCH) {
+        for (int u = 0; u < NAX; ++u) {
+          const int idx = u * NTH + tid;
+          if (idx < C::M * OCH) {
+            const int r = idx / OCH, c8 = idx - r * OCH;
+            st16(otile + r * C::OSTR + c8 * 16, axr[KIND == 1 ? u : 0]);
+          }
+        }
+      } else {
+        const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
+        for (int idx = tid; idx < C::M * OCH; idx += NTH) {
           const int r = idx / OCH, c8 = idx - r * OCH;
-          st16(otile + r * C::OSTR + c8 * 16, axr[u]);
+          st16(otile + r * C::OSTR + c8 * 16, ld16(aux + dst_pix(r) * (size_t)p.ldaux + c8 * 8));
         }
       }
       __syncthreads();
@@ -512,8 +522,8 @@ int by_pro(const FrConvArgs& a, hipStream_t st) {
 // low-res rows per workgroup for a served shape (0 = not served): the four IR stage transitions
 int s2_rows(int C, int WL) {
   if (C == 64 && WL == 56) return 2;
-  if (C == 128 && WL == 28) return 4;
-  if (C == 256 && WL == 14) return 7;
+  if (C == 128 && WL == 28) return 7;
+  if (C == 256 && WL == 14) return 7;  // whole images (14 rows, 13 M tiles per wave) spill: 0.115 -> 0.228 ms
   if (C == 512 && WL == 7) return 7;
   return 0;
 }
@@ -554,7 +564,9 @@ extern "C" int fr_conv3x3_s2_strip(const FrConvArgs* args, void* stream) {
     return by_pro<c, c, wl, rows, wn, nw, 1>(a, st);                  \
   }
   SHAPE(64, 56, 2, 2, 4)
-  SHAPE(128, 28, 4, 4, 8)
+  // 128 -> 128: 7-row strips (196 pixels per weight pass) although only one workgroup then fits a CU: 0.166 -> 0.140 ms
+  // forward, 0.221 -> 0.206 ms gradient against the 4-row strips (the kernel is bound by the weight stream)
+  SHAPE(128, 28, 7, 4, 8)
   SHAPE(256, 14, 7, 8, 8)
   SHAPE(512, 7, 7, 8, 8)
 #undef SHAPE
