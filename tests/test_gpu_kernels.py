@@ -835,6 +835,29 @@ def test_conv3x3_s2_strip_dgrad(K, s2_walk, C, WL, B, walk):
                                atol=tol * 10 * float((gx * aux).abs().sum() / C))
 
 
+@pytest.mark.parametrize("Cavg,ldk", [(0, 32), (3, 64)], ids=["ir", "psp"])
+@pytest.mark.parametrize("B,S", [(3, 9), (2, 112)])
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_stem_im2col_rows(K, Cavg, ldk, B, S, dt):
+    """fr_stem_im2col: row p = pixel (b, h, w), column (kh*3 + kw) * Ct + c = input (or average-image) channel c at
+    (h + kh - 1, w + kw - 1), zero outside the image and in the K tail -- both the row-per-thread bf16 kernel of the two
+    shipped stems and the generic one, against F.unfold."""
+    dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    x = synth.normal(75, "ix", (B, 3, S, S))
+    avg = synth.normal(75, "ia", (Cavg, S, S)) if Cavg else None
+    full = x if avg is None else torch.cat([x, avg.unsqueeze(0).expand(B, -1, -1, -1)], 1)
+    Ct = 3 + Cavg
+    cols = F.unfold(full, 3, padding=1).view(B, Ct, 9, S * S)          # [b][c][tap][pixel]
+    want = torch.zeros(B * S * S, ldk)
+    want[:, :9 * Ct] = cols.permute(0, 3, 2, 1).reshape(B * S * S, 9 * Ct)
+    out = torch.full((B * S * S, ldk), 7.0, device="cuda", dtype=dtype)
+    fr = K.fr_dtype(torch.empty(0, dtype=dtype))
+    K.call("fr_stem_im2col", x.cuda(), avg.cuda() if avg is not None else None, out, B, S, S, 3, Cavg, ldk, fr,
+           K.current_stream_ptr())()
+    torch.cuda.synchronize()
+    assert torch.equal(out.float().cpu(), want.to(dtype).float())
+
+
 @pytest.mark.parametrize("Kp", [32, 64])
 @pytest.mark.parametrize("M", [16, 1000, 4099])
 def test_stem_gemm_and_wgrad(K, Kp, M):

@@ -99,8 +99,12 @@ def test_full_step_matches_reference(golden_dir, fixture, kind, batch):
 # captured gradient tensors cos 0.979 .. 0.9999 (lowest: the 64 PReLU slopes of unit 0 and the stem weight, which sit
 # behind the rounding of the whole backward pass), their norm ratios within 0.5 % (4.6 % for one slope vector), all
 # per-parameter gradient norms: median deviation 0.3 - 0.6 %, worst 5 - 9 %.
-# The worst norms are the squeeze-excite MLP weights of the first units of IR-SE-101 at batch 4 (gradients of ~1e-4 that
-# are sums of 4 cancelling per-image terms): 26 % there, 5 - 9 % for everything else.
+# The worst norms are the squeeze-excite MLP weights of the first units of IR-SE-101 at batch 4 (sums of 4 cancelling
+# per-image terms): their ABSOLUTE deviation is 0.002 - 0.01 whatever the tensor's own norm (0.007 for unit 1's fc1, 0.05 -
+# 0.15 for its siblings), and which tensor comes out worst depends on the kernel selection -- four valid selections
+# (FRHIP_S2ROLL / FRHIP_ROLL64 = 0 / 1) gave 26 %, 48 % and 72 % on the 0.007 tensor and 8 - 19 % on the others.  The deviation
+# is therefore taken relative to max(|reference norm|, NORM_FLOOR): 5 - 19 % for everything.
+NORM_FLOOR = 0.03
 BF16_BARS = dict(loss_rel=5e-3, feat_cos=0.999, grad_cos=0.97, grad_norm_ratio=0.07, all_norms_median=0.012,
                  all_norms_p95=0.08, all_norms_worst=0.35)
 # per-channel shifts that only ever reach BatchNorms: their true gradient is exactly zero, both sides hold noise
@@ -145,7 +149,7 @@ def test_bf16_full_step_tracks_reference(golden_dir, fixture, kind, batch):
             per[k[2:]] = (float(cosf(mine, ref)), float(mine.norm() / ref.norm()))
     names = list(g["grad_names"])
     got = np.array([float(named[n].grad.double().norm()) for n in names])
-    ratio = np.abs(got / np.maximum(g["grad_norms"], 1e-30) - 1.0)
+    ratio = np.abs(got - g["grad_norms"]) / np.maximum(g["grad_norms"], NORM_FLOOR)
     big = np.array([not n.endswith(ZERO_GRAD_SUFFIXES) for n in names])
     m["all_norms_median"], m["all_norms_worst"] = float(np.median(ratio[big])), float(ratio[big].max())
     m["all_norms_p95"] = float(np.percentile(ratio[big], 95))
