@@ -98,6 +98,12 @@ def suite_cases(B):
         ("strip_64_64_112_dgrad", lambda it: conv_case("strip", 64, 64, 112, B, pro=0, epi=3, mode=1, iters=it)),
         ("s2_64_56_fwd", lambda it: conv_case("s2", 64, 64, 112, B, stride=2, pro=2, epi=1, iters=it)),
         ("s2_64_56_dgrad", lambda it: conv_case("s2", 64, 64, 112, B, stride=2, pro=0, epi=2, mode=2, iters=it)),
+        ("s2_128_28_fwd", lambda it: conv_case("s2", 128, 128, 56, B, stride=2, pro=2, epi=1, iters=it)),
+        ("s2_128_28_dgrad", lambda it: conv_case("s2", 128, 128, 56, B, stride=2, pro=0, epi=2, mode=2, iters=it)),
+        ("s2_256_14_fwd", lambda it: conv_case("s2", 256, 256, 28, B, stride=2, pro=2, epi=1, iters=it)),
+        ("s2_256_14_dgrad", lambda it: conv_case("s2", 256, 256, 28, B, stride=2, pro=0, epi=2, mode=2, iters=it)),
+        ("s2_512_7_fwd", lambda it: conv_case("s2", 512, 512, 14, B, stride=2, pro=2, epi=1, iters=it)),
+        ("s2_512_7_dgrad", lambda it: conv_case("s2", 512, 512, 14, B, stride=2, pro=0, epi=2, mode=2, iters=it)),
         ("strip_64_64_56_fwd_bn", lambda it: conv_case("strip", 64, 64, 56, B, pro=1, epi=0, iters=it)),
         ("strip_64_64_56_fwd_prelu", lambda it: conv_case("strip", 64, 64, 56, B, pro=2, epi=1, iters=it)),
         ("strip_64_64_56_dgrad", lambda it: conv_case("strip", 64, 64, 56, B, pro=0, epi=2, mode=1, iters=it)),
@@ -108,6 +114,7 @@ def suite_cases(B):
         ("strip_256_256_14_fwd_prelu", lambda it: conv_case("strip", 256, 256, 14, B, pro=2, epi=1, iters=it)),
         ("strip_256_256_14_dgrad", lambda it: conv_case("strip", 256, 256, 14, B, pro=0, epi=2, mode=1, iters=it)),
         ("wgs_256_256_14", lambda it: wgrad_case("wgs", 256, 256, 14, B, pro=2, iters=it)),
+        ("wgs_128_128_28", lambda it: wgrad_case("wgs", 128, 128, 28, B, pro=2, iters=it)),
         ("strip_512_512_7_fwd", lambda it: conv_case("strip", 512, 512, 7, B, pro=1, epi=0, iters=it)),
     ]
 
