@@ -755,9 +755,10 @@ def test_conv_dgrad_stride2_by_parity(K, name, dtype, tol, fused):
 
 S2_SHAPES = [(64, 56), (128, 28), (256, 14), (512, 7)]
 # 64 channels run on the rolling-window kernel (conv3x3_s2_roll64.hip), whose walk depends on the batch: B = 3 / 2: 28 row
-# segments per image (2-row walks); B = 40: 7 segments, 280 work items on 256 persistent workgroups (item loop); B = 130: 2
-# segments; "whole": FRHIP_S2ROLL_NSEG=1 = the 56-row walk of the B >= 256 step, on three images
-S2_CASES = [s + (3, "") for s in S2_SHAPES] + [(64, 56, 40, ""), (64, 56, 130, ""), (64, 56, 3, "whole")]
+# segments per image (2-row walks); B = 20: 14 segments; B = 40: 7 segments, 280 work items on 256 persistent workgroups
+# (item loop); B = 64: 4 segments; B = 130: 2 segments; "whole": FRHIP_S2ROLL_NSEG=1 = the 56-row walk of the B >= 256 step, on three images
+S2_CASES = [s + (3, "") for s in S2_SHAPES] + [(64, 56, 20, ""), (64, 56, 40, ""), (64, 56, 64, ""), (64, 56, 130, ""),
+                                                (64, 56, 3, "whole")]
 
 
 @pytest.fixture
