@@ -95,8 +95,8 @@ int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi);
 /* Stride-2 3x3 convolution (bf16, Cin == Cout: the first unit of every IR stage) on LDS-resident parity planes:
  * mode 0 = forward (SH = 2*RH), mode 2 with par_h = par_w = -1 = data gradient of all four output parity classes
  * (RH = 2*SH, w = [Cin][tap][Cout]).  Same FrConvArgs contract and epilogues as fr_conv_igemm; partial rows:
- * forward part[workgroup][2][N], gradient part[class][workgroup][2][N]; rows are image-major (all rows of image b
- * before those of image b + 1), the same number per image.  fr_conv3x3_s2_strip_parts returns the number of partial
+ * forward part[workgroup][2][N], gradient part[class][workgroup][2][N]; forward rows are image-major (all rows of
+ * image b before those of image b + 1), the same number per image.  fr_conv3x3_s2_strip_parts returns the number of partial
  * rows for (B, channels, low-res width WL, mode), 0 when the shape is not served -- callers size and sum `part` with
  * that number and nothing else: the 64-channel layer (112 -> 56) runs on a persistent rolling-window kernel that
  * writes ONE row per work item (image x row segment) in both directions.
