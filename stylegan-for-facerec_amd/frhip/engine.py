@@ -231,6 +231,14 @@ class BackbonePlan(object):
         self.stream2 = ctypes.c_void_p(self.stream2_t.cuda_stream)
         self.S = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
         self.generation = 0
+        # FRHIP_GRAPH=1: the two launch lists are captured into HIP graphs after the first eager step and replayed from then
+        # on (single-process steps only).  Opt-in, because on this stack replay is SLOWER than eager launches at every batch
+        # size (ms per step, eager / graph: B = 8: 6.05 / 6.86, 32: 6.71 / 7.30, 64: 7.67 / 8.11, 128: 10.0 / 10.6, 256: 16.0 /
+        # 16.4).  The small-batch floor of ~6 ms is ~500 dependent dispatches at ~12 us each on the GPU side, and the host's
+        # 6.5 ms of enqueue per step is inside hipLaunchKernel, not in Python: a packed native list executor (one foreign call
+        # per list, built and measured in round 2, then removed) left both the enqueue time and the step time unchanged.
+        self.graph_mode = os.environ.get("FRHIP_GRAPH", "0") == "1"
+        self._graphs = None
         self.use_strip = os.environ.get("FRHIP_NO_STRIP", "0") != "1"
         self.use_stem_gemm = (self.fr == FR_BF16 and os.environ.get("FRHIP_NO_STEM_GEMM", "0") != "1" and
                               not self.body_only)
@@ -986,6 +994,70 @@ class BackbonePlan(object):
         ops.run(self.bwd_list)
         return self.g_input.view(B, first.H, first.H, first.cin).permute(0, 3, 1, 2).float()
 
+    # ---- HIP graphs ---------------------------------------------------------------------------------
+    def _capture(self, launches):
+        """Record a launch list into a HIP graph.  The lists carry the caller's stream (usually the default stream, which
+        cannot capture) as ONE shared ctypes value: it is pointed at a capture stream for the duration, and the event
+        edges to the side stream are re-targeted the same way; the side stream joins the capture through those edges and
+        the lists end with its join, so the graph holds the two-stream schedule as branches."""
+        cap = torch.cuda.Stream(device=self.device)
+        trans = []
+        for l in launches:
+            if isinstance(l, _EvRecord) and l.stream is self.stream1_t:
+                l = _EvRecord(l.ev, cap)
+            elif isinstance(l, _EvWait) and l.stream is self.stream1_t:
+                l = _EvWait(cap, l.ev)
+            trans.append(l)
+        saved = (self.stream.value, self.stream2.value)
+        g = torch.cuda.CUDAGraph()
+        try:
+            self.stream.value = cap.cuda_stream
+            if not self.dual:
+                self.stream2.value = cap.cuda_stream
+            with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
+                ops.run(trans)
+        finally:
+            self.stream.value, self.stream2.value = saved
+        return g
+
+    def _split_at(self, launches, dyn):
+        """[segment | launch with per-step arguments | segment]: the Dropout launches carry the step's seed.  Accepts a
+        plain list or the result of an earlier split."""
+        if launches and not isinstance(launches[0], list) and not any(isinstance(x, list) for x in launches):
+            launches = [launches]
+        out = []
+        for seg in launches:
+            if isinstance(seg, list) and dyn is not None and any(x is dyn for x in seg):
+                k = [x is dyn for x in seg].index(True)
+                out += [seg[:k], dyn, seg[k + 1:]]
+            else:
+                out.append(seg)
+        return out
+
+    def _ensure_graphs(self):
+        if self._graphs is None and self.graph_mode and self.generation >= 1:
+            try:
+                fwd = [seg if isinstance(seg, ops.Launch) else self._capture(seg)
+                       for seg in self._split_at(self.pack_list + self.fwd_list, getattr(self, "l_drop_fwd", None))]
+                bwd = None
+                if not self.infer:
+                    bwd = [seg if isinstance(seg, ops.Launch) else self._capture(seg)
+                           for seg in self._split_at(self.bwd_list, getattr(self, "l_drop_bwd", None))]
+                self._graphs = (fwd, bwd)
+            except Exception as e:  # noqa: BLE001 -- a capture that fails must not take the training run with it
+                import warnings
+                warnings.warn("frhip: HIP graph capture failed (%s); continuing with eager launches" % (e,), RuntimeWarning)
+                self.graph_mode = False
+        return self._graphs is not None
+
+    @staticmethod
+    def _replay(segments):
+        for seg in segments:
+            if isinstance(seg, ops.Launch):
+                seg()
+            else:
+                seg.replay()
+
     def run_forward(self, x, avg_image, seed):
         B, S = self.B, self.S
         st = self.stream
@@ -998,8 +1070,11 @@ class BackbonePlan(object):
         if not self.infer:
             self.l_drop_bwd.args[4] = p
             self.l_drop_bwd.args[5] = seed
-        ops.run(self.pack_list)
-        ops.run(self.fwd_list)
+        if self._ensure_graphs():
+            self._replay(self._graphs[0])
+        else:
+            ops.run(self.pack_list)
+            ops.run(self.fwd_list)
         self.generation += 1
         return self.feat
 
@@ -1015,7 +1090,10 @@ class BackbonePlan(object):
             if p.grad is not v and p.requires_grad:
                 p.grad = v
         if on_ready is None:
-            ops.run(self.bwd_list)
+            if self._ensure_graphs():
+                self._replay(self._graphs[1])
+            else:
+                ops.run(self.bwd_list)
             return
         # Readiness callbacks (gradient all-reduce) run on their own stream, ordered behind the main stream up to this
         # point and behind the unit's side-stream weight gradients -- the main stream itself never waits for the side

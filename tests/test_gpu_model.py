@@ -617,6 +617,57 @@ def test_step_is_reproducible_and_side_stream_is_bit_identical():
     assert not sched, "side-stream and single-stream schedules differ (missing dependency edge?): %s" % sched[:5]
 
 
+def test_hip_graph_replay_is_bit_identical_to_eager_launches():
+    """FRHIP_GRAPH=1: after the first eager step the forward and backward launch lists (two streams, event edges, ~450
+    launches) are captured into HIP graphs and replayed; the Dropout launches, whose seed changes every step, stay eager
+    between the graph segments.  Four bf16 training steps with Dropout(0.5) must leave bit-identical parameters and BN
+    running statistics either way, and the graphs must really have been built."""
+    _need_gpu()
+    import os
+    from backbone.model_irse import IR_50
+    from frhip import synth
+    from frhip.optim import SGD
+    from head.metrics import ArcFace
+    from loss.focal import FocalLoss
+    from util.utils import separate_irse_bn_paras
+
+    def run(graph):
+        os.environ["FRHIP_GRAPH"] = graph
+        try:
+            m = IR_50([112, 112])
+            synth.fill_state_dict(m.state_dict(), 15)
+            m.compute_dtype = torch.bfloat16
+            m = m.cuda().train()
+            head = ArcFace(512, 100, None).cuda()
+            with torch.no_grad():
+                head.weight.copy_(synth.uniform(16, "full.head", (100, 512), -0.1, 0.1))
+            bn, wo = separate_irse_bn_paras(m)
+            opt = SGD([{"params": wo + list(head.parameters()), "weight_decay": 2e-3}, {"params": bn}], lr=0.03,
+                      momentum=0.9)
+            x = synth.uniform(16, "full.x", (6, 3, 112, 112)).cuda()
+            y = synth.labels(16, "full.label", 6, 100).cuda()
+            losses = []
+            for _ in range(4):
+                loss, _ = FocalLoss()(head(m(x), y), y)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.detach()))
+            torch.cuda.synchronize()
+            out = {n: t.detach().clone() for n, t in m.state_dict().items()}
+            plan = m._runner[0].plan
+            return out, losses, plan._graphs
+        finally:
+            os.environ.pop("FRHIP_GRAPH")
+
+    (a, la, ga), (b, lb, gb) = run("0"), run("1")
+    assert ga is None and gb is not None and gb[1] is not None, "the graph run did not capture"
+    assert sum(not isinstance(seg, type(gb[0][1])) for seg in gb[0]) == 2, "forward = graph | dropout launch | graph"
+    assert la == lb and len(set(la)) == 4, (la, lb)  # four different dropout masks, the same ones in both runs
+    diff = [n for n in a if not torch.equal(a[n], b[n])]
+    assert not diff, "graph replay and eager launches differ: %s" % diff[:5]
+
+
 def test_full_size_step_strip_and_generic_paths_agree():
     """BASELINE configs[1] at its full size (IR-50, batch 256, bf16): too big for the CPU oracle, so the check is a
     property -- the LDS-strip kernels (stride 1 / stride 2 / stem, incl. the two-images-per-workgroup and side-stream
