@@ -24,7 +24,10 @@ Besides the contract fields the line carries
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -38,13 +41,6 @@ for _p in (os.path.join(REPO, "stylegan-for-facerec_amd"), REPO):
 # runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
-PEAK_F32_TFLOPS = 157.3     # f32-input MFMA == vector peak
-IR50_FLOPS_PER_IMG = 37.7356e9   # conv + Linear, fwd+bwd, 2 flop/MAC (measured on the reference)
-FLOPS_PER_IMG = {"IR_50": IR50_FLOPS_PER_IMG, "IR_SE_50": 37.7356e9, "IR_SE_101": 72.4194e9, "IR_101": 72.4194e9}
 
 
 def parse():
@@ -55,30 +51,95 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--classes", type=int, default=7000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--model", default="IR_50", choices=["IR_50", "IR_101", "IR_152", "IR_SE_50", "IR_SE_101", "IR_SE_152"],
+    ap.add_argument("--model", default="IR_50", choices=["IR_50", "IR_101", "IR_152", "IR_SE_50", "IR_SE_101", "IR_SE_152",
+                                                         "pSp"],
                     help="IR_50 is the BASELINE.json workload; the others are for kernel tables of the SE / deep variants")
+    ap.add_argument("--head", default="ArcFace", choices=["ArcFace", "CosFace"])
+    ap.add_argument("--resident-batches", type=int, default=16,
+                    help="distinct synthetic batches kept in HBM and rotated through the timed loop (one batch alone is "
+                         "memorised within the warm-up: the loss, and with it every gradient, goes to ~0)")
     ap.add_argument("--sharded-head", action="store_true",
                     help="class-sharded ArcFace + focal loss over the ranks (frhip/sharded_head.py) instead of the "
                          "replicated head; off by default: the BASELINE configs replicate the head")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short timings of the other BASELINE.json configs after the headline")
     ap.add_argument("--kernel-table", default="", help="write the per-launch timing table of the instrumented step")
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it: start the N ranks as a CHILD
+    ``torch.distributed.run`` (one process per GPU, RCCL) and relay rank 0's JSON line and the exit code.  Runs before
+    torch is imported, i.e. before anything in this process has touched the GPU, and never re-execs."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=REPO)
+    for line in proc.stdout:  # rank 0's contract line goes to our stdout, anything else the ranks print to stderr
+        if line.startswith("{"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _early = parse()
+    if _early.gpus > 1:
+        sys.exit(spawn_ranks(_early))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_F32_TFLOPS = 157.3     # f32-input MFMA == vector peak
+IR50_FLOPS_PER_IMG = 37.7356e9   # conv + Linear, fwd+bwd, 2 flop/MAC (SURVEY.md 8d, measured on the reference)
+FLOPS_PER_IMG = {"IR_50": IR50_FLOPS_PER_IMG, "IR_SE_50": 37.7356e9, "IR_SE_101": 72.4194e9, "IR_101": 72.4194e9,
+                 "pSp": 37.8236e9}
+
+
+def synthetic_batches(n, batch, classes, device, rank):
+    """n distinct synthetic batches resident in HBM: x ~ U(-1, 1) [batch, 3, 112, 112] fp32, labels uniform.  Batch 0 is
+    the counter-based host stream (frhip.synth, regenerates bit-identically anywhere); the others come from a seeded
+    device generator (a host stream of 16 x 9.6 M floats would cost seconds of start-up per rank)."""
+    from frhip import synth
+    xs = [synth.uniform(1000 + rank, "bench.x", (batch, 3, 112, 112)).to(device)]
+    ys = [synth.labels(1000 + rank, "bench.y", batch, classes).to(device)]
+    g = torch.Generator(device=device)
+    g.manual_seed(900 + 7919 * rank)
+    for _ in range(1, n):
+        xs.append(torch.rand(batch, 3, 112, 112, device=device, generator=g) * 2.0 - 1.0)
+        ys.append(torch.randint(0, classes, (batch,), device=device, generator=g))
+    return xs, ys
+
+
 def build_job(args, device, rank):
+    """args: model, head, classes, batch, dtype, sharded_head, resident_batches."""
     import backbone.model_irse as irse
+    import head.metrics as metrics
     from frhip import synth
     from frhip.optim import SGD
-    from head.metrics import ArcFace
     from loss.focal import FocalLoss
     from util.utils import separate_irse_bn_paras
     torch.manual_seed(900)
-    model = getattr(irse, args.model)([112, 112])  # BASELINE metric: IR_50 (other factories: kernel tables only)
-    synth.fill_state_dict(model.state_dict(), 15)   # identical "trained-looking" weights on every rank
-    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.model == "pSp":  # BASELINE configs[0] / [4]: IR-SE-50 trunk, 6-channel stem fed with the average image
+        from backbone.restyle_psp import pSp
+        model = pSp(size=112, encoder_type="BackboneEncoder", avg_image=synth.uniform(2, "bench.avg", (3, 112, 112)))
+        synth.fill_state_dict(model.state_dict(), 15)
+        model.encoder.compute_dtype = cdt
+    else:
+        model = getattr(irse, args.model)([112, 112])  # BASELINE metric: IR_50
+        synth.fill_state_dict(model.state_dict(), 15)   # identical "trained-looking" weights on every rank
+        model.compute_dtype = cdt
     model = model.to(device).train()
-    head = ArcFace(512, args.classes, None, s=64.0)
+    head = getattr(metrics, getattr(args, "head", "ArcFace"))(512, args.classes, None, s=64.0)
     with torch.no_grad():
         head.weight.copy_(synth.uniform(16, "bench.head", (args.classes, 512), -0.05, 0.05))
     head = head.to(device).train()
@@ -88,9 +149,8 @@ def build_job(args, device, rank):
     bn, wo = separate_irse_bn_paras(model)
     _, hwo = separate_irse_bn_paras(head)
     opt = SGD([{"params": wo + hwo, "weight_decay": 2e-3}, {"params": bn}], lr=0.03, momentum=0.9)
-    x = synth.uniform(1000 + rank, "bench.x", (args.batch, 3, 112, 112)).to(device)
-    y = synth.labels(1000 + rank, "bench.y", args.batch, args.classes).to(device)
-    return model, head, FocalLoss(), opt, x, y
+    xs, ys = synthetic_batches(max(1, getattr(args, "resident_batches", 16)), args.batch, args.classes, device, rank)
+    return model, head, FocalLoss(), opt, xs, ys
 
 
 def make_step(model, head, loss_fn, opt, dp):
@@ -229,16 +289,24 @@ def host_cores():
     return n
 
 
-def cpu_baseline(classes, seconds_budget=15.0):
-    """The oracle (CPU port of the reference path) on this box's host cores: IR-50 + ArcFace + focal + SGD, fp32,
-    batch 32: one warm-up step, then as many timed steps as fit the budget (at least 1)."""
+def cpu_baseline(classes, seconds_budget=15.0, model="IR_50", B=32):
+    """The oracle (CPU port of the reference path) on this box's host cores: backbone + ArcFace + focal + SGD, fp32
+    (IR-50 at batch 32, and BASELINE configs[0] -- pSp IR-SE-50 with the 6-channel stem at batch 100):
+    one warm-up step, then as many timed steps as fit the budget (at least 1)."""
     from frhip import synth
     from oracle import irse_ref as O
-    from backbone.model_irse import IR_50
     cores = host_cores()
     torch.set_num_threads(cores)
-    B = 32
-    sd = {k: v.detach().clone() for k, v in IR_50([112, 112]).state_dict().items()}
+    kw = {}
+    if model == "pSp":
+        from backbone.restyle_psp import pSp
+        m = pSp(size=112, encoder_type="BackboneEncoder", avg_image=None)
+        kw = dict(se=True, prefix="encoder.", avg_image=synth.uniform(2, "bench.avg", (3, 112, 112)))
+    else:
+        from backbone.model_irse import IR_50
+        m = IR_50([112, 112])
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    del m
     synth.fill_state_dict(sd, 15)
     names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
     for k in names:
@@ -249,7 +317,7 @@ def cpu_baseline(classes, seconds_budget=15.0):
     bufs = {n: None for n in names + ["head"]}
 
     def one():
-        _f, logits, _loss, grads = O.train_step(sd, x, y, hw)
+        _f, logits, _loss, grads = O.train_step(sd, x, y, hw, **kw)
         O.topk_accuracy(logits.detach(), y)
         with torch.no_grad():
             for n in names:
@@ -263,16 +331,159 @@ def cpu_baseline(classes, seconds_budget=15.0):
         one()
         n += 1
     dt = time.time() - t0
+    what = "IR-50" if model == "IR_50" else "pSp(IR-SE-50, 6-ch stem, avg image)"
     return {"value": round(B * n / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "oracle/irse_ref.py train_step+sgd, IR-50+ArcFace(%d)+Focal, fp32, batch %d, %d steps in %.1fs"
-                      % (classes, B, n, dt)}
+            "sample": "oracle/irse_ref.py train_step+sgd, %s+ArcFace(%d)+Focal, fp32, batch %d, %d steps in %.1fs"
+                      % (what, classes, B, n, dt)}
+
+
+class ClockSampler(threading.Thread):
+    """Shader clock / board power of this rank's GPU every 100 ms while the timed loop runs ("the clocks
+    observed").  Reads the amdgpu sysfs nodes of the device (hwmon freq1_input = current sclk in Hz, power1_average /
+    power1_input in uW, else the starred line of pp_dpm_sclk); no sysfs access -> one ``rocm-smi --showclocks`` child
+    per sample.  The MFMA peak scales with the clock the chip holds under load (MI355X_MICROARCH.md, DVFS give-back), so
+    the roofline fraction is also quoted against peak x clock / 2400 MHz.  The in-kernel clock can read up to ~10 % below
+    these nodes (same guide); tools/stamps.py measures that one for single kernels."""
+
+    def __init__(self, device_index, period=0.1):
+        super().__init__(daemon=True)
+        self.period, self.samples, self.power, self.source = period, [], [], None
+        self._stop_ev = threading.Event()
+        self.freq_file = self.power_file = self.dpm_file = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            base = "/sys/bus/pci/devices/" + bdf
+            import glob
+            for h in glob.glob(base + "/hwmon/hwmon*"):
+                if os.path.exists(h + "/freq1_input"):
+                    self.freq_file = h + "/freq1_input"
+                for n in ("power1_average", "power1_input"):
+                    if os.path.exists(h + "/" + n):
+                        self.power_file = h + "/" + n
+                        break
+            if os.path.exists(base + "/pp_dpm_sclk"):
+                self.dpm_file = base + "/pp_dpm_sclk"
+        except Exception:  # noqa: BLE001
+            pass
+        self.smi = None
+        if self.freq_file is None and self.dpm_file is None:
+            import shutil
+            self.smi = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi")
+                                                    else None)
+            self.device_index = device_index
+
+    def _read(self):
+        import re
+        try:
+            if self.freq_file:
+                self.source = "sysfs hwmon freq1_input"
+                mhz = int(open(self.freq_file).read()) / 1e6
+            elif self.dpm_file:
+                self.source = "sysfs pp_dpm_sclk"
+                m = re.search(r"(\d+)Mhz \*", open(self.dpm_file).read())
+                mhz = float(m.group(1)) if m else None
+            elif self.smi:
+                self.source = "rocm-smi --showclocks"
+                txt = subprocess.run([self.smi, "-d", str(self.device_index), "--showclocks"], capture_output=True,
+                                     text=True, timeout=5).stdout
+                m = re.search(r"sclk clock level:? *\d*:? *\((\d+)Mhz\)", txt)
+                mhz = float(m.group(1)) if m else None
+            else:
+                return
+            if mhz:
+                self.samples.append(mhz)
+            if self.power_file:
+                self.power.append(int(open(self.power_file).read()) / 1e6)
+        except Exception:  # noqa: BLE001
+            pass
+
+    def run(self):
+        while not self._stop_ev.is_set():
+            self._read()
+            self._stop_ev.wait(self.period)
+
+    def stop(self):
+        self._stop_ev.set()
+        self.join(timeout=10)
+        if not self.samples:
+            return None
+        v = sorted(self.samples)
+        out = {"mhz_median": round(v[len(v) // 2], 1), "mhz_min": round(v[0], 1), "mhz_max": round(v[-1], 1),
+               "samples": len(v), "source": self.source}
+        if self.power:
+            w = sorted(self.power)
+            out["watts_median"] = round(w[len(w) // 2], 1)
+        return out
+
+
+def timed_loop(step, xs, ys, warmup, steps, world, device, sampler=None):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+    nb = len(xs)
+    for i in range(warmup):
+        step(xs[i % nb], ys[i % nb])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if sampler is not None:
+        sampler.start()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss, _prec = step(xs[(warmup + i) % nb], ys[(warmup + i) % nb])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    clocks = sampler.stop() if sampler is not None else None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    return dt, float(loss), clocks
+
+
+# The other BASELINE.json configs, timed briefly behind the headline (same step function, same data parallelism when
+# world > 1).  FLOPs per image: SURVEY.md 8(d).
+OTHER_CONFIGS = (
+    ("configs[2] IR-50 + ArcFace(28000), bs=256/GPU", dict(model="IR_50", head="ArcFace", classes=28000, batch=256)),
+    ("configs[3] IR-SE-101 + CosFace(28000), bs=128/GPU", dict(model="IR_SE_101", head="CosFace", classes=28000, batch=128)),
+    ("configs[4] pSp IR-SE-50 6-ch stem + ArcFace(28000), bs=256/GPU", dict(model="pSp", head="ArcFace", classes=28000,
+                                                                           batch=256)),
+)
+
+
+def run_other_config(label, spec, args, device, rank, world, peak, steps=10, warmup=4):
+    import gc
+    a = argparse.Namespace(dtype=args.dtype, sharded_head=False, resident_batches=4, **spec)
+    model, head, loss_fn, opt, xs, ys = build_job(a, device, rank)
+    dp = None
+    if world > 1:
+        from frhip.parallel import DataParallel
+        dp = DataParallel(model, head)
+    step = make_step(model, head, loss_fn, opt, dp)
+    dt, loss_val, _ = timed_loop(step, xs, ys, warmup, steps, world, device)
+    ips = a.batch * world * steps / dt
+    flops_img = FLOPS_PER_IMG[a.model] + 6.0 * 512 * a.classes
+    rec = {"config": label, "value": round(ips, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
+           "steps": steps, "warmup": warmup, "n_gpus": world, "final_loss": float("%.3e" % loss_val),
+           "step_frac": round(flops_img * ips / world / 1e12 / peak, 4)}
+    inner = model.encoder if hasattr(model, "encoder") else model
+    inner._runner[0].plans.clear()
+    inner._runner[0].plan = None
+    del model, head, opt, xs, ys, step, dp
+    gc.collect()
+    torch.cuda.empty_cache()
+    return rec
 
 
 def main():
     args = parse()
+    json_out, sys.stdout = sys.stdout, sys.stderr  # the modules print while they build; stdout carries the ONE JSON line
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert args.gpus == world, ("bench.py --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` (it spawns the "
+                                "ranks itself) or under torch.distributed.run with --nproc-per-node N" % (args.gpus, world))
     if os.environ.get("FRHIP_BENCH_ONE_DEVICE") == "1":
         local = 0  # test hook: several ranks share GPU 0 (with FRHIP_DIST_BACKEND=gloo; RCCL refuses duplicate devices)
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback for the product path)"
@@ -287,49 +498,38 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    model, head, loss_fn, opt, x, y = build_job(args, device, rank)
+    model, head, loss_fn, opt, xs, ys = build_job(args, device, rank)
     dp = None
     if world > 1 or force_dp:
         from frhip.parallel import DataParallel
         dp = DataParallel(model, None if args.sharded_head else head)  # a weight shard is complete on its owner
     step = make_step(model, head, loss_fn, opt, dp)
+    x, y = xs[0], ys[0]
 
-    for _ in range(args.warmup):
-        step(x, y)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _prec = step(x, y)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    loss_val = float(loss)
+    sampler = ClockSampler(local) if rank == 0 else None
+    dt, loss_val, clocks = timed_loop(step, xs, ys, args.warmup, args.steps, world, device, sampler)
     assert loss_val == loss_val, "loss is NaN"
 
     ms = dt / args.steps * 1e3
     ips = args.batch * world * args.steps / dt
+    mname = "pSp(IR-SE-50, 6-ch stem)" if args.model == "pSp" else args.model.replace("IR_", "IR-")
     out = {
         "metric": "images/sec/GPU IR-50+ArcFace 112x112 bs=256; 1->8 GPU scaling eff.",
         "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "%s + ArcFace(%d ids) + Focal + SGD train step, synthetic 112x112x3, bs=%d/GPU"
-                               % (args.model.replace("IR_", "IR-"), args.classes, args.batch),
+        "config": {"workload": "%s + %s(%d ids) + Focal + SGD train step, synthetic 112x112x3, bs=%d/GPU"
+                               % (mname, args.head, args.classes, args.batch),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world + ("+class-sharded head" if args.sharded_head else ""),
-                   "images_per_sec_per_gpu": round(ips / world, 1), "final_loss": float("%.3e" % loss_val)},
+                   "images_per_sec_per_gpu": round(ips / world, 1), "final_loss": float("%.3e" % loss_val),
+                   "resident_batches": len(xs)},
     }
     fams = None
+    inner = model.encoder if hasattr(model, "encoder") else model
     if not args.no_roofline:
         # per-kernel timing needs the weight gradients back on the main stream (no co-running kernels).  Every rank
         # runs the same two extra steps (they contain the gradient all-reduce); only rank 0 wraps its launches in events.
-        model._runner[0].single_stream = True
+        inner._runner[0].single_stream = True
         step(x, y)
         torch.cuda.synchronize()
         if rank == 0:
@@ -337,8 +537,8 @@ def main():
         else:
             step(x, y)
             torch.cuda.synchronize()
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
     if rank == 0:
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         flops_img = FLOPS_PER_IMG.get(args.model, IR50_FLOPS_PER_IMG) + 6.0 * 512 * args.classes
         step_tflops = flops_img * ips / world / 1e12
         if fams is not None:
@@ -376,14 +576,27 @@ def main():
                                                 "launches": sum(g[0] for g in groups.values())},
                                    "channelwise_ms": round(sum(v[1] for k, v in fams.items() if k.startswith(
                                        ("fr_bn_", "fr_reduce_parts", "fr_channel_stats", "fr_se_"))), 3),
+                                   "launches_per_step": sum(v[0] for v in fams.values()),
                                    "step_kernel_ms_single_stream": round(total_ms, 3),
                                    "step_achieved": round(step_tflops, 2), "step_frac": round(step_tflops / peak, 4)}
+                if clocks is not None:
+                    # the MFMA rate is per clock: peak at the clock the chip held during the timed loop
+                    out["roofline"]["clock_mhz"] = clocks["mhz_median"]
+                    out["roofline"]["clock"] = clocks
+                    scale = clocks["mhz_median"] / 2400.0
+                    out["roofline"]["frac_at_clock"] = round(ach / (peak * scale), 4)
+                    out["roofline"]["step_frac_at_clock"] = round(step_tflops / (peak * scale), 4)
                 # HBM bytes per launch cannot be counted from inside this process; they come from the committed
                 # rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections) over the same
                 # kernel instances (tools/pmc_round.sh + tools/pmc_summary.py), averaged over this family's launches
-                pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_kernels.json")
+                pmc = None
+                for tag in ("r03", "r02"):
+                    cand = os.path.join(REPO, "profiles", "%s_pmc_kernels.json" % tag)
+                    if os.path.exists(cand):
+                        pmc = cand
+                        break
                 m = re.match(r"conv3x3_strip<(\d+),(\d+),(\d+)>", name)
-                if os.path.exists(pmc) and m:
+                if pmc and m:
                     with open(pmc) as f:
                         recs = {r["kernel"]: r for r in json.load(f)["kernels"]}
                     pre = "strip_%s_%s_%s_" % m.groups()
@@ -398,10 +611,31 @@ def main():
                     if den:
                         out["roofline"]["traffic"] = int(num / den)
                         out["roofline"]["traffic_algorithmic"] = int(alg / den)
-                        out["roofline"]["traffic_source"] = "profiles/r02_pmc_kernels.json"
+                        out["roofline"]["traffic_source"] = os.path.relpath(pmc, REPO)
+        elif clocks is not None:
+            out["clock"] = clocks
+    # ---- the other BASELINE configs (short), then the CPU legs
+    default_workload = (args.model, args.head, args.classes, args.batch, args.dtype) == ("IR_50", "ArcFace", 7000, 256, "bf16")
+    if default_workload and not args.no_other_configs and not args.sharded_head and \
+            os.environ.get("FRHIP_BENCH_OTHER", "1") != "0":
+        import gc
+        inner._runner[0].plans.clear()
+        inner._runner[0].plan = None
+        del model, head, opt, xs, ys, x, y, step, dp
+        gc.collect()
+        torch.cuda.empty_cache()
+        others = []
+        for label, spec in OTHER_CONFIGS:
+            others.append(run_other_config(label, spec, args, device, rank, world, peak))
+        if rank == 0:
+            out["other_configs"] = others
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.classes)
-        print(json.dumps(out))
+            if default_workload:
+                # BASELINE configs[0] (the reference's own CPU-runnable case): pSp IR-SE-50, batch 100, 100 identities
+                out["cpu_baseline_config0"] = cpu_baseline(100, seconds_budget=8.0, model="pSp", B=100)
+        print(json.dumps(out), file=json_out, flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

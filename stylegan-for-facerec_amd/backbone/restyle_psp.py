@@ -87,7 +87,10 @@ class pSp(nn.Module):
             return avg_image.detach().float()
         import numpy as np
         from PIL import Image
-        arr = np.asarray(Image.open(avg_image).convert("RGB"))
+        if str(avg_image).endswith(".npy"):  # uint8 HWC array (what imageio.imread returns in the reference)
+            arr = np.load(avg_image)
+        else:
+            arr = np.asarray(Image.open(avg_image).convert("RGB"))
         t = torch.from_numpy(arr.copy()).permute(2, 0, 1).float() / 255.0
         return ((t - 0.5) / 0.5).detach()
 

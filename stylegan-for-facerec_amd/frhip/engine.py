@@ -979,7 +979,9 @@ class BackbonePlan(object):
         ops.run(self.fwd_list)
         self.generation += 1
         last = self.units[-1]
-        return self.feat.view(B, last.Ho, last.Ho, last.depth).permute(0, 3, 1, 2).float()
+        # an OWNED tensor: on the fp32 path .float() would be a view of the plan's static buffer, which the next call of
+        # the same unit overwrites
+        return self.feat.view(B, last.Ho, last.Ho, last.depth).permute(0, 3, 1, 2).to(torch.float32, copy=True)
 
     def run_body_backward(self, g):
         """dL/d(output) [B, depth, Ho, Ho] -> dL/d(input) fp32 NCHW; parameter gradients land in the arena views."""
@@ -992,7 +994,7 @@ class BackbonePlan(object):
             if p.grad is not v and p.requires_grad:
                 p.grad = v
         ops.run(self.bwd_list)
-        return self.g_input.view(B, first.H, first.H, first.cin).permute(0, 3, 1, 2).float()
+        return self.g_input.view(B, first.H, first.H, first.cin).permute(0, 3, 1, 2).to(torch.float32, copy=True)
 
     # ---- HIP graphs ---------------------------------------------------------------------------------
     def _capture(self, launches):

@@ -140,8 +140,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("FRHIP_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
-        # Rank 0 alone runs the per-epoch RFW verification (4 x 12 k images with flip-TTA) while the others wait in the
-        # next collective: give them well more than the default 10-minute watchdog.
+        # Generous watchdog: the per-epoch RFW verification (4 x 12 k images with flip-TTA, sharded over the ranks) and the
+        # checkpoint writes of rank 0 sit between collectives.
         import datetime
         patience = datetime.timedelta(hours=2)
         if backend == "nccl":
@@ -226,11 +226,12 @@ def main():
         else:
             print("No Checkpoint Found at '{}'. Please Have a Check or Continue to Train from Scratch".format(opt_resume))
     runner = (backbone.encoder if hasattr(backbone, "encoder") else backbone)._runner[0]
-    start_epoch, batch = cfg.get("START_EPOCH", 0), 0
+    start_epoch, batch, lr_stage_done = cfg.get("START_EPOCH", 0), 0, None
     state_resume = cfg.get("STATE_RESUME_ROOT")
     if state_resume and os.path.isfile(state_resume):
         state = torch.load(state_resume, map_location="cpu")
         start_epoch, batch, runner.step_seed = int(state["epoch"]), int(state["batch"]), int(state["dropout_stream"])
+        lr_stage_done = state.get("lr_stage_applied")  # an unfinished epoch whose LR stage is already in the optimizer file
         if "torch_rng" in state:
             torch.set_rng_state(state["torch_rng"])
             n = state["numpy_rng"]
@@ -246,7 +247,7 @@ def main():
     FRF.CHECK_LABELS = False  # labels come from the dataset's own class index
     for epoch in range(start_epoch, cfg["NUM_EPOCH"]):
         epoch_first_batch = batch
-        if epoch in cfg["STAGES"]:
+        if epoch in cfg["STAGES"] and epoch != lr_stage_done:
             schedule_lr(optimizer)
         backbone.train()
         head.train()
@@ -309,20 +310,24 @@ def main():
             if logger is not None:
                 logger.log({"train_loss_ep": losses.avg, "train_acc_ep": top1.avg, "train_acc_top5_ep": top5.avg,
                             "epoch": epoch + 1, "step": samples_seen})
-        if rank == 0 and val is not None and val[-2] is not None:
-            # per-epoch verification on the RFW subsets (reference train.py:403-410); flip-TTA, k-fold accuracy
+        if val is not None and val[-2] is not None:
+            # per-epoch verification on the RFW subsets (reference train.py:403-410); flip-TTA, k-fold accuracy.  Every
+            # rank embeds its share of the batches (collective), rank 0 logs.
             rfw, rfw_issame = val[-2], val[-1]
-            print("=" * 60)
+            if rank == 0:
+                print("=" * 60)
             for eth in ("African", "Asian", "Caucasian", "Indian"):
                 if eth not in rfw:
                     continue
                 acc, thr, roc = perform_val(True, device, cfg["EMBEDDING_SIZE"], cfg["BATCH_SIZE"], BACKBONE, rfw[eth],
                                             rfw_issame[eth], dset_name="RFW_" + eth,
-                                            ccrop=cfg.get("CCROP_AT_VAL", True))
-                if logger is not None:
-                    buffer_val(logger, "RFW_" + eth, acc, thr, roc, epoch + 1, samples_seen)
-                print("Evaluation: RFW {} Acc: {}".format(eth, acc))
-            print("=" * 60)
+                                            ccrop=cfg.get("CCROP_AT_VAL", True), rank=rank, world=world)
+                if rank == 0:
+                    if logger is not None:
+                        buffer_val(logger, "RFW_" + eth, acc, thr, roc, epoch + 1, samples_seen)
+                    print("Evaluation: RFW {} Acc: {}".format(eth, acc))
+            if rank == 0:
+                print("=" * 60)
             BACKBONE.module.train()
         if crit is not None:
             with torch.no_grad():
@@ -341,8 +346,12 @@ def main():
             # with the weights of the checkpoint (mid-epoch positions are not restored).
             epoch_len = len(loader) if limit_batches is None else min(len(loader), limit_batches)
             finished = not (args.max_steps and batch >= args.max_steps and (batch - epoch_first_batch) < epoch_len)
-            torch.save({"epoch": epoch + 1 if finished else epoch, "batch": batch, "dropout_stream": runner.step_seed,
-                        "epoch_finished": finished, "torch_rng": torch.get_rng_state(),
+            # the repeated epoch restarts the batch counter at its first batch (warm-up, logging axis) and must not divide
+            # the LR a second time if it is a stage epoch (the Optimizer_* file already holds the divided LR)
+            torch.save({"epoch": epoch + 1 if finished else epoch, "batch": batch if finished else epoch_first_batch,
+                        "dropout_stream": runner.step_seed, "epoch_finished": finished,
+                        "lr_stage_applied": int(epoch) if (not finished and epoch in cfg["STAGES"]) else None,
+                        "torch_rng": torch.get_rng_state(),
                         "numpy_rng": _np_state_plain(np.random.get_state())},
                        os.path.join(root, "State_{}_{}".format(cfg["HEAD_NAME"], tag)))
         if args.max_steps and batch >= args.max_steps:

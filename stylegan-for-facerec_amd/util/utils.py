@@ -235,12 +235,17 @@ def gen_plot(fpr, tpr):
 
 
 def perform_val(multi_gpu, device, embedding_size, batch_size, backbone, carray, issame, nrof_folds=10, tta=True,
-                dset_name=None, ccrop=True):
+                dset_name=None, ccrop=True, rank=0, world=1, group=None):
     """Flip-TTA verification of ``backbone`` on interleaved image pairs (reference util/utils.py:254-307; SURVEY 8f
     rank 2).  Same protocol: eval mode, batches of ``batch_size`` plus the remainder, optional centre-crop, embedding =
     f(img) + f(hflip(img)) summed on the host, ``l2_norm``, then the k-fold metrics of util/verification.py.  Returns
     (mean accuracy, mean best threshold, ROC-curve image tensor or None).  ``carray``: [2P, 3, 112, 112] (or NHWC)
-    float array in [-1, 1] (bcolz carray or numpy)."""
+    float array in [-1, 1] (bcolz carray or numpy).
+
+    ``world > 1`` (one process per GPU; collective -- every rank calls it): batch k of the SAME batch partition goes to
+    rank k % world, the embedding sums are combined with one all-reduce (every row is written by exactly one rank and is
+    zero elsewhere, so the sum is exact) and every rank computes the same metrics.  The batches themselves are the ones a
+    single rank would run, so the result equals the single-rank result bit for bit."""
     import numpy as np
     from util.verification import evaluate
     if multi_gpu:
@@ -249,12 +254,12 @@ def perform_val(multi_gpu, device, embedding_size, batch_size, backbone, carray,
     backbone.eval()
     n = len(carray)
     is_dev = torch.device(device).type == "cuda"
-    sums = torch.empty(n, embedding_size, device=device, dtype=torch.float32)  # f(img) [+ f(hflip(img))], on the device
+    sums = torch.zeros(n, embedding_size, device=device, dtype=torch.float32)  # f(img) [+ f(hflip(img))], on the device
     # two pinned staging buffers: the host prepares batch i+1 while the GPU works on batch i, and nothing in the loop waits
     # for the device (the reference copies every batch's embeddings back before it reads the next batch)
     stage, free = [None, None], [None, None]
     with torch.no_grad():
-        for k, idx in enumerate(range(0, n, batch_size)):
+        for k, idx in enumerate(range(rank * batch_size, n, batch_size * world)):
             host = torch.from_numpy(np.ascontiguousarray(carray[idx:idx + batch_size], dtype=np.float32))
             if host.shape[-1] == 3:
                 host = host.permute(0, 3, 1, 2)
@@ -275,6 +280,9 @@ def perform_val(multi_gpu, device, embedding_size, batch_size, backbone, carray,
             if tta:
                 emb = emb + backbone(hflip_batch(cropped))  # fp32 add: same bits as on the host
             sums[idx:idx + batch.shape[0]] = emb
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     embeddings = np.zeros([n, embedding_size])
     embeddings[:] = l2_norm(sums.cpu()).numpy()  # one copy back; normalisation on the host, as in the reference
     tpr, fpr, acc, best_thresholds = evaluate(embeddings, issame, nrof_folds)

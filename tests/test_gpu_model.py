@@ -1136,3 +1136,185 @@ def test_other_psp_encoders_match_oracle_forward(encoder_type, layers):
     fo = O.backbone_forward(sd, x, layers, True, bn_train=True, prefix="encoder.", avg_image=avg)
     fo = fo[0] if isinstance(fo, tuple) else fo
     assert float((f.detach().cpu() - fo).abs().max()) < 1e-3, float((f.detach().cpu() - fo).abs().max())
+
+
+def test_unit_called_twice_returns_owned_tensors():
+    """A residual unit called on its own twice in fp32: the first output (and the first input gradient) must not alias
+    the plan's static buffers, which the second call overwrites (round-2 advisor finding, engine.run_body_forward)."""
+    _need_gpu()
+    from backbone.model_irse import bottleneck_IR
+    blk = bottleneck_IR(64, 64, 1)
+    synth.fill_state_dict(blk.state_dict(), 5)
+    blk.compute_dtype = torch.float32
+    blk = blk.cuda().train()
+    x1 = synth.normal(1, "twice.x1", (2, 64, 16, 16)).cuda().requires_grad_(True)
+    x2 = synth.normal(1, "twice.x2", (2, 64, 16, 16)).cuda().requires_grad_(True)
+    a = blk(x1)
+    a_copy = a.detach().clone()
+    a.sum().backward()
+    g1 = x1.grad
+    g1_copy = g1.clone()
+    b = blk(x2)
+    b.square().sum().backward()
+    torch.cuda.synchronize()
+    assert not torch.equal(a_copy, b.detach())
+    assert torch.equal(a.detach(), a_copy), "the first output was overwritten by the second call"
+    assert torch.equal(g1, g1_copy), "the first input gradient was overwritten by the second backward"
+    assert a.data_ptr() != b.data_ptr() and x1.grad.data_ptr() != x2.grad.data_ptr()
+
+
+def test_include_dropout_units_run_in_eval_mode_and_refuse_training():
+    """``pSp(include_dropout=p)`` (reference restyle_psp.py:401-405, restyle_psp_helpers.py:201-209, used by
+    test_RFW.py:69,91 to load checkpoints trained with unit dropout): Dropout sits at ModuleList indices 2 / 5 of every
+    residual branch (and 1 of a conv shortcut), shifting the state-dict indices of what follows.  In eval mode Dropout is
+    the identity: the engine must give the same features as the dropout-free network holding the same tensors.  In train
+    mode the accelerated path refuses loudly (no silent skip of the mask)."""
+    _need_gpu()
+    from backbone.restyle_psp import pSp
+    avg = synth.uniform(15, "avg_image", (3, 112, 112))
+    plain = pSp(size=112, checkpoint_path=None, avg_image=avg, include_dropout=False)
+    synth.fill_state_dict(plain.state_dict(), 31)
+    withd = pSp(size=112, checkpoint_path=None, avg_image=avg, include_dropout=0.15)
+    # same tensors, shifted child indices: res_layer 2.. -> +1, 4.. -> +2 (reference insert(2), insert(5)); shortcut 1 -> 2
+    res_map, sc_map = {0: 0, 1: 1, 2: 3, 3: 4, 4: 6, 5: 7}, {0: 0, 1: 2}
+    src = plain.state_dict()
+    dst = withd.state_dict()
+    assert len(dst) == len(src)
+    moved = 0
+    for k, v in src.items():
+        parts = k.split(".")
+        if "res_layer" in parts:
+            i = parts.index("res_layer") + 1
+            parts[i] = str(res_map[int(parts[i])])
+        elif "shortcut_layer" in parts:
+            i = parts.index("shortcut_layer") + 1
+            parts[i] = str(sc_map[int(parts[i])])
+        k2 = ".".join(parts)
+        moved += k2 != k
+        dst[k2].copy_(v)
+    assert moved > 100 and "encoder.body.0.res_layer.3.weight" in dst and "encoder.body.0.res_layer.7.fc1.weight" in dst
+    x = synth.uniform(3, "drop.x", (4, 3, 112, 112)).cuda()
+    for m in (plain, withd):
+        m.encoder.compute_dtype = torch.float32
+        m.cuda().eval()
+    with torch.no_grad():
+        f0, f1 = plain(x), withd(x)
+    torch.cuda.synchronize()
+    assert torch.isfinite(f0).all() and float((f0 - f1).abs().max()) < 1e-5, float((f0 - f1).abs().max())
+    withd.train()
+    with pytest.raises(NotImplementedError, match="Dropout inside residual units"):
+        withd(x)
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` with no launcher around it (the form the driver uses for N = 1) must start two ranks
+    itself -- as a child torch.distributed.run before the parent touches the GPU -- and relay rank 0's single JSON line
+    with ``n_gpus == 2``.  Both ranks share GPU 0 over gloo here (one-GPU box); reference DP: train.py:219-222."""
+    _need_gpu()
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FRHIP_BENCH_ONE_DEVICE="1", FRHIP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16", "--classes", "1000",
+           "--no-cpu-baseline", "--no-roofline", "--resident-batches", "2"]
+    out = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 32 and rec["config"]["parallelism"] == "dp2"
+    # a world size that contradicts --gpus is refused instead of silently printing n_gpus: 1
+    bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29549", "bench.py", "--gpus", "2", "--steps", "1",
+                          "--warmup", "0", "--batch", "16", "--classes", "1000", "--no-cpu-baseline", "--no-roofline"],
+                         cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
+def _write_stage2_checkpoint(path, seed=19):
+    """A Stage-2 (ReStyle) checkpoint in the G9 layout: {'state_dict': encoder.input_layer.* / encoder.body.* + decoder and
+    style-head keys that Stage 3 ignores, 'latent_avg', 'opts'} (reference restyle_psp.py:419-437)."""
+    from backbone.restyle_psp import pSp
+    src = pSp(size=112)
+    sd = {k: v.clone() for k, v in src.state_dict().items()
+          if k.startswith("encoder.input_layer") or k.startswith("encoder.body")}
+    synth.fill_state_dict(sd, seed)
+    ck = dict(sd)
+    ck["encoder.styles.0.convs.0.weight"] = torch.ones(2, 2)
+    ck["decoder.style.1.weight"] = torch.ones(3)
+    torch.save({"state_dict": ck, "latent_avg": torch.zeros(18, 512), "opts": {"x": 1}}, path)
+    return sd
+
+
+def _freeze_run(tmp_path, tag, ranks):
+    """train.py, BASELINE configs[4] in miniature: pSp from a Stage-2 checkpoint + average image file, epoch 0 with the
+    body frozen (FREEZE_BACKBONE_EPOCHS=0 -> ``epoch <= 0``), epoch 1 unfrozen; one rank, or two ranks sharing GPU 0."""
+    import subprocess
+    import sys
+    from PIL import Image
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stylegan-for-facerec_amd")
+    ck = str(tmp_path / "stage2.pt")
+    stage2 = _write_stage2_checkpoint(ck)
+    avg = str(tmp_path / "avg.png")
+    Image.fromarray((synth.uniform(5, "avg.png", (112, 112, 3), 0, 255)).numpy().astype(np.uint8)).save(avg)
+    model_dir = tmp_path / tag
+    script = tmp_path / ("run_%s.py" % tag)
+    script.write_text(
+        "import sys, runpy\n"
+        "import configs.config_synthetic_smoke as c\n"
+        "c.configurations[1].update(BATCH_SIZE=%d, NUM_EPOCH=2, FREEZE_BACKBONE_EPOCHS=0, ENCODER_CHECKPOINT=r'%s', "
+        "ENCODER_AVG_IMAGE=r'%s', MODEL_ROOT=r'%s', LOG_ROOT=r'%s')\n"
+        "sys.argv = ['train.py', '--config', 'configs/config_synthetic_smoke.py', '--synthetic', '12x10']\n"
+        "runpy.run_path('train.py', run_name='__main__')\n" % (20 // ranks, ck, avg, model_dir, tmp_path / "log"))
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if ranks == 1:
+        cmd = [sys.executable, str(script)]
+    else:
+        env.update(FRHIP_TRAIN_ONE_DEVICE="1", FRHIP_DIST_BACKEND="gloo")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+               "127.0.0.1", "--master-port", "29581", str(script)]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout[-2500:] + out.stderr[-2500:]
+    return model_dir, stage2, out.stdout
+
+
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_freeze_then_unfreeze_from_a_stage2_checkpoint(tmp_path, ranks):
+    """BASELINE configs[4] end to end through train.py (reference train.py:156-166 builds pSp from ENCODER_CHECKPOINT /
+    ENCODER_AVG_IMAGE, :263-274 freezes ``.module.encoder.body`` while ``epoch <= FREEZE_BACKBONE_EPOCHS``,
+    restyle_psp.py:419-437 imports the Stage-2 encoder).  Epoch 0: every body PARAMETER is bit-unchanged from the Stage-2
+    file (no gradient, no weight-decay drift, no momentum buffer) while its BatchNorm statistics move (train mode) and the
+    stem / output layer / head train; the gradient buckets that contain frozen slots still flush (two ranks: the run
+    finishes).  Epoch 1: the body moves and gets momentum buffers.  The checkpoints load back into a fresh pSp."""
+    _need_gpu()
+    from backbone.restyle_psp import pSp
+    from util.utils import separate_irse_bn_paras
+    model_dir, stage2, log = _freeze_run(tmp_path, "freeze%d" % ranks, ranks)
+    assert "Loading ReStyle pSp from checkpoint" in log
+    e1 = torch.load(_ckpt(model_dir, "Backbone_IR_50_ReStyle_Epoch_1_Batch_6_"), map_location="cpu")
+    e2 = torch.load(_ckpt(model_dir, "Backbone_IR_50_ReStyle_Epoch_2_Batch_12_"), map_location="cpu")
+    ref = pSp(size=112)
+    pnames = {n for n, _ in ref.named_parameters()}
+    body_params = [k for k in stage2 if k.startswith("encoder.body") and k in pnames]
+    assert len(body_params) > 200
+    for k in body_params:
+        assert torch.equal(e1[k], stage2[k]), "frozen parameter %s moved in epoch 0" % k
+    moved_stats = sum(not torch.equal(e1[k], stage2[k]) for k in stage2
+                      if k.startswith("encoder.body") and k.endswith("running_mean"))
+    assert moved_stats > 40, "the frozen body's BatchNorms stay in train mode (train.py:260): statistics must move"
+    assert not torch.equal(e1["encoder.input_layer.0.weight"], stage2["encoder.input_layer.0.weight"])
+    assert sum(not torch.equal(e2[k], e1[k]) for k in body_params) == len(body_params), "epoch 1 must move the whole body"
+    # optimizer state: momentum buffers only for what trained
+    bn, wo = separate_irse_bn_paras(ref)
+    body_ids = {id(p) for p in ref.encoder.body.parameters()}
+    n_unfrozen = sum(id(p) not in body_ids for p in bn + wo) + 1  # + the head weight
+    o1 = torch.load(_ckpt(model_dir, "Optimizer_ArcFace_Epoch_1_Batch_6_"), map_location="cpu")
+    o2 = torch.load(_ckpt(model_dir, "Optimizer_ArcFace_Epoch_2_Batch_12_"), map_location="cpu")
+    assert len(o1["state"]) == n_unfrozen, (len(o1["state"]), n_unfrozen)
+    assert len(o2["state"]) == len(bn) + len(wo) + 1
+    # the files load back (strict) and the head checkpoint has the reference layout
+    ref.load_state_dict(e2, strict=True)
+    h = torch.load(_ckpt(model_dir, "Head_ArcFace_Epoch_2_Batch_12_"), map_location="cpu")
+    assert list(h.keys()) == ["weight"] and tuple(h["weight"].shape) == (12, 512) and torch.isfinite(h["weight"]).all()

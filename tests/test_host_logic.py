@@ -340,3 +340,22 @@ def test_sgd_state_dict_round_trips_with_torch_sgd():
         SGD(p, lr=0.1, momentum=0.9, nesterov=True)
     with pytest.raises(NotImplementedError):
         SGD(p, lr=0.1, momentum=0.9, dampening=0.1)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """``python bench.py --gpus 2`` with no launcher around it spawns two ranks (child torch.distributed.run, before torch
+    is imported in the parent).  Without a GPU each rank stops at the product path's "needs a ROCm GPU" assertion -- which
+    is the observable proof here that two rank processes were started with WORLD_SIZE=2 and that the exit code propagates.
+    The GPU half (n_gpus == 2 in the JSON line) is tests/test_gpu_model.py::test_bench_spawns_its_own_ranks."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check; the GPU box runs test_bench_spawns_its_own_ranks")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=repo, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert out.stderr.count("bench.py needs a ROCm GPU") >= 2, out.stderr[-3000:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

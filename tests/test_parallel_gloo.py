@@ -143,3 +143,50 @@ def test_parameter_broadcast_handles_channels_last_weights_world2():
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def _val_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        import numpy as np
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path.insert(0, os.path.join(os.path.dirname(here), "stylegan-for-facerec_amd"))
+        from util.utils import perform_val
+        torch.manual_seed(7)  # the same stand-in embedder on both ranks
+        net = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(3 * 112 * 112, 32))
+        rng = np.random.RandomState(3)
+        pairs = 23  # 46 images, batch 8 -> 6 batches incl. a ragged last one, dealt 3 / 3 over two ranks
+        base = rng.uniform(-1, 1, size=(pairs, 3, 112, 112)).astype(np.float32)
+        other = np.where(rng.rand(pairs, 1, 1, 1) < 0.5, base + 0.05 * rng.randn(pairs, 3, 112, 112).astype(np.float32),
+                         rng.uniform(-1, 1, size=(pairs, 3, 112, 112)).astype(np.float32)).astype(np.float32)
+        carray = np.clip(np.stack([base, other], 1).reshape(2 * pairs, 3, 112, 112), -1, 1)
+        issame = rng.rand(pairs) < 0.5
+        one = perform_val(False, "cpu", 32, 8, net, carray, issame, nrof_folds=5, ccrop=False)
+        two = perform_val(False, "cpu", 32, 8, net, carray, issame, nrof_folds=5, ccrop=False, rank=rank, world=world)
+        assert one[0] == two[0] and one[1] == two[1], (one[:2], two[:2])  # bit-equal metrics on every rank
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_perform_val_sharded_over_ranks_world2():
+    """``perform_val`` with the batches dealt over two ranks (one all-reduce of the embedding sums) returns exactly what
+    one rank computes alone -- the per-epoch RFW evaluation of train.py no longer runs on rank 0 only
+    (reference: util/utils.py:254-307, train.py:403-410)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_val_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
