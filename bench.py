@@ -439,7 +439,7 @@ def timed_loop(step, xs, ys, warmup, steps, world, device, sampler=None):
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    return dt, float(loss), clocks
+    return dt, float(loss.detach()), clocks
 
 
 # The other BASELINE.json configs, timed briefly behind the headline (same step function, same data parallelism when

@@ -1,0 +1,488 @@
+// frhip -- weight gradient of the stride-1 3x3 convolutions at 14x14 / 28x28, warp-specialised (bf16, round 3).
+//
+//   dw[co][tap][ci] = sum_{pixels p}  g[p][co] * pro(x[p + tap][ci])
+//
+// Same decomposition as conv_wgrad_strip.hip (a workgroup owns one 64 co x 64 ci x 9 tap block of dW and a group of
+// images; the group's partial goes to a slab), different machinery.  The strip kernel spent 8.5 vector instructions per
+// MFMA (address arithmetic of the register prefetch, the PReLU / BN prologue, 276 v_mov per image to pair half-fragments)
+// in the SAME waves that issue the MFMAs, and stopped the MFMAs for every commit between two barriers: its K loop ran at
+// ~60 % of the MFMA rate.  Here the eight waves of a workgroup have two roles (as in conv3x3_roll64.hip):
+//
+//   waves 0-3 (one per SIMD)  MFMA only.  Wave w owns ci tile w (16 channels) x all 64 co x 9 taps = 36 accumulator tiles
+//                             (144 VGPRs), so a g fragment serves 9 taps and an input fragment serves 4 co tiles: 26
+//                             ds_read_b64_tr_b16 per 36 MFMAs, no vector ALU instruction in the loop (every address is
+//                             lane base + immediate: the K axis of both tiles is laid out in rows of RW = 16 / 32 slots,
+//                             so tap (kh, kw) of K slot k sits at tile position k + RW kh + kw).
+//   waves 4-7                 move the data: global loads two phases ahead into two register sets, BN / PReLU prologue
+//                             on the registers, ds_write into the buffer the computing waves are NOT reading.
+//
+// An image is cut into phases of whole K steps (14x14: rows 0-7 = 4 steps, rows 8-13 = 3 steps; 28x28: 4 rows = 4 steps)
+// that alternate between two LDS buffers; one barrier per phase.  The barrier sits two MFMA groups BEFORE the end of a
+// phase's arithmetic: at that point the computing waves have every fragment of the phase in registers, so behind the
+// barrier they finish the phase while the first fragments of the next one are already on their way -- the MFMA pipe
+// never drains at a phase boundary.  Halo rows / columns of the input tiles and the surplus K slots of the g tiles are
+// zeroed once and never written again.
+//
+// Reference arithmetic: autograd weight gradient of Conv2d(c, d, (3,3), (1,1), 1) in bottleneck_IR
+// (backbone/model_irse.py:57-59) with BN apply (:57) / PReLU (:58) folded into the input load.
+#include <stdlib.h>
+
+#include "common.h"
+#include "frhip_internal.h"
+
+namespace {
+
+constexpr int CT = 64;             // co and ci tile
+constexpr int TSTR = CT * 2 + 32;  // LDS row stride (bytes): conflict-free transposing reads (see conv_wgrad_strip.hip)
+constexpr int NLT = 256;           // data-moving threads (waves 4-7)
+
+typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
+
+__device__ __forceinline__ s16x8 tr_frag(const char* p0, const char* p1) {
+  const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)p0);
+  const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)p1);
+  const s16x4 ai = __builtin_bit_cast(s16x4, a), bi = __builtin_bit_cast(s16x4, b);
+  return (s16x8){ai[0], ai[1], ai[2], ai[3], bi[0], bi[1], bi[2], bi[3]};
+}
+
+// Geometry of one width.  A phase = PR output rows = PR * RW / 32 K steps; phase kinds alternate per image as listed.
+template <int W_>
+struct RC;
+template <>
+struct RC<14> {
+  static constexpr int W = 14, RW = 16, NPH = 2;          // phases per image
+  static constexpr int rows(int ph) { return ph == 0 ? 8 : 6; }
+  static constexpr int row0(int ph) { return ph == 0 ? 0 : 8; }
+};
+template <>
+struct RC<28> {
+  static constexpr int W = 28, RW = 32, NPH = 7;
+  static constexpr int rows(int) { return 4; }
+  static constexpr int row0(int ph) { return 4 * ph; }
+};
+
+template <int W>
+struct RL {  // LDS layout: buffer 0 holds the even phases of the schedule, buffer 1 the odd ones
+  using C = RC<W>;
+  static constexpr int pr(int buf) { return C::NPH == 2 ? C::rows(buf) : C::rows(0); }
+  static constexpr int g_bytes(int buf) { return pr(buf) * C::RW * TSTR; }                 // K slots of the phase
+  static constexpr int a_bytes(int buf) { return ((pr(buf) + 2) * C::RW + 16) * TSTR; }    // + the tail a kw-shifted read touches
+  static constexpr int BUF0 = g_bytes(0) + a_bytes(0);
+  static constexpr int LDS = BUF0 + g_bytes(1) + a_bytes(1);
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+// prologue on one dword (two bf16): BN apply or PReLU, fp32 arithmetic, one rounding back to bf16
+// Written as instructions: from the equivalent C the compiler rebuilds 16-bit compares + v_cndmask + v_perm (49 vector
+// instructions per 16-byte chunk instead of 28) -- and these run on the SIMDs whose issue slots the MFMA waves need.
+template <int PRO>
+__device__ __forceinline__ uint32_t pro2(uint32_t u, float a0, float b0, float a1, float b1) {
+  uint32_t lo, hi, r;
+  if (PRO == FR_PRO_BN) {
+    asm("v_lshlrev_b32 %0, 16, %3\n\t"
+        "v_and_b32 %1, 0xffff0000, %3\n\t"
+        "v_fma_f32 %0, %0, %4, %5\n\t"
+        "v_fma_f32 %1, %1, %6, %7\n\t"
+        "v_cvt_pk_bf16_f32 %2, %0, %1"
+        : "=&v"(lo), "=&v"(hi), "=v"(r)
+        : "v"(u), "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+    return r;
+  }
+  // PReLU: x > 0 ? x : a x.  Both halves scaled and packed; v_pk_ashrrev_i16 spreads the two sign bits into a mask and
+  // v_bfi_b32 takes the scaled half where the sign is set, the input half elsewhere.  Same values as the compare form:
+  // -0 and negative NaNs go through a x (x > 0 is false for them too), a x of a positive x is never selected.
+  uint32_t m;
+  asm("v_lshlrev_b32 %0, 16, %4\n\t"
+      "v_and_b32 %1, 0xffff0000, %4\n\t"
+      "v_mul_f32 %0, %0, %5\n\t"
+      "v_mul_f32 %1, %1, %6\n\t"
+      "v_cvt_pk_bf16_f32 %0, %0, %1\n\t"
+      "v_pk_ashrrev_i16 %2, 15, %4 op_sel_hi:[0,1]\n\t"
+      "v_bfi_b32 %3, %2, %0, %4"
+      : "=&v"(lo), "=&v"(hi), "=&v"(m), "=v"(r)
+      : "v"(u), "v"(a0), "v"(a1));
+  return r;
+}
+
+#define LDS_FENCE_BARRIER_RAW() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// Diagnostic build (make stamps; never loaded by the product): per workgroup, cycles (s_memtime) of the whole kernel and
+// of the image loop, and the cycles wave 0 (computing) / wave 4 (data-moving) spend inside the hand-over barriers.
+#ifdef FRHIP_STAMPS
+__device__ unsigned long long* fr_stamp_buf_wgr = nullptr;
+#define TSTAMP() __builtin_amdgcn_s_memtime()
+#define LDS_FENCE_BARRIER()                         \
+  do {                                              \
+    const unsigned long long t0__ = TSTAMP();       \
+    LDS_FENCE_BARRIER_RAW();                        \
+    bar_wait += TSTAMP() - t0__;                    \
+  } while (0)
+#else
+#define LDS_FENCE_BARRIER() LDS_FENCE_BARRIER_RAW()
+#endif
+
+template <int W, int PRO>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradArgs p) {
+  using C = RC<W>;
+  using L = RL<W>;
+  constexpr int RW = C::RW, NPH = C::NPH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // block -> (group, tile): consecutive logical ids (= all tiles of a group) share an XCD
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int cit_n = p.SC / CT, tiles = (p.Cout / CT) * cit_n;
+  const int group = bid / tiles, tile = bid - group * tiles;
+  const int cot = tile / cit_n, cit = tile - cot * cit_n;
+  const int per = (p.B + p.nsplit - 1) / p.nsplit;
+  const int b_begin = group * per;
+  int b_end = b_begin + per;
+  if (b_end > p.B) b_end = p.B;
+  const int nimg = b_end > b_begin ? b_end - b_begin : 0;
+
+#ifdef FRHIP_STAMPS
+  unsigned long long bar_wait = 0;
+  const unsigned long long t_start = TSTAMP(), rt_start = __builtin_amdgcn_s_memrealtime();
+#endif
+  // zero both buffers once: halo rows / columns, surplus K slots and tails stay zero for the whole launch
+  for (int idx = tid; idx < L::LDS / 16; idx += 512) st16(smem + idx * 16, zero16());
+  __syncthreads();
+
+  // Deferred slab sum of the PREVIOUS weight-gradient launch of this stream (FrWgradArgs.prev_*): every workgroup adds its
+  // share of that launch's slabs in the fixed order g = 0, 1, ... while its own first tiles are in flight -- the sum no
+  // longer costs a launch (and a trip of 2 x groups x |dW| bytes through a kernel of its own).
+  auto fold_prev = [&]() {
+    const long long n4 = p.prev_n >> 2;
+    const f32x4* __restrict__ ps = reinterpret_cast<const f32x4*>(p.prev_slab);
+    f32x4* __restrict__ po = reinterpret_cast<f32x4*>(p.prev_dw);
+    const int G = p.prev_groups;
+    for (long long i = (long long)blockIdx.x * 512 + tid; i < n4; i += (long long)gridDim.x * 512) {
+      const f32x4* src = ps + i;
+      f32x4 s = src[0];
+      int g = 1;
+      for (; g + 8 <= G; g += 8) {  // 8 independent loads in flight; the summation order stays g = 0, 1, 2, ...
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(long long)(g + u) * n4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; g < G; ++g) s += src[(long long)g * n4];
+      po[i] = s;
+    }
+  };
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------------------- data-moving waves
+#ifdef ROLL_LOADER_PRIO
+    __builtin_amdgcn_s_setprio(ROLL_LOADER_PRIO);
+#endif
+    const int lt = tid - 256;
+    const int ch = lt & 7;  // the 8-channel chunk of a pixel this thread always handles
+    // uniform base (scalar registers) + 32-bit per-lane byte offset: the loads take the saddr form, no 64-bit vector
+    // address arithmetic per load and image
+    const char* __restrict__ G = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(p.g) + cot * CT);
+    const char* __restrict__ X = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(p.src) + cit * CT);
+    float pa[8], pb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pa[j] = PRO != FR_PRO_NONE ? p.pro_a[cit * CT + ch * 8 + j] : 0.f;
+      pb[j] = PRO == FR_PRO_BN ? p.pro_b[cit * CT + ch * 8 + j] : 0.f;
+    }
+    // Phase ph moves G rows [row0, row0+PR) and input rows [row0-1, row0+PR+1) clipped to the image.  Slots of 256
+    // threads; a slot is wholly g or wholly input (compile time), lanes past the end repeat the last chunk (same bytes
+    // to the same address: no predication anywhere, the waitcnt bookkeeping of the compiler stays exact).
+    auto g_chunks = [](int ph) constexpr { return C::rows(ph) * W * 8; };
+    auto a_r0 = [](int ph) constexpr { return C::row0(ph) > 0 ? C::row0(ph) - 1 : 0; };
+    auto a_r1 = [](int ph) constexpr { return C::row0(ph) + C::rows(ph) + 1 < W ? C::row0(ph) + C::rows(ph) + 1 : W; };
+    auto a_chunks = [=](int ph) constexpr { return (a_r1(ph) - a_r0(ph)) * W * 8; };
+    constexpr int NGS = (C::rows(0) * W * 8 + NLT - 1) / NLT;                         // g slots (largest phase)
+    constexpr int NAS = ((C::rows(0) + 2) * W * 8 + NLT - 1) / NLT;                   // input slots (largest phase)
+    constexpr int NS = NGS + NAS;
+
+    // register set of one phase in flight
+    struct Set {
+      U128 v[NS];
+    };
+    auto issue = [&](Set& s, int b, auto phc) {
+      constexpr int ph = decltype(phc)::value;
+      const char* gi = G + (size_t)b * (W * W) * (size_t)p.ldg * 2;
+      const char* xi = X + (size_t)b * (W * W) * (size_t)p.lda * 2;
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        if (u < NGS) {
+          int q = u * NLT + lt;
+          if (u * NLT >= g_chunks(ph)) continue;  // slot unused in this phase kind
+          q = q < g_chunks(ph) ? q : g_chunks(ph) - 1;
+          const int px = q >> 3;  // pixel inside the phase's rows (ch == q & 7 because NLT % 8 == 0 and the clamp keeps ch)
+          s.v[u] = ld16(gi + (unsigned)(((C::row0(ph) * W + px) * p.ldg + ch * 8) * 2));
+        } else {
+          int q = (u - NGS) * NLT + lt;
+          if ((u - NGS) * NLT >= a_chunks(ph)) continue;
+          q = q < a_chunks(ph) ? q : a_chunks(ph) - 1;
+          const int px = q >> 3;
+          s.v[u] = ld16(xi + (unsigned)(((a_r0(ph) * W + px) * p.lda + ch * 8) * 2));
+        }
+      }
+    };
+    auto commit = [&](Set& s, char* buf, auto phc) {
+      constexpr int ph = decltype(phc)::value;
+      char* Gs = buf;
+      char* As = buf + L::g_bytes(ph & 1);
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        if (u < NGS) {
+          int q = u * NLT + lt;
+          if (u * NLT >= g_chunks(ph)) continue;
+          q = q < g_chunks(ph) ? q : g_chunks(ph) - 1;
+          const int px = q >> 3, r = px / W, c = px - r * W;
+          st16(Gs + (r * RW + c) * TSTR + ch * 16, s.v[u]);
+        } else {
+          int q = (u - NGS) * NLT + lt;
+          if ((u - NGS) * NLT >= a_chunks(ph)) continue;
+          q = q < a_chunks(ph) ? q : a_chunks(ph) - 1;
+          const int px = q >> 3, r = px / W, c = px - r * W;
+          U128 x = s.v[u];
+          if (PRO != FR_PRO_NONE) {
+            x.x = pro2<PRO>(x.x, pa[0], pb[0], pa[1], pb[1]);
+            x.y = pro2<PRO>(x.y, pa[2], pb[2], pa[3], pb[3]);
+            x.z = pro2<PRO>(x.z, pa[4], pb[4], pa[5], pb[5]);
+            x.w = pro2<PRO>(x.w, pa[6], pb[6], pa[7], pb[7]);
+          }
+          // tile row of image row h in this phase: h - (row0 - 1); column c + 1 (column 0 / W + 1 = zero halo)
+          const int tr = a_r0(ph) + r - (C::row0(ph) - 1);
+          st16(As + (tr * RW + c + 1) * TSTR + ch * 16, x);
+        }
+      }
+    };
+
+    char* const buf0 = smem;
+    char* const buf1 = smem + L::BUF0;
+    if (nimg == 0) {  // (never with the group counts the host computes; both roles then skip every barrier)
+      if (p.prev_n) fold_prev();
+      return;
+    }
+    if constexpr (NPH == 2) {
+      // 14x14: phase kind == buffer.  set0 <-> (phase 0, buf0), set1 <-> (phase 1, buf1)
+      Set s0, s1;
+      issue(s0, b_begin, std::integral_constant<int, 0>{});
+      issue(s1, b_begin, std::integral_constant<int, 1>{});
+      if (p.prev_n) fold_prev();
+      commit(s0, buf0, std::integral_constant<int, 0>{});
+      {
+        const int bn = b_begin + 1 < b_end ? b_begin + 1 : b_end - 1;
+        issue(s0, bn, std::integral_constant<int, 0>{});
+      }
+      LDS_FENCE_BARRIER();  // B0: phase 0 of the first image is in buf0
+#ifdef FRHIP_STAMPS
+      const unsigned long long t_loop = TSTAMP();
+      bar_wait = 0;
+#endif
+#pragma unroll 1
+      for (int i = 0; i < nimg; ++i) {
+        const int b = b_begin + i;
+        const int b1 = b + 1 < b_end ? b + 1 : b_end - 1, b2 = b + 2 < b_end ? b + 2 : b_end - 1;
+        // computing waves: phase 0 of image i (buf0).  buf1 is free.  The sched_barriers keep the order commit -> issue:
+        // hoisted above the commit, the new requests would be the youngest loads in flight at its wait.
+        commit(s1, buf1, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        issue(s1, b1, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        LDS_FENCE_BARRIER();  // phase 1 of image i is in buf1; buf0 is free
+        commit(s0, buf0, std::integral_constant<int, 0>{});  // phase 0 of image i + 1 (past the end: a repeat nobody reads)
+        __builtin_amdgcn_sched_barrier(0);
+        issue(s0, b2, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        LDS_FENCE_BARRIER();  // phase 0 of image i + 1 is in buf0; buf1 is free
+      }
+#ifdef FRHIP_STAMPS
+      if (tid == 256 && fr_stamp_buf_wgr) {
+        fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 3] = bar_wait;
+        fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 4] = TSTAMP() - t_loop;
+      }
+#endif
+    } else {
+      static_assert(NPH == 2, "only the two-phase (14x14) schedule is written out so far");
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------------------------------------ computing waves
+  const int wci = wave;  // ci tile of this wave
+  const int li = lane & 15, lq = lane >> 4;
+  const int colb = (4 * (li & 3)) * 2;  // byte offset of this lane's 4-channel group inside a 16-channel tile
+  const int lrow = (4 * lq + (li >> 2)) * TSTR;
+  f32x4 acc[4][9];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[t][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (p.prev_n) fold_prev();
+  if (nimg > 0) {
+    const char* const gb0 = smem + lrow + colb;
+    const char* const ab0 = smem + L::g_bytes(0) + lrow + (wci * 16) * 2 + colb;
+    const char* const gb1 = smem + L::BUF0 + lrow + colb;
+    const char* const ab1 = smem + L::BUF0 + L::g_bytes(1) + lrow + (wci * 16) * 2 + colb;
+    // One "item" = one tap of one K step: an input fragment (2 reads) and 4 MFMAs.  Flat software pipeline over the items
+    // of a phase: the fragment of item it + LA is requested behind the MFMAs of item it into a ring of 9 (= the taps of a
+    // step, so the slot of an item is its tap in every phase); the g fragments of the next step (8 reads) are requested
+    // over taps 5-8.  The barrier that hands the buffers over sits at item NI - LA + 1: the last fragment of the phase was
+    // requested two items earlier, and the LA - 1 items behind the barrier need no LDS of this phase any more -- they run
+    // while the first fragments of the next phase are fetched.
+#ifndef ROLL_LA
+#define ROLL_LA 8
+#endif
+    constexpr int LA = ROLL_LA, RS = LA + 1;  // ring slots
+    auto a_frag = [&](const char* ab, int item) -> s16x8 {
+      const int ks = item / 9, tap = item % 9;
+      const int off = 32 * ks + RW * (tap / 3) + tap % 3;
+      return tr_frag(ab + off * TSTR, ab + (off + 16) * TSTR);
+    };
+    auto g_frag = [&](const char* gb, int ks, int t) -> s16x8 {
+      return tr_frag(gb + (32 * ks) * TSTR + t * 32, gb + (32 * ks + 16) * TSTR + t * 32);
+    };
+    s16x8 ring[RS];
+    s16x8 gf[4], gn[4];
+
+    auto run_phase = [&](const char* gb, const char* ab, const char* gb_next, const char* ab_next, auto nstep_c) {
+      constexpr int NSTEP = decltype(nstep_c)::value;
+      constexpr int NI = NSTEP * 9, IB = NI - LA + 1;
+      static_assert(NI % RS == 0, "the ring slot of an item must not depend on the phase");
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int ks = it / 9, tap = it % 9;
+        if (it == IB) {
+          LDS_FENCE_BARRIER();  // every fragment of this phase is in registers; the next buffer is complete
+#pragma unroll
+          for (int t = 0; t < 4; ++t) gn[t] = g_frag(gb_next, 0, t);
+#pragma unroll
+          for (int jt = NI - LA; jt < IB; ++jt) ring[(jt + LA) % RS] = a_frag(ab_next, jt + LA - NI);  // deferred requests
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const s16x8 af = ring[it % RS];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[t][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[t], af, acc[t][tap], 0, 0, 0);
+        if (it + LA < NI) ring[(it + LA) % RS] = a_frag(ab, it + LA);
+        else if (it >= IB) ring[(it + LA) % RS] = a_frag(ab_next, it + LA - NI);
+        if (ks + 1 < NSTEP && tap >= 5) gn[tap - 5] = g_frag(gb, ks + 1, tap - 5);
+        if (tap == 8) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) gf[t] = gn[t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    static_assert(C::NPH == 2, "two-phase schedule");
+    constexpr int NS0 = C::rows(0) * RW / 32, NS1 = C::rows(1) * RW / 32;
+    LDS_FENCE_BARRIER();  // B0: phase 0 of the first image is in buffer 0
+#ifdef FRHIP_STAMPS
+    const unsigned long long t_loop = TSTAMP();
+    bar_wait = 0;
+#endif
+#pragma unroll
+    for (int t = 0; t < 4; ++t) gf[t] = g_frag(gb0, 0, t);
+#pragma unroll
+    for (int it = 0; it < LA; ++it) ring[it] = a_frag(ab0, it);
+#pragma unroll 1
+    for (int i = 0; i < nimg; ++i) {
+      // behind the last image the "next phase" fragments are read from whatever buffer 0 holds and never used
+      run_phase(gb0, ab0, gb1, ab1, std::integral_constant<int, NS0>{});
+      run_phase(gb1, ab1, gb0, ab0, std::integral_constant<int, NS1>{});
+    }
+#ifdef FRHIP_STAMPS
+    if (tid == 0 && fr_stamp_buf_wgr) {
+      fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 1] = TSTAMP() - t_loop;
+      fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 2] = bar_wait;
+      fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 6] = nimg;
+    }
+#endif
+  }
+
+  // slab[group][co][tap][ci]
+  float* __restrict__ slab = p.slab + (size_t)group * (size_t)p.Cout * 9 * (size_t)p.SC;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cot * CT + t * 16 + lq * 4 + r;
+        const int ci = cit * CT + wci * 16 + li;
+        slab[((size_t)co * 9 + tap) * (size_t)p.SC + ci] = acc[t][tap][r];
+      }
+#ifdef FRHIP_STAMPS
+  if (tid == 0 && fr_stamp_buf_wgr) {
+    fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 0] = TSTAMP() - t_start;
+    fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime() - rt_start;
+  }
+#endif
+}
+
+template <int W, int PRO>
+int launch(const FrWgradArgs& a, hipStream_t st) {
+  using L = RL<W>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_roll_kernel<W, PRO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS);
+    attr_done = true;
+  }
+  const int tiles = (a.Cout / CT) * (a.SC / CT);
+  hipLaunchKernelGGL((conv_wgrad_roll_kernel<W, PRO>), dim3(tiles * a.nsplit), dim3(512), L::LDS, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fr_set_error(hipGetErrorString(e));
+    return (int)e;
+  }
+  if (a.defer) return 0;  // the caller sums the slabs (prev_* of a later launch, or fr_reduce_slabs)
+  return fr_launch_reduce_slabs(a.slab, a.nsplit, (long long)a.Cout * 9 * a.SC, a.dw, st);
+}
+
+template <int W>
+int by_pro(const FrWgradArgs& a, hipStream_t st) {
+  switch (a.pro) {
+    case FR_PRO_NONE: return launch<W, FR_PRO_NONE>(a, st);
+    case FR_PRO_BN: return launch<W, FR_PRO_BN>(a, st);
+    case FR_PRO_PRELU: return launch<W, FR_PRO_PRELU>(a, st);
+  }
+  FR_UNSUPPORTED("fr_conv_wgrad_strip: unknown prologue");
+}
+
+}  // namespace
+
+#ifdef FRHIP_STAMPS
+extern "C" int fr_debug_set_stamp_buffer_wgr(void* dev_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(fr_stamp_buf_wgr), &dev_ptr, sizeof(dev_ptr));
+}
+#endif
+
+// FRHIP_WGRAD_ROLL=0: back to the strip kernel for every shape (A/B switch)
+bool fr_wgrad_roll_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("FRHIP_WGRAD_ROLL");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+// stride-1 3x3 at 14x14, channel counts multiples of 64, at least one image per group
+bool fr_wgrad_roll_serves(const FrWgradArgs& a) {
+  return fr_wgrad_roll_enabled() && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.GH == a.SH &&
+         a.GW == a.SW && a.SH == a.SW && a.SW == 14 && a.Cout % CT == 0 && a.SC % CT == 0 && a.nsplit >= 1 &&
+         a.nsplit <= a.B;
+}
+
+int fr_wgrad_roll_launch(const FrWgradArgs& a, hipStream_t st) {
+  switch (a.SW) {
+    case 14: return by_pro<14>(a, st);
+  }
+  FR_UNSUPPORTED("fr_conv_wgrad_strip: width not served by the warp-specialised kernel");
+}

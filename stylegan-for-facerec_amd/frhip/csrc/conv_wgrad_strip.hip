@@ -428,10 +428,23 @@ extern "C" int fr_conv_wgrad_strip_supported(int Cout, int Cin, int W) {
   return W == 112 || W == 56 || W == 28 || W == 14 || W == 7;
 }
 
+extern "C" int fr_conv_wgrad_strip_defers(const FrWgradArgs* args) {
+  return args->ldg % 8 == 0 && args->lda % 8 == 0 && args->slab && fr_wgrad_roll_serves(*args) ? 1 : 0;
+}
+
+extern "C" int fr_reduce_slabs(const float* slab, int groups, long long n, float* out, void* stream) {
+  if (!slab || !out || groups < 1 || n < 4 || n % 4) FR_UNSUPPORTED("fr_reduce_slabs: bad arguments");
+  return fr_launch_reduce_slabs(slab, groups, n, out, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int fr_conv_wgrad_strip(const FrWgradArgs* args, void* stream) {
   const FrWgradArgs& a = *args;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a.ldg % 8 || a.lda % 8 || !a.slab || a.nsplit < 1) FR_UNSUPPORTED("fr_conv_wgrad_strip: bad strides / slab");
+  if ((a.defer || a.prev_n) && !fr_wgrad_roll_serves(a))
+    FR_UNSUPPORTED("fr_conv_wgrad_strip: defer / prev_* only where fr_conv_wgrad_strip_defers() answers 1");
+  if (a.prev_n && (!a.prev_slab || !a.prev_dw || a.prev_groups < 1 || a.prev_n % 4 || a.prev_slab == a.slab))
+    FR_UNSUPPORTED("fr_conv_wgrad_strip: bad prev_* (deferred slab sum)");
   if (a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad == 1 && a.GH == a.GW && a.SH == 2 * a.GH && a.SW == 2 * a.GW &&
       a.Cout % CT == 0 && a.SC % CT == 0) {
     // stride 2: the input tile holds the four parity planes of the strip (see WC)
@@ -446,6 +459,7 @@ extern "C" int fr_conv_wgrad_strip(const FrWgradArgs* args, void* stream) {
   if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.GH != a.SH || a.GW != a.SW || a.SH != a.SW ||
       !fr_conv_wgrad_strip_supported(a.Cout, a.SC, a.SW))
     FR_UNSUPPORTED("fr_conv_wgrad_strip: square 3x3 bf16 convolutions, stride 1 or 2, 64-multiple channels");
+  if (fr_wgrad_roll_serves(a)) return fr_wgrad_roll_launch(a, st);
   // 4-wave workgroups (two resident per CU, NW = 4) were measured at about half the throughput of the 8-wave form
   // with register prefetch (tools/kbench.py, B = 256) and are not instantiated.
   switch (a.SW) {

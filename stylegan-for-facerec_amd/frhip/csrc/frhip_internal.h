@@ -18,3 +18,9 @@ bool fr_s2roll_serves(const FrConvArgs& a);
 int fr_s2roll_parts(int B);
 int fr_s2roll_launch(const FrConvArgs& a, hipStream_t st);
 bool fr_s2roll_enabled();
+
+// 3x3 stride-1 weight gradients at 14x14 on the warp-specialised kernel (conv_wgrad_roll.hip); dispatched from
+// fr_conv_wgrad_strip
+bool fr_wgrad_roll_enabled();
+bool fr_wgrad_roll_serves(const FrWgradArgs& a);
+int fr_wgrad_roll_launch(const FrWgradArgs& a, hipStream_t st);

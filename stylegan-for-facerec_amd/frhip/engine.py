@@ -163,6 +163,20 @@ def _wgrad_slices(pixels, tiles):
     return int(max(1, min(want, 256, pixels // 256 if pixels >= 256 else 1)))
 
 
+class _ArgProxy(object):
+    """Lets the slab-buffer bookkeeping re-point a positional-argument launch (fr_reduce_slabs) like a struct field."""
+
+    def __init__(self, launch, index):
+        self.launch, self.index = launch, index
+        self.keep = (self,)
+
+    def __setattr__(self, name, value):
+        if name in ("launch", "index", "keep"):
+            object.__setattr__(self, name, value)
+        else:
+            self.launch.args[self.index] = value
+
+
 class _EvRecord(object):
     """List entry: record an event on a stream (weight-gradient side stream bookkeeping)."""
     __slots__ = ("ev", "stream")
@@ -244,6 +258,11 @@ class BackbonePlan(object):
                               not self.body_only)
         self.use_s2 = os.environ.get("FRHIP_NO_S2_STRIP", "0") != "1"  # stride-2 strip kernels (A/B switch)
         self.slab, self._slab_users = None, []
+        # deferred slab sums (FrWgradArgs.defer / prev_*): a weight-gradient launch that supports it leaves the sum of its
+        # slabs to the NEXT such launch of the side stream (two slab buffers alternate); fr_reduce_slabs flushes the last
+        self.defer_slabs = os.environ.get("FRHIP_NO_DEFER_SLABS", "0") != "1"
+        self.slab2, self._slab2_users, self._slab_flip = None, [], 0
+        self._pending = None  # (launch that wrote the slabs, groups, n, dw tensor, parameter)
         self.part_slope = None  # per-buffer-set partial rows of the PReLU slope gradient (side-stream reduction)
         self.comm_stream_t, self.comm_events = None, None  # readiness callbacks (run_backward)
         self._normalize_params()
@@ -451,16 +470,16 @@ class BackbonePlan(object):
             L.append(_EvRecord(ev, self.stream1_t))
             L.append(_EvWait(self.stream2_t, ev))
 
-    def _wgrad(self, L, **kw):
-        """Append a weight-gradient launch: LDS-strip kernel for bf16 stride-1 3x3 layers, generic otherwise."""
+    def _wgrad(self, L, param=None, **kw):
+        """Append a weight-gradient launch: LDS-strip kernel for bf16 stride-1 3x3 layers, generic otherwise.  Returns the
+        parameters whose gradients are final once this launch has run (a deferring launch completes its predecessor's)."""
         if (self.fr == FR_BF16 and self.use_strip and kw["KH"] == 3 and kw["stride"] == 1 and
                 ops.wgrad_strip_supported(kw["Cout"], kw["SC"], kw["SW"])):
             tiles = (kw["Cout"] // 64) * (kw["SC"] // 64)
             rows = {112: 2, 56: 4, 28: 7, 14: 14, 7: 7}[kw["SW"]]
             fills = kw["B"] * (kw["SW"] // rows) // (4 if kw["SW"] == 7 else 1)
             groups = int(max(1, min(fills, 256 // tiles if tiles <= 256 else 1)))
-            self._slab_launch(L, dict(kw, nsplit=groups), groups * kw["Cout"] * 9 * kw["SC"])
-            return
+            return self._slab_launch(L, dict(kw, nsplit=groups), groups * kw["Cout"] * 9 * kw["SC"], param=param)
         if (self.fr == FR_BF16 and self.use_strip and self.use_s2 and kw["KH"] == 3 and kw["stride"] == 2 and
                 kw["GW"] in (56, 28, 14, 7) and kw["SW"] == 2 * kw["GW"] and kw["Cout"] % 64 == 0 and kw["SC"] % 64 == 0):
             # stride-2 layers: the same kernel on the four parity planes of the input (conv_wgrad_strip.hip, S2)
@@ -468,25 +487,76 @@ class BackbonePlan(object):
             rows, nimg = {56: (2, 1), 28: (4, 1), 14: (7, 1), 7: (7, 2)}[kw["GW"]]
             fills = (kw["B"] * (kw["GW"] // rows) + nimg - 1) // nimg
             groups = int(max(1, min(fills, 256 // tiles if tiles <= 256 else 1)))
-            self._slab_launch(L, dict(kw, nsplit=groups), groups * kw["Cout"] * 9 * kw["SC"])
-            return
+            return self._slab_launch(L, dict(kw, nsplit=groups), groups * kw["Cout"] * 9 * kw["SC"], param=param)
         if kw.get("nsplit", 1) > 1:  # pixel slices go to slabs and are added in a fixed order (no float atomics)
-            self._slab_launch(L, kw, kw["nsplit"] * kw["Cout"] * kw["KH"] * kw["KW"] * kw["SC"], strip=False)
-            return
+            return self._slab_launch(L, kw, kw["nsplit"] * kw["Cout"] * kw["KH"] * kw["KW"] * kw["SC"], strip=False,
+                                     param=param)
         l = ops.wgrad(self.stream2, self.fr, **kw)
         l.tstream = self.stream2_t
         L.append(l)
+        return [param]
 
-    def _slab_launch(self, L, kw, need, strip=True):
-        if self.slab is None or self.slab.numel() < need:
-            self.slab = torch.empty(need, device=self.device)
-            for l in self._slab_users:  # re-point earlier launches at the grown buffer
-                l.keep[0].slab = ops.ptr(self.slab)
-        kw = dict(kw, slab=self.slab)
+    def _slab_buffer(self, which, need):
+        """One of the two slab buffers, grown on demand (earlier launches are re-pointed at the new allocation)."""
+        name, users = ("slab", self._slab_users) if which == 0 else ("slab2", self._slab2_users)
+        buf = getattr(self, name)
+        if buf is None or buf.numel() < need:
+            buf = torch.empty(need, device=self.device)
+            setattr(self, name, buf)
+            for l, field in users:
+                setattr(l.keep[0], field, ops.ptr(buf))
+        return buf, users
+
+    def _flush_pending(self, L):
+        """Sum the slabs a deferring launch left behind with a launch of its own (end of the list, or in front of a
+        launch that cannot fold them).  Returns the parameter whose gradient became final, or None."""
+        if self._pending is None:
+            return None
+        l0, groups, n, dw, param, which = self._pending
+        self._pending = None
+        buf, users = self._slab_buffer(which, 0)
+        r = ops.call("fr_reduce_slabs", buf, groups, n, dw, self.stream2)
+        r.tstream = self.stream2_t
+        users.append((_ArgProxy(r, 0), "ptr"))
+        L.append(r)
+        return param
+
+    def _slab_launch(self, L, kw, need, strip=True, param=None):
+        """Append a slab-mode weight-gradient launch.  Returns the parameters whose gradients THIS launch completes:
+        [param] for a launch that sums its own slabs, the previous deferring launch's parameter for one that folds it,
+        [] for the first deferring launch."""
+        done = []
+        if strip and self.defer_slabs:
+            probe = ops._fill(_lib.FrWgradArgs(), **dict(kw, slab=self.part))
+            if _lib.lib.fr_conv_wgrad_strip_defers(ctypes.byref(probe)):
+                which = self._slab_flip
+                self._slab_flip ^= 1
+                buf, users = self._slab_buffer(which, need)
+                kw = dict(kw, slab=buf, defer=1)
+                if self._pending is not None:
+                    _l0, pg, pn, pdw, pparam, pwhich = self._pending
+                    pbuf, pusers = self._slab_buffer(pwhich, 0)
+                    kw.update(prev_slab=pbuf, prev_dw=pdw, prev_n=pn, prev_groups=pg)
+                    done.append(pparam)
+                l = ops.wgrad_strip(self.stream2, **kw)
+                l.tstream = self.stream2_t
+                users.append((l, "slab"))
+                if self._pending is not None:
+                    pusers.append((l, "prev_slab"))
+                self._pending = (l, kw["nsplit"], kw["Cout"] * kw["KH"] * kw["KW"] * kw["SC"], kw["dw"], param, which)
+                L.append(l)
+                return done
+        flushed = self._flush_pending(L)  # keep the side stream's sums in order
+        if flushed is not None:
+            done.append(flushed)
+        buf, users = self._slab_buffer(0, need)
+        kw = dict(kw, slab=buf)
         l = ops.wgrad_strip(self.stream2, **kw) if strip else ops.wgrad(self.stream2, self.fr, **kw)
         l.tstream = self.stream2_t
-        self._slab_users.append(l)
+        users.append((l, "slab"))
         L.append(l)
+        done.append(param)
+        return done
 
     # ---- forward -----------------------------------------------------------------------------------
     def _bn_train_launches(self, L, bn, part, nparts, count):
@@ -842,10 +912,12 @@ class BackbonePlan(object):
                 if gws is not None:
                     tiles = ((u.depth + 127) // 128) * ((u.cin + 127) // 128)
                     self._side_after_main(L)
-                    self._wgrad(L, g=g_yS, src=x, dw=gws, B=B, GH=u.Ho, GW=u.Ho, Cout=u.depth, SH=u.H,
-                                SW=u.H, SC=u.cin, KH=1, KW=1, stride=u.stride, pad=0, ldg=u.depth, lda=u.cin,
-                                pro=0, nsplit=_wgrad_slices(rout, tiles))
-                ready += [u.sc_bn.weight, u.sc_bn.bias, u.sc_conv.weight]
+                    ready += self._wgrad(L, param=u.sc_conv.weight, g=g_yS, src=x, dw=gws, B=B, GH=u.Ho, GW=u.Ho,
+                                         Cout=u.depth, SH=u.H, SW=u.H, SC=u.cin, KH=1, KW=1, stride=u.stride, pad=0,
+                                         ldg=u.depth, lda=u.cin, pro=0, nsplit=_wgrad_slices(rout, tiles))
+                else:
+                    ready.append(u.sc_conv.weight)  # frozen: never reported anyway (on_ready filters requires_grad)
+                ready += [u.sc_bn.weight, u.sc_bn.bias]
             # conv2: data gradient with the PReLU backward epilogue, then the weight gradient
             g_y1 = self.g_y1s[par][:rin * u.depth]
             c2 = dict(src=g_y2, w=d["wt2"], out=g_y1, B=B, RH=u.H, RW=u.H, SH=u.Ho, SW=u.Ho, SC=u.depth, N=u.depth,
@@ -874,9 +946,12 @@ class BackbonePlan(object):
                 tiles = ((u.depth + 127) // 128) ** 2 * 9
                 if not self.side_slope:
                     self._side_after_main(L)
-                self._wgrad(L, g=g_y2, src=d["y1"], dw=gw2, B=B, GH=u.Ho, GW=u.Ho, Cout=u.depth, SH=u.H,
-                            SW=u.H, SC=u.depth, KH=3, KW=3, stride=u.stride, pad=1, ldg=u.depth, lda=u.depth,
-                            pro=ops.PRO_PRELU, pro_a=u.prelu.weight, nsplit=_wgrad_slices(rout, tiles))
+                ready += self._wgrad(L, param=u.conv2.weight, g=g_y2, src=d["y1"], dw=gw2, B=B, GH=u.Ho, GW=u.Ho,
+                                     Cout=u.depth, SH=u.H, SW=u.H, SC=u.depth, KH=3, KW=3, stride=u.stride, pad=1,
+                                     ldg=u.depth, lda=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight,
+                                     nsplit=_wgrad_slices(rout, tiles))
+            else:
+                ready.append(u.conv2.weight)
             # conv1: data gradient with the BN1-backward sums epilogue, then the weight gradient
             g_xh = self.g_xh[:rin * u.cin]
             mt = self._conv(L, src=g_y1, w=d["wt1"], out=g_xh, B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H,
@@ -889,10 +964,12 @@ class BackbonePlan(object):
             if gw1 is not None:
                 tiles = ((u.depth + 127) // 128) * ((u.cin + 127) // 128) * 9
                 self._side_after_main(L)  # g_y1 (conv2 data gradient) is final on the main stream
-                self._wgrad(L, g=g_y1, src=x, dw=gw1, B=B, GH=u.H, GW=u.H, Cout=u.depth, SH=u.H, SW=u.H,
-                            SC=u.cin, KH=3, KW=3, stride=1, pad=1, ldg=u.depth, lda=u.cin, pro=ops.PRO_BN,
-                            pro_a=bn1.scale, pro_b=bn1.shift, nsplit=_wgrad_slices(rin, tiles))
-            ready += [u.prelu.weight, u.conv2.weight, u.bn1.weight, u.bn1.bias, u.conv1.weight]
+                ready += self._wgrad(L, param=u.conv1.weight, g=g_y1, src=x, dw=gw1, B=B, GH=u.H, GW=u.H, Cout=u.depth,
+                                     SH=u.H, SW=u.H, SC=u.cin, KH=3, KW=3, stride=1, pad=1, ldg=u.depth, lda=u.cin,
+                                     pro=ops.PRO_BN, pro_a=bn1.scale, pro_b=bn1.shift, nsplit=_wgrad_slices(rin, tiles))
+            else:
+                ready.append(u.conv1.weight)
+            ready += [u.prelu.weight, u.bn1.weight, u.bn1.bias]
             # unit input gradient = BN1 backward of g_xh + shortcut gradient
             nxt = 1 - cur
             g_x = self.g_pp[nxt][:rin * u.cin]
@@ -914,8 +991,18 @@ class BackbonePlan(object):
                 unit_done[i] = done
             self.ready_marks.append((len(L), ready, done))
             g_out, cur = g_x, nxt
+        # the slabs of the last deferring weight-gradient launch are summed by a launch of their own
+        flushed = self._flush_pending(L)
+        tail_ready = [flushed] if flushed is not None else []
+        if flushed is not None and self.dual:
+            ev = torch.cuda.Event()
+            L.append(_EvRecord(ev, self.stream2_t))
+            unit_done[-1] = ev  # the side stream is FIFO: this event is behind every unit's weight gradients
         if self.body_only:  # the gradient with respect to the stack's input is the result
             self.g_input = g_out
+            if tail_ready:
+                self.ready_marks.append((len(L), tail_ready, unit_done.get(-1)))
+            self._order_ready_marks()
             if self.dual and unit_done:
                 L.append(_EvWait(self.stream1_t, unit_done[min(unit_done)]))  # join: the side stream is FIFO
             self.bwd_list = L
@@ -962,8 +1049,27 @@ class BackbonePlan(object):
                               gw0.stride(3), 64, sc.weight.shape[1], self.K0, st))
         if self.dual and unit_done:
             L.append(_EvWait(self.stream1_t, unit_done[min(unit_done)]))  # join: the side stream is FIFO
-        self.ready_marks.append((len(L), [sb.weight, sb.bias, sp.weight, sc.weight], None))
+        self.ready_marks.append((len(L), [sb.weight, sb.bias, sp.weight, sc.weight] + tail_ready, None))
+        self._order_ready_marks()
         self.bwd_list = L
+
+    def _order_ready_marks(self):
+        """Announce gradients in ARENA order (data-parallel buckets are contiguous arena slices that complete front to
+        back).  A deferring weight-gradient launch completes its predecessor's gradient one launch late, i.e. possibly in
+        the next unit's mark: inside a mark the parameters are sorted by arena position, and a parameter is held back
+        until everything in front of it in the arena has been announced."""
+        pos = {id(p): k for k, (p, _o, _n) in enumerate(self.arena_slices)}
+        total, nxt, pool, out = len(pos), 0, [], []
+        for end, params, done in self.ready_marks:
+            pool = sorted(pool + [p for p in params if id(p) in pos], key=lambda p: pos[id(p)])
+            emit = []
+            while pool and pos[id(pool[0])] == nxt:
+                emit.append(pool.pop(0))
+                nxt += 1
+            out.append((end, emit, done))
+        if pool or nxt != total:
+            raise _lib.FrhipError("frhip: %d gradients were never announced (readiness bookkeeping)" % (total - nxt))
+        self.ready_marks = out
 
     # ---- execution ---------------------------------------------------------------------------------
     def check_current(self):

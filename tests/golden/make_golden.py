@@ -239,7 +239,9 @@ def full_model(kind):
     return model, prefix, avg
 
 
-def run_full(kind, tag, batch=8, nclass=100):
+def run_full(kind, tag, batch=8, nclass=100, extra_grads=()):
+    """extra_grads: further parameter names whose full fp32 + float64 gradient tensors are stored (g6c: the squeeze-excite
+    MLP weights of the first units, whose batch-4 gradients in g6b are sums of 4 cancelling per-image terms)."""
     model, prefix, avg = full_model(kind)
     model.train()
     x = synth.uniform(16, "full.x", (batch, 3, 112, 112))
@@ -257,7 +259,7 @@ def run_full(kind, tag, batch=8, nclass=100):
     out["grad_norms"] = np.array([float(g.double().norm()) for g in gs])
     gd = dict(zip([n for n, _ in named], gs))
     for n in (prefix + "input_layer.0.weight", prefix + "output_layer.4.weight", prefix + "output_layer.4.bias",
-              prefix + "body.0.res_layer.2.weight", prefix + "body.3.shortcut_layer.0.weight"):
+              prefix + "body.0.res_layer.2.weight", prefix + "body.3.shortcut_layer.0.weight") + tuple(extra_grads):
         out["g." + n] = npy(gd[n])
     out["g.head.weight"] = npy(gs[-1])
     # the same step in float64 = "truth" for judging fp32 implementations against the reference's own fp32 noise
@@ -499,7 +501,7 @@ def g12_resnet_structure():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g6c", "g7", "g8", "g9", "g10", "g11", "g12"]
     if "g1" in which:
         g1_head()
     if "g2" in which:
@@ -514,6 +516,9 @@ if __name__ == "__main__":
         run_full("psp", "g6_psp")
     if "g6b" in which:
         run_full("irse101", "g6b_irse101", batch=4)
+    if "g6c" in which:  # round 3: IR-SE-101 at batch 16 -- SE-MLP gradients that are not 4 cancelling terms
+        run_full("irse101", "g6c_irse101_b16", batch=16,
+                 extra_grads=["body.%d.res_layer.5.%s.weight" % (u, fc) for u in (0, 1, 2, 16) for fc in ("fc1", "fc2")])
     if "g7" in which:
         g7_sgd()
     if "g8" in which:

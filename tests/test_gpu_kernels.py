@@ -10,6 +10,8 @@ to the fp32 path only.
 """
 import math
 
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -662,8 +664,8 @@ def test_bf16_engine_with_and_without_strip_agree():
         head = ArcFace(512, 100, None).cuda()
         with torch.no_grad():
             head.weight.copy_(synth.uniform(16, "full.head", (100, 512), -0.1, 0.1))
-        x = synth.uniform(16, "full.x", (4, 3, 112, 112)).cuda()
-        y = synth.labels(16, "full.label", 4, 100).cuda()
+        x = synth.uniform(16, "full.x", (16, 3, 112, 112)).cuda()
+        y = synth.labels(16, "full.label", 16, 100).cuda()
         feats = m(x)
         loss, _ = FocalLoss()(head(feats, y), y)
         loss.backward()
@@ -676,7 +678,14 @@ def test_bf16_engine_with_and_without_strip_agree():
               "input_layer.0.weight", "body.7.res_layer.0.weight"):
         d = float((g0[n] - g1[n]).norm() / (g1[n].norm() + 1e-12))
         c = float(torch.nn.functional.cosine_similarity(g0[n].reshape(1, -1), g1[n].reshape(1, -1)))
-        assert d < 0.3 and c > 0.95, (n, d, c)  # two bf16 implementations, batch 4: rounding noise only
+        print("   strip vs generic %-32s rel diff %.4f cos %.5f" % (n, d, c))
+        # two bf16 implementations against EACH OTHER (noise of both), batch 16.  The 64 PReLU slopes of unit 0 sit behind
+        # the rounding of the whole backward pass (measured 0.154 / 0.9882; the conv weights 0.12 / 0.992 and better); the
+        # test against the reference itself is test_bf16_full_step_tracks_reference.
+        if n.endswith("res_layer.2.weight"):
+            assert d < 0.2 and c > 0.98, (n, d, c)
+        else:
+            assert d < 0.15 and c > 0.99, (n, d, c)
 
 
 WGS_SHAPES = [(64, 64, 112, "bn"), (64, 64, 56, "prelu"), (128, 64, 56, "bn"), (128, 128, 28, "prelu"),
@@ -721,6 +730,55 @@ def test_conv_wgrad_strip(K, cout, cin, W, pro, B, groups):
     torch.cuda.synchronize()
     got = dw.cpu().reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
     assert relerr(got, gw) < tol
+
+
+def test_conv_wgrad_deferred_slab_sum_is_bit_identical(K):
+    """FrWgradArgs.defer / prev_* (round 3): a launch that leaves the sum of its slabs to the NEXT weight-gradient launch
+    of the stream (whose workgroups add them while their first tiles load) or to fr_reduce_slabs must give bit for bit the
+    dW of the launch that sums its own slabs -- three layers chained A -> B -> C -> flush against three plain launches,
+    ragged group sizes included; the entry point refuses prev_* where fr_conv_wgrad_strip_defers() says no."""
+    from frhip import _lib
+    dtype = torch.bfloat16
+    st = K.current_stream_ptr()
+    layers = [(256, 256, 14, 37, 5, 2), (128, 64, 14, 9, 4, 1), (64, 192, 14, 6, 6, 0)]  # cout, cin, W, B, groups, pro
+    plain, chained, slabs, kws = [], [], [], []
+    for k, (cout, cin, W, B, groups, pro) in enumerate(layers):
+        g = (torch.randn(B, W, W, cout, device="cuda") * 0.5).to(dtype)
+        x = torch.randn(B, W, W, cin, device="cuda").to(dtype)
+        pa, pb = torch.rand(cin, device="cuda") + 0.25, torch.rand(cin, device="cuda") - 0.5
+        kw = dict(g=g, src=x, B=B, GH=W, GW=W, Cout=cout, SH=W, SW=W, SC=cin, KH=3, KW=3, stride=1, pad=1, ldg=cout,
+                  lda=cin, pro=pro, nsplit=groups, pro_a=pa, pro_b=pb)
+        dw = torch.full((cout, 9, cin), 3.0, device="cuda")
+        K.wgrad_strip(st, dw=dw, slab=torch.zeros(groups * cout * 9 * cin, device="cuda"), **kw)()
+        plain.append(dw)
+        kws.append(kw)
+        chained.append(torch.full((cout, 9, cin), 5.0, device="cuda"))
+        slabs.append(torch.zeros(groups * cout * 9 * cin, device="cuda"))
+    probe = K._fill(_lib.FrWgradArgs(), dw=chained[0], slab=slabs[0], **kws[0])
+    assert _lib.lib.fr_conv_wgrad_strip_defers(ctypes.byref(probe)) == 1
+    prev = None
+    for k, kw in enumerate(kws):
+        extra = {}
+        if prev is not None:
+            pk = kws[prev]
+            extra = dict(prev_slab=slabs[prev], prev_dw=chained[prev], prev_groups=pk["nsplit"],
+                         prev_n=pk["Cout"] * 9 * pk["SC"])
+        K.wgrad_strip(st, dw=chained[k], slab=slabs[k], defer=1, **extra, **kw)()
+        prev = k
+    last = kws[-1]
+    K.call("fr_reduce_slabs", slabs[-1], last["nsplit"], last["Cout"] * 9 * last["SC"], chained[-1], st)()
+    torch.cuda.synchronize()
+    for k in range(len(layers)):
+        assert torch.equal(plain[k], chained[k]), "layer %d: deferred sum differs by %g" % (
+            k, float((plain[k] - chained[k]).abs().max()))
+    # a 28x28 layer is served by the strip kernel, which sums its own slabs: prev_* must be refused, not ignored
+    g = torch.randn(2, 28, 28, 64, device="cuda").to(dtype)
+    x = torch.randn(2, 28, 28, 64, device="cuda").to(dtype)
+    bad = dict(g=g, src=x, B=2, GH=28, GW=28, Cout=64, SH=28, SW=28, SC=64, KH=3, KW=3, stride=1, pad=1, ldg=64, lda=64,
+               pro=0, nsplit=2, dw=torch.zeros(64, 9, 64, device="cuda"), slab=torch.zeros(2 * 64 * 9 * 64, device="cuda"))
+    if not _lib.lib.fr_conv_wgrad_strip_defers(ctypes.byref(K._fill(_lib.FrWgradArgs(), **bad))):
+        with pytest.raises(_lib.FrhipError):
+            K.wgrad_strip(st, defer=1, **bad)()
 
 
 @pytest.mark.parametrize("name,dtype,tol", DT)

@@ -36,7 +36,7 @@ def build(kind):
     return m.cuda(), prefix
 
 
-FULL = [("g5_ir50", "IR_50", 8), ("g6_psp", "pSp", 8), ("g6b_irse101", "IR_SE_101", 4)]
+FULL = [("g5_ir50", "IR_50", 8), ("g6_psp", "pSp", 8), ("g6b_irse101", "IR_SE_101", 4), ("g6c_irse101_b16", "IR_SE_101", 16)]
 
 
 @pytest.mark.parametrize("fixture,kind,batch", FULL, ids=[f[0] for f in FULL])
@@ -82,7 +82,9 @@ def test_full_step_matches_reference(golden_dir, fixture, kind, batch):
             noise = float((ref32 - ref64).norm() / ref64.norm())
             print("   %-44s vs ref fp32 %.2e (bar 2.5e-3)  vs float64 %.2e (reference's own fp32: %.2e, bar 4x)"
                   % (k[2:], d32, d64, noise))
-            assert d32 < 2.5e-3, "%s: relative gradient error vs reference fp32 %g" % (k, d32)
+            # (a) cannot be tighter than the reference's own distance from the truth: g6c holds one SE-MLP gradient (unit 1,
+            # norm 0.005) whose reference fp32 value is 7e-3 off its float64 value
+            assert d32 < max(2.5e-3, noise), "%s: relative gradient error vs reference fp32 %g" % (k, d32)
             assert d64 < max(4.0 * noise, 2e-5), "%s: error vs float64 truth %g (reference fp32: %g)" % (k, d64, noise)
     d64 = float((logits.detach().cpu().double() - torch.from_numpy(g["logits64"])).abs().max())
     assert d64 < 1e-3
@@ -104,9 +106,23 @@ def test_full_step_matches_reference(golden_dir, fixture, kind, batch):
 # 0.15 for its siblings), and which tensor comes out worst depends on the kernel selection -- four valid selections
 # (FRHIP_S2ROLL / FRHIP_ROLL64 = 0 / 1) gave 26 %, 48 % and 72 % on the 0.007 tensor and 8 - 19 % on the others.  The deviation
 # is therefore taken relative to max(|reference norm|, NORM_FLOOR): 5 - 19 % for everything.
+# Round 3: g6c is the same IR-SE-101 at batch 16, captured so that those tensors are sums of 16 terms: there the deviation
+# is plain relative (no floor), the worst norm must stay within 10 %, and the squeeze-excite MLP gradients of units 0, 1, 2
+# and 16 are compared ELEMENT-WISE (cosine + norm ratio, like the other captured tensors) -- a broken bf16 se_mlp_wgrad
+# cannot hide behind the floor.  The floor stays for the batch-4 / batch-8 fixtures only.
 NORM_FLOOR = 0.03
 BF16_BARS = dict(loss_rel=5e-3, feat_cos=0.999, grad_cos=0.97, grad_norm_ratio=0.07, all_norms_median=0.012,
                  all_norms_p95=0.08, all_norms_worst=0.35)
+BF16_BARS_B16 = dict(BF16_BARS, all_norms_worst=0.10)
+# What the batch-16 capture showed (round 3, MI355X): every per-parameter norm within 9.2 % except ONE tensor, the fc1
+# gradient of unit 1's squeeze-excite MLP (norm 0.0048, the smallest non-trivial gradient of the network: 24 %, cos 0.60).
+# That tensor is ill-conditioned in the reference itself -- its fp32 norm is 0.4 % off its float64 norm (fixture keys
+# grad_norms / grad_norms64), 4 - 40 x its siblings -- and the SE-MLP kernels are fp32 on both paths (se_mlp_fwd / _bwd /
+# _wgrad take fp32 pooled sums; pinned to 1e-6 by the g3 block fixtures), so the bf16 noise reaches it through the pooled
+# sums of bf16 activations, not through a bf16 kernel of its own.  Rule, from the fixture's own numbers: a parameter whose
+# reference fp32 norm deviates from the float64 norm by more than ILL_COND is reported and only bounded loosely (norm
+# within 50 %, at most two such tensors); everything else takes the strict bars.
+ILL_COND = 2e-3
 # per-channel shifts that only ever reach BatchNorms: their true gradient is exactly zero, both sides hold noise
 ZERO_GRAD_SUFFIXES = ("res_layer.4.bias", "shortcut_layer.1.bias", "output_layer.0.bias", "output_layer.3.bias")
 
@@ -149,8 +165,21 @@ def test_bf16_full_step_tracks_reference(golden_dir, fixture, kind, batch):
             per[k[2:]] = (float(cosf(mine, ref)), float(mine.norm() / ref.norm()))
     names = list(g["grad_names"])
     got = np.array([float(named[n].grad.double().norm()) for n in names])
-    ratio = np.abs(got - g["grad_norms"]) / np.maximum(g["grad_norms"], NORM_FLOOR)
+    strict = batch >= 16
+    ratio = np.abs(got - g["grad_norms"]) / (np.maximum(g["grad_norms"], 1e-12) if strict else
+                                             np.maximum(g["grad_norms"], NORM_FLOOR))
     big = np.array([not n.endswith(ZERO_GRAD_SUFFIXES) for n in names])
+    ill = set()
+    if strict:
+        cond = np.abs(g["grad_norms"] - g["grad_norms64"]) / np.maximum(g["grad_norms64"], 1e-30)
+        ill = {n for n, c, b_ in zip(names, cond, big) if b_ and c > ILL_COND}
+        assert len(ill) <= 2, ill
+        for n in ill:
+            k = names.index(n)
+            print("   ill-conditioned in the reference (fp32 vs float64 norm %.1e): %s, bf16 norm deviation %.3f"
+                  % (cond[k], n, ratio[k]))
+            assert ratio[k] < 0.5, (n, ratio[k])
+        big = big & np.array([n not in ill for n in names])
     m["all_norms_median"], m["all_norms_worst"] = float(np.median(ratio[big])), float(ratio[big].max())
     m["all_norms_p95"] = float(np.percentile(ratio[big], 95))
     order = np.argsort(-np.where(big, ratio, 0))[:5]
@@ -159,9 +188,12 @@ def test_bf16_full_step_tracks_reference(golden_dir, fixture, kind, batch):
     print("\nbf16 vs golden %s: %s" % (fixture, json.dumps(m)))
     for n, (c, r) in per.items():
         print("   grad %-40s cos %.5f  norm ratio %.4f" % (n, c, r))
-    b = BF16_BARS
+    b = BF16_BARS_B16 if strict else BF16_BARS
     assert m["loss_rel"] < b["loss_rel"] and m["feat_cos_min"] > b["feat_cos"], m
     for n, (c, r) in per.items():
+        if n in ill:
+            assert c > 0.5, (n, c, r)
+            continue
         assert c > b["grad_cos"] and abs(r - 1) < b["grad_norm_ratio"], (n, c, r)
     assert m["all_norms_median"] < b["all_norms_median"] and m["all_norms_worst"] < b["all_norms_worst"], m
     assert m["all_norms_p95"] < b["all_norms_p95"], m
@@ -714,7 +746,10 @@ def test_full_size_step_strip_and_generic_paths_agree():
               "body.23.res_layer.1.weight", "output_layer.3.weight"):
         c = float(torch.nn.functional.cosine_similarity(g0[n].reshape(1, -1).float(), g1[n].reshape(1, -1).float()))
         d = float((g0[n] - g1[n]).norm() / (g1[n].norm() + 1e-20))
-        assert c > 0.98 and d < 0.2, (n, c, d)
+        print("   full-size strip vs generic %-32s cos %.5f rel diff %.4f" % (n, c, d))
+        # two bf16 implementations against each other (the noise of both): measured 0.9898 / 0.143 on the first 112x112
+        # convolution, better everywhere else; the comparison with the reference is test_bf16_full_step_tracks_reference
+        assert c > 0.985 and d < 0.16, (n, c, d)
 
 
 def test_perform_val_matches_oracle_protocol():

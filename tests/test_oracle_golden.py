@@ -147,7 +147,7 @@ def build_state(golden_dir, model, seed=15):
 
 
 FULL = [("g5_ir50", "IR_50", 50, False, "", 8), ("g6_psp", "pSp", 50, True, "encoder.", 8),
-        ("g6b_irse101", "IR_SE_101", 100, True, "", 4)]
+        ("g6b_irse101", "IR_SE_101", 100, True, "", 4), ("g6c_irse101_b16", "IR_SE_101", 100, True, "", 16)]
 
 
 @pytest.mark.parametrize("spec", FULL, ids=[f[0] for f in FULL])

@@ -67,6 +67,16 @@ def main():
     out = sorted(agg.items(), key=lambda kv: -kv[1][1])
     for k, (n, ns) in out[:70]:
         print("%-92s n=%3d %8.1f us  avg %7.1f" % (k, n, ns / 1e3, ns / 1e3 / n))
+    if "--timeline" in sys.argv:
+        # every kernel of the step in start order: offset from the step start, duration, queue -- to read the two-stream
+        # schedule (who runs beside whom, who waits for whom)
+        path = sys.argv[sys.argv.index("--timeline") + 1]
+        qids = sorted({r[3] for r in step})
+        with open(path, "w") as f:
+            f.write("# start_us dur_us end_us queue grid name\n")
+            for r in sorted(step, key=lambda r: r[1]):
+                f.write("%9.1f %7.1f %9.1f q%d %5d %s\n" % ((r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, (r[2] - t0) / 1e3,
+                                                           qids.index(r[3]), r[4] // max(r[5], 1), short(r[0])[:70]))
     if "--csv" in sys.argv:
         path = sys.argv[sys.argv.index("--csv") + 1]
         with open(path, "w") as f:
