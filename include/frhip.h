@@ -119,11 +119,11 @@ typedef struct FrWgradArgs {
   float* slab;     /* [nsplit][Cout][taps][SC] fp32 partial gradients: required by fr_conv_wgrad_strip; optional for
                       fr_conv_wgrad (NULL: pixel slices are combined with fp32 atomics onto a zeroed dw; non-NULL: each
                       slice stores its slab and a second launch adds them in a fixed order -- reproducible) */
-  /* Deferred slab sum (fr_conv_wgrad_strip, launches for which fr_conv_wgrad_strip_defers() answers 1).  defer != 0:
+  /* Deferred slab sum (fr_conv_wgrad_strip only; fr_conv_wgrad ignores these fields).  defer != 0:
    * this launch only writes its slabs; the caller owes them a sum -- either as the prev_* of a later deferring launch
    * on the same stream (whose workgroups add them while their first tiles are in flight: no launch of their own) or
    * through fr_reduce_slabs.  prev_n != 0: before its own work the launch writes
-   * prev_dw[i] = sum_{g < prev_groups} prev_slab[g * prev_n + i] in the fixed order g = 0, 1, ... (bit-identical to
+   * prev_dw[i] = sum_{g < prev_groups} prev_slab[g * prev_n + i] in the library's fixed order (bit-identical to
    * fr_reduce_slabs).  prev_slab must not be this launch's slab. */
   const float* prev_slab;
   float* prev_dw;
@@ -142,9 +142,10 @@ int fr_conv_wgrad(const FrWgradArgs* args, int dtype, void* stream);
  * GW in {56, 28, 14, 7}, channels multiples of 64): the input tile holds the four parity planes of the strip. */
 int fr_conv_wgrad_strip(const FrWgradArgs* args, void* stream);
 int fr_conv_wgrad_strip_supported(int Cout, int Cin, int W);
-/* 1 when fr_conv_wgrad_strip serves these arguments with the kernel that honours defer / prev_* (else the fields must
- * be zero).  out[i] = sum_g slab[g*n + i], g = 0 .. groups-1 in that order (n % 4 == 0): the sum a deferring launch
- * left to its caller. */
+/* 1 when fr_conv_wgrad_strip serves these arguments (every served shape honours defer / prev_*; 0 also when the
+ * deferral is switched off with FRHIP_WGRAD_DEFER=0).  fr_reduce_slabs: out[i] = sum over the slabs g = 0 .. groups-1
+ * of slab[g*n + i] in the library's fixed order (chunks of 16 slabs, csrc/slab_sum.h; n % 4 == 0, groups <= 256): the
+ * sum a deferring launch left to its caller. */
 int fr_conv_wgrad_strip_defers(const FrWgradArgs* args);
 int fr_reduce_slabs(const float* slab, int groups, long long n, float* out, void* stream);
 

@@ -29,6 +29,7 @@
 
 #include "common.h"
 #include "frhip_internal.h"
+#include "slab_sum.h"
 
 namespace {
 
@@ -140,11 +141,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
   const int cit_n = p.SC / CT, tiles = (p.Cout / CT) * cit_n;
   const int group = bid / tiles, tile = bid - group * tiles;
   const int cot = tile / cit_n, cit = tile - cot * cit_n;
-  const int per = (p.B + p.nsplit - 1) / p.nsplit;
+  // work of a group: whole images (two-phase schedule) or a run of phases that may start inside an image (uniform)
+  const int units = NPH == 2 ? p.B : p.B * NPH;
+  const int per = (units + p.nsplit - 1) / p.nsplit;
   const int b_begin = group * per;
   int b_end = b_begin + per;
-  if (b_end > p.B) b_end = p.B;
-  const int nimg = b_end > b_begin ? b_end - b_begin : 0;
+  if (b_end > units) b_end = units;
+  const int nimg = b_end > b_begin ? b_end - b_begin : 0;  // images / phases of this workgroup
 
 #ifdef FRHIP_STAMPS
   unsigned long long bar_wait = 0;
@@ -159,23 +162,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
   // longer costs a launch (and a trip of 2 x groups x |dW| bytes through a kernel of its own).
   auto fold_prev = [&]() {
     const long long n4 = p.prev_n >> 2;
-    const f32x4* __restrict__ ps = reinterpret_cast<const f32x4*>(p.prev_slab);
-    f32x4* __restrict__ po = reinterpret_cast<f32x4*>(p.prev_dw);
-    const int G = p.prev_groups;
-    for (long long i = (long long)blockIdx.x * 512 + tid; i < n4; i += (long long)gridDim.x * 512) {
-      const f32x4* src = ps + i;
-      f32x4 s = src[0];
-      int g = 1;
-      for (; g + 8 <= G; g += 8) {  // 8 independent loads in flight; the summation order stays g = 0, 1, 2, ...
-        f32x4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(long long)(g + u) * n4];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
-      }
-      for (; g < G; ++g) s += src[(long long)g * n4];
-      po[i] = s;
-    }
+    const long long per = (n4 + gridDim.x - 1) / gridDim.x;
+    const long long e0 = (long long)blockIdx.x * per;
+    long long e1 = e0 + per;
+    if (e1 > n4) e1 = n4;
+    // computing waves only (tid < 256): at this point their accumulator registers are free, while a batch of 16-byte
+    // loads on top of the two register sets of a data-moving wave would set the kernel's register allocation -- and every
+    // register this kernel does not take is one a co-resident BatchNorm wave of the main stream can use
+    if (e0 < e1) slab_sum_range<256>(p.prev_slab, p.prev_groups, n4, e0, e1, p.prev_dw, tid);
   };
 
   if (wave >= 4) {
@@ -264,16 +258,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
 
     char* const buf0 = smem;
     char* const buf1 = smem + L::BUF0;
-    if (nimg == 0) {  // (never with the group counts the host computes; both roles then skip every barrier)
-      if (p.prev_n) fold_prev();
-      return;
-    }
+    if (nimg == 0) return;  // (never with the group counts the host computes; both roles then skip every barrier)
     if constexpr (NPH == 2) {
       // 14x14: phase kind == buffer.  set0 <-> (phase 0, buf0), set1 <-> (phase 1, buf1)
       Set s0, s1;
       issue(s0, b_begin, std::integral_constant<int, 0>{});
       issue(s1, b_begin, std::integral_constant<int, 1>{});
-      if (p.prev_n) fold_prev();
       commit(s0, buf0, std::integral_constant<int, 0>{});
       {
         const int bn = b_begin + 1 < b_end ? b_begin + 1 : b_end - 1;
@@ -308,7 +298,108 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
       }
 #endif
     } else {
-      static_assert(NPH == 2, "only the two-phase (14x14) schedule is written out so far");
+      // Uniform schedule (28x28: 7 phases of 4 rows per image).  Phase k of the workgroup lives in buffer k & 1 and in
+      // register set k & 1; a phase moves g rows [r0, r0+4) and input rows [r0-1, r0+5) -- the two halo rows are data of
+      // the neighbouring phases here, or zeros at the image border (loaded from a clamped row, replaced on the way to LDS).
+      constexpr int PR = C::rows(0), GCH = PR * W * 8, ACH = (PR + 2) * W * 8;
+      constexpr int NGS = (GCH + NLT - 1) / NLT, NAS = (ACH + NLT - 1) / NLT;
+      struct Set {
+        U128 g[NGS], a[NAS];
+        int img_row0;  // first output row of the phase (uniform)
+      };
+      // per-thread constants of the slots
+      int goff[NGS], gdst[NGS], aoff_c[NAS], atr[NAS], adst[NAS];
+#pragma unroll
+      for (int u = 0; u < NGS; ++u) {
+        int q = u * NLT + lt;
+        q = q < GCH ? q : GCH - 1;
+        const int px = q >> 3, r = px / W, c = px - r * W;
+        goff[u] = (px * p.ldg + ch * 8) * 2;
+        gdst[u] = (r * RW + c) * TSTR + ch * 16;
+      }
+#pragma unroll
+      for (int u = 0; u < NAS; ++u) {
+        int q = u * NLT + lt;
+        q = q < ACH ? q : ACH - 1;
+        const int px = q >> 3, r = px / W, c = px - r * W;
+        atr[u] = r;                                  // tile row 0 .. PR+1 <-> image row r0 - 1 + r
+        aoff_c[u] = (c * p.lda + ch * 8) * 2;        // + clamped image row * W * lda * 2
+        adst[u] = (r * RW + c + 1) * TSTR + ch * 16;
+      }
+      auto issue = [&](Set& s, int f) {
+        const int img = f / NPH, ph = f - img * NPH, r0 = ph * PR;
+        s.img_row0 = r0;
+        const char* gi = G + ((size_t)img * (W * W) + (size_t)r0 * W) * (size_t)p.ldg * 2;
+        const char* xi = X + (size_t)img * (W * W) * (size_t)p.lda * 2;
+#pragma unroll
+        for (int u = 0; u < NGS; ++u) s.g[u] = ld16(gi + (unsigned)goff[u]);
+#pragma unroll
+        for (int u = 0; u < NAS; ++u) {
+          int row = r0 - 1 + atr[u];
+          row = row < 0 ? 0 : (row > W - 1 ? W - 1 : row);
+          s.a[u] = ld16(xi + (unsigned)(row * W * p.lda * 2 + aoff_c[u]));
+        }
+      };
+      auto commit = [&](Set& s, char* buf) {
+        char* Gs = buf;
+        char* As = buf + L::g_bytes(0);
+#pragma unroll
+        for (int u = 0; u < NGS; ++u) st16(Gs + gdst[u], s.g[u]);
+#pragma unroll
+        for (int u = 0; u < NAS; ++u) {
+          U128 x = s.a[u];
+          if (PRO != FR_PRO_NONE) {
+            x.x = pro2<PRO>(x.x, pa[0], pb[0], pa[1], pb[1]);
+            x.y = pro2<PRO>(x.y, pa[2], pb[2], pa[3], pb[3]);
+            x.z = pro2<PRO>(x.z, pa[4], pb[4], pa[5], pb[5]);
+            x.w = pro2<PRO>(x.w, pa[6], pb[6], pa[7], pb[7]);
+          }
+          // slots that can hold a row outside the image (tile row 0 of the first phase, row PR+1 of the last)
+          if (u * NLT < W * 8 || (u + 1) * NLT > (PR + 1) * W * 8) {
+            const int row = s.img_row0 - 1 + atr[u];
+            const bool out = row < 0 || row > W - 1;
+            x.x = out ? 0u : x.x;
+            x.y = out ? 0u : x.y;
+            x.z = out ? 0u : x.z;
+            x.w = out ? 0u : x.w;
+          }
+          st16(As + adst[u], x);
+        }
+      };
+      Set s0, s1;
+      const int fl = b_end - 1;  // requests past the run are clamped to its last phase and never read
+      issue(s0, b_begin);
+      issue(s1, b_begin + 1 < b_end ? b_begin + 1 : fl);
+      commit(s0, buf0);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(s0, b_begin + 2 < b_end ? b_begin + 2 : fl);
+      __builtin_amdgcn_sched_barrier(0);
+      LDS_FENCE_BARRIER();  // B0: phase 0 is in buffer 0
+#ifdef FRHIP_STAMPS
+      const unsigned long long t_loop = TSTAMP();
+      bar_wait = 0;
+#endif
+#pragma unroll 1
+      for (int k = 0; k < nimg; k += 2) {
+        const int f = b_begin + k;
+        // computing waves: phase k (buffer 0); buffer 1 is free
+        commit(s1, buf1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(s1, f + 3 < b_end ? f + 3 : fl);
+        __builtin_amdgcn_sched_barrier(0);
+        LDS_FENCE_BARRIER();  // phase k + 1 is in buffer 1; buffer 0 is free
+        commit(s0, buf0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(s0, f + 4 < b_end ? f + 4 : fl);
+        __builtin_amdgcn_sched_barrier(0);
+        LDS_FENCE_BARRIER();  // phase k + 2 is in buffer 0; buffer 1 is free
+      }
+#ifdef FRHIP_STAMPS
+      if (tid == 256 && fr_stamp_buf_wgr) {
+        fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 3] = bar_wait;
+        fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 4] = TSTAMP() - t_loop;
+      }
+#endif
     }
     return;
   }
@@ -330,72 +421,90 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
     const char* const ab0 = smem + L::g_bytes(0) + lrow + (wci * 16) * 2 + colb;
     const char* const gb1 = smem + L::BUF0 + lrow + colb;
     const char* const ab1 = smem + L::BUF0 + L::g_bytes(1) + lrow + (wci * 16) * 2 + colb;
-    // One "item" = one tap of one K step: an input fragment (2 reads) and 4 MFMAs.  Flat software pipeline over the items
-    // of a phase: the fragment of item it + LA is requested behind the MFMAs of item it into a ring of 9 (= the taps of a
-    // step, so the slot of an item is its tap in every phase); the g fragments of the next step (8 reads) are requested
-    // over taps 5-8.  The barrier that hands the buffers over sits at item NI - LA + 1: the last fragment of the phase was
-    // requested two items earlier, and the LA - 1 items behind the barrier need no LDS of this phase any more -- they run
-    // while the first fragments of the next phase are fetched.
+    // One "item" = one tap of one K step for HALF of the output channels (2 of the 4 co tiles): an input fragment (2 reads)
+    // and 2 MFMAs; a step is 18 items (co half 0: taps 0-8, co half 1: taps 0-8).  Only the g fragments of the running
+    // half and of the next one are live (16 registers instead of 32 with all four tiles per tap), the input fragments
+    // go through a ring of RS = 6 (the slot of an item is its index mod 6 in every phase: 72 and 54 items) filled LA = 5
+    // items ahead -- 194 registers instead of 222, i.e. one more BatchNorm wave of the main stream per SIMD beside this
+    // kernel, which is worth more to the step than the 18 extra ds_reads per step cost here (LDS: 352 of 576 clocks).
+    // The barrier that hands the buffers over sits at item NI - LA + 1: the last fragment of the phase was requested two
+    // items earlier, and the LA - 1 items behind the barrier need no LDS of this phase any more -- they run while the first
+    // fragments of the next phase are fetched.
 #ifndef ROLL_LA
-#define ROLL_LA 8
+#define ROLL_LA 5
 #endif
     constexpr int LA = ROLL_LA, RS = LA + 1;  // ring slots
     auto a_frag = [&](const char* ab, int item) -> s16x8 {
-      const int ks = item / 9, tap = item % 9;
+      const int ks = item / 18, tap = item % 9;
       const int off = 32 * ks + RW * (tap / 3) + tap % 3;
       return tr_frag(ab + off * TSTR, ab + (off + 16) * TSTR);
     };
-    auto g_frag = [&](const char* gb, int ks, int t) -> s16x8 {
-      return tr_frag(gb + (32 * ks) * TSTR + t * 32, gb + (32 * ks + 16) * TSTR + t * 32);
+    auto g_frag = [&](const char* gb, int hs, int t) -> s16x8 {  // hs = 2 * step + half; t = tile inside the half
+      const int ks = hs >> 1, ct = (hs & 1) * 2 + t;
+      return tr_frag(gb + (32 * ks) * TSTR + ct * 32, gb + (32 * ks + 16) * TSTR + ct * 32);
     };
     s16x8 ring[RS];
-    s16x8 gf[4], gn[4];
+    s16x8 gf[2], gn[2];
 
     auto run_phase = [&](const char* gb, const char* ab, const char* gb_next, const char* ab_next, auto nstep_c) {
       constexpr int NSTEP = decltype(nstep_c)::value;
-      constexpr int NI = NSTEP * 9, IB = NI - LA + 1;
+      constexpr int NI = NSTEP * 18, IB = NI - LA + 1;
       static_assert(NI % RS == 0, "the ring slot of an item must not depend on the phase");
+      static_assert(IB % 9 <= 5 && IB / 9 == 2 * NSTEP - 1, "the barrier sits in the last half-step, before its g prefetch taps");
 #pragma unroll
       for (int it = 0; it < NI; ++it) {
-        const int ks = it / 9, tap = it % 9;
+        const int hs = it / 9, tap = it % 9;
         if (it == IB) {
           LDS_FENCE_BARRIER();  // every fragment of this phase is in registers; the next buffer is complete
-#pragma unroll
-          for (int t = 0; t < 4; ++t) gn[t] = g_frag(gb_next, 0, t);
 #pragma unroll
           for (int jt = NI - LA; jt < IB; ++jt) ring[(jt + LA) % RS] = a_frag(ab_next, jt + LA - NI);  // deferred requests
           __builtin_amdgcn_sched_barrier(0);
         }
         const s16x8 af = ring[it % RS];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-          acc[t][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[t], af, acc[t][tap], 0, 0, 0);
+        for (int t = 0; t < 2; ++t)
+          acc[(hs & 1) * 2 + t][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[t], af, acc[(hs & 1) * 2 + t][tap], 0, 0, 0);
         if (it + LA < NI) ring[(it + LA) % RS] = a_frag(ab, it + LA);
         else if (it >= IB) ring[(it + LA) % RS] = a_frag(ab_next, it + LA - NI);
-        if (ks + 1 < NSTEP && tap >= 5) gn[tap - 5] = g_frag(gb, ks + 1, tap - 5);
+        // the g fragments of the next half-step (4 reads): taps 3 and 4, i.e. five items ahead; those of the next PHASE must
+        // stay behind the barrier: taps 5 and 6 of the last half-step
+        if (hs + 1 < 2 * NSTEP) {
+          if (tap == 3 || tap == 4) gn[tap - 3] = g_frag(gb, hs + 1, tap - 3);
+        } else {
+          if (tap == 5 || tap == 6) gn[tap - 5] = g_frag(gb_next, 0, tap - 5);
+        }
         if (tap == 8) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) gf[t] = gn[t];
+          gf[0] = gn[0];
+          gf[1] = gn[1];
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    static_assert(C::NPH == 2, "two-phase schedule");
-    constexpr int NS0 = C::rows(0) * RW / 32, NS1 = C::rows(1) * RW / 32;
+    constexpr int NS0 = C::rows(0) * RW / 32, NS1 = C::rows(NPH == 2 ? 1 : 0) * RW / 32;
     LDS_FENCE_BARRIER();  // B0: phase 0 of the first image is in buffer 0
 #ifdef FRHIP_STAMPS
     const unsigned long long t_loop = TSTAMP();
     bar_wait = 0;
 #endif
-#pragma unroll
-    for (int t = 0; t < 4; ++t) gf[t] = g_frag(gb0, 0, t);
+    gf[0] = g_frag(gb0, 0, 0);
+    gf[1] = g_frag(gb0, 0, 1);
 #pragma unroll
     for (int it = 0; it < LA; ++it) ring[it] = a_frag(ab0, it);
+    if constexpr (NPH == 2) {
 #pragma unroll 1
-    for (int i = 0; i < nimg; ++i) {
-      // behind the last image the "next phase" fragments are read from whatever buffer 0 holds and never used
-      run_phase(gb0, ab0, gb1, ab1, std::integral_constant<int, NS0>{});
-      run_phase(gb1, ab1, gb0, ab0, std::integral_constant<int, NS1>{});
+      for (int i = 0; i < nimg; ++i) {
+        // behind the last image the "next phase" fragments are read from whatever buffer 0 holds and never used
+        run_phase(gb0, ab0, gb1, ab1, std::integral_constant<int, NS0>{});
+        run_phase(gb1, ab1, gb0, ab0, std::integral_constant<int, NS1>{});
+      }
+    } else {
+      // uniform schedule: the data-moving waves run their loop two phases at a time; an odd run leaves one barrier over
+#pragma unroll 1
+      for (int k = 0; k < nimg; k += 2) {
+        run_phase(gb0, ab0, gb1, ab1, std::integral_constant<int, NS0>{});
+        if (k + 1 < nimg) run_phase(gb1, ab1, gb0, ab0, std::integral_constant<int, NS0>{});
+        else LDS_FENCE_BARRIER();
+      }
     }
 #ifdef FRHIP_STAMPS
     if (tid == 0 && fr_stamp_buf_wgr) {
@@ -473,16 +582,20 @@ bool fr_wgrad_roll_enabled() {
   return on;
 }
 
-// stride-1 3x3 at 14x14, channel counts multiples of 64, at least one image per group
+// stride-1 3x3 at 14x14 / 28x28, channel counts multiples of 64, at least one image (14x14) / phase (28x28) per group
 bool fr_wgrad_roll_serves(const FrWgradArgs& a) {
-  return fr_wgrad_roll_enabled() && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.GH == a.SH &&
-         a.GW == a.SW && a.SH == a.SW && a.SW == 14 && a.Cout % CT == 0 && a.SC % CT == 0 && a.nsplit >= 1 &&
-         a.nsplit <= a.B;
+  if (!(fr_wgrad_roll_enabled() && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.GH == a.SH &&
+        a.GW == a.SW && a.SH == a.SW && a.Cout % CT == 0 && a.SC % CT == 0 && a.nsplit >= 1))
+    return false;
+  if (a.SW == 14) return a.nsplit <= a.B;
+  if (a.SW == 28) return a.nsplit <= a.B * RC<28>::NPH;
+  return false;
 }
 
 int fr_wgrad_roll_launch(const FrWgradArgs& a, hipStream_t st) {
   switch (a.SW) {
     case 14: return by_pro<14>(a, st);
+    case 28: return by_pro<28>(a, st);
   }
   FR_UNSUPPORTED("fr_conv_wgrad_strip: width not served by the warp-specialised kernel");
 }

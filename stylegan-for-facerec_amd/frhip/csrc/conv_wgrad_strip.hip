@@ -17,6 +17,7 @@
 
 #include "common.h"
 #include "frhip_internal.h"
+#include "slab_sum.h"
 
 namespace {
 
@@ -269,6 +270,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_strip_kernel(const FrWg
   const int li = lane & 15, lq = lane >> 4;
   const int colb = (4 * (li & 3)) * 2;  // byte offset of this lane's 4-channel group inside a 16-channel tile
   if (C::PF && f_begin < f_end) issue(f_begin);
+  if (p.prev_n) {
+    // deferred slab sum of the previous weight-gradient launch of this stream (FrWgradArgs.prev_*), added while the
+    // first strip of this one is in flight
+    const long long n4 = p.prev_n >> 2;
+    const long long per_wg = (n4 + gridDim.x - 1) / gridDim.x;
+    const long long e0 = (long long)blockIdx.x * per_wg;
+    long long e1 = e0 + per_wg;
+    if (e1 > n4) e1 = n4;
+    if (e0 < e1) slab_sum_range<NTH>(p.prev_slab, p.prev_groups, n4, e0, e1, p.prev_dw, tid);
+  }
   for (int f = f_begin; f < f_end; ++f) {
     __syncthreads();  // previous strip fully consumed
     if (C::PF) commit();
@@ -350,29 +361,23 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_strip_kernel(const FrWg
       }
 }
 
-__global__ void reduce_slabs_kernel(const float* __restrict__ slab, int groups, long long n4, float* __restrict__ out) {
-  // n4 = elements / 4
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(slab) + i;
-    f32x4 s = src[0];
-    int g = 1;
-    for (; g + 8 <= groups; g += 8) {  // 8 independent loads in flight; the summation order stays g = 0, 1, 2, ...
-      f32x4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = src[(long long)(g + u) * n4];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    for (; g < groups; ++g) s += src[(long long)g * n4];
-    reinterpret_cast<f32x4*>(out)[i] = s;
-  }
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, int groups, long long n4,
+                                                           float* __restrict__ out) {
+  // n4 = elements / 4; every workgroup takes a contiguous share (slab_sum.h fixes the order of the additions)
+  const long long per = (n4 + gridDim.x - 1) / gridDim.x;
+  const long long e0 = (long long)blockIdx.x * per;
+  long long e1 = e0 + per;
+  if (e1 > n4) e1 = n4;
+  if (e0 < e1) slab_sum_range<256>(slab, groups, n4, e0, e1, out, threadIdx.x);
 }
 
 }  // namespace
 
 int fr_launch_reduce_slabs(const float* slab, int groups, long long n, float* out, hipStream_t st) {
+  if (groups > 256) FR_UNSUPPORTED("weight-gradient slabs: at most 256 groups");
   const long long n4 = n / 4;
-  long long g = (n4 + 255) / 256;
+  const int lpe = groups <= 16 ? 1 : (groups <= 32 ? 2 : (groups <= 64 ? 4 : (groups <= 128 ? 8 : 16)));
+  long long g = (n4 * lpe + 255) / 256;  // one pass per workgroup where the grid allows
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)g), dim3(256), 0, st, slab, groups, n4, out);
@@ -398,6 +403,7 @@ int launch(const FrWgradArgs& a, hipStream_t st) {
     fr_set_error(hipGetErrorString(e));
     return (int)e;
   }
+  if (a.defer) return 0;  // the caller sums the slabs (prev_* of a later launch, or fr_reduce_slabs)
   return fr_launch_reduce_slabs(a.slab, a.nsplit, (long long)a.Cout * 9 * a.SC, a.dw, st);
 }
 
@@ -428,8 +434,18 @@ extern "C" int fr_conv_wgrad_strip_supported(int Cout, int Cin, int W) {
   return W == 112 || W == 56 || W == 28 || W == 14 || W == 7;
 }
 
+// every shape fr_conv_wgrad_strip serves honours defer / prev_* (FRHIP_WGRAD_DEFER=0 turns the answer off: A/B switch)
 extern "C" int fr_conv_wgrad_strip_defers(const FrWgradArgs* args) {
-  return args->ldg % 8 == 0 && args->lda % 8 == 0 && args->slab && fr_wgrad_roll_serves(*args) ? 1 : 0;
+  static const bool on = [] {
+    const char* e = getenv("FRHIP_WGRAD_DEFER");
+    return !(e && e[0] == '0');
+  }();
+  const FrWgradArgs& a = *args;
+  if (!on || a.ldg % 8 || a.lda % 8 || !a.slab || a.nsplit < 1 || a.nsplit > 256 || a.KH != 3 || a.KW != 3 || a.pad != 1 ||
+      a.Cout % CT || a.SC % CT)
+    return 0;
+  if (a.stride == 2) return a.GH == a.GW && a.SH == 2 * a.GH && a.SW == 2 * a.GW && (a.GW == 56 || a.GW == 28 || a.GW == 14 || a.GW == 7);
+  return a.stride == 1 && a.GH == a.SH && a.GW == a.SW && a.SH == a.SW && fr_conv_wgrad_strip_supported(a.Cout, a.SC, a.SW);
 }
 
 extern "C" int fr_reduce_slabs(const float* slab, int groups, long long n, float* out, void* stream) {
@@ -441,9 +457,8 @@ extern "C" int fr_conv_wgrad_strip(const FrWgradArgs* args, void* stream) {
   const FrWgradArgs& a = *args;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a.ldg % 8 || a.lda % 8 || !a.slab || a.nsplit < 1) FR_UNSUPPORTED("fr_conv_wgrad_strip: bad strides / slab");
-  if ((a.defer || a.prev_n) && !fr_wgrad_roll_serves(a))
-    FR_UNSUPPORTED("fr_conv_wgrad_strip: defer / prev_* only where fr_conv_wgrad_strip_defers() answers 1");
-  if (a.prev_n && (!a.prev_slab || !a.prev_dw || a.prev_groups < 1 || a.prev_n % 4 || a.prev_slab == a.slab))
+  if (a.prev_n && (!a.prev_slab || !a.prev_dw || a.prev_groups < 1 || a.prev_groups > 256 || a.prev_n % 4 ||
+                   a.prev_slab == a.slab))
     FR_UNSUPPORTED("fr_conv_wgrad_strip: bad prev_* (deferred slab sum)");
   if (a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad == 1 && a.GH == a.GW && a.SH == 2 * a.GH && a.SW == 2 * a.GW &&
       a.Cout % CT == 0 && a.SC % CT == 0) {

@@ -46,7 +46,7 @@ def main():
         floss, _ = FocalLoss()(logits, yc)
         floss.backward()
         e1, e5 = accuracy(logits.detach(), yc, topk=(1, 5))
-        assert abs(float(loss) - float(floss)) <= 2e-6 * max(1.0, abs(float(floss))), (float(loss), float(floss))
+        assert abs(float(loss.detach()) - float(floss)) <= 2e-6 * max(1.0, abs(float(floss))), (float(loss.detach()), float(floss))
         assert float(p1) == float(e1) and float(p5) == float(e5), (float(p1), float(e1), float(p5), float(e5))
         gx_e = xc.grad[rank * B:(rank + 1) * B] * world
         err = (x.grad - gx_e).norm() / gx_e.norm()
@@ -60,7 +60,7 @@ def main():
         fwd = O.arcface_forward if kind == "ArcFace" else O.cosface_forward
         lo_ = O.focal_loss(fwd(xo, wo, torch.cat(labs), s=64.0, m=0.5), torch.cat(labs), 2)
         ogx, ogw = torch.autograd.grad(lo_, [xo, wo])
-        assert abs(float(loss) - float(lo_)) < 1e-3, (float(loss), float(lo_))
+        assert abs(float(loss.detach()) - float(lo_)) < 1e-3, (float(loss.detach()), float(lo_))
         err = (x.grad.cpu() / world - ogx[rank * B:(rank + 1) * B]).norm() / ogx[rank * B:(rank + 1) * B].norm()
         assert err < 1e-3, ("oracle gx", float(err))
         err = (crit.weight.grad.cpu() - ogw[lo:hi]).norm() / ogw[lo:hi].norm()

@@ -63,7 +63,7 @@ def test_full_step_matches_reference(golden_dir, fixture, kind, batch):
         fixture, float((feats.detach().cpu() - torch.from_numpy(g["features"])).abs().max()), dl,
         abs(float(loss.detach()) - float(g["loss"]))))
     assert dl < 1e-3, "logits differ from the reference by %g" % dl
-    assert abs(float(loss) - float(g["loss"])) < 1e-4
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4
     named = dict(model.named_parameters())
     named["head.weight"] = head.weight
     names = list(g["grad_names"])
@@ -153,7 +153,7 @@ def test_bf16_full_step_tracks_reference(golden_dir, fixture, kind, batch):
     plan = inner._runner[0].plan
     assert plan.tdtype == torch.bfloat16 and plan.use_strip, "the test must run the bf16 strip path"
     cosf = torch.nn.functional.cosine_similarity
-    m = {"loss_rel": abs(float(loss) - float(g["loss"])) / abs(float(g["loss"])),
+    m = {"loss_rel": abs(float(loss.detach()) - float(g["loss"])) / abs(float(g["loss"])),
          "feat_cos_min": float(cosf(feats.detach().cpu(), torch.from_numpy(g["features"]), dim=1).min()),
          "logit_max_abs": float((logits.detach().cpu() - torch.from_numpy(g["logits"])).abs().max())}
     named = dict(model.named_parameters())
@@ -278,7 +278,7 @@ def test_two_sgd_steps_match_reference(golden_dir):
         logits = head(model(x), label)
         loss, _ = FocalLoss()(logits, label)
         p1, p5 = accuracy(logits.data, label, topk=(1, 5))
-        assert abs(float(loss) - g["loss"][step]) < 2e-3
+        assert abs(float(loss.detach()) - g["loss"][step]) < 2e-3
         assert float(p1) == g["prec1"][step] and float(p5) == g["prec5"][step]
         opt.zero_grad()
         loss.backward()

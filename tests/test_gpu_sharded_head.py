@@ -99,7 +99,7 @@ def test_one_rank_equals_replicated_head(kind, N, B):
     floss, _ = FocalLoss()(logits, y.cuda())
     floss.backward()
     e1, e5 = accuracy(logits.detach(), y.cuda(), topk=(1, 5))
-    assert abs(float(loss) - float(floss)) <= 2e-6 * max(1.0, abs(float(floss)))
+    assert abs(float(loss.detach()) - float(floss)) <= 2e-6 * max(1.0, abs(float(floss)))
     assert float(p1) == float(e1) and float(p5) == float(e5)
     assert (x.grad - xr.grad).norm() <= 1e-5 * xr.grad.norm()
     assert (crit.weight.grad - head.weight.grad).norm() <= 1e-5 * head.weight.grad.norm()
@@ -107,7 +107,7 @@ def test_one_rank_equals_replicated_head(kind, N, B):
     fwd = O.arcface_forward if kind == "ArcFace" else O.cosface_forward
     lo = O.focal_loss(fwd(xo, wo, y, s=64.0, m=0.5), y, 2)
     ogx, ogw = torch.autograd.grad(lo, [xo, wo])
-    assert abs(float(loss) - float(lo)) < 1e-3
+    assert abs(float(loss.detach()) - float(lo)) < 1e-3
     assert (x.grad.cpu() - ogx).norm() < 1e-3 * ogx.norm()
     assert (crit.weight.grad.cpu() - ogw).norm() < 1e-3 * ogw.norm()
     with pytest.raises(RuntimeError):

@@ -188,7 +188,7 @@ def test_g7_two_sgd_steps(golden_dir):
         label = synth.labels(17, "sgd.label%d" % step, 8, 100)
         feats, logits, loss, grads = O.train_step(sd, x, label, hw)
         p1, p5 = O.topk_accuracy(logits.detach(), label)
-        assert abs(float(loss) - g["loss"][step]) < 1e-4
+        assert abs(float(loss.detach()) - g["loss"][step]) < 1e-4
         assert float(p1) == g["prec1"][step] and float(p5) == g["prec5"][step]
         with torch.no_grad():
             for n in names:

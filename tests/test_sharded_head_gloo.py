@@ -83,7 +83,7 @@ def _worker(rank, world, port, kind, n_classes, q):
         loss, p1, p5 = crit(x, labs[rank])
         loss.backward()
         e_loss, e_gx, e_gw, e_p1, e_p5 = _expected(xs, labs, w_full, kind, s, m, gamma)
-        assert abs(float(loss) - float(e_loss)) < 1e-5 * max(1.0, abs(float(e_loss))), (float(loss), float(e_loss))
+        assert abs(float(loss.detach()) - float(e_loss)) < 1e-5 * max(1.0, abs(float(e_loss))), (float(loss.detach()), float(e_loss))
         assert float(p1) == pytest.approx(e_p1) and float(p5) == pytest.approx(e_p5)
         # feature gradient: the global-loss gradient of this rank's rows, times world (consumed by an averaging reducer)
         torch.testing.assert_close(x.grad / world, e_gx[rank * B:(rank + 1) * B], rtol=1e-4, atol=1e-6)
