@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short timings of the other BASELINE.json configs after the headline")
     ap.add_argument("--kernel-table", default="", help="write the per-launch timing table of the instrumented step")
+    ap.add_argument("--clock-log", default="", help="write every shader-clock / power sample of the timed loop (rank 0)")
     return ap.parse_args()
 
 
@@ -348,6 +349,7 @@ class ClockSampler(threading.Thread):
     def __init__(self, device_index, period=0.1):
         super().__init__(daemon=True)
         self.period, self.samples, self.power, self.source = period, [], [], None
+        self.series, self.t0 = [], time.perf_counter()
         self._stop_ev = threading.Event()
         self.freq_file = self.power_file = self.dpm_file = None
         try:
@@ -391,14 +393,17 @@ class ClockSampler(threading.Thread):
                 mhz = float(m.group(1)) if m else None
             else:
                 return
+            watts = int(open(self.power_file).read()) / 1e6 if self.power_file else None
             if mhz:
                 self.samples.append(mhz)
-            if self.power_file:
-                self.power.append(int(open(self.power_file).read()) / 1e6)
+                self.series.append((time.perf_counter() - self.t0, mhz, watts))
+            if watts is not None:
+                self.power.append(watts)
         except Exception:  # noqa: BLE001
             pass
 
     def run(self):
+        self.t0 = time.perf_counter()
         while not self._stop_ev.is_set():
             self._read()
             self._stop_ev.wait(self.period)
@@ -509,6 +514,12 @@ def main():
     sampler = ClockSampler(local) if rank == 0 else None
     dt, loss_val, clocks = timed_loop(step, xs, ys, args.warmup, args.steps, world, device, sampler)
     assert loss_val == loss_val, "loss is NaN"
+    if sampler is not None and args.clock_log:
+        with open(args.clock_log, "w") as f:
+            f.write("# shader clock / board power of GPU %d during the timed loop of bench.py (%d steps, %.3f ms per step); "
+                    "source: %s\n# t_s mhz watts\n" % (local, args.steps, dt / args.steps * 1e3, sampler.source))
+            for t, mhz, w in sampler.series:
+                f.write("%.3f %.0f %s\n" % (t, mhz, "%.0f" % w if w is not None else "-"))
 
     ms = dt / args.steps * 1e3
     ips = args.batch * world * args.steps / dt

@@ -535,6 +535,328 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 56x56 / 112x112 (the 64-channel stages: ONE or two dW tiles, 128 - 256 groups): "virtual rows".  A workgroup walks a run
+// of image rows; every input row is fetched ONCE into a ring of 4 LDS rows (the strip kernel re-fetched the halo rows of
+// every strip: 1.5 - 2 x the input bytes of layers that are HBM-bound to begin with).  An image is VH = W + 2 virtual rows:
+// its W rows between a zero row above and below; phase V (one virtual row = RW / 32 K steps) multiplies the g row of
+// virtual row V with the input rows V-1, V, V+1.  The two halo rows of an image are phases too -- with a g row of zeros
+// (2 / (W + 2) of the arithmetic wasted) -- which keeps the schedule uniform: one new input row and one g row per phase,
+// whatever the position in the image, and a run may start and end anywhere.  Ring slots are relative to the run's first
+// row, so four phases unrolled give compile-time LDS addresses again.  Same roles, barriers, fragment pipeline and
+// register budget as the kernel above.
+template <int W_>
+struct VC {
+  static constexpr int W = W_, RW = W_ <= 64 ? 64 : 128, VH = W_ + 2, NSTEP = RW / 32;
+  static constexpr int AROW = (RW + 16) * TSTR;  // positions 0 .. RW+15: column c sits at position c + 1
+  static constexpr int GROW = RW * TSTR;
+  static constexpr int A_OFF = 2 * GROW;         // [g row ring of 2][input row ring of 4]
+  static constexpr int LDS = A_OFF + 4 * AROW;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+template <int W, int PRO>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_vr_kernel(const FrWgradArgs p) {
+  using C = VC<W>;
+  constexpr int RW = C::RW, VH = C::VH, NSTEP = C::NSTEP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int cit_n = p.SC / CT, tiles = (p.Cout / CT) * cit_n;
+  const int group = bid / tiles, tile = bid - group * tiles;
+  const int cot = tile / cit_n, cit = tile - cot * cit_n;
+  const int total = p.B * VH;  // virtual rows of the launch
+  const int per = (total + p.nsplit - 1) / p.nsplit;
+  const int v_begin = group * per;
+  int v_end = v_begin + per;
+  if (v_end > total) v_end = total;
+  const int nph = v_end > v_begin ? v_end - v_begin : 0;  // phases of this workgroup
+
+#ifdef FRHIP_STAMPS
+  unsigned long long bar_wait = 0;
+  const unsigned long long t_start = TSTAMP(), rt_start = __builtin_amdgcn_s_memrealtime();
+#endif
+  for (int idx = tid; idx < C::LDS / 16; idx += 512) st16(smem + idx * 16, zero16());
+  __syncthreads();
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------------------- data-moving waves
+#ifdef ROLL_LOADER_PRIO
+    __builtin_amdgcn_s_setprio(ROLL_LOADER_PRIO);
+#endif
+    if (nph == 0) return;
+    const int lt = tid - 256;
+    const int ch = lt & 7;
+    const char* __restrict__ G = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(p.g) + cot * CT);
+    const char* __restrict__ X = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(p.src) + cit * CT);
+    float pa[8], pb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pa[j] = PRO != FR_PRO_NONE ? p.pro_a[cit * CT + ch * 8 + j] : 0.f;
+      pb[j] = PRO == FR_PRO_BN ? p.pro_b[cit * CT + ch * 8 + j] : 0.f;
+    }
+    constexpr int RCH = W * 8;                          // 16-byte chunks of one row
+    constexpr int NRS = (RCH + NLT - 1) / NLT;          // slots per row
+    int goff[NRS], xoff[NRS], gdst[NRS], adst[NRS];
+#pragma unroll
+    for (int u = 0; u < NRS; ++u) {
+      int q = u * NLT + lt;
+      q = q < RCH ? q : RCH - 1;  // lanes past the row repeat its last chunk (same bytes, same address)
+      const int c = q >> 3;
+      goff[u] = (c * p.ldg + ch * 8) * 2;
+      xoff[u] = (c * p.lda + ch * 8) * 2;
+      gdst[u] = c * TSTR + ch * 16;
+      adst[u] = (c + 1) * TSTR + ch * 16;
+    }
+    struct Row {
+      U128 v[NRS];
+      bool zero;  // uniform: a halo row, or a row outside the tensor
+    };
+    // virtual row V (any int): image row or zero row
+    auto row_of = [&](int V, int& img, int& r) -> bool {
+      if (V < 0 || V >= total) return false;
+      img = V / VH;
+      r = V - img * VH - 1;
+      return r >= 0 && r < W;
+    };
+    auto issue_a = [&](Row& s, int V) {
+      int img = 0, r = 0;
+      const bool ok = row_of(V, img, r);
+      s.zero = !ok;
+      const char* xi = X + ((size_t)(ok ? img : 0) * (W * W) + (size_t)(ok ? r : 0) * W) * (size_t)p.lda * 2;
+#pragma unroll
+      for (int u = 0; u < NRS; ++u) s.v[u] = ld16(xi + (unsigned)xoff[u]);
+    };
+    auto issue_g = [&](Row& s, int V) {
+      int img = 0, r = 0;
+      const bool ok = row_of(V, img, r);
+      s.zero = !ok;
+      const char* gi = G + ((size_t)(ok ? img : 0) * (W * W) + (size_t)(ok ? r : 0) * W) * (size_t)p.ldg * 2;
+#pragma unroll
+      for (int u = 0; u < NRS; ++u) s.v[u] = ld16(gi + (unsigned)goff[u]);
+    };
+    auto commit_a = [&](Row& s, int slot) {
+      char* As = smem + C::A_OFF + slot * C::AROW;
+#pragma unroll
+      for (int u = 0; u < NRS; ++u) {
+        U128 x = s.v[u];
+        if (PRO != FR_PRO_NONE) {
+          x.x = pro2<PRO>(x.x, pa[0], pb[0], pa[1], pb[1]);
+          x.y = pro2<PRO>(x.y, pa[2], pb[2], pa[3], pb[3]);
+          x.z = pro2<PRO>(x.z, pa[4], pb[4], pa[5], pb[5]);
+          x.w = pro2<PRO>(x.w, pa[6], pb[6], pa[7], pb[7]);
+        }
+        if (s.zero) x = zero16();
+        st16(As + adst[u], x);
+      }
+    };
+    auto commit_g = [&](Row& s, int slot) {
+      char* Gs = smem + slot * C::GROW;
+#pragma unroll
+      for (int u = 0; u < NRS; ++u) st16(Gs + gdst[u], s.zero ? zero16() : s.v[u]);
+    };
+    // phase j (relative to the run) = virtual row v_begin + j: g slot j & 1, input rows j-1, j, j+1 in slots j, j+1, j+2 (mod 4)
+    {
+      Row t;
+      issue_a(t, v_begin - 1);
+      commit_a(t, 0);
+      issue_a(t, v_begin);
+      commit_a(t, 1);
+      issue_a(t, v_begin + 1);
+      commit_a(t, 2);
+      issue_g(t, v_begin);
+      commit_g(t, 0);
+    }
+    Row a0, g0, a1, g1;  // set 0: rows for the commits of even phases, set 1: odd phases
+    issue_a(a0, v_begin + 2);
+    issue_g(g0, v_begin + 1);
+    issue_a(a1, v_begin + 3);
+    issue_g(g1, v_begin + 2);
+    LDS_FENCE_BARRIER();  // B0: phase 0 is resident
+#ifdef FRHIP_STAMPS
+    const unsigned long long t_loop = TSTAMP();
+    bar_wait = 0;
+#endif
+#pragma unroll 1
+    for (int j = 0; j < nph; j += 4) {
+      const int V = v_begin + j;
+      // computing waves: phase j.  Row j + 2 goes to slot (j + 3) & 3, the g row of phase j + 1 to slot (j + 1) & 1; then
+      // the same register set requests the rows of two phases later.  (Past the run: rows nobody reads.)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        Row& ra = (s & 1) ? a1 : a0;
+        Row& rg = (s & 1) ? g1 : g0;
+        commit_a(ra, (s + 3) & 3);
+        commit_g(rg, (s + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_a(ra, V + s + 4);
+        issue_g(rg, V + s + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        LDS_FENCE_BARRIER();
+      }
+    }
+#ifdef FRHIP_STAMPS
+    if (tid == 256 && fr_stamp_buf_wgr) {
+      fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 3] = bar_wait;
+      fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 4] = TSTAMP() - t_loop;
+    }
+#endif
+    return;
+  }
+
+  // ------------------------------------------------------------------------------------------------ computing waves
+  const int wci = wave;
+  const int li = lane & 15, lq = lane >> 4;
+  const int colb = (4 * (li & 3)) * 2;
+  const int lrow = (4 * lq + (li >> 2)) * TSTR;
+  f32x4 acc[4][9];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[t][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (p.prev_n) {
+    const long long n4 = p.prev_n >> 2;
+    const long long perw = (n4 + gridDim.x - 1) / gridDim.x;
+    const long long e0 = (long long)blockIdx.x * perw;
+    long long e1 = e0 + perw;
+    if (e1 > n4) e1 = n4;
+    if (e0 < e1) slab_sum_range<256>(p.prev_slab, p.prev_groups, n4, e0, e1, p.prev_dw, tid);
+  }
+  if (nph > 0) {
+    const char* const gbase = smem + lrow + colb;
+    const char* const abase = smem + C::A_OFF + lrow + (wci * 16) * 2 + colb;
+    constexpr int LA = 5, RS = 6;
+    constexpr int NI = NSTEP * 18, IB = NI - LA + 1;
+    static_assert(NI % RS == 0 && IB % 9 <= 5 && IB / 9 == 2 * NSTEP - 1, "item pipeline");
+    // item -> (half-step hs = it / 9, tap); input fragment of (step ks = hs / 2, tap): row slot of kh, position 32 ks + kw
+    auto a_frag = [&](int slot0, int item) -> s16x8 {  // slot0 = ring slot of the phase's row V - 1
+      const int ks = item / 18, tap = item % 9;
+      const char* ab = abase + ((slot0 + tap / 3) & 3) * C::AROW + (32 * ks + tap % 3) * TSTR;
+      return tr_frag(ab, ab + 16 * TSTR);
+    };
+    auto g_frag = [&](int gslot, int hs, int t) -> s16x8 {
+      const int ks = hs >> 1, ct = (hs & 1) * 2 + t;
+      const char* gb = gbase + gslot * C::GROW + (32 * ks) * TSTR + ct * 32;
+      return tr_frag(gb, gb + 16 * TSTR);
+    };
+    s16x8 ring[RS];
+    s16x8 gf[2], gn[2];
+    // phase with relative index s (mod 4): g slot s & 1, input rows in slots s, s+1, s+2; `live` = false past the run:
+    // only the barrier (the data-moving waves run their loop in fours)
+    auto run_phase = [&](auto sc, bool live) {
+      constexpr int s = decltype(sc)::value;
+      if (!live) {
+        LDS_FENCE_BARRIER();
+        return;
+      }
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int hs = it / 9, tap = it % 9;
+        if (it == IB) {
+          LDS_FENCE_BARRIER();
+#pragma unroll
+          for (int jt = NI - LA; jt < IB; ++jt) ring[(jt + LA) % RS] = a_frag((s + 1) & 3, jt + LA - NI);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const s16x8 af = ring[it % RS];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          acc[(hs & 1) * 2 + t][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[t], af, acc[(hs & 1) * 2 + t][tap], 0, 0, 0);
+        if (it + LA < NI) ring[(it + LA) % RS] = a_frag(s, it + LA);
+        else if (it >= IB) ring[(it + LA) % RS] = a_frag((s + 1) & 3, it + LA - NI);
+        if (hs + 1 < 2 * NSTEP) {
+          if (tap == 3 || tap == 4) gn[tap - 3] = g_frag(s & 1, hs + 1, tap - 3);
+        } else {
+          if (tap == 5 || tap == 6) gn[tap - 5] = g_frag((s + 1) & 1, 0, tap - 5);
+        }
+        if (tap == 8) {
+          gf[0] = gn[0];
+          gf[1] = gn[1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    LDS_FENCE_BARRIER();  // B0
+#ifdef FRHIP_STAMPS
+    const unsigned long long t_loop = TSTAMP();
+    bar_wait = 0;
+#endif
+    gf[0] = g_frag(0, 0, 0);
+    gf[1] = g_frag(0, 0, 1);
+#pragma unroll
+    for (int it = 0; it < LA; ++it) ring[it] = a_frag(0, it);
+#pragma unroll 1
+    for (int j = 0; j < nph; j += 4) {
+      run_phase(std::integral_constant<int, 0>{}, true);
+      run_phase(std::integral_constant<int, 1>{}, j + 1 < nph);
+      run_phase(std::integral_constant<int, 2>{}, j + 2 < nph);
+      run_phase(std::integral_constant<int, 3>{}, j + 3 < nph);
+    }
+#ifdef FRHIP_STAMPS
+    if (tid == 0 && fr_stamp_buf_wgr) {
+      fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 1] = TSTAMP() - t_loop;
+      fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 2] = bar_wait;
+      fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 6] = nph;
+    }
+#endif
+  }
+
+  float* __restrict__ slab = p.slab + (size_t)group * (size_t)p.Cout * 9 * (size_t)p.SC;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cot * CT + t * 16 + lq * 4 + r;
+        const int ci = cit * CT + wci * 16 + li;
+        slab[((size_t)co * 9 + tap) * (size_t)p.SC + ci] = acc[t][tap][r];
+      }
+#ifdef FRHIP_STAMPS
+  if (tid == 0 && fr_stamp_buf_wgr) {
+    fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 0] = TSTAMP() - t_start;
+    fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime() - rt_start;
+  }
+#endif
+}
+
+template <int W, int PRO>
+int launch_vr(const FrWgradArgs& a, hipStream_t st) {
+  using C = VC<W>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_vr_kernel<W, PRO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    attr_done = true;
+  }
+  const int tiles = (a.Cout / CT) * (a.SC / CT);
+  hipLaunchKernelGGL((conv_wgrad_vr_kernel<W, PRO>), dim3(tiles * a.nsplit), dim3(512), C::LDS, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fr_set_error(hipGetErrorString(e));
+    return (int)e;
+  }
+  if (a.defer) return 0;
+  return fr_launch_reduce_slabs(a.slab, a.nsplit, (long long)a.Cout * 9 * a.SC, a.dw, st);
+}
+
+template <int W>
+int by_pro_vr(const FrWgradArgs& a, hipStream_t st) {
+  switch (a.pro) {
+    case FR_PRO_NONE: return launch_vr<W, FR_PRO_NONE>(a, st);
+    case FR_PRO_BN: return launch_vr<W, FR_PRO_BN>(a, st);
+    case FR_PRO_PRELU: return launch_vr<W, FR_PRO_PRELU>(a, st);
+  }
+  FR_UNSUPPORTED("fr_conv_wgrad_strip: unknown prologue");
+}
+
 template <int W, int PRO>
 int launch(const FrWgradArgs& a, hipStream_t st) {
   using L = RL<W>;
@@ -582,13 +904,23 @@ bool fr_wgrad_roll_enabled() {
   return on;
 }
 
-// stride-1 3x3 at 14x14 / 28x28, channel counts multiples of 64, at least one image (14x14) / phase (28x28) per group
+// FRHIP_WGRAD_VR=0: 56x56 / 112x112 back on the strip kernel (A/B switch)
+static bool fr_wgrad_vr_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("FRHIP_WGRAD_VR");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+// stride-1 3x3 at 14x14 / 28x28 / 56x56 / 112x112, channel counts multiples of 64, at least one image (14x14) / phase (28x28) per group
 bool fr_wgrad_roll_serves(const FrWgradArgs& a) {
   if (!(fr_wgrad_roll_enabled() && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.GH == a.SH &&
         a.GW == a.SW && a.SH == a.SW && a.Cout % CT == 0 && a.SC % CT == 0 && a.nsplit >= 1))
     return false;
   if (a.SW == 14) return a.nsplit <= a.B;
   if (a.SW == 28) return a.nsplit <= a.B * RC<28>::NPH;
+  if (a.SW == 56 || a.SW == 112) return fr_wgrad_vr_enabled() && a.nsplit <= a.B * (a.SW + 2);
   return false;
 }
 
@@ -596,6 +928,8 @@ int fr_wgrad_roll_launch(const FrWgradArgs& a, hipStream_t st) {
   switch (a.SW) {
     case 14: return by_pro<14>(a, st);
     case 28: return by_pro<28>(a, st);
+    case 56: return by_pro_vr<56>(a, st);
+    case 112: return by_pro_vr<112>(a, st);
   }
   FR_UNSUPPORTED("fr_conv_wgrad_strip: width not served by the warp-specialised kernel");
 }

@@ -114,6 +114,8 @@ def suite_cases(B):
         ("strip_256_256_14_fwd_prelu", lambda it: conv_case("strip", 256, 256, 14, B, pro=2, epi=1, iters=it)),
         ("strip_256_256_14_dgrad", lambda it: conv_case("strip", 256, 256, 14, B, pro=0, epi=2, mode=1, iters=it)),
         ("wgs_256_256_14", lambda it: wgrad_case("wgs", 256, 256, 14, B, pro=2, iters=it)),
+        ("wgs_256_256_14_bn", lambda it: wgrad_case("wgs", 256, 256, 14, B, pro=1, iters=it)),
+        ("wgs_512_512_7", lambda it: wgrad_case("wgs", 512, 512, 7, B, pro=2, iters=it)),
         ("wgs_128_128_28", lambda it: wgrad_case("wgs", 128, 128, 28, B, pro=2, iters=it)),
         ("strip_512_512_7_fwd", lambda it: conv_case("strip", 512, 512, 7, B, pro=1, epi=0, iters=it)),
     ]

@@ -29,6 +29,7 @@ def act(W, C):
 def table():
     w3 = lambda ci, co: ci * co * 9 * 2  # noqa: E731
     f3 = lambda W, ci, co: 2.0 * B * W * W * ci * co * 9  # noqa: E731
+    dw = lambda ci, co: ci * co * 9 * 4  # noqa: E731
     return {
         "strip_64_64_112_fwd": (r"conv3x3_roll64_kernel<112, 1, false>|conv3x3_strip_kernel<64, 64, 112, \d+, \d+, \d+, 1, 1,", 2 * act(112, 64) + w3(64, 64), f3(112, 64, 64)),
         "strip_64_64_112_dgrad": (r"conv3x3_roll64_kernel<112, 0, true>|conv3x3_strip_kernel<64, 64, 112, \d+, \d+, \d+, 1, 0,", 3 * act(112, 64) + w3(64, 64), f3(112, 64, 64)),
@@ -43,14 +44,17 @@ def table():
         "strip_64_64_56_fwd_bn": (r"conv3x3_roll64_kernel<56, 1, false>|conv3x3_strip_kernel<64, 64, 56, \d+, \d+, \d+, 1, 1,", 2 * act(56, 64) + w3(64, 64), f3(56, 64, 64)),
         "strip_64_64_56_fwd_prelu": (r"conv3x3_roll64_kernel<56, 2, false>|conv3x3_strip_kernel<64, 64, 56, \d+, \d+, \d+, 1, 2,", 2 * act(56, 64) + w3(64, 64), f3(56, 64, 64)),
         "strip_64_64_56_dgrad": (r"conv3x3_roll64_kernel<56, 0, true>|conv3x3_strip_kernel<64, 64, 56, \d+, \d+, \d+, 1, 0,", 3 * act(56, 64) + w3(64, 64), f3(56, 64, 64)),
-        "wgs_64_64_112": (r"conv_wgrad_strip_kernel<112,", 2 * act(112, 64), f3(112, 64, 64)),
-        "wgs_64_64_56": (r"conv_wgrad_strip_kernel<56, \d+, \d+, \d+, 2, false", 2 * act(56, 64), f3(56, 64, 64)),
+        # weight gradients: algorithmic bytes = both operands once + dW (fp32) once; the slabs are overhead
+        "wgs_64_64_112": (r"conv_wgrad_vr_kernel<112, 1>|conv_wgrad_strip_kernel<112,", 2 * act(112, 64) + dw(64, 64), f3(112, 64, 64)),
+        "wgs_64_64_56": (r"conv_wgrad_vr_kernel<56, 2>|conv_wgrad_strip_kernel<56, \d+, \d+, \d+, 2, false", 2 * act(56, 64) + dw(64, 64), f3(56, 64, 64)),
         "strip_128_128_28_fwd": (r"conv3x3_strip_kernel<128, 128, 28, \d+, \d+, \d+, 1, 1,", 2 * act(28, 128) + w3(128, 128), f3(28, 128, 128)),
         "strip_256_256_14_fwd_bn": (r"conv3x3_strip_kernel<256, 256, 14, \d+, \d+, \d+, 1, 1,", 2 * act(14, 256) + w3(256, 256), f3(14, 256, 256)),
         "strip_256_256_14_fwd_prelu": (r"conv3x3_strip_kernel<256, 256, 14, \d+, \d+, \d+, 1, 2,", 2 * act(14, 256) + w3(256, 256), f3(14, 256, 256)),
         "strip_256_256_14_dgrad": (r"conv3x3_strip_kernel<256, 256, 14, \d+, \d+, \d+, 1, 0,", 3 * act(14, 256) + w3(256, 256), f3(14, 256, 256)),
-        "wgs_256_256_14": (r"conv_wgrad_strip_kernel<14,", 2 * act(14, 256), f3(14, 256, 256)),
-        "wgs_128_128_28": (r"conv_wgrad_strip_kernel<28,", 2 * act(28, 128), f3(28, 128, 128)),
+        "wgs_256_256_14": (r"conv_wgrad_roll_kernel<14, 2>|conv_wgrad_strip_kernel<14,", 2 * act(14, 256) + dw(256, 256), f3(14, 256, 256)),
+        "wgs_256_256_14_bn": (r"conv_wgrad_roll_kernel<14, 1>", 2 * act(14, 256) + dw(256, 256), f3(14, 256, 256)),
+        "wgs_128_128_28": (r"conv_wgrad_roll_kernel<28, 2>|conv_wgrad_strip_kernel<28,", 2 * act(28, 128) + dw(128, 128), f3(28, 128, 128)),
+        "wgs_512_512_7": (r"conv_wgrad_strip_kernel<7, 7, 4,", 2 * act(7, 512) + dw(512, 512), f3(7, 512, 512)),
         "strip_512_512_7_fwd": (r"conv3x3_strip_kernel<512, 256, 7,", 2 * act(7, 512) + w3(512, 512), f3(7, 512, 512)),
     }
 
@@ -82,6 +86,7 @@ def main():
         if line.startswith("KBENCH_SUITE "):
             times = json.loads(line[len("KBENCH_SUITE "):])
     f, w, s = load(os.path.join(src, "f")), load(os.path.join(src, "w")), load(os.path.join(src, "s"))
+    im = load(os.path.join(src, "i")) if os.path.isdir(os.path.join(src, "i")) else {}
     recs, lines = [], []
     for label, (rx, alg_bytes, flops) in table().items():
         fk, wk = pick(f, rx, "FETCH_SIZE"), pick(w, rx, "WRITE_SIZE")
@@ -112,10 +117,21 @@ def main():
                 if sq[c] is not None:
                     rec[k] = round(sq[c] / wc, 3)
             rec["sq_raw"] = sq
+        mix = {c: pick(im, rx, c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
+                                            "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU")}
+        if mix["SQ_INSTS_MFMA"]:
+            # SQ_INSTS_VALU counts the MFMAs too: vector-ALU instructions proper = VALU - MFMA
+            mf = mix["SQ_INSTS_MFMA"]
+            rec["valu_per_mfma"] = round(((mix["SQ_INSTS_VALU"] or 0) - mf) / mf, 2)
+            rec["lds_per_mfma"] = round((mix["SQ_INSTS_LDS"] or 0) / mf, 2)
+            rec["vmem_per_mfma"] = round(((mix["SQ_INSTS_VMEM_RD"] or 0) + (mix["SQ_INSTS_VMEM_WR"] or 0)) / mf, 3)
+            rec["inst_mix_raw"] = mix
         recs.append(rec)
-        lines.append("%-28s %7s ms  x%-5s HBM floor  traffic/alg %-6s  %6s GB/s  mfma_util %-6s frac_peak %-6s wait_any %-6s wait_lds %-6s"
+        lines.append("%-28s %7s ms  x%-5s HBM floor  traffic/alg %-6s  %6s GB/s  mfma_util %-6s frac_peak %-6s wait_any %-6s wait_inst %-6s "
+                     "wait_lds %-6s valu/mfma %-5s lds/mfma %-5s"
                      % (label, ms, rec.get("x_hbm_floor"), rec.get("traffic_over_algorithmic"), rec.get("hbm_GBps"),
-                        rec.get("mfma_util"), rec.get("frac_mfma_peak"), rec.get("wait_any"), rec.get("wait_lds")))
+                        rec.get("mfma_util"), rec.get("frac_mfma_peak"), rec.get("wait_any"), rec.get("wait_inst"),
+                        rec.get("wait_lds"), rec.get("valu_per_mfma"), rec.get("lds_per_mfma")))
     out = {"batch": B, "dtype": "bf16", "corrections": "FETCH_SIZE, WRITE_SIZE in KB; FETCH_SIZE doubled (gfx950 counts half of a "
            "16-B/lane streaming read); separate --pmc passes (MI355X_MICROARCH.md HBM / rocprofv3 sections)",
            "hbm_achievable_Bps": HBM_ACHIEVABLE, "mfma_peak": MFMA_PEAK, "kernels": recs}
