@@ -421,61 +421,57 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
     const char* const ab0 = smem + L::g_bytes(0) + lrow + (wci * 16) * 2 + colb;
     const char* const gb1 = smem + L::BUF0 + lrow + colb;
     const char* const ab1 = smem + L::BUF0 + L::g_bytes(1) + lrow + (wci * 16) * 2 + colb;
-    // One "item" = one tap of one K step for HALF of the output channels (2 of the 4 co tiles): an input fragment (2 reads)
-    // and 2 MFMAs; a step is 18 items (co half 0: taps 0-8, co half 1: taps 0-8).  Only the g fragments of the running
-    // half and of the next one are live (16 registers instead of 32 with all four tiles per tap), the input fragments
-    // go through a ring of RS = 6 (the slot of an item is its index mod 6 in every phase: 72 and 54 items) filled LA = 5
-    // items ahead -- 194 registers instead of 222, i.e. one more BatchNorm wave of the main stream per SIMD beside this
-    // kernel, which is worth more to the step than the 18 extra ds_reads per step cost here (LDS: 352 of 576 clocks).
-    // The barrier that hands the buffers over sits at item NI - LA + 1: the last fragment of the phase was requested two
-    // items earlier, and the LA - 1 items behind the barrier need no LDS of this phase any more -- they run while the first
-    // fragments of the next phase are fetched.
+    // One "item" = one tap of one K step: an input fragment (2 reads) and 4 MFMAs (one per co tile).  Flat software
+    // pipeline over the items of a phase: the fragment of item it + LA is requested behind the MFMAs of item it into a ring
+    // of RS = LA + 1 = 3 (the slot of an item is its index mod 3 in every phase: 36 and 27 items); the g fragments of the
+    // next step (8 reads) are requested over taps 4-7 into a second register set.  Register budget: 144 accumulators + 12
+    // ring + 32 g = 194 with addresses, i.e. 112 registers per SIMD stay free beside the two waves of this kernel -- room
+    // for BatchNorm waves of the main stream, whose speed beside this kernel decides the step (a 9-deep ring, 222
+    // registers, is no faster alone and serialises them; two co tiles per item, 190 registers, costs 70 % more LDS
+    // instructions: 1.35 per MFMA by PMC, a quarter of the wave cycles in LDS-issue stalls).
+    // The barrier that hands the buffers over sits at the last item of a phase: its fragment was requested two items
+    // earlier; the first fragments of the next phase are requested right behind the barrier, under that item's MFMAs.
 #ifndef ROLL_LA
-#define ROLL_LA 5
+#define ROLL_LA 2
 #endif
     constexpr int LA = ROLL_LA, RS = LA + 1;  // ring slots
     auto a_frag = [&](const char* ab, int item) -> s16x8 {
-      const int ks = item / 18, tap = item % 9;
+      const int ks = item / 9, tap = item % 9;
       const int off = 32 * ks + RW * (tap / 3) + tap % 3;
       return tr_frag(ab + off * TSTR, ab + (off + 16) * TSTR);
     };
-    auto g_frag = [&](const char* gb, int hs, int t) -> s16x8 {  // hs = 2 * step + half; t = tile inside the half
-      const int ks = hs >> 1, ct = (hs & 1) * 2 + t;
-      return tr_frag(gb + (32 * ks) * TSTR + ct * 32, gb + (32 * ks + 16) * TSTR + ct * 32);
+    auto g_frag = [&](const char* gb, int ks, int t) -> s16x8 {
+      return tr_frag(gb + (32 * ks) * TSTR + t * 32, gb + (32 * ks + 16) * TSTR + t * 32);
     };
     s16x8 ring[RS];
-    s16x8 gf[2], gn[2];
+    s16x8 gf[4], gn[4];
 
     auto run_phase = [&](const char* gb, const char* ab, const char* gb_next, const char* ab_next, auto nstep_c) {
       constexpr int NSTEP = decltype(nstep_c)::value;
-      constexpr int NI = NSTEP * 18, IB = NI - LA + 1;
+      constexpr int NI = NSTEP * 9, IB = NI - LA + 1;
       static_assert(NI % RS == 0, "the ring slot of an item must not depend on the phase");
-      static_assert(IB % 9 <= 5 && IB / 9 == 2 * NSTEP - 1, "the barrier sits in the last half-step, before its g prefetch taps");
+      static_assert(IB / 9 == NSTEP - 1 && IB % 9 >= 4, "the barrier sits in the last step, not before its g prefetch taps");
 #pragma unroll
       for (int it = 0; it < NI; ++it) {
-        const int hs = it / 9, tap = it % 9;
+        const int ks = it / 9, tap = it % 9;
         if (it == IB) {
           LDS_FENCE_BARRIER();  // every fragment of this phase is in registers; the next buffer is complete
+#pragma unroll
+          for (int t = 0; t < 4; ++t) gn[t] = g_frag(gb_next, 0, t);
 #pragma unroll
           for (int jt = NI - LA; jt < IB; ++jt) ring[(jt + LA) % RS] = a_frag(ab_next, jt + LA - NI);  // deferred requests
           __builtin_amdgcn_sched_barrier(0);
         }
         const s16x8 af = ring[it % RS];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-          acc[(hs & 1) * 2 + t][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[t], af, acc[(hs & 1) * 2 + t][tap], 0, 0, 0);
+        for (int t = 0; t < 4; ++t)
+          acc[t][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[t], af, acc[t][tap], 0, 0, 0);
         if (it + LA < NI) ring[(it + LA) % RS] = a_frag(ab, it + LA);
         else if (it >= IB) ring[(it + LA) % RS] = a_frag(ab_next, it + LA - NI);
-        // the g fragments of the next half-step (4 reads): taps 3 and 4, i.e. five items ahead; those of the next PHASE must
-        // stay behind the barrier: taps 5 and 6 of the last half-step
-        if (hs + 1 < 2 * NSTEP) {
-          if (tap == 3 || tap == 4) gn[tap - 3] = g_frag(gb, hs + 1, tap - 3);
-        } else {
-          if (tap == 5 || tap == 6) gn[tap - 5] = g_frag(gb_next, 0, tap - 5);
-        }
+        if (ks + 1 < NSTEP && tap >= 4 && tap < 8) gn[tap - 4] = g_frag(gb, ks + 1, tap - 4);
         if (tap == 8) {
-          gf[0] = gn[0];
-          gf[1] = gn[1];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) gf[t] = gn[t];
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -486,8 +482,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
     const unsigned long long t_loop = TSTAMP();
     bar_wait = 0;
 #endif
-    gf[0] = g_frag(gb0, 0, 0);
-    gf[1] = g_frag(gb0, 0, 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) gf[t] = g_frag(gb0, 0, t);
 #pragma unroll
     for (int it = 0; it < LA; ++it) ring[it] = a_frag(ab0, it);
     if constexpr (NPH == 2) {
@@ -732,22 +728,21 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_vr_kernel(const FrWgradArgs
   if (nph > 0) {
     const char* const gbase = smem + lrow + colb;
     const char* const abase = smem + C::A_OFF + lrow + (wci * 16) * 2 + colb;
-    constexpr int LA = 5, RS = 6;
-    constexpr int NI = NSTEP * 18, IB = NI - LA + 1;
-    static_assert(NI % RS == 0 && IB % 9 <= 5 && IB / 9 == 2 * NSTEP - 1, "item pipeline");
-    // item -> (half-step hs = it / 9, tap); input fragment of (step ks = hs / 2, tap): row slot of kh, position 32 ks + kw
+    constexpr int LA = 2, RS = 3;  // tap-major items, ring of 3: see the kernel above
+    constexpr int NI = NSTEP * 9, IB = NI - LA + 1;
+    static_assert(NI % RS == 0 && IB / 9 == NSTEP - 1 && IB % 9 >= 4, "item pipeline");
+    // input fragment of item (step ks = it / 9, tap): row slot of kh, position 32 ks + kw
     auto a_frag = [&](int slot0, int item) -> s16x8 {  // slot0 = ring slot of the phase's row V - 1
-      const int ks = item / 18, tap = item % 9;
+      const int ks = item / 9, tap = item % 9;
       const char* ab = abase + ((slot0 + tap / 3) & 3) * C::AROW + (32 * ks + tap % 3) * TSTR;
       return tr_frag(ab, ab + 16 * TSTR);
     };
-    auto g_frag = [&](int gslot, int hs, int t) -> s16x8 {
-      const int ks = hs >> 1, ct = (hs & 1) * 2 + t;
-      const char* gb = gbase + gslot * C::GROW + (32 * ks) * TSTR + ct * 32;
+    auto g_frag = [&](int gslot, int ks, int t) -> s16x8 {
+      const char* gb = gbase + gslot * C::GROW + (32 * ks) * TSTR + t * 32;
       return tr_frag(gb, gb + 16 * TSTR);
     };
     s16x8 ring[RS];
-    s16x8 gf[2], gn[2];
+    s16x8 gf[4], gn[4];
     // phase with relative index s (mod 4): g slot s & 1, input rows in slots s, s+1, s+2; `live` = false past the run:
     // only the barrier (the data-moving waves run their loop in fours)
     auto run_phase = [&](auto sc, bool live) {
@@ -758,27 +753,25 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_vr_kernel(const FrWgradArgs
       }
 #pragma unroll
       for (int it = 0; it < NI; ++it) {
-        const int hs = it / 9, tap = it % 9;
+        const int ks = it / 9, tap = it % 9;
         if (it == IB) {
           LDS_FENCE_BARRIER();
+#pragma unroll
+          for (int t = 0; t < 4; ++t) gn[t] = g_frag((s + 1) & 1, 0, t);
 #pragma unroll
           for (int jt = NI - LA; jt < IB; ++jt) ring[(jt + LA) % RS] = a_frag((s + 1) & 3, jt + LA - NI);
           __builtin_amdgcn_sched_barrier(0);
         }
         const s16x8 af = ring[it % RS];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-          acc[(hs & 1) * 2 + t][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[t], af, acc[(hs & 1) * 2 + t][tap], 0, 0, 0);
+        for (int t = 0; t < 4; ++t)
+          acc[t][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[t], af, acc[t][tap], 0, 0, 0);
         if (it + LA < NI) ring[(it + LA) % RS] = a_frag(s, it + LA);
         else if (it >= IB) ring[(it + LA) % RS] = a_frag((s + 1) & 3, it + LA - NI);
-        if (hs + 1 < 2 * NSTEP) {
-          if (tap == 3 || tap == 4) gn[tap - 3] = g_frag(s & 1, hs + 1, tap - 3);
-        } else {
-          if (tap == 5 || tap == 6) gn[tap - 5] = g_frag((s + 1) & 1, 0, tap - 5);
-        }
+        if (ks + 1 < NSTEP && tap >= 4 && tap < 8) gn[tap - 4] = g_frag(s & 1, ks + 1, tap - 4);
         if (tap == 8) {
-          gf[0] = gn[0];
-          gf[1] = gn[1];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) gf[t] = gn[t];
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -788,8 +781,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_vr_kernel(const FrWgradArgs
     const unsigned long long t_loop = TSTAMP();
     bar_wait = 0;
 #endif
-    gf[0] = g_frag(0, 0, 0);
-    gf[1] = g_frag(0, 0, 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) gf[t] = g_frag(0, 0, t);
 #pragma unroll
     for (int it = 0; it < LA; ++it) ring[it] = a_frag(0, it);
 #pragma unroll 1
