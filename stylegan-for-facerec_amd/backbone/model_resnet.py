@@ -2,9 +2,10 @@
 
 Plain PyTorch, OFF the accelerated path: these bottleneck ResNets with the face-recognition output head are imported
 by the reference driver but named by no shipped config and not by BASELINE.json (SURVEY.md 2.1, 8b-i: "must import;
-plain PyTorch is fine").  They exist so that a driver selecting ``BACKBONE_NAME = 'ResNet_50'`` gets a working
-``nn.Module`` with the reference's state-dict keys, shapes and initialisation (pinned by
-tests/golden/g12_resnet_structure.json); they run through ATen / MIOpen like any torch model, not through libfrhip.
+plain PyTorch is fine").  Importable and state-dict compatible only: the classes carry the reference's keys, shapes and
+initialisation (pinned by tests/golden/g12_resnet_structure.json) and run through ATen / MIOpen like any torch model,
+but this repo's ``train.py`` does not wire them up (``build_backbone`` raises for ``BACKBONE_NAME = 'ResNet_*'``: its
+loop is built around the frhip runner, ``separate_irse_bn_paras`` and the gradient arena).
 """
 import torch.nn as nn
 

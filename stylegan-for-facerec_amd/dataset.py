@@ -26,7 +26,9 @@ class TrainTransform(object):
 
     def __call__(self, img):
         from PIL import Image
-        img = img.resize((self.big, self.big), Image.BILINEAR)
+        # grayscale / CMYK / RGBA files: same three channels as StageTransform (the GPU input path) sees, so both input
+        # pipelines train on the same sample set (the reference's host transform drops such files in its Normalize)
+        img = img.convert("RGB").resize((self.big, self.big), Image.BILINEAR)
         x0, y0 = random.randint(0, self.big - self.size), random.randint(0, self.big - self.size)
         arr = np.asarray(img.crop((x0, y0, x0 + self.size, y0 + self.size)), np.float32) / 255.0
         if random.random() < 0.5:
@@ -105,8 +107,8 @@ class FacesDataset(Dataset):
         try:
             if self.transform:
                 img = self.transform(img)
-        except Exception:  # noqa: BLE001
-            print("[Error during transforming image]")
+        except Exception as e:  # noqa: BLE001
+            print("[Error during transforming image] %s: %s" % (fn, e))
             return None
         return (img, label)
 

@@ -504,11 +504,11 @@ template <int W>
 int by_pro(const FrConvArgs& a, hipStream_t st) {
   if (a.epi == FR_EPI_PRELU_BWD || a.epi == FR_EPI_BNBWD) {
     // the fused backward epilogues come with the data gradients, which have no prologue
-    if (a.pro != FR_PRO_NONE || !a.aux) return -1;
+    if (a.pro != FR_PRO_NONE || !a.aux) FR_UNSUPPORTED("rolling-window convolution: data-gradient epilogues take no prologue and need aux");
     return launch<W, FR_PRO_NONE, true>(a, st);
   }
   if (a.epi == FR_EPI_BIAS_RES) {  // inference conv2: PReLU prologue, folded shifts + shortcut epilogue
-    if (a.pro != FR_PRO_PRELU || !a.aux || !a.epi_a || !a.epi_b) return -1;
+    if (a.pro != FR_PRO_PRELU || !a.aux || !a.epi_a || !a.epi_b) FR_UNSUPPORTED("rolling-window convolution: the folded epilogue needs the PReLU prologue, aux, epi_a and epi_b");
     return launch<W, FR_PRO_PRELU, true>(a, st);
   }
   switch (a.pro) {
@@ -516,7 +516,7 @@ int by_pro(const FrConvArgs& a, hipStream_t st) {
     case FR_PRO_BN: return launch<W, FR_PRO_BN, false>(a, st);
     case FR_PRO_PRELU: return launch<W, FR_PRO_PRELU, false>(a, st);
   }
-  return -1;
+  FR_UNSUPPORTED("rolling-window convolution: prologue / epilogue combination not served");
 }
 
 }  // namespace
@@ -536,5 +536,5 @@ int fr_roll64_parts(int B, int W) { return B * (W / R64::BW) * roll_nseg(B, W); 
 int fr_roll64_launch(const FrConvArgs& a, hipStream_t st) {
   if (a.SW == 112) return by_pro<112>(a, st);
   if (a.SW == 56) return by_pro<56>(a, st);
-  return -1;
+  FR_UNSUPPORTED("rolling-window convolution: prologue / epilogue combination not served");
 }

@@ -570,5 +570,5 @@ int fr_s2roll_launch(const FrConvArgs& a, hipStream_t st) {
     case FR_PRO_BN: return launch<0, FR_PRO_BN>(a, st);
     case FR_PRO_PRELU: return launch<0, FR_PRO_PRELU>(a, st);
   }
-  return -1;
+  FR_UNSUPPORTED("rolling-window convolution: prologue / epilogue combination not served");
 }

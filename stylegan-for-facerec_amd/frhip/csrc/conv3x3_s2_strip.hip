@@ -516,7 +516,7 @@ int by_pro(const FrConvArgs& a, hipStream_t st) {
     case FR_PRO_BN: return launch<CIN, COUT, WL, ROWS, WN, NW, KIND, FR_PRO_BN>(a, st);
     case FR_PRO_PRELU: return launch<CIN, COUT, WL, ROWS, WN, NW, KIND, FR_PRO_PRELU>(a, st);
   }
-  return -1;
+  FR_UNSUPPORTED("fr_conv3x3_s2_strip: unknown prologue");
 }
 
 // low-res rows per workgroup for a served shape (0 = not served): the four IR stage transitions
@@ -558,6 +558,14 @@ extern "C" int fr_conv3x3_s2_strip(const FrConvArgs* args, void* stream) {
   if (WLo != HLo || WHi != 2 * WLo || HHi != 2 * HLo || a.SC != a.N)
     FR_UNSUPPORTED("fr_conv3x3_s2_strip: square images, high-res side = 2 x low-res side, Cin == Cout");
   if (fr_s2roll_serves(a)) return fr_s2roll_launch(a, st);
+  // fr_conv3x3_s2_strip_parts() has no epilogue argument: for the 64-channel layer it answers with the row count of the
+  // rolling-window kernel.  A summing epilogue that kernel does not serve would make the strip kernel below write a
+  // DIFFERENT number of partial rows into a buffer sized from that answer -- refuse instead of overrunning it.
+  if (a.SC == 64 && WLo == 56 && fr_s2roll_enabled() && a.part &&
+      (a.epi == FR_EPI_STATS || a.epi == FR_EPI_PRELU_BWD || a.epi == FR_EPI_BNBWD))
+    FR_UNSUPPORTED("fr_conv3x3_s2_strip: this prologue / epilogue combination of the 64-channel layer writes partial rows "
+                   "in the strip kernel's layout, not the one fr_conv3x3_s2_strip_parts() reports (set FRHIP_S2ROLL=0 or "
+                   "use fr_conv_igemm)");
 #define SHAPE(c, wl, rows, wn, nw)                                   \
   if (a.SC == c && WLo == wl) {                                      \
     if (a.mode == 0) return by_pro<c, c, wl, rows, wn, nw, 0>(a, st); \

@@ -443,7 +443,7 @@ int by_pro(const FrConvArgs& a, hipStream_t st) {
     case FR_PRO_BN: return launch<CIN, COUT, W, ROWS, WN, NW, NSPL, FR_PRO_BN, NIMG, KSPL>(a, st);
     case FR_PRO_PRELU: return launch<CIN, COUT, W, ROWS, WN, NW, NSPL, FR_PRO_PRELU, NIMG, KSPL>(a, st);
   }
-  return -1;
+  FR_UNSUPPORTED("fr_conv3x3_strip: unknown prologue");
 }
 
 }  // namespace

@@ -414,7 +414,7 @@ int by_pro(const FrWgradArgs& a, hipStream_t st) {
     case FR_PRO_BN: return launch<W, ROWS, NIMG, NW, FR_PRO_BN, S2, RK>(a, st);
     case FR_PRO_PRELU: return launch<W, ROWS, NIMG, NW, FR_PRO_PRELU, S2, RK>(a, st);
   }
-  return -1;
+  FR_UNSUPPORTED("fr_conv_wgrad_strip: unknown prologue");
 }
 
 // FRHIP_WGRAD_ROWK=0: the 28x28 / 14x14 instances without the row-aligned K layout (A/B switch)

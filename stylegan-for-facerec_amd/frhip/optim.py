@@ -145,7 +145,7 @@ class Adam(torch.optim.Optimizer):
     def _build(self):
         for group in self.param_groups:  # a loaded state dict may carry settings this kernel does not implement
             if group.get("dampening", 0) != 0 or group.get("nesterov", False) or group.get("maximize", False):
-                raise NotImplementedError("frhip.optim.SGD: dampening / nesterov / maximize are not implemented")
+                raise NotImplementedError("frhip.optim.Adam: dampening / nesterov / maximize are not implemented")
         chunk = _lib.lib.fr_sgd_chunk_elems()
         self._tables = []
         for gi, group in enumerate(self.param_groups):

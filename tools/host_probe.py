@@ -1,20 +1,80 @@
 #!/usr/bin/env python3
-"""How long does the host take to ENQUEUE one training step (no device sync inside the loop)?"""
-import os, sys, time
+"""Where is the host relative to the GPU inside one training step?  For every phase boundary of the bench.py step
+(forward enqueued, head + loss, zero_grad, backward enqueued, optimizer) prints the host time at which the boundary was
+reached and the GPU time at which the work enqueued up to there finished (HIP events): a boundary where host >= GPU is a
+place where the GPU idles waiting for launches.
+
+    python tools/host_probe.py
+"""
+import os
+import sys
+import time
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "stylegan-for-facerec_amd"))
-import torch
-import bench
-class A: batch=256; classes=7000; dtype="bf16"; model="IR_50"
-dev = torch.device("cuda", 0)
-model, head, loss_fn, opt, x, y = bench.build_job(A, dev, 0)
-step = bench.make_step(model, head, loss_fn, opt, None)
-for _ in range(5): step(x, y)
-torch.cuda.synchronize()
-for rep in range(3):
-    t0 = time.perf_counter()
-    for _ in range(10): step(x, y)
-    t1 = time.perf_counter()
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "stylegan-for-facerec_amd"))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import argparse  # noqa: E402
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from frhip import functional as FRF  # noqa: E402
+from util.utils import accuracy  # noqa: E402
+
+
+def main():
+    args = argparse.Namespace(model="IR_50", head="ArcFace", classes=7000, batch=256, dtype="bf16", sharded_head=False,
+                              resident_batches=4)
+    dev = torch.device("cuda", 0)
+    model, head, loss_fn, opt, xs, ys = bench.build_job(args, dev, 0)
+    FRF.CHECK_LABELS = False
+    names = ["forward", "head", "loss", "accuracy", "zero_grad", "backward", "opt.step"]
+
+    def step(x, y, rec=None):
+        def mark():
+            if rec is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                rec.append((time.perf_counter(), ev))
+        mark()
+        feats = model(x)
+        mark()
+        logits = head(feats, y)
+        mark()
+        loss, _ = loss_fn(logits, y)
+        mark()
+        accuracy(logits.data, y, topk=(1, 5))
+        mark()
+        opt.zero_grad(set_to_none=False)
+        mark()
+        loss.backward()
+        mark()
+        opt.step()
+        mark()
+
+    for i in range(6):
+        step(xs[i % 4], ys[i % 4])
     torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    print("enqueue %.2f ms/step, total %.2f ms/step" % ((t1 - t0) * 100, (t2 - t0) * 100))
+    t_host0 = time.perf_counter()
+    for rep in range(3):
+        step(xs[rep % 4], ys[rep % 4])  # steady state: the host runs ahead
+    recs = []
+    for rep in range(3):
+        r = []
+        step(xs[rep % 4], ys[rep % 4], r)
+        recs.append(r)
+    torch.cuda.synchronize()
+    base_t, base_ev = recs[0][0]
+    print("phase boundary     host reached (ms)   GPU reached (ms)   host lead (ms)   [times relative to the first boundary]")
+    for r in recs:
+        for k, (t, ev) in enumerate(r):
+            th = (t - base_t) * 1e3
+            tg = base_ev.elapsed_time(ev)
+            # GPU times are relative to the GPU reaching the first boundary; the host reached it `lead0` earlier
+            print("  %-14s %12.3f %18.3f" % ("start" if k == 0 else names[k - 1], th, tg))
+        print("  --")
+
+
+if __name__ == "__main__":
+    main()
