@@ -459,7 +459,7 @@ OTHER_CONFIGS = (
 
 def run_other_config(label, spec, args, device, rank, world, peak, steps=10, warmup=4):
     import gc
-    a = argparse.Namespace(dtype=args.dtype, sharded_head=False, resident_batches=4, **spec)
+    a = argparse.Namespace(dtype=args.dtype, sharded_head=False, resident_batches=warmup + steps, **spec)  # a new batch every step
     model, head, loss_fn, opt, xs, ys = build_job(a, device, rank)
     dp = None
     if world > 1:

@@ -13,7 +13,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     prof, pmc, dst = (os.path.join(REPO, "gpurun_out", "prof_" + tag), os.path.join(REPO, "gpurun_out", "pmc_" + tag),
                       os.path.join(REPO, "profiles"))
     pairs = [(os.path.join(prof, "bench.json"), tag + "_bench.json"),
@@ -26,7 +26,12 @@ def main():
              (os.path.join(pmc, "summary.txt"), tag + "_pmc_kernels.txt"),
              (os.path.join(pmc, "f", "f_counter_collection.csv"), tag + "_pmc_fetch_size_counters.csv"),
              (os.path.join(pmc, "w", "w_counter_collection.csv"), tag + "_pmc_write_size_counters.csv"),
-             (os.path.join(pmc, "s", "s_counter_collection.csv"), tag + "_pmc_sq_counters.csv")]
+             (os.path.join(pmc, "s", "s_counter_collection.csv"), tag + "_pmc_sq_counters.csv"),
+             (os.path.join(pmc, "i", "i_counter_collection.csv"), tag + "_pmc_inst_mix_counters.csv"),
+             (os.path.join(prof, "clocks.txt"), tag + "_clocks.txt"),
+             (os.path.join(prof, "bench_200.json"), tag + "_bench_200_steps.json"),
+             (os.path.join(prof, "timeline_two.txt"), tag + "_timeline_two_streams.txt"),
+             (os.path.join(prof, "timeline_single.txt"), tag + "_timeline_single_stream.txt")]
     for src, name in pairs:
         if os.path.exists(src):
             shutil.copyfile(src, os.path.join(dst, name))
@@ -42,7 +47,8 @@ def main():
                           "CYCLES counts 16 cycles per v_mfma_f32_16x16x32_bf16 summed over all SIMDs; GRBM_GUI_ACTIVE is summed "
                           "over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)",
                "kernels": [{k: r.get(k) for k in ("kernel", "ms_event_timed", "tflops", "frac_mfma_peak", "mfma_util",
-                                                  "wait_any", "wait_inst", "wait_lds", "active", "hbm_GBps",
+                                                  "wait_any", "wait_inst", "wait_lds", "active", "valu_per_mfma", "lds_per_mfma",
+                                                  "vmem_per_mfma", "hbm_GBps",
                                                   "traffic_over_algorithmic", "x_hbm_floor")} for r in d["kernels"]]}
         with open(os.path.join(dst, tag + "_mfma_util.json"), "w") as f:
             json.dump(out, f, indent=1)
