@@ -234,6 +234,15 @@ typedef struct FrBnBwdArgs {
   int32_t add_kind;
   int32_t H, W, add_stride; /* geometry of gx for add_kind 2 */
   int32_t nblocks;
+  /* fr_bn_bwd_apply only, optional (ABI v2; bf16, add_kind 1, no se / slope, else refused): gx is at the same time the
+   * upstream gradient of the NEXT BatchNorm of the backward pass (BN2 of the unit in front, model_irse.py:60), whose
+   * input is nx.  The launch then also writes that BatchNorm's backward partial sums, npart[nblocks][3][C] =
+   * (sum gx, sum gx * (nx - nmean) * ninvstd, 0) formed from the ROUNDED gx exactly as fr_bn_bwd_reduce (same nblocks)
+   * would -- one pass over gx and one launch less per residual unit. */
+  const void* nx;
+  const float* nmean;
+  const float* ninvstd;
+  float* npart;
 } FrBnBwdArgs;
 int fr_bn_bwd_reduce(const FrBnBwdArgs* args, int dtype, void* stream);
 int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream);

@@ -605,8 +605,9 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_reduce_lean_kernel(const FrBnBwd
   block_col_reduce<3, LV>(acc, red, p.part + (size_t)blockIdx.x * 3 * C, C, cpr, tid);
 }
 
-template <bool ADD, bool SE = false>
+template <bool ADD, bool SE = false, bool NEXT = false>
 __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdArgs p) {
+  __shared__ float red[NEXT ? NT * 3 * LV : 1];
   const int C = p.C, cpr = C / LV, tid = threadIdx.x;
   const int cc = tid % cpr, rt = tid / cpr, rtc = NT / cpr, c0 = cc * LV;
   const bf16_t* __restrict__ g = reinterpret_cast<const bf16_t*>(p.g) + c0;
@@ -622,9 +623,19 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdA
     a[j] = p.s0[c0 + j] * p.inv_count;
     bb[j] = p.s1[c0 + j] * p.inv_count;
   }
+  // NEXT: the backward sums of the BatchNorm in front (input nx), formed from the rounded gx in the order
+  // bn_bwd_reduce_lean_kernel<false, false> uses (same rows per thread, same block reduction): bit-identical partial rows
+  const bf16_t* __restrict__ nx = NEXT ? reinterpret_cast<const bf16_t*>(p.nx) + c0 : nullptr;
+  float nmu[LV], nis[LV], nacc[3][LV];
+#pragma unroll
+  for (int j = 0; j < LV; ++j) {
+    nmu[j] = NEXT ? p.nmean[c0 + j] : 0.f;
+    nis[j] = NEXT ? p.ninvstd[c0 + j] : 0.f;
+    nacc[0][j] = nacc[1][j] = nacc[2][j] = 0.f;
+  }
   const int nrows = (int)p.rows, rstep = gridDim.x * rtc * LUNRB;
   for (int r0 = blockIdx.x * rtc * LUNRB + rt; r0 < nrows; r0 += rstep) {
-    uint2 gr[LUNRB], xr[LUNRB], er[LUNRB];
+    uint2 gr[LUNRB], xr[LUNRB], er[LUNRB], nr[LUNRB];
 #pragma unroll
     for (int u = 0; u < LUNRB; ++u) {
       const int r = r0 + u * rtc;
@@ -632,6 +643,7 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdA
         gr[u] = ld8(g + (size_t)r * C);
         xr[u] = ld8(x + (size_t)r * C);
         if (ADD) er[u] = ld8(add + (size_t)r * C);
+        if (NEXT) nr[u] = ld8(nx + (size_t)r * C);
       }
     }
 #pragma unroll
@@ -648,10 +660,22 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdA
           o[j] = coef[j] * (gv[j] - a[j] - (xv[j] - mu[j]) * is[j] * bb[j]);
           if (ADD) o[j] += e[j];
         }
-        *reinterpret_cast<uint2*>(gx + (size_t)r * C) = pack4bf(o);
+        const uint2 packed = pack4bf(o);
+        *reinterpret_cast<uint2*>(gx + (size_t)r * C) = packed;
+        if (NEXT) {
+          float ov[LV], nv[LV];
+          unpack4bf(packed, ov);
+          unpack4bf(nr[u], nv);
+#pragma unroll
+          for (int j = 0; j < LV; ++j) {
+            nacc[0][j] += ov[j];
+            nacc[1][j] = fmaf(ov[j], (nv[j] - nmu[j]) * nis[j], nacc[1][j]);
+          }
+        }
       }
     }
   }
+  if (NEXT) block_col_reduce<3, LV>(nacc, red, p.npart + (size_t)blockIdx.x * 3 * C, C, cpr, tid);
 }
 
 // ------------------------------------------------------------------------------------------ SE
@@ -1171,6 +1195,13 @@ extern "C" int fr_bn_bwd_reduce(const FrBnBwdArgs* args, int dtype, void* stream
 extern "C" int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream) {
   if (!chan_ok(args->C, dtype)) FR_UNSUPPORTED("fr_bn_bwd_apply: unsupported channel count");
   hipStream_t st = (hipStream_t)stream;
+  if (args->nx) {  // + the backward sums of the BatchNorm in front: the plain bf16 residual case only
+    if (!(dtype == FR_BF16 && lean_ok(args->C) && !args->slope && !args->se && args->add_kind == 1 &&
+          args->rows < (1ll << 31) && args->nmean && args->ninvstd && args->npart))
+      FR_UNSUPPORTED("fr_bn_bwd_apply: nx / nmean / ninvstd / npart need bf16, add_kind 1, no se / slope");
+    hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<true, false, true>), dim3(args->nblocks), dim3(NT), 0, st, *args);
+    FR_LAUNCH_CHECK();
+  }
   if (dtype == FR_BF16 && lean_ok(args->C) && !args->slope && args->add_kind != 2 && args->rows < (1ll << 31)) {
     const dim3 grid(args->nblocks), blk(NT);
     if (args->se) {

@@ -261,6 +261,11 @@ class BackbonePlan(object):
         # deferred slab sums (FrWgradArgs.defer / prev_*): a weight-gradient launch that supports it leaves the sum of its
         # slabs to the NEXT such launch of the side stream (two slab buffers alternate); fr_reduce_slabs flushes the last
         self.defer_slabs = os.environ.get("FRHIP_NO_DEFER_SLABS", "0") != "1"
+        # FrBnBwdArgs.nx: the kernel that writes a unit's input gradient also forms the BN2-backward sums of the unit in
+        # front.  Bit-identical, one pass + one launch less per unit -- and 0.04 ms SLOWER per step (16.45 vs 16.41 ms, three
+        # A/B pairs on one box): the fused kernel needs 80 registers and runs one wave per SIMD beside the weight
+        # gradients where the two separate kernels run two.  Opt-in.
+        self.fuse_bn_sums = os.environ.get("FRHIP_FUSED_BN_SUMS", "0") == "1"
         self.slab2, self._slab2_users, self._slab_flip = None, [], 0
         self._pending = None  # (launch that wrote the slabs, groups, n, dw tensor, parameter)
         self.part_slope = None  # per-buffer-set partial rows of the PReLU slope gradient (side-stream reduction)
@@ -856,6 +861,7 @@ class BackbonePlan(object):
         B, st, fr = self.B, self.stream, self.fr
         # ---- residual units in reverse
         unit_done = {}  # unit index -> event recorded on the side stream after its weight gradients
+        fused_sums = -1  # unit whose BN2-backward partial sums the previous unit's last kernel has already written
         for i in range(len(self.units) - 1, -1, -1):
             u, d = self.units[i], self.ubuf[i]
             x = self.ubuf[i - 1]["out"] if i > 0 else self.z0
@@ -885,7 +891,8 @@ class BackbonePlan(object):
             db, dg = self._bn_grads(bn2)
             common = dict(g=g_out, x=d["y2"], mean=bn2.mean, invstd=bn2.invstd, rows=rout, C=u.depth,
                           rows_per_image=HWo, nblocks=nb, **se_kw)
-            L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
+            if fused_sums != i:  # else: the kernel that wrote g_out has left these partial rows in self.part already
+                L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
             self._reduce(L, nb, 3, u.depth, db, dg)
             s0, s1 = self._s01(bn2, db, dg)
             L.append(ops.bn_bwd_apply(st, fr, gx=g_y2, gamma=u.bn2.weight, s0=s0, s1=s1, inv_count=1.0 / rout,
@@ -981,6 +988,13 @@ class BackbonePlan(object):
                 kw.update(add=g_xS, add_kind=2, H=u.H, W=u.H, add_stride=u.stride)
             elif u.stride == 1:
                 kw.update(add=g_out, add_kind=1)
+                # g_x is the upstream gradient of BN2 of the unit in front: form its backward sums here (one pass over
+                # g_x and one launch less per unit; bit-identical partial rows, FrBnBwdArgs.nx).  bf16, no SE there.
+                if (self.fuse_bn_sums and i > 0 and fr == FR_BF16 and self.units[i - 1].se is None and u.se is None
+                        and u.cin % 4 == 0 and 256 % (u.cin // 4) == 0 and self.units[i - 1].depth == u.cin):
+                    pb = self.ubuf[i - 1]["bn2"]
+                    kw.update(nx=self.ubuf[i - 1]["y2"], nmean=pb.mean, ninvstd=pb.invstd, npart=self.part)
+                    fused_sums = i - 1
             else:
                 kw.update(add=g_out, add_kind=2, H=u.H, W=u.H, add_stride=u.stride)
             L.append(ops.bn_bwd_apply(st, fr, **kw))

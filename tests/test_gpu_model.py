@@ -1353,3 +1353,43 @@ def test_freeze_then_unfreeze_from_a_stage2_checkpoint(tmp_path, ranks):
     ref.load_state_dict(e2, strict=True)
     h = torch.load(_ckpt(model_dir, "Head_ArcFace_Epoch_2_Batch_12_"), map_location="cpu")
     assert list(h.keys()) == ["weight"] and tuple(h["weight"].shape) == (12, 512) and torch.isfinite(h["weight"]).all()
+
+
+def test_fused_bn_backward_sums_are_bit_identical():
+    """FrBnBwdArgs.nx (round 3): the kernel that writes a unit's input gradient also forms the backward sums of the
+    BatchNorm in front of it (BN2 of the previous unit, reference model_irse.py:60) from the ROUNDED gradient, in the order
+    fr_bn_bwd_reduce uses -- one pass and one launch less per residual unit, and every parameter gradient of a bf16
+    IR-50 step bit for bit what the separate launches give.  (Opt-in, FRHIP_FUSED_BN_SUMS=1: measured 0.04 ms slower per
+    step beside the weight-gradient kernels, engine.py.)"""
+    _need_gpu()
+    from backbone.model_irse import IR_50
+    from head.metrics import ArcFace
+    from loss.focal import FocalLoss
+
+    def run(fuse):
+        os.environ["FRHIP_FUSED_BN_SUMS"] = fuse
+        try:
+            m = IR_50([112, 112])
+            synth.fill_state_dict(m.state_dict(), 15)
+            m.output_layer[1].p = 0.0
+            m.compute_dtype = torch.bfloat16
+            m = m.cuda().train()
+            head = ArcFace(512, 100, None).cuda()
+            with torch.no_grad():
+                head.weight.copy_(synth.uniform(16, "full.head", (100, 512), -0.1, 0.1))
+            x = synth.uniform(16, "full.x", (6, 3, 112, 112)).cuda()
+            y = synth.labels(16, "full.label", 6, 100).cuda()
+            loss, _ = FocalLoss()(head(m(x), y), y)
+            loss.backward()
+            torch.cuda.synchronize()
+            plan = m._runner[0].plan
+            n_reduce = sum(getattr(l, "name", "") == "fr_bn_bwd_reduce" for l in plan.bwd_list)
+            return {n: p.grad.detach().clone() for n, p in m.named_parameters()}, n_reduce
+        finally:
+            os.environ.pop("FRHIP_FUSED_BN_SUMS")
+
+    fused, n_fused = run("1")
+    plain, n_plain = run("0")
+    assert n_plain - n_fused == 20, (n_plain, n_fused)  # every unit behind a stride-1 identity unit: 24 - 4 stage heads
+    bad = [n for n in plain if not torch.equal(plain[n], fused[n])]
+    assert not bad, bad[:5]
