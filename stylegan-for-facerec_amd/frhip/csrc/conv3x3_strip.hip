@@ -531,6 +531,12 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
   // 256 -> 256 @14 (half of all FLOPs): 8 waves x (13 x 2) accumulator tiles on the whole image.  Measured and rejected
   // at B=256 (tools/kbench.py): 4-wave half-height strips 0.101 ms, the same with the channels split over two
   // workgroups (NSPL = 2, no spills) 0.093 ms, 8 waves x (7 x 4) tiles 0.114 ms (spills) -- against 0.062 ms here.
+  // Round 3: two 4-wave workgroups per image and CU (<256, 128, 14, 14, 4, 4, 2, 1, 2>: 128 output channels each, 128
+  // input channels resident at a time, 77 KB of LDS, so that one's strip load / epilogue overlaps the other's MFMAs):
+  // 0.068 / 0.071 / 0.075 ms (forward BN / forward PReLU / data gradient) against 0.057 / 0.061 / 0.064 -- the strip is
+  // loaded and its prologue applied twice per image, 176-200 B of scratch; a 9-deep fragment ring here: 0.0623 vs 0.0596
+  // (256 registers + scratch); a 6-deep one over two channel chunks per trip: 84 B of scratch; s_setprio 1 for the younger
+  // half of the waves: no effect.  None instantiated.
   // small batches (fewer whole-image workgroups than CUs): split the output channels over two workgroups per image
   // (measured at B = 128: 0.034 instead of 0.049 ms per launch -- IR-SE-101 trains at 128 images per GPU)
   if (a.SC == 256 && a.N == 256 && a.SW == 14 && small_batch(a.B)) return by_pro<256, 128, 14, 14, 8, 8, 2>(a, st);
