@@ -112,6 +112,9 @@ __device__ __forceinline__ uint32_t pro2(uint32_t u, float a0, float b0, float a
 #ifdef FRHIP_STAMPS
 __device__ unsigned long long* fr_stamp_buf_wgr = nullptr;
 #define TSTAMP() __builtin_amdgcn_s_memtime()
+// one region of 4096 workgroups x 16 qwords per width (14, 28, 56, 112), so that a whole training step leaves the stamps
+// of the LAST launch of every width
+#define STAMP_SLOT(W) ((size_t)((W) == 14 ? 0 : (W) == 28 ? 1 : (W) == 56 ? 2 : 3) * 4096 * 16 + (size_t)blockIdx.x * 16)
 #define LDS_FENCE_BARRIER()                         \
   do {                                              \
     const unsigned long long t0__ = TSTAMP();       \
@@ -160,16 +163,20 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
   // Deferred slab sum of the PREVIOUS weight-gradient launch of this stream (FrWgradArgs.prev_*): every workgroup adds its
   // share of that launch's slabs in the fixed order g = 0, 1, ... while its own first tiles are in flight -- the sum no
   // longer costs a launch (and a trip of 2 x groups x |dW| bytes through a kernel of its own).
-  auto fold_prev = [&]() {
+  // The computing waves (tid < 256; their accumulator registers are not live yet) take two thirds of this workgroup's
+  // share with two elements per thread and pass, the data-moving waves one third with one element, squeezed in between
+  // their first two tile requests -- one memory round trip for the whole sum at every shape of the step (three sequential
+  // ones cost 8.5-9.9 us per launch in situ, tools/stamps_step.py).
+  auto fold_prev = [&](bool movers) {
     const long long n4 = p.prev_n >> 2;
     const long long per = (n4 + gridDim.x - 1) / gridDim.x;
     const long long e0 = (long long)blockIdx.x * per;
     long long e1 = e0 + per;
     if (e1 > n4) e1 = n4;
-    // computing waves only (tid < 256): at this point their accumulator registers are free, while a batch of 16-byte
-    // loads on top of the two register sets of a data-moving wave would set the kernel's register allocation -- and every
-    // register this kernel does not take is one a co-resident BatchNorm wave of the main stream can use
-    if (e0 < e1) slab_sum_range<256>(p.prev_slab, p.prev_groups, n4, e0, e1, p.prev_dw, tid);
+    if (e0 >= e1) return;
+    const long long cut = e0 + ((e1 - e0) * 2 + 2) / 3;  // [e0, cut): computing waves, [cut, e1): data-moving waves
+    if (!movers) slab_sum_range<256, 2>(p.prev_slab, p.prev_groups, n4, e0, cut, p.prev_dw, tid);
+    else if (cut < e1) slab_sum_range<256, 1>(p.prev_slab, p.prev_groups, n4, cut, e1, p.prev_dw, tid - 256);
   };
 
   if (wave >= 4) {
@@ -258,11 +265,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
 
     char* const buf0 = smem;
     char* const buf1 = smem + L::BUF0;
-    if (nimg == 0) return;  // (never with the group counts the host computes; both roles then skip every barrier)
+    if (nimg == 0) {  // (never with the group counts the host computes; both roles then skip every barrier)
+      if (p.prev_n) fold_prev(true);
+      return;
+    }
     if constexpr (NPH == 2) {
       // 14x14: phase kind == buffer.  set0 <-> (phase 0, buf0), set1 <-> (phase 1, buf1)
       Set s0, s1;
       issue(s0, b_begin, std::integral_constant<int, 0>{});
+      if (p.prev_n) fold_prev(true);
+      __builtin_amdgcn_sched_barrier(0);
       issue(s1, b_begin, std::integral_constant<int, 1>{});
       commit(s0, buf0, std::integral_constant<int, 0>{});
       {
@@ -293,8 +305,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
       }
 #ifdef FRHIP_STAMPS
       if (tid == 256 && fr_stamp_buf_wgr) {
-        fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 3] = bar_wait;
-        fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 4] = TSTAMP() - t_loop;
+        fr_stamp_buf_wgr[STAMP_SLOT(W) + 3] = bar_wait;
+        fr_stamp_buf_wgr[STAMP_SLOT(W) + 4] = TSTAMP() - t_loop;
       }
 #endif
     } else {
@@ -369,6 +381,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
       Set s0, s1;
       const int fl = b_end - 1;  // requests past the run are clamped to its last phase and never read
       issue(s0, b_begin);
+      if (p.prev_n) fold_prev(true);
+      __builtin_amdgcn_sched_barrier(0);
       issue(s1, b_begin + 1 < b_end ? b_begin + 1 : fl);
       commit(s0, buf0);
       __builtin_amdgcn_sched_barrier(0);
@@ -396,8 +410,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
       }
 #ifdef FRHIP_STAMPS
       if (tid == 256 && fr_stamp_buf_wgr) {
-        fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 3] = bar_wait;
-        fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 4] = TSTAMP() - t_loop;
+        fr_stamp_buf_wgr[STAMP_SLOT(W) + 3] = bar_wait;
+        fr_stamp_buf_wgr[STAMP_SLOT(W) + 4] = TSTAMP() - t_loop;
       }
 #endif
     }
@@ -409,13 +423,23 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
   const int li = lane & 15, lq = lane >> 4;
   const int colb = (4 * (li & 3)) * 2;  // byte offset of this lane's 4-channel group inside a 16-channel tile
   const int lrow = (4 * lq + (li >> 2)) * TSTR;
+#ifdef FRHIP_STAMPS
+  const unsigned long long t_zero = TSTAMP();
+#endif
+  if (p.prev_n) fold_prev(false);  // before the accumulators exist: the sum may use their registers
+  __builtin_amdgcn_sched_barrier(0);
   f32x4 acc[4][9];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[t][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  if (p.prev_n) fold_prev();
+#ifdef FRHIP_STAMPS
+  const unsigned long long t_fold = TSTAMP();
+  if (tid == 0 && fr_stamp_buf_wgr) {
+    fr_stamp_buf_wgr[STAMP_SLOT(W) + 8] = t_zero - t_start;   // LDS zero fill
+    fr_stamp_buf_wgr[STAMP_SLOT(W) + 9] = t_fold - t_zero;    // slab sum of the previous launch
+  }
+#endif
   if (nimg > 0) {
     const char* const gb0 = smem + lrow + colb;
     const char* const ab0 = smem + L::g_bytes(0) + lrow + (wci * 16) * 2 + colb;
@@ -481,6 +505,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
 #ifdef FRHIP_STAMPS
     const unsigned long long t_loop = TSTAMP();
     bar_wait = 0;
+    if (tid == 0 && fr_stamp_buf_wgr)
+      fr_stamp_buf_wgr[STAMP_SLOT(W) + 10] = t_loop - t_fold;  // wait for the first tiles
 #endif
 #pragma unroll
     for (int t = 0; t < 4; ++t) gf[t] = g_frag(gb0, 0, t);
@@ -504,9 +530,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
     }
 #ifdef FRHIP_STAMPS
     if (tid == 0 && fr_stamp_buf_wgr) {
-      fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 1] = TSTAMP() - t_loop;
-      fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 2] = bar_wait;
-      fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 6] = nimg;
+      fr_stamp_buf_wgr[STAMP_SLOT(W) + 1] = TSTAMP() - t_loop;
+      fr_stamp_buf_wgr[STAMP_SLOT(W) + 2] = bar_wait;
+      fr_stamp_buf_wgr[STAMP_SLOT(W) + 6] = nimg;
     }
 #endif
   }
@@ -525,8 +551,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
       }
 #ifdef FRHIP_STAMPS
   if (tid == 0 && fr_stamp_buf_wgr) {
-    fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 0] = TSTAMP() - t_start;
-    fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime() - rt_start;
+    fr_stamp_buf_wgr[STAMP_SLOT(W) + 0] = TSTAMP() - t_start;
+    fr_stamp_buf_wgr[STAMP_SLOT(W) + 5] = __builtin_amdgcn_s_memrealtime() - rt_start;
   }
 #endif
 }
@@ -581,12 +607,28 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_vr_kernel(const FrWgradArgs
   for (int idx = tid; idx < C::LDS / 16; idx += 512) st16(smem + idx * 16, zero16());
   __syncthreads();
 
+  // deferred slab sum of the previous launch, split between the wave roles (see conv_wgrad_roll_kernel)
+  auto fold_prev = [&](bool movers) {
+    const long long n4 = p.prev_n >> 2;
+    const long long perw = (n4 + gridDim.x - 1) / gridDim.x;
+    const long long e0 = (long long)blockIdx.x * perw;
+    long long e1 = e0 + perw;
+    if (e1 > n4) e1 = n4;
+    if (e0 >= e1) return;
+    const long long cut = e0 + ((e1 - e0) * 2 + 2) / 3;
+    if (!movers) slab_sum_range<256, 2>(p.prev_slab, p.prev_groups, n4, e0, cut, p.prev_dw, tid);
+    else if (cut < e1) slab_sum_range<256, 1>(p.prev_slab, p.prev_groups, n4, cut, e1, p.prev_dw, tid - 256);
+  };
+
   if (wave >= 4) {
     // ------------------------------------------------------------------------------------------- data-moving waves
 #ifdef ROLL_LOADER_PRIO
     __builtin_amdgcn_s_setprio(ROLL_LOADER_PRIO);
 #endif
-    if (nph == 0) return;
+    if (nph == 0) {
+      if (p.prev_n) fold_prev(true);
+      return;
+    }
     const int lt = tid - 256;
     const int ch = lt & 7;
     const char* __restrict__ G = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(p.g) + cot * CT);
@@ -659,15 +701,18 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_vr_kernel(const FrWgradArgs
     };
     // phase j (relative to the run) = virtual row v_begin + j: g slot j & 1, input rows j-1, j, j+1 in slots j, j+1, j+2 (mod 4)
     {
-      Row t;
-      issue_a(t, v_begin - 1);
-      commit_a(t, 0);
-      issue_a(t, v_begin);
-      commit_a(t, 1);
-      issue_a(t, v_begin + 1);
-      commit_a(t, 2);
-      issue_g(t, v_begin);
-      commit_g(t, 0);
+      // the three input rows and the g row of phase 0 in ONE round trip, the slab sum's loads queued behind them
+      Row t0, t1, t2, tg;
+      issue_a(t0, v_begin - 1);
+      issue_a(t1, v_begin);
+      issue_a(t2, v_begin + 1);
+      issue_g(tg, v_begin);
+      if (p.prev_n) fold_prev(true);
+      __builtin_amdgcn_sched_barrier(0);
+      commit_a(t0, 0);
+      commit_a(t1, 1);
+      commit_a(t2, 2);
+      commit_g(tg, 0);
     }
     Row a0, g0, a1, g1;  // set 0: rows for the commits of even phases, set 1: odd phases
     issue_a(a0, v_begin + 2);
@@ -699,8 +744,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_vr_kernel(const FrWgradArgs
     }
 #ifdef FRHIP_STAMPS
     if (tid == 256 && fr_stamp_buf_wgr) {
-      fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 3] = bar_wait;
-      fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 4] = TSTAMP() - t_loop;
+      fr_stamp_buf_wgr[STAMP_SLOT(W) + 3] = bar_wait;
+      fr_stamp_buf_wgr[STAMP_SLOT(W) + 4] = TSTAMP() - t_loop;
     }
 #endif
     return;
@@ -711,20 +756,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_vr_kernel(const FrWgradArgs
   const int li = lane & 15, lq = lane >> 4;
   const int colb = (4 * (li & 3)) * 2;
   const int lrow = (4 * lq + (li >> 2)) * TSTR;
+
+  if (p.prev_n) fold_prev(false);
+  __builtin_amdgcn_sched_barrier(0);
   f32x4 acc[4][9];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[t][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  if (p.prev_n) {
-    const long long n4 = p.prev_n >> 2;
-    const long long perw = (n4 + gridDim.x - 1) / gridDim.x;
-    const long long e0 = (long long)blockIdx.x * perw;
-    long long e1 = e0 + perw;
-    if (e1 > n4) e1 = n4;
-    if (e0 < e1) slab_sum_range<256>(p.prev_slab, p.prev_groups, n4, e0, e1, p.prev_dw, tid);
-  }
   if (nph > 0) {
     const char* const gbase = smem + lrow + colb;
     const char* const abase = smem + C::A_OFF + lrow + (wci * 16) * 2 + colb;
@@ -794,9 +833,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_vr_kernel(const FrWgradArgs
     }
 #ifdef FRHIP_STAMPS
     if (tid == 0 && fr_stamp_buf_wgr) {
-      fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 1] = TSTAMP() - t_loop;
-      fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 2] = bar_wait;
-      fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 6] = nph;
+      fr_stamp_buf_wgr[STAMP_SLOT(W) + 1] = TSTAMP() - t_loop;
+      fr_stamp_buf_wgr[STAMP_SLOT(W) + 2] = bar_wait;
+      fr_stamp_buf_wgr[STAMP_SLOT(W) + 6] = nph;
     }
 #endif
   }
@@ -814,8 +853,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_vr_kernel(const FrWgradArgs
       }
 #ifdef FRHIP_STAMPS
   if (tid == 0 && fr_stamp_buf_wgr) {
-    fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 0] = TSTAMP() - t_start;
-    fr_stamp_buf_wgr[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime() - rt_start;
+    fr_stamp_buf_wgr[STAMP_SLOT(W) + 0] = TSTAMP() - t_start;
+    fr_stamp_buf_wgr[STAMP_SLOT(W) + 5] = __builtin_amdgcn_s_memrealtime() - rt_start;
   }
 #endif
 }

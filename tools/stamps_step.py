@@ -30,26 +30,35 @@ def main():
     for i in range(8):
         step(xs[i % 4], ys[i % 4])
     torch.cuda.synchronize()
-    buf = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(4 * 4096 * 16, dtype=torch.int64, device="cuda")
     dbg = ctypes.CDLL(_lib.LIB_PATH)
     dbg.fr_debug_set_stamp_buffer_wgr.argtypes = [ctypes.c_void_p]
     assert dbg.fr_debug_set_stamp_buffer_wgr(ctypes.c_void_p(buf.data_ptr())) == 0
     for i in range(3):
         step(xs[i % 4], ys[i % 4])
     torch.cuda.synchronize()
-    s = buf.cpu().numpy().reshape(-1, 8)
-    s = s[s[:, 6] != 0].astype(np.float64)
-    nimg = s[:, 6]
-    mhz = np.median(s[:, 0] / (s[:, 5] * 10e-9)) / 1e6
+    raw = buf.cpu().numpy().reshape(4, 4096, 16)
     med = lambda v: float(np.median(v))  # noqa: E731
-    print("last warp-specialised wgrad launch of the step: %d workgroups, %d images each, in-kernel clock %.0f MHz"
-          % (len(s), int(nimg[0]), mhz))
-    print("  kernel (per workgroup)  median %7.0f cycles = %6.2f us   p90 %6.2f us" % (
-        med(s[:, 0]), med(s[:, 0]) / mhz, float(np.percentile(s[:, 0], 90)) / mhz))
-    print("  image loop              %7.0f cycles = %6.2f us = %6.0f cycles per image" % (
-        med(s[:, 1]), med(s[:, 1]) / mhz, med(s[:, 1] / nimg)))
-    print("  computing wave waits in barriers   %4.1f %% of the loop" % (100 * med(s[:, 2] / s[:, 1])))
-    print("  data-moving wave waits in barriers %4.1f %% of its loop" % (100 * med(s[:, 3] / np.maximum(s[:, 4], 1))))
+    for region, W in enumerate((14, 28, 56, 112)):
+        s = raw[region]
+        s = s[s[:, 6] != 0].astype(np.float64)
+        if not len(s):
+            continue
+        nimg = s[:, 6]
+        mhz = np.median(s[:, 0] / (s[:, 5] * 10e-9)) / 1e6
+        print("last %dx%d weight-gradient launch of the step: %d workgroups, %d images / phases each, in-kernel clock %.0f MHz"
+              % (W, W, len(s), int(nimg[0]), mhz))
+        print("  kernel (per workgroup)  median %7.0f cycles = %6.2f us   p90 %6.2f us" % (
+            med(s[:, 0]), med(s[:, 0]) / mhz, float(np.percentile(s[:, 0], 90)) / mhz))
+        print("  loop                    %7.0f cycles = %6.2f us = %6.0f cycles per image / phase" % (
+            med(s[:, 1]), med(s[:, 1]) / mhz, med(s[:, 1] / nimg)))
+        if s[:, 8].any():
+            print("  before the loop (wave 0): LDS zero fill %.2f us, previous launch's slab sum %.2f us, wait for the first "
+                  "tiles %.2f us; after the loop (slab store) %.2f us" % (
+                      med(s[:, 8]) / mhz, med(s[:, 9]) / mhz, med(s[:, 10]) / mhz,
+                      med(s[:, 0] - s[:, 1] - s[:, 8] - s[:, 9] - s[:, 10]) / mhz))
+        print("  computing wave waits in barriers   %4.1f %% of the loop" % (100 * med(s[:, 2] / s[:, 1])))
+        print("  data-moving wave waits in barriers %4.1f %% of its loop" % (100 * med(s[:, 3] / np.maximum(s[:, 4], 1))))
 
 
 if __name__ == "__main__":

@@ -24,7 +24,7 @@ def main():
     cout, cin, W = (int(v) for v in sys.argv[1:4])
     pro = int(sys.argv[4]) if len(sys.argv) > 4 else 2
     B = int(sys.argv[5]) if len(sys.argv) > 5 else 256
-    buf = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(4 * 4096 * 16, dtype=torch.int64, device="cuda")
     dbg = ctypes.CDLL(_lib.LIB_PATH)
     dbg.fr_debug_set_stamp_buffer_wgr.argtypes = [ctypes.c_void_p]
     for _ in range(3):  # ~2 s of back-to-back launches first: the clock the chip settles at under this load
@@ -32,7 +32,8 @@ def main():
     assert dbg.fr_debug_set_stamp_buffer_wgr(ctypes.c_void_p(buf.data_ptr())) == 0
     ms, tf = kbench.wgrad_case("wgs", cout, cin, W, B, pro=pro, iters=20)
     torch.cuda.synchronize()
-    s = buf.cpu().numpy().reshape(-1, 8)
+    region = {14: 0, 28: 1, 56: 2, 112: 3}[W]
+    s = buf.cpu().numpy().reshape(4, 4096, 16)[region]
     s = s[s[:, 6] != 0].astype(np.float64)
     nimg = s[:, 6]
     mhz = np.median(s[:, 0] / (s[:, 5] * 10e-9)) / 1e6
