@@ -359,3 +359,27 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     assert out.returncode != 0
     assert out.stderr.count("bench.py needs a ROCm GPU") >= 2, out.stderr[-3000:]
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_readiness_marks_follow_the_arena_order():
+    """engine.BackbonePlan._order_ready_marks (round 3): a deferring weight-gradient launch completes its predecessor's
+    gradient one launch late, possibly in the NEXT unit's mark.  Announcements must still walk the gradient arena front to
+    back (data-parallel buckets are contiguous arena slices): inside a mark parameters are sorted by arena position and a
+    parameter is held back until everything in front of it has been announced; a gradient that is never announced is an
+    error, not a silent hang of its bucket."""
+    from types import SimpleNamespace
+    from frhip.engine import BackbonePlan
+    from frhip._lib import FrhipError
+    ps = [torch.nn.Parameter(torch.zeros(1)) for _ in range(8)]
+    fake = SimpleNamespace(arena_slices=[(p, 64 * k, 1) for k, p in enumerate(ps)])
+    # unit A announces 0, 1, 3 (its conv1 gradient, slot 2, is still a pending slab sum); unit B's first launch completes
+    # slot 2 and B announces 4, 5, 2 in launch order; the tail announces 7, 6
+    fake.ready_marks = [(10, [ps[0], ps[1], ps[3]], "evA"), (20, [ps[4], ps[5], ps[2]], "evB"), (30, [ps[7], ps[6]], None)]
+    BackbonePlan._order_ready_marks(fake)
+    where = {id(p): k for k, p in enumerate(ps)}
+    got = [[where[id(p)] for p in params] for _end, params, _ev in fake.ready_marks]
+    assert got == [[0, 1], [2, 3, 4, 5], [6, 7]], got
+    assert [m[0] for m in fake.ready_marks] == [10, 20, 30] and [m[2] for m in fake.ready_marks] == ["evA", "evB", None]
+    fake.ready_marks = [(10, [ps[0], ps[1]], None), (20, [ps[3]], None)]
+    with pytest.raises(FrhipError):
+        BackbonePlan._order_ready_marks(fake)
