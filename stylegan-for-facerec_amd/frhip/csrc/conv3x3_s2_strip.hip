@@ -211,6 +211,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
   // (one workgroup per CU at 256 / 512 channels: nothing else hides the load latency of the four phases).
   // Only where the register budget is spent anyway: at 64 / 128 channels the 20-32 extra registers cost a resident workgroup
   // (128 -> 128 @28: 0.166 -> 0.196 ms with the prefetch).
+  // Round 3, measured again with 7-row strips (tools/ab_libs.sh, one box): the prefetch at 128 channels 0.1355 -> 0.1372 ms;
+  // two plane buffers (commit into the buffer the taps are not reading, one barrier per plane instead of two)
+  // 128 ch 0.1355 -> 0.137, 256 ch 0.1066 -> 0.118 (costs the second resident workgroup), 512 ch 0.148 -> 0.147: the plane
+  // loads are not what these kernels wait for.  4-wave workgroups at 128 channels (13 M tiles per wave, half the weight
+  // stream): 170-3000 bytes of scratch per lane in every instance.
   constexpr bool PFP = KIND == 0 && CIN >= 256;
   constexpr int NPF = (TOTAL + NTH - 1) / NTH;
   U128 pf[PFP ? NPF : 1];

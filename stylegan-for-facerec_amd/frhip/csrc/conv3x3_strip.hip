@@ -170,7 +170,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
     // (tools/stamps.py) showed the two batches of 8 of a 58-KB strip taking 5.4 us -- two HBM round trips with too
     // few bytes in flight per CU -- next to 5.6 us of MFMA loop.
     constexpr int PER = (TOTAL + NTH - 1) / NTH;
-    constexpr int UNR = (NW == 4 && PER <= 18) ? PER : 8;
+#ifndef FRHIP_STRIP_LOAD_BATCH
+#define FRHIP_STRIP_LOAD_BATCH 18
+#endif
+    constexpr int UNR = ((NW == 4 && PER <= 18) || PER <= FRHIP_STRIP_LOAD_BATCH) ? PER : 8;
     load_pro();
     for (int base = 0; base < TOTAL; base += NTH * UNR) {
       U128 v[UNR];
@@ -293,14 +296,33 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
 
     // ---------------------------------------------------------------- epilogue
     FR_STAMP(3);
+    const size_t rowbase = (size_t)(b * C::H + row0) * W;
+    // The aux tile (the PReLU input / BN input of the fused backward epilogues) is requested in ONE batch, before the
+    // barrier that ends the K loop: as a load -> wait -> LDS-store loop it cost one HBM round trip per 16 bytes of a
+    // thread (13 of them, ~7 us of a 55-us 14x14 launch); the registers are those of the dead fragment rings.
+    constexpr int NAUX = (C::M * OCH + NTH - 1) / NTH;
+    const bool has_aux = epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD || epi == FR_EPI_BIAS_RES;
+    U128 av[NAUX];
+    if (has_aux) {
+      const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
+#pragma unroll
+      for (int u = 0; u < NAUX; ++u) {
+        int idx = u * NTH + tid;
+        idx = idx < C::M * OCH ? idx : C::M * OCH - 1;  // clamp: the batch stays one basic block
+        const int r = idx / OCH, c8 = idx - r * OCH;
+        av[u] = ld16(aux + (rowbase + r) * (size_t)p.ldaux + ncol0 + c8 * 8);
+      }
+    }
     __syncthreads();  // every wave is done with the input strip; LDS is now the output tile
     FR_STAMP(4);
-    const size_t rowbase = (size_t)(b * C::H + row0) * W;
-    if (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD || epi == FR_EPI_BIAS_RES) {
-      const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
-      for (int idx = tid; idx < C::M * OCH; idx += NTH) {
-        const int r = idx / OCH, c8 = idx - r * OCH;
-        st16(smem + r * C::OSTR + c8 * 16, ld16(aux + (rowbase + r) * (size_t)p.ldaux + ncol0 + c8 * 8));
+    if (has_aux) {
+#pragma unroll
+      for (int u = 0; u < NAUX; ++u) {
+        const int idx = u * NTH + tid;
+        if (idx < C::M * OCH) {
+          const int r = idx / OCH, c8 = idx - r * OCH;
+          st16(smem + r * C::OSTR + c8 * 16, av[u]);
+        }
       }
       __syncthreads();
     }
@@ -389,9 +411,23 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
     }
     __syncthreads();
     FR_STAMP(5);
-    for (int idx = tid; idx < C::M * OCH; idx += NTH) {
-      const int r = idx / OCH, c8 = idx - r * OCH;
-      st16(out + (rowbase + r) * (size_t)p.ldc + ncol0 + c8 * 8, ld16(smem + r * C::OSTR + c8 * 16));
+    {  // all LDS reads of a thread first, then its stores (as a read -> wait -> store loop: one LDS latency per 16 bytes)
+      U128 ov[NAUX];
+#pragma unroll
+      for (int u = 0; u < NAUX; ++u) {
+        int idx = u * NTH + tid;
+        idx = idx < C::M * OCH ? idx : C::M * OCH - 1;
+        const int r = idx / OCH, c8 = idx - r * OCH;
+        ov[u] = ld16(smem + r * C::OSTR + c8 * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < NAUX; ++u) {
+        const int idx = u * NTH + tid;
+        if (idx < C::M * OCH) {
+          const int r = idx / OCH, c8 = idx - r * OCH;
+          st16(out + (rowbase + r) * (size_t)p.ldc + ncol0 + c8 * 8, ov[u]);
+        }
+      }
     }
     FR_STAMP(6);
 #ifdef FRHIP_STAMPS
