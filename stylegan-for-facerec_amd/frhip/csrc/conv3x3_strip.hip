@@ -173,7 +173,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
 #ifndef FRHIP_STRIP_LOAD_BATCH
 #define FRHIP_STRIP_LOAD_BATCH 18
 #endif
-    constexpr int UNR = ((NW == 4 && PER <= 18) || PER <= FRHIP_STRIP_LOAD_BATCH) ? PER : 8;
+    // (channel stages: the accumulators are live across the load -- one batch only beside small accumulator tiles)
+    constexpr bool ONE = (NW == 4 && PER <= 18) || (PER <= FRHIP_STRIP_LOAD_BATCH && (KSPL == 1 || C::TM * C::TN * 4 <= 64));
+    constexpr int UNR = ONE ? PER : 8;
     load_pro();
     for (int base = 0; base < TOTAL; base += NTH * UNR) {
       U128 v[UNR];
@@ -490,14 +492,15 @@ int by_pro(const FrConvArgs& a, hipStream_t st) {
 }  // namespace
 
 // Shape table.  Variant >= 1 serves the 64- and 128-channel layers with 4-wave workgroups on shorter strips so
-// that two workgroups are resident per CU and overlap each other's load / epilogue phases; variant 2 (default) adds the
-// two-images-per-workgroup instance of the 7x7 stage; FRHIP_STRIP_VARIANT=0 is the one-workgroup-per-CU table
-// (A/B switch for tools/kbench.py and bench.py).
+// that two workgroups are resident per CU and overlap each other's load / epilogue phases; variant 2 adds the
+// two-images-per-workgroup instance of the 7x7 stage, variant 3 the four-images one, variant 4 (default) the
+// one-output-tile-column-per-wave instances of the stage-entry shapes; FRHIP_STRIP_VARIANT=0 is the one-workgroup-per-CU
+// table (A/B switch for tools/kbench.py, tools/ab_variant.sh and bench.py).
 static int strip_variant() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("FRHIP_STRIP_VARIANT");
-    v = e ? atoi(e) : 2;
+    v = e ? atoi(e) : 4;
   }
   return v;
 }
@@ -529,6 +532,7 @@ static int strip_rows(int Cin, int Cout, int W) {
   SHAPE(256, 128, 28, 7, 7)
   SHAPE(256, 256, 14, 14, 14)
   SHAPE(256, 512, 14, 14, 14)
+  if (Cin == 512 && Cout == 256 && W == 14 && strip_variant() >= 4) return 14;
   SHAPE(512, 256, 14, 7, 7)
   SHAPE(512, 512, 7, 7, 7)
 #undef SHAPE
@@ -540,6 +544,7 @@ extern "C" int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi) 
   if (Cin == 256 && Cout == 512 && W == 14 && epi != FR_EPI_STORE) return 0;
   if (Cin == 64 && Cout == 64 && (W == 112 || W == 56) && fr_roll64_enabled()) return fr_roll64_parts(B, W);
   const int rows = strip_rows(Cin, Cout, W);
+  if (Cin == 512 && Cout == 512 && W == 7 && strip_variant() >= 3 && B % 4 == 0) return B / 4;  // four images per strip
   if (Cin == 512 && Cout == 512 && W == 7 && strip_variant() >= 2 && B % 2 == 0) return B / 2;  // two images per strip
   return rows ? B * (W / rows) : 0;
 }
@@ -578,12 +583,28 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
   if (a.SC == 256 && a.N == 256 && a.SW == 14 && small_batch(a.B)) return by_pro<256, 128, 14, 14, 8, 8, 2>(a, st);
   SHAPE(256, 256, 14, 14, 8, 8)
   SHAPE(64, 128, 56, 7, 4, 8)
+  // Round 3: what a wave pays per MFMA is its private weight stream (16 B per lane from L2 for every (tap, 32 channels,
+  // 16 output channels)): an instance is fast when one weight fragment feeds ~13 M tiles.  The data gradients of the three
+  // stage-entry convolutions ran 7 tiles x 2 columns per wave; with ONE 16-channel column per wave and 13 tiles (128 -> 64:
+  // 4 x 2 waves; 256 -> 128: 8 x 1; 512 -> 256: the whole image in two channel stages, output channels over two workgroups)
+  // the same launches take 0.254 -> 0.202, 0.202 -> 0.150 and 0.177 -> 0.132 ms (tools/ab_variant.sh, same box), the step
+  // 0.2 ms less.
+  if (strip_variant() >= 4) {
+    SHAPE(128, 64, 56, 7, 4, 8)
+    SHAPE(256, 128, 28, 7, 8, 8)
+    if (a.SC == 512 && a.N == 256 && a.SW == 14) return by_pro<512, 128, 14, 14, 8, 8, 2, 1, 2>(a, st);
+  }
   SHAPE(128, 64, 56, 7, 2, 8)
   SHAPE(128, 256, 28, 7, 8, 8)
   SHAPE(256, 128, 28, 7, 4, 8)
   SHAPE(512, 256, 14, 7, 8, 8)
   // 512 -> 512 @7: two images per workgroup, 256 resident input channels at a time, output channels split over two
   // workgroups: every weight fragment now feeds 98 pixels instead of 49 and the M tiles are 12 % instead of 23 % padding
+  // Round 3: FOUR images per workgroup, 128 resident input channels at a time (four stages of the strip), output channels
+  // split over four workgroups: 196 pixels (13 M tiles, 6 % padding) per weight fragment, 13 MFMAs per 16-byte weight
+  // load instead of 7 x 2 per 2 loads, half the weight stream per launch (302 MB): 0.092 -> 0.073 ms forward, 0.095 -> 0.070
+  // data gradient at B = 256 (tools/kbench.py, same box), no scratch, 100 KB of LDS.
+  if (a.SC == 512 && a.N == 512 && a.SW == 7 && strip_variant() >= 3 && a.B % 4 == 0) return by_pro<512, 128, 7, 7, 8, 8, 4, 4, 4>(a, st);
   if (a.SC == 512 && a.N == 512 && a.SW == 7 && strip_variant() >= 2 && a.B % 2 == 0) return by_pro<512, 256, 7, 7, 8, 8, 2, 2, 2>(a, st);
   SHAPE(512, 512, 7, 7, 8, 8)
 #undef SHAPE
