@@ -25,7 +25,9 @@
 
 namespace {
 
-template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND>
+// COUT is the width ONE workgroup computes (NSPL workgroups share a strip, conv3x3_strip.hip); NIMG > 1: a workgroup owns
+// NIMG whole images (ROWS == WL) stacked in LDS, so that a weight fragment feeds NIMG x ROWS x WL pixels.
+template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND, int NIMG = 1>
 struct S2 {
   static constexpr int NTH = NW * 64;
   static constexpr int HL = WL;
@@ -35,9 +37,13 @@ struct S2 {
   static constexpr int PPAD = CIN == 64 ? 16 : 32;         // see conv3x3_strip.hip: conflict-free pixel stride
   static constexpr int PSTR = CIN * 2 + PPAD;
   // row stride: the 16-byte slot index keeps counting across a row wrap of an M tile (slot(h+1, 0) == slot(h, WL) mod 16)
-  static constexpr int RSTR = GW * PSTR + (256 - PSTR % 256) % 256;
-  static constexpr int IMG_BYTES = GH * RSTR + 512;        // + slack for ring reads past the last channel chunk
-  static constexpr int M = ROWS * WL;
+  // (multi-image instances: the same residue with the next row starting INSIDE the last pixel's 32 padding bytes -- 256 B
+  // less per row, which is what lets two 512-channel gradient images sit beside the output tile)
+  static constexpr bool TIGHT = NIMG > 1 && PSTR % 256 <= PPAD;
+  static constexpr int RSTR = TIGHT ? GW * PSTR - PSTR % 256 : GW * PSTR + (256 - PSTR % 256) % 256;
+  static constexpr int ISTR = GH * RSTR;                   // one image (NIMG > 1)
+  static constexpr int IMG_BYTES = NIMG * ISTR + 512;      // + slack for ring reads past the last channel chunk
+  static constexpr int M = NIMG * ROWS * WL;
   static constexpr int MT = (M + 15) / 16;
   static constexpr int WM = NW / WN;
   static constexpr int TN = COUT / 16 / WN;
@@ -51,6 +57,7 @@ struct S2 {
                                        : OUT_OFF + OUT_BYTES + RED_BYTES;
   static constexpr int NS = HL / ROWS;
   static_assert(HL % ROWS == 0, "strip rows must divide the low-res image");
+  static_assert(NIMG == 1 || ROWS == WL, "multi-image workgroups own whole images");
   static_assert(NTH % CH == 0, "threads must be a multiple of the chunks per pixel");
   static_assert(COUT % (16 * WN) == 0 && NW % WN == 0, "bad wave split");
   static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -82,8 +89,11 @@ __device__ __forceinline__ void mma_taps(const char* smem, const int (&abase0)[C
   constexpr int QB = UC * NT;          // tap-steps per body: 2, 2, 2, 4
   constexpr int DB = 2;                // weight ring depth == request distance in tap-steps
   constexpr int NSTEP = QB * C::TM;
-  constexpr int D = C::TM;             // A ring depth (divides NSTEP)
-  static_assert((CIN / 32) % UC == 0 && QB % DB == 0, "bad body shape");
+  // A ring depth (divides NSTEP): one slot per M tile; 2 in the whole-image 256-channel instance (13 slots: 8-76 bytes of
+  // scratch, same time)
+  constexpr int D = (C::TM == 13 && CIN >= 256) ? 2 : C::TM;
+  static_assert(D * 4 + C::TM * C::TN * 4 <= 140, "fragment ring + accumulators: register budget");
+  static_assert((CIN / 32) % UC == 0 && QB % DB == 0 && NSTEP % D == 0, "bad body shape");
   int abase[C::TM];
 #pragma unroll
   for (int i = 0; i < C::TM; ++i) abase[i] = abase0[i];
@@ -135,9 +145,9 @@ __device__ __forceinline__ void mma_taps(const char* smem, const int (&abase0)[C
   }
 }
 
-template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND, int PRO>
+template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND, int PRO, int NSPL = 1, int NIMG = 1>
 __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs p, const int xcd) {
-  using C = S2<CIN, COUT, WL, ROWS, WN, NW, KIND>;
+  using C = S2<CIN, COUT, WL, ROWS, WN, NW, KIND, NIMG>;
   constexpr int NTH = C::NTH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const otile = smem + C::OUT_OFF;
@@ -148,11 +158,18 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
   const bf16_t* __restrict__ wgt = reinterpret_cast<const bf16_t*>(p.w);
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
 
-  const int sblk = xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;  // halo-sharing strips meet in one XCD's L2
-  const int b = sblk / C::NS, row0 = (sblk - b * C::NS) * ROWS;
+  const int lb = xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;  // halo-sharing strips (and the NSPL parts of one
+                                                                         // strip) meet in one XCD's L2
+  const int nh = NSPL > 1 ? lb % NSPL : 0;
+  const int ncol0 = nh * COUT;                                           // first output channel of this workgroup
+  const int sblk = NSPL > 1 ? lb / NSPL : lb;
+  const int nstrips = gridDim.x / NSPL;
+  const int b = NIMG > 1 ? sblk * NIMG : sblk / C::NS;                   // (first) image of the strip
+  const int row0 = NIMG > 1 ? 0 : (sblk - b * C::NS) * ROWS;
+  constexpr int PLANE = C::GH * C::GW;                                   // staged pixels per image
 
   // ------------------------------------------------------------------ image loader (prologue applied once)
-  constexpr int TOTAL = C::GH * C::GW * C::CH;
+  constexpr int TOTAL = NIMG * C::GH * C::GW * C::CH;
   const int ch = tid % C::CH;
   float pa[8], pb[8];
   if (PRO != FR_PRO_NONE) {
@@ -163,24 +180,29 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
     }
   }
   auto load_image = [&](int ph, int pw) {
-    constexpr int UNR = 8;
+    // one batch when it is at most 16 loads per thread: a second trip of this loop costs a second HBM round trip, and the
+    // compiler answered the two-trip form with kilobytes of scratch in the whole-image 256-channel instance
+    constexpr int PER = (TOTAL + NTH - 1) / NTH;
+    constexpr int UNR = PER <= 16 ? PER : 8;
     for (int base = 0; base < TOTAL; base += NTH * UNR) {
       U128 v[UNR];
       bool ok[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int idx = base + u * NTH + tid;
-        const int pc = idx / C::CH;
+        int pc = idx / C::CH;
+        const int img = NIMG > 1 ? pc / PLANE : 0;
+        pc -= img * PLANE;
         const int gh = pc / C::GW, gw = pc - gh * C::GW;
         size_t pix;
         if (KIND == 0) {  // plane (ph, pw) of the high-res input: low-res rows row0-1 .. row0+ROWS-1, columns -1 .. WL-1
           const int i = row0 + gh - 1, j = gw - 1;
           ok[u] = idx < TOTAL && i >= 0 && j >= 0;
-          pix = ((size_t)(b * 2 * C::HL + 2 * i + ph) * (2 * WL) + 2 * j + pw);
+          pix = ((size_t)((b + img) * 2 * C::HL + 2 * i + ph) * (2 * WL) + 2 * j + pw);
         } else {          // low-res gradient rows row0 .. row0+ROWS, columns 0 .. WL
           const int i = row0 + gh, j = gw;
           ok[u] = idx < TOTAL && i < C::HL && j < WL;
-          pix = ((size_t)(b * C::HL + i) * WL + j);
+          pix = ((size_t)((b + img) * C::HL + i) * WL + j);
         }
         v[u] = ok[u] ? ld16(src + pix * (size_t)p.lda + ch * 8) : zero16();
       }
@@ -188,7 +210,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
       for (int u = 0; u < UNR; ++u) {
         const int idx = base + u * NTH + tid;
         if (idx < TOTAL) {
-          const int pc = idx / C::CH;
+          int pc = idx / C::CH;
+          const int img = NIMG > 1 ? pc / PLANE : 0;
+          pc -= img * PLANE;
           const int gh = pc / C::GW, gw = pc - gh * C::GW;
           U128 x = v[u];
           if (PRO != FR_PRO_NONE && ok[u]) {
@@ -201,7 +225,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
             }
             x = pack16<bf16_t>(f);
           }
-          st16(smem + gh * C::RSTR + gw * C::PSTR + ch * 16, x);
+          st16(smem + img * C::ISTR + gh * C::RSTR + gw * C::PSTR + ch * 16, x);
         }
       }
     }
@@ -216,8 +240,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
   // 128 ch 0.1355 -> 0.137, 256 ch 0.1066 -> 0.118 (costs the second resident workgroup), 512 ch 0.148 -> 0.147: the plane
   // loads are not what these kernels wait for.  4-wave workgroups at 128 channels (13 M tiles per wave, half the weight
   // stream): 170-3000 bytes of scratch per lane in every instance.
-  constexpr bool PFP = KIND == 0 && CIN >= 256;
   constexpr int NPF = (TOTAL + NTH - 1) / NTH;
+#ifndef FRHIP_S2_PFP_BUDGET
+#define FRHIP_S2_PFP_BUDGET 150
+#endif
+  // ... and only where prefetch registers + accumulators + fragment ring fit (the whole-image 256-channel instance: 15
+  // prefetch registers x 4 + 52 + 52 -> 370-520 bytes of scratch with it)
+  constexpr bool PFP = KIND == 0 && CIN >= 256 && NPF * 4 + C::TM * C::TN * 4 + C::TM * 4 <= FRHIP_S2_PFP_BUDGET;
   U128 pf[PFP ? NPF : 1];
   unsigned pfok = 0;
   auto issue_plane = [&](int ph, int pw) {
@@ -225,11 +254,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
 #pragma unroll
     for (int u = 0; u < NPF; ++u) {
       const int idx = u * NTH + tid;
-      const int pc = idx / C::CH;
+      int pc = idx / C::CH;
+      const int img = NIMG > 1 ? pc / PLANE : 0;
+      pc -= img * PLANE;
       const int gh = pc / C::GW, gw = pc - gh * C::GW;
       const int i = row0 + gh - 1, j = gw - 1;
       const bool ok = idx < TOTAL && i >= 0 && j >= 0;
-      const size_t pix = ((size_t)(b * 2 * C::HL + 2 * i + ph) * (2 * WL) + 2 * j + pw);
+      const size_t pix = ((size_t)((b + img) * 2 * C::HL + 2 * i + ph) * (2 * WL) + 2 * j + pw);
       pf[PFP ? u : 0] = ok ? ld16(src + pix * (size_t)p.lda + ch * 8) : zero16();
       pfok |= ok ? (1u << u) : 0u;
     }
@@ -239,7 +270,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
     for (int u = 0; u < NPF; ++u) {
       const int idx = u * NTH + tid;
       if (idx < TOTAL) {
-        const int pc = idx / C::CH;
+        int pc = idx / C::CH;
+        const int img = NIMG > 1 ? pc / PLANE : 0;
+        pc -= img * PLANE;
         const int gh = pc / C::GW, gw = pc - gh * C::GW;
         U128 x = pf[PFP ? u : 0];
         if (PRO != FR_PRO_NONE && ((pfok >> u) & 1u)) {
@@ -252,7 +285,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
           }
           x = pack16<bf16_t>(f);
         }
-        st16(smem + gh * C::RSTR + gw * C::PSTR + ch * 16, x);
+        st16(smem + img * C::ISTR + gh * C::RSTR + gw * C::PSTR + ch * 16, x);
       }
     }
   };
@@ -261,14 +294,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
   const int n0 = wn * C::TN * 16;
   const bf16_t* wrow[C::TN];
 #pragma unroll
-  for (int j = 0; j < C::TN; ++j) wrow[j] = wgt + (size_t)(n0 + j * 16 + fr) * 9 * CIN + fq * 8;
+  for (int j = 0; j < C::TN; ++j) wrow[j] = wgt + (size_t)(ncol0 + n0 + j * 16 + fr) * 9 * CIN + fq * 8;
   int abase[C::TM];
 #pragma unroll
   for (int i = 0; i < C::TM; ++i) {
     int m = (wm * C::TM + i) * 16 + fr;
     m = m < C::M ? m : 0;
+    const int img = NIMG > 1 ? m / (ROWS * WL) : 0;
+    m -= img * (ROWS * WL);
     const int h = m / WL, w = m - h * WL;
-    abase[i] = h * C::RSTR + w * C::PSTR + fq * 16;
+    abase[i] = img * C::ISTR + h * C::RSTR + w * C::PSTR + fq * 16;
   }
   const int epi = p.epi;
   const bool stats = epi == FR_EPI_STATS || epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD;
@@ -290,9 +325,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
   const bool has_aux = epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD || epi == FR_EPI_BIAS_RES;
   auto out_pix = [&](int cls, int r) -> size_t {
     const int ph = cls < 0 ? 0 : cls >> 1, pw = cls < 0 ? 0 : cls & 1;
+    const int img = NIMG > 1 ? r / (ROWS * WL) : 0;
+    r -= img * (ROWS * WL);
     const int h = r / WL, w = r - h * WL;
-    if (KIND == 0) return (size_t)(b * C::HL + row0 + h) * WL + w;
-    return (size_t)(b * 2 * C::HL + 2 * (row0 + h) + ph) * (2 * WL) + 2 * w + pw;
+    if (KIND == 0) return (size_t)((b + img) * C::HL + row0 + h) * WL + w;
+    return (size_t)((b + img) * 2 * C::HL + 2 * (row0 + h) + ph) * (2 * WL) + 2 * w + pw;
   };
   auto issue_aux = [&](int cls) {
     if (KIND == 1 && has_aux) {
@@ -302,7 +339,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
         int idx = u * NTH + tid;
         idx = idx < C::M * OCH ? idx : C::M * OCH - 1;
         const int r = idx / OCH, c8 = idx - r * OCH;
-        axr[KIND == 1 ? u : 0] = ld16(aux + out_pix(cls, r) * (size_t)p.ldaux + c8 * 8);
+        axr[KIND == 1 ? u : 0] = ld16(aux + out_pix(cls, r) * (size_t)p.ldaux + ncol0 + c8 * 8);
       }
     }
   };
@@ -322,7 +359,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
         const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
         for (int idx = tid; idx < C::M * OCH; idx += NTH) {
           const int r = idx / OCH, c8 = idx - r * OCH;
-          st16(otile + r * C::OSTR + c8 * 16, ld16(aux + dst_pix(r) * (size_t)p.ldaux + c8 * 8));
+          st16(otile + r * C::OSTR + c8 * 16, ld16(aux + dst_pix(r) * (size_t)p.ldaux + ncol0 + c8 * 8));
         }
       }
       __syncthreads();
@@ -338,7 +375,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
       for (int j = 0; j < C::TN; ++j)
   #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int n = n0 + j * 16 + fq * 4 + r;
+          const int n = ncol0 + n0 + j * 16 + fq * 4 + r;
           ea[j][r] = (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD || E == FR_EPI_BIAS_RES) ? p.epi_a[n] : 0.f;
           eb[j][r] = (E == FR_EPI_BNBWD || E == FR_EPI_BIAS_RES) ? p.epi_b[n] : 0.f;
           s0[j][r] = s1[j][r] = 0.f;
@@ -410,16 +447,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
     __syncthreads();
     for (int idx = tid; idx < C::M * OCH; idx += NTH) {
       const int r = idx / OCH, c8 = idx - r * OCH;
-      st16(out + dst_pix(r) * (size_t)p.ldc + c8 * 8, ld16(otile + r * C::OSTR + c8 * 16));
+      st16(out + dst_pix(r) * (size_t)p.ldc + ncol0 + c8 * 8, ld16(otile + r * C::OSTR + c8 * 16));
     }
     if (stats) {
-      const size_t prow = (size_t)(cls < 0 ? 0 : cls) * gridDim.x + sblk;  // gradient: rows ordered [class][workgroup]
+      const size_t prow = (size_t)(cls < 0 ? 0 : cls) * nstrips + sblk;  // gradient: rows ordered [class][strip]
       for (int c = tid; c < 2 * COUT; c += NTH) {
         const int k = c / COUT, n = c - k * COUT;
         float t = 0.f;
 #pragma unroll
         for (int g = 0; g < C::WM; ++g) t += red[(g * 2 + k) * COUT + n];
-        p.part[(prow * 2 + k) * COUT + n] = t;
+        p.part[(prow * 2 + k) * (COUT * NSPL) + ncol0 + n] = t;
       }
     }
     __syncthreads();  // the tile and the reduction scratch are free again
@@ -500,36 +537,55 @@ static int s2_xcd_order() {  // FRHIP_XCD_ORDER=0: strips in dispatch order (A/B
   return v;
 }
 
-template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND, int PRO>
+template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND, int PRO, int NSPL, int NIMG>
 int launch(const FrConvArgs& a, hipStream_t st) {
-  using C = S2<CIN, COUT, WL, ROWS, WN, NW, KIND>;
+  using C = S2<CIN, COUT, WL, ROWS, WN, NW, KIND, NIMG>;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_s2_kernel<CIN, COUT, WL, ROWS, WN, NW, KIND, PRO>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv3x3_s2_kernel<CIN, COUT, WL, ROWS, WN, NW, KIND, PRO, NSPL, NIMG>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv3x3_s2_kernel<CIN, COUT, WL, ROWS, WN, NW, KIND, PRO>), dim3(a.B * C::NS), dim3(C::NTH), C::LDS,
-                     st, a, s2_xcd_order());
+  hipLaunchKernelGGL((conv3x3_s2_kernel<CIN, COUT, WL, ROWS, WN, NW, KIND, PRO, NSPL, NIMG>),
+                     dim3(a.B * C::NS / NIMG * NSPL), dim3(C::NTH), C::LDS, st, a, s2_xcd_order());
   FR_LAUNCH_CHECK();
 }
 
-template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND>
+template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND, int NSPL = 1, int NIMG = 1>
 int by_pro(const FrConvArgs& a, hipStream_t st) {
   switch (a.pro) {
-    case FR_PRO_NONE: return launch<CIN, COUT, WL, ROWS, WN, NW, KIND, FR_PRO_NONE>(a, st);
-    case FR_PRO_BN: return launch<CIN, COUT, WL, ROWS, WN, NW, KIND, FR_PRO_BN>(a, st);
-    case FR_PRO_PRELU: return launch<CIN, COUT, WL, ROWS, WN, NW, KIND, FR_PRO_PRELU>(a, st);
+    case FR_PRO_NONE: return launch<CIN, COUT, WL, ROWS, WN, NW, KIND, FR_PRO_NONE, NSPL, NIMG>(a, st);
+    case FR_PRO_BN: return launch<CIN, COUT, WL, ROWS, WN, NW, KIND, FR_PRO_BN, NSPL, NIMG>(a, st);
+    case FR_PRO_PRELU: return launch<CIN, COUT, WL, ROWS, WN, NW, KIND, FR_PRO_PRELU, NSPL, NIMG>(a, st);
   }
   FR_UNSUPPORTED("fr_conv3x3_s2_strip: unknown prologue");
 }
 
-// low-res rows per workgroup for a served shape (0 = not served): the four IR stage transitions
-int s2_rows(int C, int WL) {
-  if (C == 64 && WL == 56) return 2;
-  if (C == 128 && WL == 28) return 7;
-  if (C == 256 && WL == 14) return 7;  // whole images (14 rows, 13 M tiles per wave) spill: 0.115 -> 0.228 ms
-  if (C == 512 && WL == 7) return 7;
+// FRHIP_S2_VARIANT=0: the round-2 table (A/B switch, tools/kbench.py).  Default 1 (round 3): instances in which ONE weight
+// fragment feeds as many M tiles as the registers allow -- a wave's cost per MFMA is its private weight stream from L2
+// (conv3x3_strip.hip, variant 4):
+//   128 @28: 8 waves x (13 tiles x 1 column) instead of 4 x 2 waves x (7 x 2): 0.139 -> 0.116 ms forward, 0.193 -> 0.168 gradient
+//   256 @14 forward: the whole image (13 tiles) x 1 column, output channels over two workgroups (123 KB plane);
+//            the gradient keeps 7-row strips: its g strip stays resident beside the output tile (178 KB otherwise)
+//   512 @7:  two images per workgroup (7 tiles x 1 column), output channels over four workgroups; odd batches keep the
+//            one-image instance
+int s2_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FRHIP_S2_VARIANT");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
+// strips (= partial-sum rows per output class) of a served shape, 0 = not served: the four IR stage transitions
+int s2_strips(int B, int C, int WL, int mode) {
+  const bool v1 = s2_variant() >= 1;
+  if (C == 64 && WL == 56) return B * 28;   // 2 low-res rows per workgroup
+  if (C == 128 && WL == 28) return B * 4;   // 7 rows
+  if (C == 256 && WL == 14) return (v1 && mode == 0) ? B : B * 2;
+  if (C == 512 && WL == 7) return (v1 && B % 2 == 0) ? B / 2 : B;
   return 0;
 }
 
@@ -542,10 +598,8 @@ extern "C" int fr_conv3x3_s2_strip_parts(int B, int Cin, int Cout, int WL, int m
   // 64 channels: one row per work item of the rolling-window kernel.  NOTE: the caller's epilogue decides whether that kernel
   // serves the launch (forward STORE / STATS, gradient PReLU backward); the combinations it does not serve write no sums.
   if (Cin == 64 && WL == 56 && fr_s2roll_enabled()) return fr_s2roll_parts(B);
-  const int rows = s2_rows(Cin, WL);
-  if (!rows) return 0;
-  const int wgs = B * (WL / rows);
-  return mode == 2 ? 4 * wgs : wgs;
+  const int strips = s2_strips(B, Cin, WL, mode);
+  return mode == 2 ? 4 * strips : strips;
 }
 
 extern "C" int fr_conv3x3_s2_strip(const FrConvArgs* args, void* stream) {
@@ -579,6 +633,14 @@ extern "C" int fr_conv3x3_s2_strip(const FrConvArgs* args, void* stream) {
   SHAPE(64, 56, 2, 2, 4)
   // 128 -> 128: 7-row strips (196 pixels per weight pass) although only one workgroup then fits a CU: 0.166 -> 0.140 ms
   // forward, 0.221 -> 0.206 ms gradient against the 4-row strips (the kernel is bound by the weight stream)
+  if (s2_variant() >= 1) {
+    SHAPE(128, 28, 7, 8, 8)
+    if (a.SC == 256 && WLo == 14 && a.mode == 0) return by_pro<256, 128, 14, 14, 8, 8, 0, 2, 1>(a, st);
+    if (a.SC == 512 && WLo == 7 && a.B % 2 == 0) {
+      if (a.mode == 0) return by_pro<512, 128, 7, 7, 8, 8, 0, 4, 2>(a, st);
+      return by_pro<512, 128, 7, 7, 8, 8, 1, 4, 2>(a, st);
+    }
+  }
   SHAPE(128, 28, 7, 4, 8)
   SHAPE(256, 14, 7, 8, 8)
   SHAPE(512, 7, 7, 8, 8)

@@ -815,8 +815,10 @@ S2_SHAPES = [(64, 56), (128, 28), (256, 14), (512, 7)]
 # 64 channels run on the rolling-window kernel (conv3x3_s2_roll64.hip), whose walk depends on the batch: B = 3 / 2: 28 row
 # segments per image (2-row walks); B = 20: 14 segments; B = 40: 7 segments, 280 work items on 256 persistent workgroups
 # (item loop); B = 64: 4 segments; B = 130: 2 segments; "whole": FRHIP_S2ROLL_NSEG=1 = the 56-row walk of the B >= 256 step, on three images
+# (512, 7, B even): the forward runs two images per workgroup with the output channels over four workgroups (one and
+# three strips); (256, 14): the forward owns whole images, output channels over two workgroups (any batch)
 S2_CASES = [s + (3, "") for s in S2_SHAPES] + [(64, 56, 20, ""), (64, 56, 40, ""), (64, 56, 64, ""), (64, 56, 130, ""),
-                                                (64, 56, 3, "whole")]
+                                                (64, 56, 3, "whole"), (512, 7, 2, ""), (512, 7, 6, "")]
 
 
 @pytest.fixture
@@ -835,7 +837,7 @@ def test_conv3x3_s2_strip_forward(K, s2_walk, C, WL, B, walk, pro):
     dtype, tol = torch.bfloat16, BF16_TOL
     s2_walk(walk)
     H = 2 * WL
-    if B > 3 and pro != "prelu":
+    if B > 6 and pro != "prelu":
         pytest.skip("large batches: the prologue the step uses")
     x = q(synth.normal(61, "sx", (B, C, H, H)), dtype)
     w = q(synth.normal(61, "sw", (C, C, 3, 3), std=0.05), dtype)
