@@ -49,23 +49,34 @@ __device__ __forceinline__ s16x8 tr_frag(const char* p0, const char* p1) {
 // Geometry of one width.  A phase = PR output rows = PR * RW / 32 K steps; phase kinds alternate per image as listed.
 template <int W_>
 struct RC;
+// krows = rows of K slots the phase's arithmetic covers (a multiple of 32 / RW); > rows only at 7x7, where the image's 7
+// rows of 8 slots are followed by one row of zero g slots -- the same row of zeros is the halo below the image.
 template <>
 struct RC<14> {
   static constexpr int W = 14, RW = 16, NPH = 2;          // phases per image
   static constexpr int rows(int ph) { return ph == 0 ? 8 : 6; }
+  static constexpr int krows(int ph) { return rows(ph); }
   static constexpr int row0(int ph) { return ph == 0 ? 0 : 8; }
 };
 template <>
 struct RC<28> {
   static constexpr int W = 28, RW = 32, NPH = 7;
   static constexpr int rows(int) { return 4; }
+  static constexpr int krows(int) { return 4; }
   static constexpr int row0(int ph) { return 4 * ph; }
+};
+template <>
+struct RC<7> {  // uniform schedule, one phase (two K steps) per image
+  static constexpr int W = 7, RW = 8, NPH = 1;
+  static constexpr int rows(int) { return 7; }
+  static constexpr int krows(int) { return 8; }
+  static constexpr int row0(int) { return 0; }
 };
 
 template <int W>
 struct RL {  // LDS layout: buffer 0 holds the even phases of the schedule, buffer 1 the odd ones
   using C = RC<W>;
-  static constexpr int pr(int buf) { return C::NPH == 2 ? C::rows(buf) : C::rows(0); }
+  static constexpr int pr(int buf) { return C::NPH == 2 ? C::krows(buf) : C::krows(0); }
   static constexpr int g_bytes(int buf) { return pr(buf) * C::RW * TSTR; }                 // K slots of the phase
   static constexpr int a_bytes(int buf) { return ((pr(buf) + 2) * C::RW + 16) * TSTR; }    // + the tail a kw-shifted read touches
   static constexpr int BUF0 = g_bytes(0) + a_bytes(0);
@@ -500,7 +511,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    constexpr int NS0 = C::rows(0) * RW / 32, NS1 = C::rows(NPH == 2 ? 1 : 0) * RW / 32;
+    constexpr int NS0 = C::krows(0) * RW / 32, NS1 = C::krows(NPH == 2 ? 1 : 0) * RW / 32;
     LDS_FENCE_BARRIER();  // B0: phase 0 of the first image is in buffer 0
 #ifdef FRHIP_STAMPS
     const unsigned long long t_loop = TSTAMP();
@@ -945,19 +956,30 @@ static bool fr_wgrad_vr_enabled() {
   return on;
 }
 
-// stride-1 3x3 at 14x14 / 28x28 / 56x56 / 112x112, channel counts multiples of 64, at least one image (14x14) / phase (28x28) per group
+// FRHIP_WGRAD_ROLL7=0: 7x7 back on the strip kernel (A/B switch)
+static bool fr_wgrad_roll7_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("FRHIP_WGRAD_ROLL7");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+// stride-1 3x3 at 7x7 / 14x14 / 28x28 / 56x56 / 112x112, channel counts multiples of 64, at least one image (14x14) / phase (28x28) per group
 bool fr_wgrad_roll_serves(const FrWgradArgs& a) {
   if (!(fr_wgrad_roll_enabled() && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.GH == a.SH &&
         a.GW == a.SW && a.SH == a.SW && a.Cout % CT == 0 && a.SC % CT == 0 && a.nsplit >= 1))
     return false;
   if (a.SW == 14) return a.nsplit <= a.B;
   if (a.SW == 28) return a.nsplit <= a.B * RC<28>::NPH;
+  if (a.SW == 7) return fr_wgrad_roll7_enabled() && a.nsplit <= a.B;
   if (a.SW == 56 || a.SW == 112) return fr_wgrad_vr_enabled() && a.nsplit <= a.B * (a.SW + 2);
   return false;
 }
 
 int fr_wgrad_roll_launch(const FrWgradArgs& a, hipStream_t st) {
   switch (a.SW) {
+    case 7: return by_pro<7>(a, st);
     case 14: return by_pro<14>(a, st);
     case 28: return by_pro<28>(a, st);
     case 56: return by_pro_vr<56>(a, st);
