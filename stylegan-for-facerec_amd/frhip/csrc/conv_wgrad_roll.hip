@@ -870,6 +870,326 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_vr_kernel(const FrWgradArgs
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stride 2 (the second convolution of the first unit of a stage, model_irse.py:59; 128 / 256 / 512 channels):
+//   dw[co][kh][kw][ci] = sum over low-res pixels (i, j) of g[i][j][co] * pro(x[2i + kh - 1][2j + kw - 1][ci])
+// The K axis is the LOW-resolution pixel, in rows of RW slots as above.  The data-moving waves split the high-res input
+// rows of a phase into the four parity planes x[2r + a][2c + b] on their way into LDS; inside a plane tap (kh, kw) is again
+// K slot + immediate: plane (a, b) = (kh != 1, kw != 1), one plane row further for kh = 2, one position further for kw >= 1
+// (position 0 of a plane row is plane column -1: the zero halo of the odd-column planes).  A phase is two K steps (PRK
+// low-res rows): 2 rows at 28x28, 4 at 14x14 (16 virtual rows per image, the last two all zero), the whole image + one
+// zero row at 7x7 -- the four planes of more rows do not fit twice into LDS.  Per K step the data-moving waves carry 4x the
+// input bytes of a stride-1 layer (9 of their 11 slots per phase are input chunks, each with the BN / PReLU prologue), so
+// this kernel is paced by them, not by the MFMA waves; same roles, barriers, fragment pipeline, accumulator layout, slab
+// format and deferred slab sum as conv_wgrad_roll_kernel.
+template <int WL_>
+struct SC2;
+template <>
+struct SC2<28> {
+  static constexpr int WL = 28, RW = 32, PRK = 2, NPH = 14;
+};
+template <>
+struct SC2<14> {
+  static constexpr int WL = 14, RW = 16, PRK = 4, NPH = 4;
+};
+template <>
+struct SC2<7> {
+  static constexpr int WL = 7, RW = 8, PRK = 8, NPH = 1;
+};
+
+template <int WL>
+struct SL2 {
+  using C = SC2<WL>;
+  static constexpr int G_BYTES = C::PRK * C::RW * TSTR;
+  static constexpr int P1 = ((C::PRK + 1) * C::RW + 16) * TSTR;  // odd high-res rows (a = 1): plane rows r0-1 .. r0+PRK-1
+  static constexpr int P0 = (C::PRK * C::RW + 16) * TSTR;        // even rows (a = 0): plane rows r0 .. r0+PRK-1
+  static constexpr int plane_off(int a, int b) { return G_BYTES + (a ? (b ? 0 : P1) : 2 * P1 + (b ? 0 : P0)); }
+  static constexpr int BUF = G_BYTES + 2 * P1 + 2 * P0;
+  static constexpr int LDS = 2 * BUF;
+  // tile offset (bytes) of tap (kh, kw) relative to the K slot
+  static constexpr int tap_off(int tap) {
+    const int kh = tap / 3, kw = tap % 3;
+    return plane_off(kh != 1, kw != 1) + ((kh == 2 ? C::RW : 0) + (kw == 0 ? 0 : 1)) * TSTR;
+  }
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+template <int WL, int PRO>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_s2roll_kernel(const FrWgradArgs p) {
+  using C = SC2<WL>;
+  using L = SL2<WL>;
+  constexpr int RW = C::RW, NPH = C::NPH, PRK = C::PRK, WH = 2 * WL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int cit_n = p.SC / CT, tiles = (p.Cout / CT) * cit_n;
+  const int group = bid / tiles, tile = bid - group * tiles;
+  const int cot = tile / cit_n, cit = tile - cot * cit_n;
+  const int units = p.B * NPH;  // phases of the launch
+  const int per = (units + p.nsplit - 1) / p.nsplit;
+  const int b_begin = group * per;
+  int b_end = b_begin + per;
+  if (b_end > units) b_end = units;
+  const int nph = b_end > b_begin ? b_end - b_begin : 0;  // phases of this workgroup
+
+  for (int idx = tid; idx < L::LDS / 16; idx += 512) st16(smem + idx * 16, zero16());
+  __syncthreads();
+
+  auto fold_prev = [&](bool movers) {  // deferred slab sum of the previous launch (see conv_wgrad_roll_kernel)
+    const long long n4 = p.prev_n >> 2;
+    const long long perw = (n4 + gridDim.x - 1) / gridDim.x;
+    const long long e0 = (long long)blockIdx.x * perw;
+    long long e1 = e0 + perw;
+    if (e1 > n4) e1 = n4;
+    if (e0 >= e1) return;
+    const long long cut = e0 + ((e1 - e0) * 2 + 2) / 3;
+    if (!movers) slab_sum_range<256, 2>(p.prev_slab, p.prev_groups, n4, e0, cut, p.prev_dw, tid);
+    else if (cut < e1) slab_sum_range<256, 1>(p.prev_slab, p.prev_groups, n4, cut, e1, p.prev_dw, tid - 256);
+  };
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------------------- data-moving waves
+    if (nph == 0) {
+      if (p.prev_n) fold_prev(true);
+      return;
+    }
+    const int lt = tid - 256;
+    const int ch = lt & 7;
+    const char* __restrict__ G = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(p.g) + cot * CT);
+    const char* __restrict__ X = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(p.src) + cit * CT);
+    float pa[8], pb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pa[j] = PRO != FR_PRO_NONE ? p.pro_a[cit * CT + ch * 8 + j] : 0.f;
+      pb[j] = PRO == FR_PRO_BN ? p.pro_b[cit * CT + ch * 8 + j] : 0.f;
+    }
+    // a phase moves g rows [r0, r0 + PRK) and high-res input rows [2 r0 - 1, 2 (r0 + PRK) - 1]; rows outside the image
+    // (above the first, below the last, the all-zero virtual rows) are read from a clamped row and replaced by zeros
+    constexpr int GCH = PRK * WL * 8, ACH = (2 * PRK + 1) * WH * 8;
+    constexpr int NGS = (GCH + NLT - 1) / NLT, NAS = (ACH + NLT - 1) / NLT;
+    struct Set {
+      U128 g[NGS], a[NAS];
+      int r0;  // first low-res row of the phase (uniform)
+    };
+    int gcol[NGS], grow[NGS], gdst[NGS], acol[NAS], ae[NAS], adst[NAS];
+#pragma unroll
+    for (int u = 0; u < NGS; ++u) {
+      int q = u * NLT + lt;
+      q = q < GCH ? q : GCH - 1;
+      const int px = q >> 3, r = px / WL, c = px - r * WL;
+      grow[u] = r;
+      gcol[u] = (c * p.ldg + ch * 8) * 2;
+      gdst[u] = (r * RW + c) * TSTR + ch * 16;
+    }
+#pragma unroll
+    for (int u = 0; u < NAS; ++u) {
+      int q = u * NLT + lt;
+      q = q < ACH ? q : ACH - 1;
+      const int px = q >> 3, e = px / WH, hc = px - e * WH;  // e: high-res row 2 r0 - 1 + e
+      ae[u] = e;
+      acol[u] = (hc * p.lda + ch * 8) * 2;
+      const int a = (e & 1) ? 0 : 1, b = hc & 1;
+      const int trow = a ? (e >> 1) : ((e - 1) >> 1);
+      adst[u] = L::plane_off(a, b) + (trow * RW + (hc >> 1) + 1) * TSTR + ch * 16;
+    }
+    auto issue = [&](Set& s, int f) {
+      const int img = f / NPH, ph = f - img * NPH, r0 = ph * PRK;
+      s.r0 = r0;
+      const char* gi = G + (size_t)img * (WL * WL) * (size_t)p.ldg * 2;
+      const char* xi = X + (size_t)img * (WH * WH) * (size_t)p.lda * 2;
+#pragma unroll
+      for (int u = 0; u < NGS; ++u) {
+        int row = r0 + grow[u];
+        row = row > WL - 1 ? WL - 1 : row;
+        s.g[u] = ld16(gi + (unsigned)(row * WL * p.ldg * 2 + gcol[u]));
+      }
+#pragma unroll
+      for (int u = 0; u < NAS; ++u) {
+        int row = 2 * r0 - 1 + ae[u];
+        row = row < 0 ? 0 : (row > WH - 1 ? WH - 1 : row);
+        s.a[u] = ld16(xi + (unsigned)(row * WH * p.lda * 2 + acol[u]));
+      }
+    };
+    auto commit = [&](Set& s, char* buf) {
+#pragma unroll
+      for (int u = 0; u < NGS; ++u) {
+        U128 x = s.g[u];
+        if (WL % PRK != 0 || NPH * PRK > WL) {  // virtual rows below the image
+          const bool out = s.r0 + grow[u] > WL - 1;
+          x.x = out ? 0u : x.x;
+          x.y = out ? 0u : x.y;
+          x.z = out ? 0u : x.z;
+          x.w = out ? 0u : x.w;
+        }
+        st16(buf + gdst[u], x);
+      }
+#pragma unroll
+      for (int u = 0; u < NAS; ++u) {
+        U128 x = s.a[u];
+        if (PRO != FR_PRO_NONE) {
+          x.x = pro2<PRO>(x.x, pa[0], pb[0], pa[1], pb[1]);
+          x.y = pro2<PRO>(x.y, pa[2], pb[2], pa[3], pb[3]);
+          x.z = pro2<PRO>(x.z, pa[4], pb[4], pa[5], pb[5]);
+          x.w = pro2<PRO>(x.w, pa[6], pb[6], pa[7], pb[7]);
+        }
+        {
+          const int row = 2 * s.r0 - 1 + ae[u];
+          const bool out = row < 0 || row > WH - 1;
+          x.x = out ? 0u : x.x;
+          x.y = out ? 0u : x.y;
+          x.z = out ? 0u : x.z;
+          x.w = out ? 0u : x.w;
+        }
+        st16(buf + adst[u], x);
+      }
+    };
+    char* const buf0 = smem;
+    char* const buf1 = smem + L::BUF;
+    Set s0, s1;
+    const int fl = b_end - 1;  // requests past the run are clamped to its last phase and never read
+    issue(s0, b_begin);
+    if (p.prev_n) fold_prev(true);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(s1, b_begin + 1 < b_end ? b_begin + 1 : fl);
+    commit(s0, buf0);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(s0, b_begin + 2 < b_end ? b_begin + 2 : fl);
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_FENCE_BARRIER_RAW();  // B0: phase 0 is in buffer 0
+#pragma unroll 1
+    for (int k = 0; k < nph; k += 2) {
+      const int f = b_begin + k;
+      commit(s1, buf1);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(s1, f + 3 < b_end ? f + 3 : fl);
+      __builtin_amdgcn_sched_barrier(0);
+      LDS_FENCE_BARRIER_RAW();  // phase k + 1 is in buffer 1; buffer 0 is free
+      commit(s0, buf0);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(s0, f + 4 < b_end ? f + 4 : fl);
+      __builtin_amdgcn_sched_barrier(0);
+      LDS_FENCE_BARRIER_RAW();  // phase k + 2 is in buffer 0; buffer 1 is free
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------------------------------------ computing waves
+  const int wci = wave;
+  const int li = lane & 15, lq = lane >> 4;
+  const int colb = (4 * (li & 3)) * 2;
+  const int lrow = (4 * lq + (li >> 2)) * TSTR;
+  if (p.prev_n) fold_prev(false);
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc[4][9];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[t][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (nph > 0) {
+    const char* const gb0 = smem + lrow + colb;
+    const char* const ab0 = smem + lrow + (wci * 16) * 2 + colb;  // + tap_off (which includes the g tile and the plane)
+    const char* const gb1 = gb0 + L::BUF;
+    const char* const ab1 = ab0 + L::BUF;
+    constexpr int LA = 2, RS = 3, NSTEP = PRK * RW / 32, NI = NSTEP * 9, IB = NI - LA + 1;
+    static_assert(NI % RS == 0 && IB / 9 == NSTEP - 1 && IB % 9 >= 4, "phase shape (see conv_wgrad_roll_kernel)");
+    auto a_frag = [&](const char* ab, int item) -> s16x8 {
+      const int ks = item / 9, tap = item % 9;
+      const int off = L::tap_off(tap) + 32 * ks * TSTR;
+      return tr_frag(ab + off, ab + off + 16 * TSTR);
+    };
+    auto g_frag = [&](const char* gb, int ks, int t) -> s16x8 {
+      return tr_frag(gb + (32 * ks) * TSTR + t * 32, gb + (32 * ks + 16) * TSTR + t * 32);
+    };
+    s16x8 ring[RS];
+    s16x8 gf[4], gn[4];
+    auto run_phase = [&](const char* gb, const char* ab, const char* gb_next, const char* ab_next) {
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int ks = it / 9, tap = it % 9;
+        if (it == IB) {
+          LDS_FENCE_BARRIER_RAW();  // every fragment of this phase is in registers; the next buffer is complete
+#pragma unroll
+          for (int t = 0; t < 4; ++t) gn[t] = g_frag(gb_next, 0, t);
+#pragma unroll
+          for (int jt = NI - LA; jt < IB; ++jt) ring[(jt + LA) % RS] = a_frag(ab_next, jt + LA - NI);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const s16x8 af = ring[it % RS];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[t][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[t], af, acc[t][tap], 0, 0, 0);
+        if (it + LA < NI) ring[(it + LA) % RS] = a_frag(ab, it + LA);
+        else if (it >= IB) ring[(it + LA) % RS] = a_frag(ab_next, it + LA - NI);
+        if (ks + 1 < NSTEP && tap >= 4 && tap < 8) gn[tap - 4] = g_frag(gb, ks + 1, tap - 4);
+        if (tap == 8) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) gf[t] = gn[t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    LDS_FENCE_BARRIER_RAW();  // B0
+#pragma unroll
+    for (int t = 0; t < 4; ++t) gf[t] = g_frag(gb0, 0, t);
+#pragma unroll
+    for (int it = 0; it < LA; ++it) ring[it] = a_frag(ab0, it);
+#pragma unroll 1
+    for (int k = 0; k < nph; k += 2) {
+      run_phase(gb0, ab0, gb1, ab1);
+      if (k + 1 < nph) run_phase(gb1, ab1, gb0, ab0);
+      else LDS_FENCE_BARRIER_RAW();
+    }
+  }
+
+  float* __restrict__ slab = p.slab + (size_t)group * (size_t)p.Cout * 9 * (size_t)p.SC;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cot * CT + t * 16 + lq * 4 + r;
+        const int ci = cit * CT + wci * 16 + li;
+        slab[((size_t)co * 9 + tap) * (size_t)p.SC + ci] = acc[t][tap][r];
+      }
+}
+
+template <int WL, int PRO>
+int launch_s2(const FrWgradArgs& a, hipStream_t st) {
+  using L = SL2<WL>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_s2roll_kernel<WL, PRO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS);
+    attr_done = true;
+  }
+  const int tiles = (a.Cout / CT) * (a.SC / CT);
+  hipLaunchKernelGGL((conv_wgrad_s2roll_kernel<WL, PRO>), dim3(tiles * a.nsplit), dim3(512), L::LDS, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fr_set_error(hipGetErrorString(e));
+    return (int)e;
+  }
+  if (a.defer) return 0;
+  return fr_launch_reduce_slabs(a.slab, a.nsplit, (long long)a.Cout * 9 * a.SC, a.dw, st);
+}
+
+template <int WL>
+int by_pro_s2(const FrWgradArgs& a, hipStream_t st) {
+  switch (a.pro) {
+    case FR_PRO_NONE: return launch_s2<WL, FR_PRO_NONE>(a, st);
+    case FR_PRO_BN: return launch_s2<WL, FR_PRO_BN>(a, st);
+    case FR_PRO_PRELU: return launch_s2<WL, FR_PRO_PRELU>(a, st);
+  }
+  FR_UNSUPPORTED("fr_conv_wgrad_strip: unknown prologue");
+}
+
 template <int W, int PRO>
 int launch_vr(const FrWgradArgs& a, hipStream_t st) {
   using C = VC<W>;
@@ -975,6 +1295,31 @@ bool fr_wgrad_roll_serves(const FrWgradArgs& a) {
   if (a.SW == 7) return fr_wgrad_roll7_enabled() && a.nsplit <= a.B;
   if (a.SW == 56 || a.SW == 112) return fr_wgrad_vr_enabled() && a.nsplit <= a.B * (a.SW + 2);
   return false;
+}
+
+// FRHIP_WGRAD_S2ROLL=0: stride-2 weight gradients back on the strip kernel (A/B switch)
+// stride-2 3x3 with a 28 / 14 / 7 wide gradient, channel counts multiples of 64, at least one phase per group
+bool fr_wgrad_s2roll_serves(const FrWgradArgs& a) {
+  static const bool on = [] {
+    const char* e = getenv("FRHIP_WGRAD_S2ROLL");
+    return !(e && e[0] == '0');
+  }();
+  if (!(on && fr_wgrad_roll_enabled() && a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad == 1 && a.GH == a.GW &&
+        a.SH == 2 * a.GH && a.SW == 2 * a.GW && a.Cout % CT == 0 && a.SC % CT == 0 && a.nsplit >= 1))
+    return false;
+  if (a.GW == 28) return a.nsplit <= a.B * SC2<28>::NPH;
+  if (a.GW == 14) return a.nsplit <= a.B * SC2<14>::NPH;
+  if (a.GW == 7) return a.nsplit <= a.B * SC2<7>::NPH;
+  return false;
+}
+
+int fr_wgrad_s2roll_launch(const FrWgradArgs& a, hipStream_t st) {
+  switch (a.GW) {
+    case 28: return by_pro_s2<28>(a, st);
+    case 14: return by_pro_s2<14>(a, st);
+    case 7: return by_pro_s2<7>(a, st);
+  }
+  FR_UNSUPPORTED("fr_conv_wgrad_strip: stride-2 width not served by the warp-specialised kernel");
 }
 
 int fr_wgrad_roll_launch(const FrWgradArgs& a, hipStream_t st) {

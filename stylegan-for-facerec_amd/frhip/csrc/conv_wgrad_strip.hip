@@ -462,6 +462,7 @@ extern "C" int fr_conv_wgrad_strip(const FrWgradArgs* args, void* stream) {
     FR_UNSUPPORTED("fr_conv_wgrad_strip: bad prev_* (deferred slab sum)");
   if (a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad == 1 && a.GH == a.GW && a.SH == 2 * a.GH && a.SW == 2 * a.GW &&
       a.Cout % CT == 0 && a.SC % CT == 0) {
+    if (fr_wgrad_s2roll_serves(a)) return fr_wgrad_s2roll_launch(a, st);
     // stride 2: the input tile holds the four parity planes of the strip (see WC)
     switch (a.GW) {
       case 56: return by_pro<56, 2, 1, 8, true>(a, st);

@@ -24,3 +24,6 @@ bool fr_s2roll_enabled();
 bool fr_wgrad_roll_enabled();
 bool fr_wgrad_roll_serves(const FrWgradArgs& a);
 int fr_wgrad_roll_launch(const FrWgradArgs& a, hipStream_t st);
+// ... and the stride-2 ones with a 28 / 14 / 7 wide gradient (conv_wgrad_s2roll_kernel, same file)
+bool fr_wgrad_s2roll_serves(const FrWgradArgs& a);
+int fr_wgrad_s2roll_launch(const FrWgradArgs& a, hipStream_t st);

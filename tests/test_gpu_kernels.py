@@ -950,9 +950,11 @@ def test_stem_gemm_and_wgrad(K, Kp, M):
 
 
 @pytest.mark.parametrize("C,WL", S2_SHAPES, ids=["%d_%d" % s for s in S2_SHAPES])
-@pytest.mark.parametrize("groups", [1, 3])
+@pytest.mark.parametrize("groups", [1, 3, 5])
 def test_conv_wgrad_strip_stride2(K, C, WL, groups):
-    """fr_conv_wgrad_strip on a stride-2 layer (input tile = four parity planes) with the PReLU prologue, vs autograd."""
+    """fr_conv_wgrad_strip on a stride-2 layer (input tile = four parity planes) with the PReLU prologue, vs autograd.
+    128 / 256 / 512 channels run on the warp-specialised kernel (conv_wgrad_s2roll_kernel): 42 / 12 / 3 phases at B = 3,
+    so 5 groups give runs that start inside an image, an odd number of phases, and (14x14, 7x7) a group without work."""
     dtype, tol = torch.bfloat16, BF16_TOL
     B, H = 3, 2 * WL
     x = q(synth.normal(65, "wx", (B, C, H, H)), dtype)

@@ -78,8 +78,12 @@ def wgrad_case(kind, cout, cin, W, B, stride=1, pro=1, iters=20):
     flops = 2.0 * B * Ho * Ho * cout * cin * 9
     if kind == "wgs":
         tiles = (cout // 64) * (cin // 64)
-        rows = {112: 2, 56: 4, 28: 7, 14: 14, 7: 7}[W]
-        fills = B * (W // rows) // (4 if W == 7 else 1)
+        if stride == 2:  # the engine's group count (engine.py _wgrad)
+            rows, nimg = {56: (2, 1), 28: (4, 1), 14: (7, 1), 7: (7, 2)}[Ho]
+            fills = (B * (Ho // rows) + nimg - 1) // nimg
+        else:
+            rows = {112: 2, 56: 4, 28: 7, 14: 14, 7: 7}[W]
+            fills = B * (W // rows) // (4 if W == 7 else 1)
         groups = max(1, min(fills, 256 // tiles))
         slab = torch.empty(groups * cout * 9 * cin, device="cuda")
         l = ops.wgrad_strip(st, nsplit=groups, slab=slab, **kw)
@@ -117,6 +121,9 @@ def suite_cases(B):
         ("wgs_256_256_14_bn", lambda it: wgrad_case("wgs", 256, 256, 14, B, pro=1, iters=it)),
         ("wgs_512_512_7", lambda it: wgrad_case("wgs", 512, 512, 7, B, pro=2, iters=it)),
         ("wgs_128_128_28", lambda it: wgrad_case("wgs", 128, 128, 28, B, pro=2, iters=it)),
+        ("wgs_s2_128_28", lambda it: wgrad_case("wgs", 128, 128, 56, B, stride=2, pro=2, iters=it)),
+        ("wgs_s2_256_14", lambda it: wgrad_case("wgs", 256, 256, 28, B, stride=2, pro=2, iters=it)),
+        ("wgs_s2_512_7", lambda it: wgrad_case("wgs", 512, 512, 14, B, stride=2, pro=2, iters=it)),
         ("strip_512_512_7_fwd", lambda it: conv_case("strip", 512, 512, 7, B, pro=1, epi=0, iters=it)),
     ]
 
