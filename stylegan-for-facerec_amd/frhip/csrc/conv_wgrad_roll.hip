@@ -885,6 +885,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_vr_kernel(const FrWgradArgs
 template <int WL_>
 struct SC2;
 template <>
+struct SC2<56> {  // 64 channels, ONE dW tile: 256 groups of 56 phases; a phase re-reads the last input row of the previous one
+  static constexpr int WL = 56, RW = 64, PRK = 1, NPH = 56;
+};
+template <>
 struct SC2<28> {
   static constexpr int WL = 28, RW = 32, PRK = 2, NPH = 14;
 };
@@ -901,8 +905,10 @@ template <int WL>
 struct SL2 {
   using C = SC2<WL>;
   static constexpr int G_BYTES = C::PRK * C::RW * TSTR;
-  static constexpr int P1 = ((C::PRK + 1) * C::RW + 16) * TSTR;  // odd high-res rows (a = 1): plane rows r0-1 .. r0+PRK-1
-  static constexpr int P0 = (C::PRK * C::RW + 16) * TSTR;        // even rows (a = 0): plane rows r0 .. r0+PRK-1
+  // tail: the positions past the last row a shifted fragment read touches (one at most; 16 kept where LDS allows)
+  static constexpr int TAIL = C::RW >= 64 ? 2 : 16;
+  static constexpr int P1 = ((C::PRK + 1) * C::RW + TAIL) * TSTR;  // odd high-res rows (a = 1): plane rows r0-1 .. r0+PRK-1
+  static constexpr int P0 = (C::PRK * C::RW + TAIL) * TSTR;        // even rows (a = 0): plane rows r0 .. r0+PRK-1
   static constexpr int plane_off(int a, int b) { return G_BYTES + (a ? (b ? 0 : P1) : 2 * P1 + (b ? 0 : P0)); }
   static constexpr int BUF = G_BYTES + 2 * P1 + 2 * P0;
   static constexpr int LDS = 2 * BUF;
@@ -1297,6 +1303,15 @@ bool fr_wgrad_roll_serves(const FrWgradArgs& a) {
   return false;
 }
 
+// FRHIP_WGRAD_S2ROLL56=0: the 64-channel stride-2 weight gradient back on the strip kernel (A/B switch)
+static bool s2roll56_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("FRHIP_WGRAD_S2ROLL56");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 // FRHIP_WGRAD_S2ROLL=0: stride-2 weight gradients back on the strip kernel (A/B switch)
 // stride-2 3x3 with a 28 / 14 / 7 wide gradient, channel counts multiples of 64, at least one phase per group
 bool fr_wgrad_s2roll_serves(const FrWgradArgs& a) {
@@ -1307,6 +1322,7 @@ bool fr_wgrad_s2roll_serves(const FrWgradArgs& a) {
   if (!(on && fr_wgrad_roll_enabled() && a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad == 1 && a.GH == a.GW &&
         a.SH == 2 * a.GH && a.SW == 2 * a.GW && a.Cout % CT == 0 && a.SC % CT == 0 && a.nsplit >= 1))
     return false;
+  if (a.GW == 56) return s2roll56_enabled() && a.nsplit <= a.B * SC2<56>::NPH;
   if (a.GW == 28) return a.nsplit <= a.B * SC2<28>::NPH;
   if (a.GW == 14) return a.nsplit <= a.B * SC2<14>::NPH;
   if (a.GW == 7) return a.nsplit <= a.B * SC2<7>::NPH;
@@ -1315,6 +1331,7 @@ bool fr_wgrad_s2roll_serves(const FrWgradArgs& a) {
 
 int fr_wgrad_s2roll_launch(const FrWgradArgs& a, hipStream_t st) {
   switch (a.GW) {
+    case 56: return by_pro_s2<56>(a, st);
     case 28: return by_pro_s2<28>(a, st);
     case 14: return by_pro_s2<14>(a, st);
     case 7: return by_pro_s2<7>(a, st);

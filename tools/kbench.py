@@ -121,6 +121,7 @@ def suite_cases(B):
         ("wgs_256_256_14_bn", lambda it: wgrad_case("wgs", 256, 256, 14, B, pro=1, iters=it)),
         ("wgs_512_512_7", lambda it: wgrad_case("wgs", 512, 512, 7, B, pro=2, iters=it)),
         ("wgs_128_128_28", lambda it: wgrad_case("wgs", 128, 128, 28, B, pro=2, iters=it)),
+        ("wgs_s2_64_56", lambda it: wgrad_case("wgs", 64, 64, 112, B, stride=2, pro=2, iters=it)),
         ("wgs_s2_128_28", lambda it: wgrad_case("wgs", 128, 128, 56, B, stride=2, pro=2, iters=it)),
         ("wgs_s2_256_14", lambda it: wgrad_case("wgs", 256, 256, 28, B, stride=2, pro=2, iters=it)),
         ("wgs_s2_512_7", lambda it: wgrad_case("wgs", 512, 512, 14, B, stride=2, pro=2, iters=it)),

@@ -57,6 +57,7 @@ def table():
         "wgs_512_512_7": (r"conv_wgrad_roll_kernel<7, 2>|conv_wgrad_strip_kernel<7, 7, 4,", 2 * act(7, 512) + dw(512, 512), f3(7, 512, 512)),
         "strip_512_512_7_fwd": (r"conv3x3_strip_kernel<512, (128|256), 7,", 2 * act(7, 512) + w3(512, 512), f3(7, 512, 512)),
         # stride-2 weight gradients: the high-res input + the low-res gradient once + dW
+        "wgs_s2_64_56": (r"conv_wgrad_s2roll_kernel<56, 2>|conv_wgrad_strip_kernel<56, 2, 1, 8, 2, true", act(112, 64) + act(56, 64) + dw(64, 64), f3(56, 64, 64)),
         "wgs_s2_128_28": (r"conv_wgrad_s2roll_kernel<28, 2>|conv_wgrad_strip_kernel<28, 4, 1, 8, 2, true", act(56, 128) + act(28, 128) + dw(128, 128), f3(28, 128, 128)),
         "wgs_s2_256_14": (r"conv_wgrad_s2roll_kernel<14, 2>|conv_wgrad_strip_kernel<14, 7, 1, 8, 2, true", act(28, 256) + act(14, 256) + dw(256, 256), f3(14, 256, 256)),
         "wgs_s2_512_7": (r"conv_wgrad_s2roll_kernel<7, 2>|conv_wgrad_strip_kernel<7, 7, 2, 8, 2, true", act(14, 512) + act(7, 512) + dw(512, 512), f3(7, 512, 512)),
