@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 2
+#define FR_ABI_VERSION 3
 
 enum { FR_F32 = 0, FR_BF16 = 1 };
 
@@ -75,6 +75,10 @@ typedef struct FrConvArgs {
   float* part;        /* [ceil(rows/128)][2][N] partial column sums */
   const int64_t* label; /* [rows] */
   float* cos_t;         /* [rows] */
+  /* fr_conv3x3_pair only (ABI v3): the second convolution of the pair */
+  const void* w2;      /* [N][9][N] packed weights of conv2 */
+  void* out2;          /* [B*RH*RW][ldc] result of conv2 (epilogue `epi`, partial sums in `part`) */
+  const float* slope2; /* [N] PReLU slopes applied between the two convolutions */
 } FrConvArgs;
 
 /* Convolution forward / data gradient / dense GEMM on MFMA.
@@ -91,6 +95,17 @@ int fr_conv_igemm(const FrConvArgs* args, int dtype, void* stream);
  * Replaces Conv2d(c, d, (3,3), (1,1), 1) of bottleneck_IR (backbone/model_irse.py:57-59) fwd + data gradient. */
 int fr_conv3x3_strip(const FrConvArgs* args, void* stream);
 int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi);
+
+/* conv1 -> PReLU -> conv2 of one residual unit in ONE launch (bf16, whole-image strips, Cin == Cout == N):
+ *   out  = conv3x3(pro(src), w)                      stored for the backward pass (epilogue STORE)
+ *   out2 = conv3x3(PReLU_{slope2}(out), w2)          epilogue `epi` (STORE / STATS), partial sums -> part[image][2][N]
+ * bit-identical to fr_conv3x3_strip(pro = BN, epi = STORE) followed by fr_conv3x3_strip(pro = PRELU, epi): the bf16 tile of
+ * the first result is turned into the second input inside LDS instead of being read back from HBM.
+ * fr_conv3x3_pair_supported: 1 when (B, C, W) has an instance (C = 256, W = 14, B above the split-channel threshold).
+ * Measured no faster than the two launches (conv3x3_strip.hip): the engine uses it only with FRHIP_PAIR=1.
+ * Replaces Conv2d(c, d, 3, 1, 1) -> PReLU(d) -> Conv2d(d, d, 3, 1, 1) of bottleneck_IR (backbone/model_irse.py:57-59). */
+int fr_conv3x3_pair(const FrConvArgs* args, void* stream);
+int fr_conv3x3_pair_supported(int B, int C, int W);
 
 /* Stride-2 3x3 convolution (bf16, Cin == Cout: the first unit of every IR stage) on LDS-resident parity planes:
  * mode 0 = forward (SH = 2*RH), mode 2 with par_h = par_w = -1 = data gradient of all four output parity classes

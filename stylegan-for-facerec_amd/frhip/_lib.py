@@ -110,7 +110,7 @@ lib = _load()
 
 
 def self_check():
-    assert lib.fr_abi_version() == 2
+    assert lib.fr_abi_version() == 3
     for i, s in enumerate((FrConvArgs, FrWgradArgs, FrApplyArgs, FrBnBwdArgs, FrSgdTensor, FrPackTensor, FrAdamTensor, FrBnEvalEntry)):
         got = lib.fr_struct_size(i)
         if got != ctypes.sizeof(s):

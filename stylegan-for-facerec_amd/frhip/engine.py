@@ -633,10 +633,23 @@ class BackbonePlan(object):
                 self._pack_reqs.append((w2, None, d["wt2"], u.depth, 9, u.depth))
                 wp1, wp2 = w1, w2
             bn1, bn2 = d["bn1"], d["bn2"]
-            self._conv(L, src=x, w=wp1, out=d["y1"], B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H, SC=u.cin,
-                       N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.cin, ldc=u.depth,
-                       pro=ops.PRO_BN, pro_a=bn1.scale, pro_b=bn1.shift, epi=ops.EPI_STORE)
             folded = fold and u.se is None and (u.sc_conv is not None or u.stride == 1)
+            # FRHIP_PAIR=1: conv1 -> PReLU -> conv2 in one launch where the strip table has a pair instance (256 channels at
+            # 14x14): y1 still goes to HBM for the backward pass, but conv2 takes it from LDS (bit-identical to two launches).
+            # Opt-in: measured 0.1-0.2 ms SLOWER per step than the two launches (csrc/conv3x3_strip.hip, tools/pair_bench.py)
+            pair = (fr == FR_BF16 and self.use_strip and not folded and u.cin == u.depth and u.stride == 1 and
+                    os.environ.get("FRHIP_PAIR", "0") == "1" and ops.strip_pair_supported(B, u.depth, u.H))
+            if pair:
+                kw = dict(src=x, w=wp1, out=d["y1"], w2=wp2, out2=d["y2"], slope2=u.prelu.weight, B=B, RH=u.H, RW=u.H,
+                          SH=u.H, SW=u.H, SC=u.cin, N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.cin,
+                          ldc=u.depth, pro=ops.PRO_BN, pro_a=bn1.scale, pro_b=bn1.shift, epi=stats_epi, part=stats_part)
+                L.append(ops.conv_strip_pair(st, **kw))
+                self._last_conv_strips = ops.strip_parts(B, u.depth, u.depth, u.H, stats_epi)
+                np2 = self._check_part(self._last_conv_strips, kw)
+            else:
+                self._conv(L, src=x, w=wp1, out=d["y1"], B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H, SC=u.cin,
+                           N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.cin, ldc=u.depth,
+                           pro=ops.PRO_BN, pro_a=bn1.scale, pro_b=bn1.shift, epi=ops.EPI_STORE)
             if folded:
                 # inference with BN2 (and the shortcut BN) folded into the packed weights: out = conv2'(PReLU(y1)) +
                 # shift2 [+ shiftS] + shortcut straight from conv2's epilogue -- y2 is never written, no BN-apply pass
@@ -660,10 +673,11 @@ class BackbonePlan(object):
                     self._bn_train_launches(L, nxt, None, 0, rout)
                 x = d["out"]
                 continue
-            np2 = self._conv(L, src=d["y1"], w=wp2, out=d["y2"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H,
-                             SC=u.depth, N=u.depth, KH=3, KW=3, stride=u.stride, pad=1, mode=0, lda=u.depth,
-                             ldc=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight, epi=stats_epi,
-                             part=stats_part)
+            if not pair:
+                np2 = self._conv(L, src=d["y1"], w=wp2, out=d["y2"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H,
+                                 SC=u.depth, N=u.depth, KH=3, KW=3, stride=u.stride, pad=1, mode=0, lda=u.depth,
+                                 ldc=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight, epi=stats_epi,
+                                 part=stats_part)
             self._bn_train_launches(L, bn2, self.part, np2, rout)
             strips2 = self._last_conv_strips if not fold else 0  # conv2's partial rows, if they are whole strips of single images
             if u.sc_conv is not None:

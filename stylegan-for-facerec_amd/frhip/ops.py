@@ -80,6 +80,17 @@ def conv_strip(stream, **kw):
     return Launch("fr_conv3x3_strip", [ctypes.byref(a), stream], keep=(a, kw))
 
 
+def conv_strip_pair(stream, **kw):
+    """fr_conv3x3_pair: conv1 -> PReLU -> conv2 of a residual unit in one launch (out = y1, out2 / w2 / slope2 = the second
+    convolution).  Same FrConvArgs fields as conv()."""
+    a = _fill(_lib.FrConvArgs(), **kw)
+    return Launch("fr_conv3x3_pair", [ctypes.byref(a), stream], keep=(a, kw))
+
+
+def strip_pair_supported(B, c, w):
+    return bool(lib.fr_conv3x3_pair_supported(int(B), int(c), int(w)))
+
+
 def strip_parts(B, cin, cout, w, epi=EPI_STORE):
     """Workgroups (= partial-sum rows) of the strip kernel for a shape + epilogue; 0 when it is not served."""
     return int(lib.fr_conv3x3_strip_parts(int(B), int(cin), int(cout), int(w), int(epi)))

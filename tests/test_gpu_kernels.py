@@ -647,6 +647,44 @@ def test_conv3x3_strip(K, cin, cout, W, B):
                                        atol=1e-2 * float((gx * xh).abs().sum() / cin))
 
 
+@pytest.mark.parametrize("B", [161, 200])
+def test_conv3x3_pair_is_bit_identical_to_two_launches(K, B):
+    """fr_conv3x3_pair (conv1 -> PReLU -> conv2 of a residual unit in one launch; the 13 all-256-channel units at 14x14 of an
+    IR-50 / IR-SE step at B > 160) against the two fr_conv3x3_strip launches it replaces: y1, y2 and the BatchNorm partial
+    sums must agree bit for bit (the PReLU between them is the same fp32 arithmetic on the same bf16 tile), and y2 is
+    checked against F.conv2d once."""
+    dtype, C, W = torch.bfloat16, 256, 14
+    if not K.strip_pair_supported(B, C, W):
+        pytest.skip("no pair instance in this strip table (FRHIP_STRIP_VARIANT=0)")
+    st = K.current_stream_ptr()
+    x = q(synth.normal(33, "px", (B, C, W, W)), dtype)
+    w1 = q(synth.normal(33, "pw1", (C, C, 3, 3), std=0.03), dtype)
+    w2 = q(synth.normal(33, "pw2", (C, C, 3, 3), std=0.03), dtype)
+    pa = synth.uniform(33, "ppa", (C,), 0.5, 1.5)
+    pb = synth.uniform(33, "ppb", (C,), -0.5, 0.5)
+    slope = synth.uniform(33, "psl", (C,), 0.05, 0.4)
+    xd, w1d, w2d = nhwc(x, dtype), pack_w(w1, dtype), pack_w(w2, dtype)
+    n = K.strip_parts(B, C, C, W, K.EPI_STATS)
+    common = dict(B=B, RH=W, RW=W, SH=W, SW=W, SC=C, N=C, KH=3, KW=3, stride=1, pad=1, mode=0, lda=C, ldc=C)
+    y1p = torch.zeros(B, W, W, C, device="cuda", dtype=dtype)
+    y2p = torch.zeros_like(y1p)
+    partp = torch.zeros(n, 2, C, device="cuda")
+    K.conv_strip_pair(st, src=xd, w=w1d, out=y1p, w2=w2d, out2=y2p, slope2=slope.cuda(), pro=K.PRO_BN, pro_a=pa.cuda(),
+                      pro_b=pb.cuda(), epi=K.EPI_STATS, part=partp, **common)()
+    y1 = torch.zeros_like(y1p)
+    y2 = torch.zeros_like(y1p)
+    part = torch.zeros(n, 2, C, device="cuda")
+    K.conv_strip(st, src=xd, w=w1d, out=y1, pro=K.PRO_BN, pro_a=pa.cuda(), pro_b=pb.cuda(), epi=K.EPI_STORE, **common)()
+    K.conv_strip(st, src=y1, w=w2d, out=y2, pro=K.PRO_PRELU, pro_a=slope.cuda(), epi=K.EPI_STATS, part=part, **common)()
+    torch.cuda.synchronize()
+    assert torch.equal(y1p, y1) and torch.equal(y2p, y2) and torch.equal(partp, part)
+    if B == 161:  # and the pair against the CPU once (first 3 images)
+        xin = q((x[:3].double() * pa.double().view(1, -1, 1, 1) + pb.double().view(1, -1, 1, 1)).float(), dtype)
+        r1 = q(F.conv2d(xin, w1, padding=1), dtype)
+        r2 = F.conv2d(q(torch.where(r1 > 0, r1, r1 * slope.view(1, -1, 1, 1)), dtype), w2, padding=1)
+        assert relerr(from_nhwc(y2p[:3]), r2) < BF16_TOL * 2
+
+
 def test_bf16_engine_with_and_without_strip_agree():
     """The LDS-strip convolutions and the generic implicit-GEMM path are two implementations of the same layers: a
     full bf16 IR-50 step must give (nearly) the same features and gradients through either."""

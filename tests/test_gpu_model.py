@@ -1411,3 +1411,46 @@ def test_fused_bn_backward_sums_are_bit_identical():
     assert n_plain - n_fused == 20, (n_plain, n_fused)  # every unit behind a stride-1 identity unit: 24 - 4 stage heads
     bad = [n for n in plain if not torch.equal(plain[n], fused[n])]
     assert not bad, bad[:5]
+
+
+def test_paired_convolutions_are_bit_identical_to_separate_launches():
+    """fr_conv3x3_pair in the engine (round 3, opt-in FRHIP_PAIR=1: measured no faster): at B > 160 the 13 all-256-channel
+    units at 14x14 of IR-50 run conv1 -> PReLU -> conv2 as ONE launch (y1 goes to HBM for the backward pass, conv2 takes it from
+    LDS).  Loss, features and every parameter gradient of a bf16 training step must be bit for bit what the default (two
+    launches per unit) gives."""
+    _need_gpu()
+    from backbone.model_irse import IR_50
+    from head.metrics import ArcFace
+    from loss.focal import FocalLoss
+    B = 162
+
+    def run(pair):
+        os.environ["FRHIP_PAIR"] = pair
+        try:
+            m = IR_50([112, 112])
+            synth.fill_state_dict(m.state_dict(), 15)
+            m.output_layer[1].p = 0.0
+            m.compute_dtype = torch.bfloat16
+            m = m.cuda().train()
+            head = ArcFace(512, 100, None).cuda()
+            with torch.no_grad():
+                head.weight.copy_(synth.uniform(16, "full.head", (100, 512), -0.1, 0.1))
+            x = synth.uniform(16, "pair.x", (B, 3, 112, 112)).cuda()
+            y = synth.labels(16, "pair.label", B, 100).cuda()
+            f = m(x)
+            loss, _ = FocalLoss()(head(f, y), y)
+            loss.backward()
+            torch.cuda.synchronize()
+            plan = m._runner[0].plan
+            n_pair = sum(getattr(l, "name", "") == "fr_conv3x3_pair" for l in plan.fwd_list)
+            grads = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+            return f.detach().clone(), float(loss.detach()), grads, n_pair
+        finally:
+            os.environ.pop("FRHIP_PAIR")
+
+    f1, l1, g1, n1 = run("1")
+    f0, l0, g0, n0 = run("0")
+    assert (n1, n0) == (13, 0), (n1, n0)
+    assert l1 == l0 and torch.equal(f1, f0)
+    bad = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+    assert not bad, bad[:5]
