@@ -642,6 +642,8 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
   const bool v1 = strip_variant() >= 1;
 #define SHAPE(ci, co, w, rows, wn, nw) \
   if (a.SC == ci && a.N == co && a.SW == w) return by_pro<ci, co, w, rows, wn, nw>(a, st);
+  // (round 3: 128 -> 128 @28 as 8 waves x (25 tiles x 1 column) on half images, one workgroup per CU, half the weight stream:
+  // 0.143 / 0.151 ms forward / data gradient against 0.068 / 0.070 for the two resident 4-wave workgroups below)
   if (v1) {  // measured (tools/kbench.py, B=256): 1.1-1.45x over the 8-wave instances at these three shapes
     SHAPE(64, 64, 112, 2, 2, 4)
     SHAPE(64, 64, 56, 7, 2, 4)
