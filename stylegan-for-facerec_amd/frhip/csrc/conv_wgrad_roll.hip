@@ -66,7 +66,8 @@ struct RC<28> {
   static constexpr int row0(int ph) { return 4 * ph; }
 };
 template <>
-struct RC<7> {  // uniform schedule, one phase (two K steps) per image
+struct RC<7> {  // uniform schedule, one phase (two K steps) per image (pairs of images per phase -- four K steps, only real
+                // pixels moved, no row clamping: 0.085 against 0.083 ms, measured and dropped)
   static constexpr int W = 7, RW = 8, NPH = 1;
   static constexpr int rows(int) { return 7; }
   static constexpr int krows(int) { return 8; }
