@@ -719,8 +719,8 @@ def test_hip_graph_replay_is_bit_identical_to_eager_launches():
 
 
 def test_full_size_step_strip_and_generic_paths_agree():
-    """BASELINE configs[1] at its full size (IR-50, batch 256, bf16): too big for the CPU oracle, so the check is a
-    property -- the LDS-strip kernels (stride 1 / stride 2 / stem, incl. the two-images-per-workgroup and side-stream
+    """BASELINE configs[1] at its full size (IR-50, batch 256, bf16), as a property (the comparison with the oracle at this
+    size is test_bench_size_step_tracks_the_oracle) -- the LDS-strip kernels (stride 1 / stride 2 / stem, incl. the two-images-per-workgroup and side-stream
     paths that only large even batches take) and the generic implicit-GEMM kernels are independent implementations of
     the same layers and must produce the same step: loss, features and gradients agree to bf16 rounding noise.  Also
     guards the 32-bit index arithmetic at 3.2 M rows x 64 channels."""
@@ -1454,3 +1454,64 @@ def test_paired_convolutions_are_bit_identical_to_separate_launches():
     assert l1 == l0 and torch.equal(f1, f0)
     bad = [n for n in g0 if not torch.equal(g0[n], g1[n])]
     assert not bad, bad[:5]
+
+
+def test_bench_size_step_tracks_the_oracle():
+    """BASELINE configs[1] at ITS size -- IR-50 + ArcFace(7000) + Focal, batch 256, bf16 storage, the instances bench.py
+    times -- against the CPU oracle (fp32, oracle/irse_ref.py train_step; ~10 s and ~20 GB on the host cores): loss,
+    features, every per-parameter gradient norm, and direction + norm of the gradient tensors along the whole depth.  At 256
+    images the bf16 noise averages down: the bars are tighter than the batch-4 / 8 / 16 golden fixtures'."""
+    _need_gpu()
+    from backbone.model_irse import IR_50
+    from head.metrics import ArcFace
+    from loss.focal import FocalLoss
+    from oracle import irse_ref as O
+    B, N = 256, 7000
+    x = synth.uniform(33, "big.x", (B, 3, 112, 112))
+    y = synth.labels(33, "big.y", B, N)
+    m = IR_50([112, 112])
+    synth.fill_state_dict(m.state_dict(), 15)
+    m.output_layer[1].p = 0.0
+    m.compute_dtype = torch.bfloat16
+    m = m.cuda().train()
+    head = ArcFace(512, N, None).cuda()
+    with torch.no_grad():
+        head.weight.copy_(synth.uniform(33, "big.head", (N, 512), -0.05, 0.05))
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+    hw = head.weight.detach().cpu().clone().requires_grad_(True)
+    feats = m(x.cuda())
+    logits = head(feats, y.cuda())
+    loss, _ = FocalLoss()(logits, y.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    plan = m._runner[0].plan
+    assert plan.tdtype == torch.bfloat16 and plan.use_strip
+    rf, rl, rloss, rg = O.train_step(sd, x, y, hw, num_layers=50, se=False, head="ArcFace", s=64.0, m=0.5)
+    cosf = torch.nn.functional.cosine_similarity
+    loss_rel = abs(float(loss.detach()) - float(rloss.detach())) / abs(float(rloss.detach()))
+    feat_cos = float(cosf(feats.detach().cpu().float(), rf.detach(), dim=1).min())
+    named = dict(m.named_parameters())
+    names = [n for n in named if n in rg and not n.endswith(ZERO_GRAD_SUFFIXES)]
+    got = np.array([float(named[n].grad.double().norm()) for n in names])
+    ref = np.array([float(rg[n].double().norm()) for n in names])
+    ratio = np.abs(got - ref) / np.maximum(ref, 1e-12)
+    worst = int(np.argmax(ratio))
+    rep = dict(loss_rel=loss_rel, feat_cos_min=feat_cos, norms_median=float(np.median(ratio)),
+               norms_p95=float(np.percentile(ratio, 95)), norms_worst=float(ratio[worst]), worst_name=names[worst])
+    print("\nbf16 B=256 step vs oracle: %s" % json.dumps(rep))
+    assert loss_rel < 2e-3 and feat_cos > 0.9995, rep
+    # measured (round 3, MI355X): loss 1e-4, features 0.99976, norms median 0.2 % / p95 2.1 % / worst 6.0 % (the BN1 weight of
+    # unit 0), captured tensors cos 0.987 (first units) ... 0.9998 (output layer), norm ratios within 0.12 %
+    assert rep["norms_median"] < 0.005 and rep["norms_p95"] < 0.03 and rep["norms_worst"] < 0.10, rep
+    for n in ("input_layer.0.weight", "body.0.res_layer.1.weight", "body.0.res_layer.3.weight", "body.3.res_layer.3.weight",
+              "body.7.shortcut_layer.0.weight", "body.12.res_layer.1.weight", "body.21.res_layer.3.weight",
+              "body.23.res_layer.1.weight", "output_layer.3.weight"):
+        c = float(cosf(named[n].grad.detach().cpu().double().reshape(1, -1), rg[n].double().reshape(1, -1)))
+        r = float(named[n].grad.double().norm()) / float(rg[n].double().norm())
+        print("   grad %-36s cos %.5f  norm ratio %.4f" % (n, c, r))
+        assert c > 0.975 and abs(r - 1) < 0.02, (n, c, r)
+    c = float(cosf(head.weight.grad.detach().cpu().double().reshape(1, -1), rg["head.weight"].double().reshape(1, -1)))
+    assert c > 0.999, c
