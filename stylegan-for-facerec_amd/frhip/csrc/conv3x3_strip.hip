@@ -602,6 +602,7 @@ extern "C" int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi) 
   if (Cin == 256 && Cout == 512 && W == 14 && epi != FR_EPI_STORE) return 0;
   if (Cin == 64 && Cout == 64 && (W == 112 || W == 56) && fr_roll64_enabled()) return fr_roll64_parts(B, W);
   const int rows = strip_rows(Cin, Cout, W);
+  if (Cin == 512 && Cout == 512 && W == 7 && strip_variant() >= 3 && B % 2 == 0 && small_batch(B)) return B / 2;
   if (Cin == 512 && Cout == 512 && W == 7 && strip_variant() >= 3 && B % 4 == 0) return B / 4;  // four images per strip
   if (Cin == 512 && Cout == 512 && W == 7 && strip_variant() >= 2 && B % 2 == 0) return B / 2;  // two images per strip
   return rows ? B * (W / rows) : 0;
@@ -688,6 +689,10 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
   // split over four workgroups: 196 pixels (13 M tiles, 6 % padding) per weight fragment, 13 MFMAs per 16-byte weight
   // load instead of 7 x 2 per 2 loads, half the weight stream per launch (302 MB): 0.092 -> 0.073 ms forward, 0.095 -> 0.070
   // data gradient at B = 256 (tools/kbench.py, same box), no scratch, 100 KB of LDS.
+  // ... at small batches (IR-SE-101 trains at 128 images per GPU: 32 four-image strips x 4 = 128 workgroups would leave half
+  // the CUs idle) two images per workgroup with the same split: B / 2 x 4 workgroups
+  if (a.SC == 512 && a.N == 512 && a.SW == 7 && strip_variant() >= 3 && a.B % 2 == 0 && small_batch(a.B))
+    return by_pro<512, 128, 7, 7, 8, 8, 4, 2, 2>(a, st);
   if (a.SC == 512 && a.N == 512 && a.SW == 7 && strip_variant() >= 3 && a.B % 4 == 0) return by_pro<512, 128, 7, 7, 8, 8, 4, 4, 4>(a, st);
   if (a.SC == 512 && a.N == 512 && a.SW == 7 && strip_variant() >= 2 && a.B % 2 == 0) return by_pro<512, 256, 7, 7, 8, 8, 2, 2, 2>(a, st);
   SHAPE(512, 512, 7, 7, 8, 8)

@@ -567,16 +567,16 @@ STRIP_SHAPES = [(64, 64, 112), (64, 64, 56), (64, 128, 56), (128, 64, 56), (128,
                 (256, 128, 28), (256, 256, 14), (256, 512, 14), (512, 256, 14), (512, 512, 7)]
 
 
-# B = 3: every shape of the dispatch table; (512, 512, 7, B): B = 6 -> two images per workgroup at 7x7 (256 resident
-# channels, two channel stages), B = 4 / 12 -> four images per workgroup (128 resident channels, four stages, output
-# channels over four workgroups: the instance bench.py's B = 256 runs), one and three strips;
+# B = 3: every shape of the dispatch table; (512, 512, 7, B): B = 4 / 6 -> two images per workgroup at 7x7, output channels
+# over four workgroups (256 resident channels, two channel stages: the small-batch instance, B <= 160), B = 164 -> four
+# images per workgroup (128 resident channels, four stages: the instance bench.py's B = 256 runs), 41 strips;
 # B = 162 (> 160, even): the instances bench.py's B = 256 step runs -- conv3x3_strip_kernel<256,256,14,14,8,8,1,...>
 # (NSPL = 1, the kernel ``roofline.kernel`` names; B <= 160 takes the split-channel NSPL = 2 instance) and the
 # 256 -> 512 two-pass path built on it -- against CPU F.conv2d / autograd (~40 GFLOP on the host)
 # 64 -> 64 (rolling-window kernel, conv3x3_roll64.hip): B = 3 walks 2-iteration row segments (14 per band); B = 162 @56
 # and B = 130 @112 give more work items than the 256 persistent workgroups (item loop, one 14- / 28-iteration walk per
 # item); B = 40 @56 takes 7-iteration segments
-STRIP_CASES = [s + (3,) for s in STRIP_SHAPES] + [(512, 512, 7, 4), (512, 512, 7, 6), (512, 512, 7, 12),
+STRIP_CASES = [s + (3,) for s in STRIP_SHAPES] + [(512, 512, 7, 4), (512, 512, 7, 6), (512, 512, 7, 164),
                                                   (256, 256, 14, 162), (256, 512, 14, 162),
                                                   (64, 64, 56, 162), (64, 64, 112, 130), (64, 64, 56, 40)]
 
