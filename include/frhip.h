@@ -296,6 +296,11 @@ int fr_se_pool_parts(const float* part, int rows_per_image, const float* scale, 
 /* s = sigmoid(W2 relu(W1 pooled)); W1 [R][C], W2 [C][R]; saves hidden [B][R] */
 int fr_se_mlp_fwd(const float* pooled, const float* w1, const float* w2, float* hidden, float* s, int B, int C,
                   int R, void* stream);
+/* fr_se_pool_parts followed by fr_se_mlp_fwd in one launch (same arithmetic, same order; pooled [B][C] is written for the
+ * weight gradient): the squeeze-excite branch of bottleneck_IR_SE (model_irse.py:23-46) behind a strip convolution */
+int fr_se_pool_parts_mlp_fwd(const float* part, int rows_per_image, const float* scale, const float* shift,
+                             const float* w1, const float* w2, float* pooled, float* hidden, float* s, int B, int HW,
+                             int C, int R, void* stream);
 /* gs[b][c] = sum_hw g * (x*scale+shift)  (gradient wrt the excite scale) */
 int fr_se_gscale(const void* g, const void* x, const float* scale, const float* shift, float* gs, int B, int HW,
                  int C, int dtype, void* stream);
@@ -304,6 +309,12 @@ int fr_se_gscale(const void* g, const void* x, const float* scale, const float* 
 int fr_se_mlp_bwd(const float* gs, const float* s, const float* hidden, const float* pooled, const float* w1,
                   const float* w2, float* gpooled, float* dw1, float* dw2, float* gz, float* gh, int B, int C, int R,
                   int HW, void* stream);
+/* fr_se_gscale followed by fr_se_mlp_bwd with one launch less (gs stays in LDS; same arithmetic, same order): the backward
+ * of the squeeze-excite branch of bottleneck_IR_SE (model_irse.py:23-46); g = gradient at the unit output branch, x = y2 */
+int fr_se_gscale_mlp_bwd(const void* g, const void* x, const float* scale, const float* shift, const float* s,
+                         const float* hidden, const float* pooled, const float* w1, const float* w2, float* gpooled,
+                         float* dw1, float* dw2, float* gz, float* gh, int B, int C, int R, int HW, int dtype,
+                         void* stream);
 
 /* ---- output layer pieces (model_irse.py:144-148) */
 /* a[b][(h*7+w)*C + c] = dropout(x*scale+shift): mask from a counter hash of (seed, element index in the

@@ -770,15 +770,29 @@ __global__ void se_pool_parts_kernel(const float* __restrict__ part, int NS, con
   }
 }
 
-// s = sigmoid(W2 relu(W1 pooled)); one block per image
-__global__ void se_mlp_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+// s = sigmoid(W2 relu(W1 pooled)); one block per image.  PARTS: the squeeze of se_pool_parts_kernel (same arithmetic, same
+// order) happens here and `pooled` is an OUTPUT (the weight gradient reads it) -- one launch less per IR-SE unit.
+template <bool PARTS>
+__global__ void se_mlp_fwd_kernel(const float* __restrict__ pooled_in, const float* __restrict__ w1,
                                   const float* __restrict__ w2, float* __restrict__ hidden, float* __restrict__ s,
-                                  int C, int R) {
+                                  int C, int R, const float* __restrict__ part, int NS,
+                                  const float* __restrict__ scale, const float* __restrict__ shift, float inv_hw,
+                                  float* __restrict__ pooled_out) {
   extern __shared__ float sm[];  // [C] pooled, [R] hidden
   float* pv = sm;
   float* hv = sm + C;
   const int b = blockIdx.x, tid = threadIdx.x;
-  for (int c = tid; c < C; c += blockDim.x) pv[c] = pooled[(size_t)b * C + c];
+  for (int c = tid; c < C; c += blockDim.x) {
+    if (PARTS) {
+      float t = 0.f;
+      for (int k = 0; k < NS; ++k) t += part[((size_t)(b * NS + k) * 2) * C + c];
+      const float v = fmaf(t * inv_hw, scale[c], shift[c]);
+      pv[c] = v;
+      pooled_out[(size_t)b * C + c] = v;
+    } else {
+      pv[c] = pooled_in[(size_t)b * C + c];
+    }
+  }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
   for (int r = wave; r < R; r += nw) {
@@ -802,17 +816,16 @@ __global__ void se_mlp_fwd_kernel(const float* __restrict__ pooled, const float*
 // backward of the MLP, image part: one block per image.  gz (gradient at the fc2 output) and gh (at the fc1 output)
 // are written out for the weight-gradient kernel below -- accumulating dW1/dW2 with atomics from 256 blocks onto the
 // same few thousand addresses took 110 us per SE module (and an unordered sum); gz and gh are [B][C] / [B][R] floats.
-__global__ void se_mlp_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ s,
-                                  const float* __restrict__ hidden, const float* __restrict__ w1,
-                                  const float* __restrict__ w2, float* __restrict__ gpooled, float* __restrict__ gz_out,
-                                  float* __restrict__ gh_out, int C, int R, float inv_hw) {
-  extern __shared__ float sm[];  // [C] gz (grad at fc2 output), [R] gh
-  float* gz = sm;
-  float* gh = sm + C;
+// gs_row: this image's gs[C] -- global memory, or LDS when the squeeze ran in the same block (se_gscale_mlp_bwd_kernel)
+__device__ __forceinline__ void se_mlp_bwd_body(const float* gs_row, const float* __restrict__ s,
+                                                const float* __restrict__ hidden, const float* __restrict__ w1,
+                                                const float* __restrict__ w2, float* __restrict__ gpooled,
+                                                float* __restrict__ gz_out, float* __restrict__ gh_out, int C, int R,
+                                                float inv_hw, float* gz, float* gh) {
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int c = tid; c < C; c += blockDim.x) {
     const float sv = s[(size_t)b * C + c];
-    const float v = gs[(size_t)b * C + c] * sv * (1.f - sv);
+    const float v = gs_row[c] * sv * (1.f - sv);
     gz[c] = v;
     gz_out[(size_t)b * C + c] = v;
   }
@@ -834,6 +847,76 @@ __global__ void se_mlp_bwd_kernel(const float* __restrict__ gs, const float* __r
     for (int r = 0; r < R; ++r) acc = fmaf(w1[(size_t)r * C + c], gh[r], acc);
     gpooled[(size_t)b * C + c] = acc * inv_hw;
   }
+}
+
+__global__ void se_mlp_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ s,
+                                  const float* __restrict__ hidden, const float* __restrict__ w1,
+                                  const float* __restrict__ w2, float* __restrict__ gpooled, float* __restrict__ gz_out,
+                                  float* __restrict__ gh_out, int C, int R, float inv_hw) {
+  extern __shared__ float sm[];  // [C] gz (grad at fc2 output), [R] gh
+  se_mlp_bwd_body(gs + (size_t)blockIdx.x * C, s, hidden, w1, w2, gpooled, gz_out, gh_out, C, R, inv_hw, sm, sm + C);
+}
+
+// fr_se_gscale + the image part of fr_se_mlp_bwd in one launch (both are one block per image): gs[b][:] never leaves LDS.
+// The squeeze is se_pool_kernel<T, true>'s loop, row for row (C / VEC <= NT: one pass), so the pair is bit-identical.
+template <typename T>
+__global__ __launch_bounds__(NT) void se_gscale_mlp_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ s,
+                                                               const float* __restrict__ hidden,
+                                                               const float* __restrict__ w1,
+                                                               const float* __restrict__ w2, float* __restrict__ gpooled,
+                                                               float* __restrict__ gz_out, float* __restrict__ gh_out,
+                                                               int HW, int C, int R, float inv_hw) {
+  constexpr int VEC = Elt<T>::VEC;
+  __shared__ float red[NT * VEC];
+  extern __shared__ float sm[];  // [C] gs, [C] gz, [R] gh
+  const int cpr = C / VEC, tid = threadIdx.x, b = blockIdx.x;
+  const int cc = tid % cpr, rtc = NT / cpr, rt = tid / cpr, c0 = cc * VEC;
+  float acc[VEC], scv[VEC], shv[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    acc[j] = 0.f;
+    scv[j] = scale[c0 + j];
+    shv[j] = shift[c0 + j];
+  }
+  constexpr int UN = 8;
+  for (int r0 = rt; r0 < HW; r0 += rtc * UN) {
+    U128 xv[UN], gq[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int r = r0 + u * rtc;
+      if (r < HW) {
+        xv[u] = ld16(x + ((size_t)b * HW + r) * C + c0);
+        gq[u] = ld16(g + ((size_t)b * HW + r) * C + c0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int r = r0 + u * rtc;
+      if (r < HW) {
+        float f[VEC], gv[VEC];
+        unpack16<T>(xv[u], f);
+        unpack16<T>(gq[u], gv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = fmaf(gv[j], fmaf(f[j], scv[j], shv[j]), acc[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[tid * VEC + j] = acc[j];
+  __syncthreads();
+  if (rt == 0) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float t = 0.f;
+      for (int r = 0; r < rtc; ++r) t += red[(r * cpr + cc) * VEC + j];
+      sm[c0 + j] = t;
+    }
+  }
+  __syncthreads();
+  se_mlp_bwd_body(sm, s, hidden, w1, w2, gpooled, gz_out, gh_out, C, R, inv_hw, sm + C, sm + 2 * C);
 }
 
 // weight part: dW1[r][c] = sum_b gh[b][r] * pooled[b][c],  dW2[c][r] = sum_b gz[b][c] * hidden[b][r].  Block = 64
@@ -1292,8 +1375,19 @@ extern "C" int fr_se_gscale(const void* g, const void* x, const float* scale, co
 
 extern "C" int fr_se_mlp_fwd(const float* pooled, const float* w1, const float* w2, float* hidden, float* s, int B,
                              int C, int R, void* stream) {
-  hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), (hipStream_t)stream, pooled,
-                     w1, w2, hidden, s, C, R);
+  hipLaunchKernelGGL(se_mlp_fwd_kernel<false>, dim3(B), dim3(256), (C + R) * sizeof(float), (hipStream_t)stream, pooled,
+                     w1, w2, hidden, s, C, R, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, 0.f,
+                     (float*)nullptr);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_se_pool_parts_mlp_fwd(const float* part, int rows_per_image, const float* scale, const float* shift,
+                                        const float* w1, const float* w2, float* pooled, float* hidden, float* s, int B,
+                                        int HW, int C, int R, void* stream) {
+  if (rows_per_image < 1 || B < 1 || C < 1 || R < 1 || !part || !pooled) FR_UNSUPPORTED("fr_se_pool_parts_mlp_fwd: bad arguments");
+  hipLaunchKernelGGL(se_mlp_fwd_kernel<true>, dim3(B), dim3(256), (C + R) * sizeof(float), (hipStream_t)stream,
+                     (const float*)nullptr, w1, w2, hidden, s, C, R, part, rows_per_image, scale, shift,
+                     1.0f / (float)HW, pooled);
   FR_LAUNCH_CHECK();
 }
 
@@ -1304,6 +1398,29 @@ extern "C" int fr_se_mlp_bwd(const float* gs, const float* s, const float* hidde
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), st, gs, s, hidden, w1, w2, gpooled,
                      gz, gh, C, R, 1.0f / (float)HW);
+  hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, gz, gh, hidden, pooled, dw1, dw2, B,
+                     C, R);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_se_gscale_mlp_bwd(const void* g, const void* x, const float* scale, const float* shift, const float* s,
+                                    const float* hidden, const float* pooled, const float* w1, const float* w2,
+                                    float* gpooled, float* dw1, float* dw2, float* gz, float* gh, int B, int C, int R,
+                                    int HW, int dtype, void* stream) {
+  if (!gz || !gh) FR_UNSUPPORTED("fr_se_gscale_mlp_bwd: gz [B][C] and gh [B][R] scratch are required");
+  if (!chan_ok(C, dtype)) FR_UNSUPPORTED("fr_se_gscale_mlp_bwd: unsupported channel count");
+  const int vec = dtype == FR_BF16 ? 8 : 4;
+  if (C % vec || C / vec > NT || NT % (C / vec)) FR_UNSUPPORTED("fr_se_gscale_mlp_bwd: C / vector width must divide the block");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)(2 * C + R) * sizeof(float);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(se_gscale_mlp_bwd_kernel<float>, dim3(B), dim3(NT), lds, st, (const float*)x,
+                                (const float*)g, scale, shift, s, hidden, w1, w2, gpooled, gz, gh, HW, C, R,
+                                1.0f / (float)HW),
+             hipLaunchKernelGGL(se_gscale_mlp_bwd_kernel<bf16_t>, dim3(B), dim3(NT), lds, st, (const bf16_t*)x,
+                                (const bf16_t*)g, scale, shift, s, hidden, w1, w2, gpooled, gz, gh, HW, C, R,
+                                1.0f / (float)HW),
+             "fr_se_gscale_mlp_bwd");
   hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, gz, gh, hidden, pooled, dw1, dw2, B,
                      C, R);
   FR_LAUNCH_CHECK();

@@ -695,14 +695,16 @@ class BackbonePlan(object):
             if u.se is not None:
                 R = u.se.fc1.out_channels
                 if strips2 and strips2 % B == 0 and u.sc_conv is None:
-                    # the squeeze from conv2's per-strip column sums (still in self.part): no pass over y2
-                    L.append(ops.call("fr_se_pool_parts", self.part, strips2 // B, bn2.scale, bn2.shift, d["pooled"], B,
-                                      u.Ho * u.Ho, u.depth, st))
+                    # the squeeze from conv2's per-strip column sums (still in self.part): no pass over y2, and in the
+                    # same launch as the MLP
+                    L.append(ops.call("fr_se_pool_parts_mlp_fwd", self.part, strips2 // B, bn2.scale, bn2.shift,
+                                      u.se.fc1.weight, u.se.fc2.weight, d["pooled"], d["hidden"], d["s"], B,
+                                      u.Ho * u.Ho, u.depth, R, st))
                 else:
                     L.append(ops.call("fr_se_pool", d["y2"], bn2.scale, bn2.shift, d["pooled"], B, u.Ho * u.Ho,
                                       u.depth, fr, st))
-                L.append(ops.call("fr_se_mlp_fwd", d["pooled"], u.se.fc1.weight, u.se.fc2.weight, d["hidden"],
-                                  d["s"], B, u.depth, R, st))
+                    L.append(ops.call("fr_se_mlp_fwd", d["pooled"], u.se.fc1.weight, u.se.fc2.weight, d["hidden"],
+                                      d["s"], B, u.depth, R, st))
             nb = ops.grid_blocks(rout, u.depth, fr)
             kw = dict(x=d["y2"], out=d["out"], scale=bn2.scale, shift=bn2.shift, part=stats_part, B=B, H=u.Ho, W=u.Ho,
                       C=u.depth, nblocks=nb)
@@ -891,15 +893,15 @@ class BackbonePlan(object):
             se_kw = {}
             if u.se is not None:
                 R = u.se.fc1.out_channels
-                L.append(ops.call("fr_se_gscale", g_out, d["y2"], bn2.scale, bn2.shift, d["gs"], B, HWo, u.depth, fr,
-                                  st))
                 g1, g2 = self.grad_of(u.se.fc1.weight), self.grad_of(u.se.fc2.weight)
                 if g1 is None:
                     g1 = self.se_scratch[0, :R * u.depth]
                 if g2 is None:
                     g2 = self.se_scratch[1, :R * u.depth]
-                L.append(ops.call("fr_se_mlp_bwd", d["gs"], d["s"], d["hidden"], d["pooled"], u.se.fc1.weight,
-                                  u.se.fc2.weight, d["gpooled"], g1, g2, d["gz"], d["gh"], B, u.depth, R, HWo, st))
+                # gradient wrt the excite scale (a pass over g and y2) + the MLP backward of the same image in one launch
+                L.append(ops.call("fr_se_gscale_mlp_bwd", g_out, d["y2"], bn2.scale, bn2.shift, d["s"], d["hidden"],
+                                  d["pooled"], u.se.fc1.weight, u.se.fc2.weight, d["gpooled"], g1, g2, d["gz"], d["gh"],
+                                  B, u.depth, R, HWo, fr, st))
                 se_kw = dict(se=d["s"], gse=d["gpooled"])
                 ready += [u.se.fc1.weight, u.se.fc2.weight]
             db, dg = self._bn_grads(bn2)

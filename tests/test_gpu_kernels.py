@@ -685,6 +685,49 @@ def test_conv3x3_pair_is_bit_identical_to_two_launches(K, B):
         assert relerr(from_nhwc(y2p[:3]), r2) < BF16_TOL * 2
 
 
+@pytest.mark.parametrize("name,dtype,tol", DT)
+def test_fused_se_launches_are_bit_identical(K, name, dtype, tol):
+    """fr_se_pool_parts_mlp_fwd == fr_se_pool_parts + fr_se_mlp_fwd and fr_se_gscale_mlp_bwd == fr_se_gscale + fr_se_mlp_bwd
+    (round 3: one launch less per IR-SE unit in each direction), bit for bit on every output."""
+    B, HW, C, R, NS = 5, 49, 128, 8, 2
+    st = K.current_stream_ptr()
+    fr = K.fr_dtype(torch.empty(0, dtype=dtype))
+    dev = lambda t: t.cuda()  # noqa: E731
+    part = dev(synth.normal(91, "sp", (B * NS, 2, C)))
+    scale, shift = dev(synth.uniform(91, "ssc", (C,), 0.5, 1.5)), dev(synth.uniform(91, "ssh", (C,), -0.3, 0.3))
+    w1, w2 = dev(synth.normal(91, "sw1", (R, C), std=0.2)), dev(synth.normal(91, "sw2", (C, R), std=0.2))
+    outs = []
+    for fused in (False, True):
+        pooled, hidden, s = torch.zeros(B, C, device="cuda"), torch.zeros(B, R, device="cuda"), torch.zeros(B, C, device="cuda")
+        if fused:
+            K.call("fr_se_pool_parts_mlp_fwd", part, NS, scale, shift, w1, w2, pooled, hidden, s, B, HW, C, R, st)()
+        else:
+            K.call("fr_se_pool_parts", part, NS, scale, shift, pooled, B, HW, C, st)()
+            K.call("fr_se_mlp_fwd", pooled, w1, w2, hidden, s, B, C, R, st)()
+        torch.cuda.synchronize()
+        outs.append((pooled, hidden, s))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    pooled, hidden, s = outs[0]
+    g = nhwc(q(synth.normal(91, "sg", (B, C, 7, 7)), dtype), dtype)
+    x = nhwc(q(synth.normal(91, "sx", (B, C, 7, 7)), dtype), dtype)
+    outs = []
+    for fused in (False, True):
+        gpooled, dw1, dw2 = torch.zeros(B, C, device="cuda"), torch.zeros(R, C, device="cuda"), torch.zeros(C, R, device="cuda")
+        gz, gh, gs = torch.zeros(B, C, device="cuda"), torch.zeros(B, R, device="cuda"), torch.zeros(B, C, device="cuda")
+        if fused:
+            K.call("fr_se_gscale_mlp_bwd", g, x, scale, shift, s, hidden, pooled, w1, w2, gpooled, dw1, dw2, gz, gh, B, C, R,
+                   HW, fr, st)()
+        else:
+            K.call("fr_se_gscale", g, x, scale, shift, gs, B, HW, C, fr, st)()
+            K.call("fr_se_mlp_bwd", gs, s, hidden, pooled, w1, w2, gpooled, dw1, dw2, gz, gh, B, C, R, HW, st)()
+        torch.cuda.synchronize()
+        outs.append((gpooled, dw1, dw2, gz, gh))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b) and torch.isfinite(a).all()
+    assert float(outs[0][1].abs().max()) > 0
+
+
 def test_bf16_engine_with_and_without_strip_agree():
     """The LDS-strip convolutions and the generic implicit-GEMM path are two implementations of the same layers: a
     full bf16 IR-50 step must give (nearly) the same features and gradients through either."""
