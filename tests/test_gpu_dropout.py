@@ -133,7 +133,7 @@ def test_full_step_with_dropout_matches_oracle():
     dl = float((logits.detach().cpu() - rlogits.detach()).abs().max())
     df = float((feats.detach().cpu() - rf.detach()).abs().max())
     print("\ndropout step: max|dfeat| %.2e  max|dlogit| %.2e  loss %.6f vs %.6f" % (df, dl, float(loss.detach()), float(rloss.detach())))
-    assert df < 1e-3 and dl < 1e-3 and abs(float(loss.detach()) - float(rloss)) < 1e-4
+    assert df < 1e-3 and dl < 1e-3 and abs(float(loss.detach()) - float(rloss.detach())) < 1e-4
     named = dict(model.named_parameters())
     named["head.weight"] = head.weight
     # Gradients against the float64 run of the oracle with the same mask.  What this test guards is the dropout path
