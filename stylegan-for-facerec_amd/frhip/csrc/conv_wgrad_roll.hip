@@ -137,6 +137,21 @@ __device__ unsigned long long* fr_stamp_buf_wgr = nullptr;
 #define LDS_FENCE_BARRIER() LDS_FENCE_BARRIER_RAW()
 #endif
 
+// This workgroup's share of the deferred slab sum of the PREVIOUS weight-gradient launch (FrWgradArgs.prev_*), split between
+// the wave roles of the three kernels below: [e0, cut) by the computing waves (tid < 256, two elements per thread and
+// pass), [cut, e1) by the data-moving waves (one element).
+__device__ __forceinline__ void fold_prev_share(const FrWgradArgs& p, bool movers, int tid) {
+  const long long n4 = p.prev_n >> 2;
+  const long long per = (n4 + gridDim.x - 1) / gridDim.x;
+  const long long e0 = (long long)blockIdx.x * per;
+  long long e1 = e0 + per;
+  if (e1 > n4) e1 = n4;
+  if (e0 >= e1) return;
+  const long long cut = e0 + ((e1 - e0) * 2 + 2) / 3;
+  if (!movers) slab_sum_range<256, 2>(p.prev_slab, p.prev_groups, n4, e0, cut, p.prev_dw, tid);
+  else if (cut < e1) slab_sum_range<256, 1>(p.prev_slab, p.prev_groups, n4, cut, e1, p.prev_dw, tid - 256);
+}
+
 template <int W, int PRO>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradArgs p) {
   using C = RC<W>;
@@ -179,17 +194,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
   // share with two elements per thread and pass, the data-moving waves one third with one element, squeezed in between
   // their first two tile requests -- one memory round trip for the whole sum at every shape of the step (three sequential
   // ones cost 8.5-9.9 us per launch in situ, tools/stamps_step.py).
-  auto fold_prev = [&](bool movers) {
-    const long long n4 = p.prev_n >> 2;
-    const long long per = (n4 + gridDim.x - 1) / gridDim.x;
-    const long long e0 = (long long)blockIdx.x * per;
-    long long e1 = e0 + per;
-    if (e1 > n4) e1 = n4;
-    if (e0 >= e1) return;
-    const long long cut = e0 + ((e1 - e0) * 2 + 2) / 3;  // [e0, cut): computing waves, [cut, e1): data-moving waves
-    if (!movers) slab_sum_range<256, 2>(p.prev_slab, p.prev_groups, n4, e0, cut, p.prev_dw, tid);
-    else if (cut < e1) slab_sum_range<256, 1>(p.prev_slab, p.prev_groups, n4, cut, e1, p.prev_dw, tid - 256);
-  };
+  auto fold_prev = [&](bool movers) { fold_prev_share(p, movers, tid); };
 
   if (wave >= 4) {
     // ------------------------------------------------------------------------------------------- data-moving waves
@@ -620,17 +625,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_vr_kernel(const FrWgradArgs
   __syncthreads();
 
   // deferred slab sum of the previous launch, split between the wave roles (see conv_wgrad_roll_kernel)
-  auto fold_prev = [&](bool movers) {
-    const long long n4 = p.prev_n >> 2;
-    const long long perw = (n4 + gridDim.x - 1) / gridDim.x;
-    const long long e0 = (long long)blockIdx.x * perw;
-    long long e1 = e0 + perw;
-    if (e1 > n4) e1 = n4;
-    if (e0 >= e1) return;
-    const long long cut = e0 + ((e1 - e0) * 2 + 2) / 3;
-    if (!movers) slab_sum_range<256, 2>(p.prev_slab, p.prev_groups, n4, e0, cut, p.prev_dw, tid);
-    else if (cut < e1) slab_sum_range<256, 1>(p.prev_slab, p.prev_groups, n4, cut, e1, p.prev_dw, tid - 256);
-  };
+  auto fold_prev = [&](bool movers) { fold_prev_share(p, movers, tid); };
 
   if (wave >= 4) {
     // ------------------------------------------------------------------------------------------- data-moving waves
@@ -948,17 +943,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_s2roll_kernel(const FrWgrad
   for (int idx = tid; idx < L::LDS / 16; idx += 512) st16(smem + idx * 16, zero16());
   __syncthreads();
 
-  auto fold_prev = [&](bool movers) {  // deferred slab sum of the previous launch (see conv_wgrad_roll_kernel)
-    const long long n4 = p.prev_n >> 2;
-    const long long perw = (n4 + gridDim.x - 1) / gridDim.x;
-    const long long e0 = (long long)blockIdx.x * perw;
-    long long e1 = e0 + perw;
-    if (e1 > n4) e1 = n4;
-    if (e0 >= e1) return;
-    const long long cut = e0 + ((e1 - e0) * 2 + 2) / 3;
-    if (!movers) slab_sum_range<256, 2>(p.prev_slab, p.prev_groups, n4, e0, cut, p.prev_dw, tid);
-    else if (cut < e1) slab_sum_range<256, 1>(p.prev_slab, p.prev_groups, n4, cut, e1, p.prev_dw, tid - 256);
-  };
+  auto fold_prev = [&](bool movers) { fold_prev_share(p, movers, tid); };
 
   if (wave >= 4) {
     // ------------------------------------------------------------------------------------------- data-moving waves
