@@ -242,6 +242,11 @@ class BackbonePlan(object):
         # leaves idle instead of splitting the machine with it (FRHIP_SIDE_PRIORITY overrides, HIP: 1 low .. -1 high)
         prio = int(os.environ.get("FRHIP_SIDE_PRIORITY", "1"))
         self.stream2_t = _side_stream(device, prio) if self.dual else self.stream1_t
+        # Workgroups of a weight-gradient launch (dW tiles x image groups).  224 of 256: the launches take the same time (a
+        # 224-workgroup 256x256@14 launch 0.069 ms against 0.068 with 256: 12 % fewer slabs to write and sum), and the 32 CUs
+        # without a persistent weight-gradient workgroup take the channel-wise kernels of the main stream at full speed:
+        # 15.06-15.10 against 15.13-15.16 ms per step (192: 15.09, 240: 15.25, 160: 15.15; FRHIP_WGRAD_WGS, one box).
+        self.wgrad_wgs = max(64, int(os.environ.get("FRHIP_WGRAD_WGS", "224")))
         self.stream2 = ctypes.c_void_p(self.stream2_t.cuda_stream)
         self.S = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
         self.generation = 0
@@ -483,7 +488,7 @@ class BackbonePlan(object):
             tiles = (kw["Cout"] // 64) * (kw["SC"] // 64)
             rows = {112: 2, 56: 4, 28: 7, 14: 14, 7: 7}[kw["SW"]]
             fills = kw["B"] * (kw["SW"] // rows) // (4 if kw["SW"] == 7 else 1)
-            groups = int(max(1, min(fills, 256 // tiles if tiles <= 256 else 1)))
+            groups = int(max(1, min(fills, self.wgrad_wgs // tiles if tiles <= self.wgrad_wgs else 1)))
             return self._slab_launch(L, dict(kw, nsplit=groups), groups * kw["Cout"] * 9 * kw["SC"], param=param)
         if (self.fr == FR_BF16 and self.use_strip and self.use_s2 and kw["KH"] == 3 and kw["stride"] == 2 and
                 kw["GW"] in (56, 28, 14, 7) and kw["SW"] == 2 * kw["GW"] and kw["Cout"] % 64 == 0 and kw["SC"] % 64 == 0):
@@ -491,7 +496,7 @@ class BackbonePlan(object):
             tiles = (kw["Cout"] // 64) * (kw["SC"] // 64)
             rows, nimg = {56: (2, 1), 28: (4, 1), 14: (7, 1), 7: (7, 2)}[kw["GW"]]
             fills = (kw["B"] * (kw["GW"] // rows) + nimg - 1) // nimg
-            groups = int(max(1, min(fills, 256 // tiles if tiles <= 256 else 1)))
+            groups = int(max(1, min(fills, self.wgrad_wgs // tiles if tiles <= self.wgrad_wgs else 1)))
             return self._slab_launch(L, dict(kw, nsplit=groups), groups * kw["Cout"] * 9 * kw["SC"], param=param)
         if kw.get("nsplit", 1) > 1:  # pixel slices go to slabs and are added in a fixed order (no float atomics)
             return self._slab_launch(L, kw, kw["nsplit"] * kw["Cout"] * kw["KH"] * kw["KW"] * kw["SC"], strip=False,
