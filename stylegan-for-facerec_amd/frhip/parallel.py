@@ -31,6 +31,10 @@ class BucketedAllReduce(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = dist.is_initialized() and os.environ.get("FRHIP_FORCE_DP", "0") == "1"  # 1-rank self test
         self.avg_native = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        # FRHIP_DP_OVERLAP=0 (A/B switch for multi-GPU runs): no collective during the backward pass -- everything is enqueued
+        # by synchronize().  RCCL's kernels need CUs of their own; while one is resident a 256-workgroup strip launch takes two
+        # rounds, so on some fabrics the un-overlapped exchange may be the faster one.  Unmeasured (no multi-GPU box so far).
+        self.overlap = os.environ.get("FRHIP_DP_OVERLAP", "1") != "0"
         self.buckets = []  # (start, end, [param ids])
         start, ids, nbytes = 0, [], 0
         esz = arena.element_size()
@@ -70,7 +74,7 @@ class BucketedAllReduce(object):
                 self.pending[b] -= 1
         # buckets complete in order because the arena is in readiness order; a bucket whose remaining members
         # are all frozen is flushed by flush_frozen()
-        while self.next_bucket < len(self.buckets) and self.pending[self.next_bucket] <= 0:
+        while self.overlap and self.next_bucket < len(self.buckets) and self.pending[self.next_bucket] <= 0:
             s, e, _ = self.buckets[self.next_bucket]
             self._launch(self.arena[s:e])
             self.next_bucket += 1
