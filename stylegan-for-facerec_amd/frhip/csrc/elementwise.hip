@@ -458,8 +458,9 @@ constexpr int LV = 4;    // channels per thread
 constexpr int LUNR = 4;  // rows in flight per thread (forward kernels: they run alone on the chip)
 // The two backward kernels run BESIDE the weight-gradient kernels of the side stream (2 waves x ~200 registers per SIMD
 // there): two rows in flight keep them at 36 - 60 registers, so that two of their waves fit a SIMD's free registers
-// instead of one (step: -0.1 ms; alone they are ~5 % slower).
-constexpr int LUNRB = 2;
+// instead of one (step: -0.1 ms; alone they are ~5 % slower).  Three rows since the weight-gradient launches leave 32 CUs
+// without a persistent workgroup (engine.py, wgrad_wgs): 15.33-15.35 against 15.36-15.42 ms per step (four rows: 15.35-15.39).
+constexpr int LUNRB = 3;
 
 __device__ __forceinline__ uint2 pack4bf(const float* f) {
   uint2 u;
