@@ -583,6 +583,7 @@ static int strip_rows(int Cin, int Cout, int W) {
   if (Cin == ci && Cout == co && W == w) return v1 ? rows1 : rows0;
   SHAPE(64, 64, 112, 4, 2)
   SHAPE(64, 64, 56, 7, 7)
+  if (Cin == 64 && Cout == 128 && W == 56 && strip_variant() >= 4) return 4;
   SHAPE(64, 128, 56, 7, 7)
   SHAPE(128, 64, 56, 7, 7)
   SHAPE(128, 128, 28, 14, 7)
@@ -667,6 +668,10 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
   // (measured at B = 128: 0.034 instead of 0.049 ms per launch -- IR-SE-101 trains at 128 images per GPU)
   if (a.SC == 256 && a.N == 256 && a.SW == 14 && small_batch(a.B)) return by_pro<256, 128, 14, 14, 8, 8, 2>(a, st);
   SHAPE(256, 256, 14, 14, 8, 8)
+  // 64 -> 128 @56 (one forward launch per step): 4-row strips, two resident 4-wave workgroups per CU: 0.170-0.174 -> 0.159-0.160 ms
+  if (strip_variant() >= 4) {
+    SHAPE(64, 128, 56, 4, 4, 4)
+  }
   SHAPE(64, 128, 56, 7, 4, 8)
   // Round 3: what a wave pays per MFMA is its private weight stream (16 B per lane from L2 for every (tap, 32 channels,
   // 16 output channels)): an instance is fast when one weight fragment feeds ~13 M tiles.  The data gradients of the three
