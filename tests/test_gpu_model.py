@@ -1457,14 +1457,15 @@ def test_paired_convolutions_are_bit_identical_to_separate_launches():
 
 
 BENCH_SIZE = [("configs1_ir50_arc7000_b256", "IR_50", 50, False, "ArcFace", 7000, 256),
+              ("configs2_ir50_arc28000_b256", "IR_50", 50, False, "ArcFace", 28000, 256),
               ("configs3_irse101_cos28000_b128", "IR_SE_101", 100, True, "CosFace", 28000, 128),
               ("configs4_psp_arc28000_b256", "pSp", 50, True, "ArcFace", 28000, 256)]
 
 
 @pytest.mark.parametrize("tag,kind,layers,se,head_name,N,B", BENCH_SIZE, ids=[c[0] for c in BENCH_SIZE])
 def test_bench_size_step_tracks_the_oracle(tag, kind, layers, se, head_name, N, B):
-    """The BASELINE configs at THEIR sizes, as bench.py times them (headline + `other_configs`) -- IR-50 + ArcFace(7000) bs 256,
-    IR-SE-101 + CosFace(28000) bs 128, pSp (IR-SE-50 trunk, 6-channel stem, average image) + ArcFace(28000) bs 256, Focal loss,
+    """The BASELINE configs at THEIR sizes, as bench.py times them (headline + `other_configs`) -- IR-50 + ArcFace(7000 / 28000)
+    bs 256, IR-SE-101 + CosFace(28000) bs 128, pSp (IR-SE-50 trunk, 6-channel stem, average image) + ArcFace(28000) bs 256, Focal loss,
     bf16 storage, the large-batch kernel instances -- against the CPU oracle (fp32, oracle/irse_ref.py train_step; 10-40 s and
     tens of GB on the host cores): loss, features, every per-parameter gradient norm, and direction + norm of gradient tensors
     along the whole depth.  At 128-256 images the bf16 noise averages down: the bars are tighter than the batch-4 / 8 / 16
