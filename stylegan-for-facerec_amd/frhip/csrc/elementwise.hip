@@ -691,17 +691,21 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdA
 // ------------------------------------------------------------------------------------------ SE
 // pooled[b][c] = mean_hw(x*scale+shift) = scale*mean_hw(x)+shift : one block per (image, 64-channel... ) simple:
 // grid = B blocks, threads [row-thread][chunk] over the image's HW rows.
-template <typename T, bool GS>
-__global__ __launch_bounds__(NT) void se_pool_kernel(const T* __restrict__ x, const T* __restrict__ g,
+// SNT threads per image: 1024 for the gradient squeeze (GS; round 3) -- with 256 a thread walked 25 rows of a 14x14 image in
+// four dependent trips, and at 128 images per GPU only half the CUs had a block at all; 32 row-threads per channel chunk
+// have every row in flight at once (IR-SE-101 bs 128: 18.8 -> see DESIGN section 3 per fused launch).
+constexpr int SNT_GS = 1024;
+template <typename T, bool GS, int SNT = NT>
+__global__ __launch_bounds__(SNT) void se_pool_kernel(const T* __restrict__ x, const T* __restrict__ g,
                                                      const float* __restrict__ scale,
                                                      const float* __restrict__ shift, float* __restrict__ out,
                                                      int HW, int C) {
   constexpr int VEC = Elt<T>::VEC;
-  __shared__ float red[NT * VEC];
+  __shared__ float red[SNT * VEC];
   const int cpr = C / VEC, tid = threadIdx.x, b = blockIdx.x;
-  for (int cbase = 0; cbase < cpr; cbase += NT) {  // C/VEC <= 256 always here, loop kept for generality
-    const int cc = (tid % (cpr < NT ? cpr : NT)) + cbase;
-    const int rtc = cpr < NT ? NT / cpr : 1, rt = cpr < NT ? tid / cpr : 0;
+  for (int cbase = 0; cbase < cpr; cbase += SNT) {  // C/VEC <= 256 always here, loop kept for generality
+    const int cc = (tid % (cpr < SNT ? cpr : SNT)) + cbase;
+    const int rtc = cpr < SNT ? SNT / cpr : 1, rt = cpr < SNT ? tid / cpr : 0;
     const int c0 = cc * VEC;
     float acc[1][VEC];
 #pragma unroll
@@ -861,7 +865,7 @@ __global__ void se_mlp_bwd_kernel(const float* __restrict__ gs, const float* __r
 // fr_se_gscale + the image part of fr_se_mlp_bwd in one launch (both are one block per image): gs[b][:] never leaves LDS.
 // The squeeze is se_pool_kernel<T, true>'s loop, row for row (C / VEC <= NT: one pass), so the pair is bit-identical.
 template <typename T>
-__global__ __launch_bounds__(NT) void se_gscale_mlp_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g,
+__global__ __launch_bounds__(SNT_GS) void se_gscale_mlp_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ shift,
                                                                const float* __restrict__ s,
@@ -871,10 +875,10 @@ __global__ __launch_bounds__(NT) void se_gscale_mlp_bwd_kernel(const T* __restri
                                                                float* __restrict__ gz_out, float* __restrict__ gh_out,
                                                                int HW, int C, int R, float inv_hw) {
   constexpr int VEC = Elt<T>::VEC;
-  __shared__ float red[NT * VEC];
+  __shared__ float red[SNT_GS * VEC];
   extern __shared__ float sm[];  // [C] gs, [C] gz, [R] gh
   const int cpr = C / VEC, tid = threadIdx.x, b = blockIdx.x;
-  const int cc = tid % cpr, rtc = NT / cpr, rt = tid / cpr, c0 = cc * VEC;
+  const int cc = tid % cpr, rtc = SNT_GS / cpr, rt = tid / cpr, c0 = cc * VEC;
   float acc[VEC], scv[VEC], shv[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
@@ -1366,9 +1370,9 @@ extern "C" int fr_se_gscale(const void* g, const void* x, const float* scale, co
   if (!chan_ok(C, dtype)) FR_UNSUPPORTED("fr_se_gscale: unsupported channel count");
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL((se_pool_kernel<float, true>), dim3(B), dim3(NT), 0, st, (const float*)x,
+             hipLaunchKernelGGL((se_pool_kernel<float, true, SNT_GS>), dim3(B), dim3(SNT_GS), 0, st, (const float*)x,
                                 (const float*)g, scale, shift, gs, HW, C),
-             hipLaunchKernelGGL((se_pool_kernel<bf16_t, true>), dim3(B), dim3(NT), 0, st, (const bf16_t*)x,
+             hipLaunchKernelGGL((se_pool_kernel<bf16_t, true, SNT_GS>), dim3(B), dim3(SNT_GS), 0, st, (const bf16_t*)x,
                                 (const bf16_t*)g, scale, shift, gs, HW, C),
              "fr_se_gscale");
   FR_LAUNCH_CHECK();
@@ -1411,14 +1415,14 @@ extern "C" int fr_se_gscale_mlp_bwd(const void* g, const void* x, const float* s
   if (!gz || !gh) FR_UNSUPPORTED("fr_se_gscale_mlp_bwd: gz [B][C] and gh [B][R] scratch are required");
   if (!chan_ok(C, dtype)) FR_UNSUPPORTED("fr_se_gscale_mlp_bwd: unsupported channel count");
   const int vec = dtype == FR_BF16 ? 8 : 4;
-  if (C % vec || C / vec > NT || NT % (C / vec)) FR_UNSUPPORTED("fr_se_gscale_mlp_bwd: C / vector width must divide the block");
+  if (C % vec || C / vec > SNT_GS || SNT_GS % (C / vec)) FR_UNSUPPORTED("fr_se_gscale_mlp_bwd: C / vector width must divide the block");
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)(2 * C + R) * sizeof(float);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(se_gscale_mlp_bwd_kernel<float>, dim3(B), dim3(NT), lds, st, (const float*)x,
+             hipLaunchKernelGGL(se_gscale_mlp_bwd_kernel<float>, dim3(B), dim3(SNT_GS), lds, st, (const float*)x,
                                 (const float*)g, scale, shift, s, hidden, w1, w2, gpooled, gz, gh, HW, C, R,
                                 1.0f / (float)HW),
-             hipLaunchKernelGGL(se_gscale_mlp_bwd_kernel<bf16_t>, dim3(B), dim3(NT), lds, st, (const bf16_t*)x,
+             hipLaunchKernelGGL(se_gscale_mlp_bwd_kernel<bf16_t>, dim3(B), dim3(SNT_GS), lds, st, (const bf16_t*)x,
                                 (const bf16_t*)g, scale, shift, s, hidden, w1, w2, gpooled, gz, gh, HW, C, R,
                                 1.0f / (float)HW),
              "fr_se_gscale_mlp_bwd");
