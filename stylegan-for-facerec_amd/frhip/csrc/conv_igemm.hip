@@ -472,7 +472,12 @@ int launch(const FrConvArgs& a, hipStream_t st) {
 
 template <typename T>
 int dispatch(const FrConvArgs& a, hipStream_t st) {
-  const bool narrow = a.N <= 64;
+  // 64-wide tiles for N <= 64, and where 128-wide ones would leave most of the chip idle (the margin head's logits GEMM at
+  // batch 256: 2 x 55 tiles on 256 CUs) -- twice the workgroups at half the width
+  const long long M = a.mode == 2 ? (long long)a.B * (a.RH / 2) * (a.RW / 2) : (long long)a.B * a.RH * a.RW;
+  const long long wgs128 = ((M + BM - 1) / BM) * ((a.N + 127) / 128) * (a.splitk > 1 ? a.splitk : 1) *
+                           (a.mode == 2 && a.par_h < 0 ? 4 : 1);
+  const bool narrow = a.N <= 64 || wgs128 < 160;
   switch (a.pro) {
     case FR_PRO_NONE:
       return narrow ? launch<T, 64, FR_PRO_NONE>(a, st) : launch<T, 128, FR_PRO_NONE>(a, st);
