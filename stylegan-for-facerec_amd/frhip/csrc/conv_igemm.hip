@@ -477,7 +477,9 @@ int dispatch(const FrConvArgs& a, hipStream_t st) {
   const long long M = a.mode == 2 ? (long long)a.B * (a.RH / 2) * (a.RW / 2) : (long long)a.B * a.RH * a.RW;
   const long long wgs128 = ((M + BM - 1) / BM) * ((a.N + 127) / 128) * (a.splitk > 1 ? a.splitk : 1) *
                            (a.mode == 2 && a.par_h < 0 ? 4 : 1);
-  const bool narrow = a.N <= 64 || wgs128 < 160;
+  // (only for the margin epilogue: with the rule applied to every small launch six fixture tests of the fp32 path moved past
+  // their bars at batches 4-16 -- the 64-wide instance is not bit-compatible with the 128-wide one there)
+  const bool narrow = a.N <= 64 || (wgs128 < 160 && a.epi == FR_EPI_MARGIN);
   switch (a.pro) {
     case FR_PRO_NONE:
       return narrow ? launch<T, 64, FR_PRO_NONE>(a, st) : launch<T, 128, FR_PRO_NONE>(a, st);
