@@ -383,3 +383,35 @@ def test_readiness_marks_follow_the_arena_order():
     fake.ready_marks = [(10, [ps[0], ps[1]], None), (20, [ps[3]], None)]
     with pytest.raises(FrhipError):
         BackbonePlan._order_ready_marks(fake)
+
+
+def test_dispatch_geometry_of_the_strip_tables():
+    """The capability / geometry queries of the C ABI are host arithmetic (no GPU call): the number of partial-sum rows a
+    strip launch writes IS the dispatch decision the engine sizes its buffers from.  Pins the round-3 tables -- 7x7: four
+    images per workgroup above the small-batch threshold, two below, one for odd batches; stride 2: whole images at 256
+    channels forward, image pairs at 512; the shapes no strip kernel serves answer 0 (the generic kernel runs them)."""
+    from frhip import _lib
+    L = _lib.lib
+    STORE, STATS, BNBWD = _lib.EPI_STORE, _lib.EPI_STATS, _lib.EPI_BNBWD
+    sp = L.fr_conv3x3_strip_parts
+    assert sp(256, 256, 256, 14, STATS) == 256                      # one workgroup per image
+    assert sp(128, 256, 256, 14, STATS) == 128                      # small batch: channels split, still one ROW per image
+    assert sp(256, 512, 512, 7, STATS) == 64                        # four images per workgroup
+    assert sp(128, 512, 512, 7, STATS) == 64 and sp(6, 512, 512, 7, STATS) == 3   # small batch: two images
+    assert sp(3, 512, 512, 7, STATS) == 3                           # odd batch: one image
+    assert sp(256, 128, 128, 28, STATS) == 1024                     # 7-row strips
+    assert sp(256, 512, 256, 14, BNBWD) == 256                      # stage-entry data gradient: whole images
+    assert sp(256, 64, 128, 56, STORE) == 256 * 14                  # 4-row strips
+    assert sp(256, 256, 512, 14, STATS) == 0 and sp(256, 256, 512, 14, STORE) > 0   # two-pass instance: plain store only
+    assert sp(256, 96, 96, 14, STORE) == 0 and sp(256, 256, 256, 20, STORE) == 0    # not in the table
+    s2 = L.fr_conv3x3_s2_strip_parts
+    assert s2(256, 128, 128, 28, 0) == 1024 and s2(256, 128, 128, 28, 2) == 4096    # mode 2: four parity classes
+    assert s2(256, 256, 256, 14, 0) == 256 and s2(256, 256, 256, 14, 2) == 4 * 512  # forward whole images, gradient 7-row strips
+    assert s2(256, 512, 512, 7, 0) == 128 and s2(256, 512, 512, 7, 2) == 4 * 128    # image pairs
+    assert s2(3, 512, 512, 7, 0) == 3                                               # odd batch: one image
+    assert s2(256, 128, 256, 28, 0) == 0                                            # Cin != Cout: generic kernel
+    assert L.fr_conv3x3_pair_supported(256, 256, 14) == 1 and L.fr_conv3x3_pair_supported(128, 256, 14) == 0
+    assert L.fr_conv3x3_pair_supported(256, 128, 28) == 0
+    ws = L.fr_conv_wgrad_strip_supported
+    assert all(ws(c, c, w) == 1 for c, w in ((64, 112), (64, 56), (128, 28), (256, 14), (512, 7)))
+    assert ws(96, 64, 56) == 0 and ws(64, 64, 20) == 0
