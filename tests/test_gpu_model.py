@@ -1377,7 +1377,7 @@ def test_fused_bn_backward_sums_are_bit_identical():
     """FrBnBwdArgs.nx (round 3): the kernel that writes a unit's input gradient also forms the backward sums of the
     BatchNorm in front of it (BN2 of the previous unit, reference model_irse.py:60) from the ROUNDED gradient, in the order
     fr_bn_bwd_reduce uses -- one pass and one launch less per residual unit, and every parameter gradient of a bf16
-    IR-50 step bit for bit what the separate launches give.  (Opt-in, FRHIP_FUSED_BN_SUMS=1: measured 0.04 ms slower per
+    IR-50 step bit for bit what the separate launches give.  (Opt-in, FRHIP_FUSED_BN_SUMS=1: measured 0.04-0.6 ms slower per
     step beside the weight-gradient kernels, engine.py.)"""
     _need_gpu()
     from backbone.model_irse import IR_50
