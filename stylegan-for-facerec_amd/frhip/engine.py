@@ -267,9 +267,10 @@ class BackbonePlan(object):
         # slabs to the NEXT such launch of the side stream (two slab buffers alternate); fr_reduce_slabs flushes the last
         self.defer_slabs = os.environ.get("FRHIP_NO_DEFER_SLABS", "0") != "1"
         # FrBnBwdArgs.nx: the kernel that writes a unit's input gradient also forms the BN2-backward sums of the unit in
-        # front.  Bit-identical, one pass + one launch less per unit -- and 0.04 ms SLOWER per step (16.45 vs 16.41 ms, three -- and 0.6 ms slower (15.8-15.9 vs 15.2-15.3) at the end of round 3, beside the 224-workgroup weight gradients and the three-row BN kernels
-        # A/B pairs on one box): the fused kernel needs 80 registers and runs one wave per SIMD beside the weight
-        # gradients where the two separate kernels run two.  Opt-in.
+        # front.  Bit-identical, one pass + one launch less per unit -- and SLOWER: 0.04 ms per step when it was written
+        # (16.45 vs 16.41 ms, three A/B pairs on one box: the fused kernel needs 80 registers and runs one wave per SIMD
+        # beside the weight gradients where the two separate kernels run two), 0.6 ms at the end of round 3 (15.8-15.9 vs
+        # 15.2-15.3 beside the 224-workgroup weight gradients and the three-row BN kernels).  Opt-in.
         self.fuse_bn_sums = os.environ.get("FRHIP_FUSED_BN_SUMS", "0") == "1"
         self.slab2, self._slab2_users, self._slab_flip = None, [], 0
         self._pending = None  # (launch that wrote the slabs, groups, n, dw tensor, parameter)
