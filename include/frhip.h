@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 3
+#define FR_ABI_VERSION 4
 
 enum { FR_F32 = 0, FR_BF16 = 1 };
 
@@ -43,6 +43,39 @@ enum {
   FR_EPI_SLAB = 6       /* split-K slice z stores its fp32 partial (+bias in slice 0) to out[z][rows][ldc]: the caller
                            adds the splitk slabs with fr_reduce_parts(out, splitk, 1, rows*ldc, ...) -- reproducible */
 };
+
+/* ---- In-launch reduction of the partial rows a launch writes (ABI v4; csrc/tail.h).
+ * Every entry point that leaves per-workgroup partial sums (part[row][K][C]) accepts a tail: with tail.ticket != NULL the
+ * launch itself adds the rows -- its workgroups count their arrivals on ticket[0] after storing their rows, the last
+ * `nred` of them add the rows in the order of fr_reduce_parts / fr_bn_finalize (bit-identical results) and write
+ *   FR_TAIL_SUMS: o_k[c] = sum_rows part[row][k][c], k < K (NULL outputs skipped)     == fr_reduce_parts(part, rows, K, C, ..)
+ *   FR_TAIL_BN  : mean / invstd / scale / shift (+ running statistics)               == fr_bn_finalize(part, rows, C, ..)
+ * ticket: 4 x uint32 of device memory, zero before the launch, zero again after it ([0] arrivals, [1] finished reducers,
+ * [2] set to 1 if a reducer gave up waiting for a producer -- never in a healthy run); one ticket must not be shared by
+ * launches that can run concurrently.  The rows stay in `part` as without a tail.
+ * Replaces the separate statistics / gradient-sum launches behind BatchNorm2d / PReLU (backbone/model_irse.py:57-60,141-148). */
+enum { FR_TAIL_NONE = 0, FR_TAIL_SUMS = 1, FR_TAIL_BN = 2 };
+typedef struct FrTail {
+  uint32_t* ticket;
+  int32_t kind;  /* FR_TAIL_* */
+  int32_t K;     /* SUMS: vectors per partial row (1..3); BN: 2 */
+  int32_t C;     /* channels per vector: must equal the launch's own column count */
+  int32_t nred;  /* workgroups that share the reduction; 0 = library default */
+  float* o0;     /* SUMS outputs [C] */
+  float* o1;
+  float* o2;
+  double count;  /* BN: the arguments of fr_bn_finalize */
+  const float* gamma;
+  const float* beta;
+  float eps, momentum;
+  float* running_mean;
+  float* running_var;
+  int64_t* nbt;
+  float* mean;
+  float* invstd;
+  float* scale;
+  float* shift;
+} FrTail;
 
 typedef struct FrConvArgs {
   const void* src; /* A operand: NHWC [B,SH,SW,SC], pixel stride lda (elements) */
@@ -75,10 +108,7 @@ typedef struct FrConvArgs {
   float* part;        /* [ceil(rows/128)][2][N] partial column sums */
   const int64_t* label; /* [rows] */
   float* cos_t;         /* [rows] */
-  /* fr_conv3x3_pair only (ABI v3): the second convolution of the pair */
-  const void* w2;      /* [N][9][N] packed weights of conv2 */
-  void* out2;          /* [B*RH*RW][ldc] result of conv2 (epilogue `epi`, partial sums in `part`) */
-  const float* slope2; /* [N] PReLU slopes applied between the two convolutions */
+  FrTail tail;         /* in-launch reduction of `part` (epilogues that write partial rows), see FrTail */
 } FrConvArgs;
 
 /* Convolution forward / data gradient / dense GEMM on MFMA.
@@ -95,17 +125,6 @@ int fr_conv_igemm(const FrConvArgs* args, int dtype, void* stream);
  * Replaces Conv2d(c, d, (3,3), (1,1), 1) of bottleneck_IR (backbone/model_irse.py:57-59) fwd + data gradient. */
 int fr_conv3x3_strip(const FrConvArgs* args, void* stream);
 int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi);
-
-/* conv1 -> PReLU -> conv2 of one residual unit in ONE launch (bf16, whole-image strips, Cin == Cout == N):
- *   out  = conv3x3(pro(src), w)                      stored for the backward pass (epilogue STORE)
- *   out2 = conv3x3(PReLU_{slope2}(out), w2)          epilogue `epi` (STORE / STATS), partial sums -> part[image][2][N]
- * bit-identical to fr_conv3x3_strip(pro = BN, epi = STORE) followed by fr_conv3x3_strip(pro = PRELU, epi): the bf16 tile of
- * the first result is turned into the second input inside LDS instead of being read back from HBM.
- * fr_conv3x3_pair_supported: 1 when (B, C, W) has an instance (C = 256, W = 14, B above the split-channel threshold).
- * Measured no faster than the two launches (conv3x3_strip.hip): the engine uses it only with FRHIP_PAIR=1.
- * Replaces Conv2d(c, d, 3, 1, 1) -> PReLU(d) -> Conv2d(d, d, 3, 1, 1) of bottleneck_IR (backbone/model_irse.py:57-59). */
-int fr_conv3x3_pair(const FrConvArgs* args, void* stream);
-int fr_conv3x3_pair_supported(int B, int C, int W);
 
 /* Stride-2 3x3 convolution (bf16, Cin == Cout: the first unit of every IR stage) on LDS-resident parity planes:
  * mode 0 = forward (SH = 2*RH), mode 2 with par_h = par_w = -1 = data gradient of all four output parity classes
@@ -176,7 +195,8 @@ int fr_stem_im2col(const float* x, const float* avg, void* out, int B, int H, in
  * fr_stem_wgrad: slab[nblocks][64][K] = per-workgroup partial of g[M][64]^T * X[M][K] (add them with fr_reduce_parts,
  *                K = 1, C = 64*K).
  * Replace the GEMM half of input_layer Conv2d(3|6,64,3,1,1) (model_irse.py:140) forward and its weight gradient. */
-int fr_stem_gemm(const void* X, const void* Wp, void* out, float* part, long long M, int K, int nblocks, void* stream);
+int fr_stem_gemm(const void* X, const void* Wp, void* out, float* part, long long M, int K, int nblocks,
+                 const FrTail* tail /* NULL or an in-launch reduction of part (FR_TAIL_BN, C = 64) */, void* stream);
 int fr_stem_wgrad(const void* G, const void* X, float* slab, long long M, int K, int nblocks, void* stream);
 /* As fr_stem_wgrad, with the backward of BatchNorm2d(64) -> PReLU(64) (model_irse.py:141-142) applied to the rows of G
  * while they are staged: G = gradient at the PReLU output, Y = BN input (the stem GEMM output), s0/s1 = the reduced
@@ -195,7 +215,8 @@ int fr_bn_finalize(const float* part, int nparts, int C, double count, const flo
                    float* mean, float* invstd, float* scale, float* shift, void* stream);
 
 /* per-channel (sum, sumsq) partials of an NHWC tensor: part[blk][2][C], blk < nblocks (= grid size) */
-int fr_channel_stats(const void* x, long long rows, int C, float* part, int nblocks, int dtype, void* stream);
+int fr_channel_stats(const void* x, long long rows, int C, float* part, int nblocks, int dtype,
+                     const FrTail* tail /* NULL or an in-launch reduction of part (K = 2) */, void* stream);
 
 /* out = [prelu]( x*scale+shift [* se[b][c]] ) [+ res]  with (sum,sumsq) partials of `out` for the next BN.
  *   res_kind 0 none | 1 identity shortcut x_in[b, h*stride, w*stride, c] (MaxPool2d(1,s), model_irse.py:53)
@@ -215,6 +236,7 @@ typedef struct FrApplyArgs {
   int32_t B, H, W, C;
   int32_t res_kind, res_stride; /* identity: res has geometry [B, H*res_stride, W*res_stride, C] */
   int32_t nblocks;     /* grid size == number of partial rows */
+  FrTail tail;         /* in-launch reduction of `part` (FR_TAIL_BN: the statistics of `out` for the next BatchNorm) */
 } FrApplyArgs;
 int fr_bn_apply(const FrApplyArgs* args, int dtype, void* stream);
 
@@ -249,15 +271,7 @@ typedef struct FrBnBwdArgs {
   int32_t add_kind;
   int32_t H, W, add_stride; /* geometry of gx for add_kind 2 */
   int32_t nblocks;
-  /* fr_bn_bwd_apply only, optional (ABI v2; bf16, add_kind 1, no se / slope, else refused): gx is at the same time the
-   * upstream gradient of the NEXT BatchNorm of the backward pass (BN2 of the unit in front, model_irse.py:60), whose
-   * input is nx.  The launch then also writes that BatchNorm's backward partial sums, npart[nblocks][3][C] =
-   * (sum gx, sum gx * (nx - nmean) * ninvstd, 0) formed from the ROUNDED gx exactly as fr_bn_bwd_reduce (same nblocks)
-   * would -- one pass over gx and one launch less per residual unit. */
-  const void* nx;
-  const float* nmean;
-  const float* ninvstd;
-  float* npart;
+  FrTail tail;         /* fr_bn_bwd_reduce: in-launch reduction of `part` (FR_TAIL_SUMS, K = 3) */
 } FrBnBwdArgs;
 int fr_bn_bwd_reduce(const FrBnBwdArgs* args, int dtype, void* stream);
 int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream);
@@ -445,7 +459,7 @@ int fr_fill_rows(float* out, const float* bias, long long rows, int C, void* str
  * fr_last_error_string()), never silently computing something else. */
 int fr_abi_version(void);
 /* sizeof() of the argument structs as compiled, for binding self-checks: 0 FrConvArgs, 1 FrWgradArgs,
- * 2 FrApplyArgs, 3 FrBnBwdArgs, 4 FrSgdTensor, 5 FrPackTensor, 6 FrAdamTensor */
+ * 2 FrApplyArgs, 3 FrBnBwdArgs, 4 FrSgdTensor, 5 FrPackTensor, 6 FrAdamTensor, 7 FrBnEvalEntry, 8 FrTail */
 int fr_struct_size(int which);
 const char* fr_last_error_string(void);
 

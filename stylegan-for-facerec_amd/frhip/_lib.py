@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("FRHIP_LIB") or os.path.join(_HERE, "lib", "libfrhip.s
 
 _SCALARS = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,
+    "uint32_t": ctypes.c_uint32,
     "long long": ctypes.c_longlong, "float": ctypes.c_float, "double": ctypes.c_double,
 }
 
@@ -34,6 +35,8 @@ def _ctype(decl, structs):
         if base in structs:
             return ctypes.POINTER(structs[base])
         return ctypes.c_void_p
+    if t in structs:  # a struct member held by value (FrTail inside the argument structs)
+        return structs[t]
     return _SCALARS[t]
 
 
@@ -82,11 +85,13 @@ FrSgdTensor = structs["FrSgdTensor"]
 FrPackTensor = structs["FrPackTensor"]
 FrAdamTensor = structs["FrAdamTensor"]
 FrBnEvalEntry = structs["FrBnEvalEntry"]
+FrTail = structs["FrTail"]
 
 # enums of the header
 FR_F32, FR_BF16 = 0, 1
 PRO_NONE, PRO_BN, PRO_PRELU = 0, 1, 2
 EPI_STORE, EPI_STATS, EPI_PRELU_BWD, EPI_BNBWD, EPI_MARGIN, EPI_ATOMIC, EPI_SLAB, EPI_BIAS_RES = range(8)
+TAIL_NONE, TAIL_SUMS, TAIL_BN = range(3)
 
 
 class FrhipError(RuntimeError):
@@ -110,8 +115,9 @@ lib = _load()
 
 
 def self_check():
-    assert lib.fr_abi_version() == 3
-    for i, s in enumerate((FrConvArgs, FrWgradArgs, FrApplyArgs, FrBnBwdArgs, FrSgdTensor, FrPackTensor, FrAdamTensor, FrBnEvalEntry)):
+    assert lib.fr_abi_version() == 4
+    for i, s in enumerate((FrConvArgs, FrWgradArgs, FrApplyArgs, FrBnBwdArgs, FrSgdTensor, FrPackTensor, FrAdamTensor, FrBnEvalEntry,
+                           FrTail)):
         got = lib.fr_struct_size(i)
         if got != ctypes.sizeof(s):
             raise FrhipError("frhip: struct %s is %d bytes in libfrhip.so but %d in the ctypes binding"

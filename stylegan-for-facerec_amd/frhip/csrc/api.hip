@@ -1,4 +1,5 @@
 // frhip -- error string + version + capability query of the C ABI.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -22,8 +23,23 @@ extern "C" int fr_struct_size(int which) {
     case 5: return (int)sizeof(FrPackTensor);
     case 6: return (int)sizeof(FrAdamTensor);
     case 7: return (int)sizeof(FrBnEvalEntry);
+    case 8: return (int)sizeof(FrTail);
   }
   return -1;
+}
+
+// Workgroups that share the in-launch reduction of a launch's partial rows (tail.h) when the caller leaves FrTail.nred 0:
+// enough that every 256-thread reduction block takes one 8-column group, capped here.  FRHIP_TAIL_NRED overrides the cap
+// (1 = the last workgroup to arrive adds everything alone).
+int fr_tail_default_nred() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FRHIP_TAIL_NRED");
+    v = e ? atoi(e) : 16;
+    if (v < 1) v = 1;
+    if (v > 64) v = 64;
+  }
+  return v;
 }
 
 namespace {

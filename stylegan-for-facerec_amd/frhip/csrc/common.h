@@ -36,6 +36,16 @@ extern "C" void fr_set_error(const char* msg);
     return 0;                                  \
   } while (0)
 
+// hipFuncSetAttribute (dynamic LDS above 64 KB) is per function AND per device: launchers keep one bit per device
+inline bool fr_attr_needed(unsigned long long& done_mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done_mask & bit) return false;
+  done_mask |= bit;
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // bf16 <-> f32
 // ---------------------------------------------------------------------------------------------------------

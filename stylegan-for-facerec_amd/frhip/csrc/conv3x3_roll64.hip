@@ -27,6 +27,7 @@
 
 #include "common.h"
 #include "frhip_internal.h"
+#include "tail.h"
 
 #ifdef FRHIP_STAMPS
 // diagnostic build only (make stamps): per-workgroup phase times, accumulated over the walk (tools/stamps.py --roll)
@@ -241,6 +242,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_roll64_kernel(const FrConvArgs
       drain_tile(row_first + (nit - 1) * K::RI);
       __syncthreads();  // end of item: the tile is empty, the ring may be primed again (+ the statistics hand-over)
     }
+    if (p.epi != FR_EPI_STORE && p.epi != FR_EPI_BIAS_RES)  // in-launch reduction of the items' rows (tail.h)
+      fr_tail<K::NTH>(p.tail, p.part, nitems, gridDim.x, smem, tid);
     return;
   }
 
@@ -461,9 +464,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_roll64_kernel(const FrConvArgs
     __syncthreads();  // end of item (matches the data-moving waves)
     if (sums && tid < 2 * K::C) {
       const int k = tid / K::C, n = tid - k * K::C;
-      p.part[((size_t)item * 2 + k) * K::C + n] = red[(0 * 2 + k) * K::C + n] + red[(1 * 2 + k) * K::C + n];
+      st_part(p.part + ((size_t)item * 2 + k) * K::C + n, red[(0 * 2 + k) * K::C + n] + red[(1 * 2 + k) * K::C + n]);
     }
   }
+  if (p.epi != FR_EPI_STORE && p.epi != FR_EPI_BIAS_RES) fr_tail<K::NTH>(p.tail, p.part, nitems, gridDim.x, smem, tid);
 }
 
 int roll_nseg(int B, int W) {
@@ -486,17 +490,19 @@ int roll_nseg(int B, int W) {
 
 template <int W, int PRO, bool AUX>
 int launch(const FrConvArgs& a, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_roll64_kernel<W, PRO, AUX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, R64::LDS);
-    attr_done = true;
   }
   const int nseg = roll_nseg(a.B, W);
   const int items = a.B * (W / R64::BW) * nseg;
   // one workgroup per CU (156 KB of LDS), persistent over its items: weights and coefficients are staged once
   const int grid = items < 256 ? items : 256;
-  hipLaunchKernelGGL((conv3x3_roll64_kernel<W, PRO, AUX>), dim3(grid), dim3(R64::NTH), R64::LDS, st, a, nseg, items);
+  FrConvArgs k = a;
+  const bool sums = a.part && a.epi != FR_EPI_STORE && a.epi != FR_EPI_BIAS_RES;
+  if (fr_tail_prepare(a.tail, 2, a.N, R64::NTH / FR_RT, &k.tail, sums)) return -1;
+  hipLaunchKernelGGL((conv3x3_roll64_kernel<W, PRO, AUX>), dim3(grid), dim3(R64::NTH), R64::LDS, st, k, nseg, items);
   FR_LAUNCH_CHECK();
 }
 

@@ -25,6 +25,7 @@
 
 #include "common.h"
 #include "frhip_internal.h"
+#include "tail.h"
 
 namespace {
 
@@ -349,6 +350,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_roll64_kernel(const FrConvA
       }
       __syncthreads();  // end of item: tiles drained, the ring may be primed again (+ the statistics hand-over)
     }
+    if (p.epi != FR_EPI_STORE && p.epi != FR_EPI_BIAS_RES)  // in-launch reduction of the items' rows (tail.h)
+      fr_tail<S2R::NTH>(p.tail, p.part, nitems, gridDim.x, smem, tid);
     return;
   }
 
@@ -509,9 +512,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_roll64_kernel(const FrConvA
     __syncthreads();  // end of item (matches the data-moving waves)
     if (sums && tid < 2 * K::C) {
       const int k = tid / K::C, n = tid - k * K::C;
-      p.part[((size_t)item * 2 + k) * K::C + n] = red[(0 * 2 + k) * K::C + n] + red[(1 * 2 + k) * K::C + n];
+      st_part(p.part + ((size_t)item * 2 + k) * K::C + n, red[(0 * 2 + k) * K::C + n] + red[(1 * 2 + k) * K::C + n]);
     }
   }
+  if (p.epi != FR_EPI_STORE && p.epi != FR_EPI_BIAS_RES) fr_tail<S2R::NTH>(p.tail, p.part, nitems, gridDim.x, smem, tid);
 }
 
 int s2roll_nseg(int B) {
@@ -529,16 +533,18 @@ int s2roll_nseg(int B) {
 template <int KIND, int PRO>
 int launch(const FrConvArgs& a, hipStream_t st) {
   using LY = S2R::L<KIND>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_s2_roll64_kernel<KIND, PRO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS);
-    attr_done = true;
   }
   const int nseg = s2roll_nseg(a.B);
   const int items = a.B * nseg;
   const int grid = items < 256 ? items : 256;  // persistent: weights are loaded into registers once per workgroup
-  hipLaunchKernelGGL((conv3x3_s2_roll64_kernel<KIND, PRO>), dim3(grid), dim3(S2R::NTH), LY::LDS, st, a, nseg, items);
+  FrConvArgs k = a;
+  const bool sums = a.part && a.epi != FR_EPI_STORE && a.epi != FR_EPI_BIAS_RES;
+  if (fr_tail_prepare(a.tail, 2, a.N, S2R::NTH / FR_RT, &k.tail, sums)) return -1;
+  hipLaunchKernelGGL((conv3x3_s2_roll64_kernel<KIND, PRO>), dim3(grid), dim3(S2R::NTH), LY::LDS, st, k, nseg, items);
   FR_LAUNCH_CHECK();
 }
 

@@ -22,6 +22,7 @@
 
 #include "common.h"
 #include "frhip_internal.h"
+#include "tail.h"
 
 namespace {
 
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
         float t = 0.f;
 #pragma unroll
         for (int g = 0; g < C::WM; ++g) t += red[(g * 2 + k) * COUT + n];
-        p.part[(prow * 2 + k) * (COUT * NSPL) + ncol0 + n] = t;
+        st_part(p.part + (prow * 2 + k) * (COUT * NSPL) + ncol0 + n, t);
       }
     }
     __syncthreads();  // the tile and the reduction scratch are free again
@@ -526,6 +527,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
     mma_taps<C, CIN, 1, 3>(smem, abase, acc, wrow);
     epilogue(3);
   }
+  // in-launch reduction of the partial rows (tail.h): forward one row per strip, gradient [class][strip]
+  if (p.epi == FR_EPI_STATS || p.epi == FR_EPI_PRELU_BWD || p.epi == FR_EPI_BNBWD)
+    fr_tail<NTH>(p.tail, p.part, (KIND == 1 ? 4 : 1) * nstrips, gridDim.x, smem, tid);
 }
 
 static int s2_xcd_order() {  // FRHIP_XCD_ORDER=0: strips in dispatch order (A/B switch)
@@ -540,15 +544,17 @@ static int s2_xcd_order() {  // FRHIP_XCD_ORDER=0: strips in dispatch order (A/B
 template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND, int PRO, int NSPL, int NIMG>
 int launch(const FrConvArgs& a, hipStream_t st) {
   using C = S2<CIN, COUT, WL, ROWS, WN, NW, KIND, NIMG>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(
         reinterpret_cast<const void*>(&conv3x3_s2_kernel<CIN, COUT, WL, ROWS, WN, NW, KIND, PRO, NSPL, NIMG>),
         hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    attr_done = true;
   }
+  FrConvArgs k = a;
+  const bool sums = a.part && (a.epi == FR_EPI_STATS || a.epi == FR_EPI_PRELU_BWD || a.epi == FR_EPI_BNBWD);
+  if (fr_tail_prepare(a.tail, 2, a.N, C::NTH / FR_RT, &k.tail, sums)) return -1;
   hipLaunchKernelGGL((conv3x3_s2_kernel<CIN, COUT, WL, ROWS, WN, NW, KIND, PRO, NSPL, NIMG>),
-                     dim3(a.B * C::NS / NIMG * NSPL), dim3(C::NTH), C::LDS, st, a, s2_xcd_order());
+                     dim3(a.B * C::NS / NIMG * NSPL), dim3(C::NTH), C::LDS, st, k, s2_xcd_order());
   FR_LAUNCH_CHECK();
 }
 

@@ -25,6 +25,7 @@
 
 #include "common.h"
 #include "frhip_internal.h"
+#include "tail.h"
 
 #ifdef FRHIP_STAMPS
 // Diagnostic build only (make stamps -> libfrhip_stamps.so; never the product library): wave 0 of every workgroup
@@ -88,16 +89,12 @@ struct SC {
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-// PAIR (round 3): conv1 -> PReLU -> conv2 of one residual unit in ONE launch (whole-image strips, CIN == COUT): stage 0 is the
-// plain kernel with the STORE epilogue (y1 = p.out, needed by the backward pass); its bf16 output tile then goes back into
-// LDS as the haloed input image of stage 1 -- the PReLU (p.slope2) applied on the way, exactly the arithmetic stage 1's own
-// prologue would apply to the tile read back from HBM, so the pair is bit-identical to two launches -- and stage 1 runs the K
-// loop with p.w2 and the epilogue p.epi into p.out2.  Saves the second strip load (an HBM burst of all workgroups at
-// once) and a launch boundary per unit.
-template <int CIN, int COUT, int W, int ROWS, int WN, int NW, int NSPL, int PRO, int NIMG = 1, int KSPL = 1,
-          bool PAIR = false>
+// (Round 3 carried a PAIR variant -- conv1 -> PReLU -> conv2 of a unit in one launch, the bf16 tile of conv1 turned into
+// conv2's haloed LDS image -- bit-identical to two launches and measured no faster as a kernel (0.1156-0.1215 ms against
+// 0.1114-0.1259) and 0.1-0.2 ms slower per step: the 4.5-us strip load it saves is paid back by the tile -> image pass, and
+// two launches let conv2's workgroups start on the CUs that finish conv1 first.  Removed in round 4 with ABI v4.)
+template <int CIN, int COUT, int W, int ROWS, int WN, int NW, int NSPL, int PRO, int NIMG = 1, int KSPL = 1>
 __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvArgs p, const int xcd) {
-  static_assert(!PAIR || (CIN == COUT && ROWS == W && NSPL == 1 && NIMG == 1 && KSPL == 1), "pair: whole single images");
   using C = SC<CIN, COUT, W, ROWS, WN, NW, NIMG, KSPL>;
   constexpr int CK = C::CK;
   constexpr int NTH = C::NTH;
@@ -108,7 +105,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
   const bf16_t* __restrict__ src = reinterpret_cast<const bf16_t*>(p.src);
   const bf16_t* __restrict__ wgt = reinterpret_cast<const bf16_t*>(p.w);
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
-  int stage = 0;  // PAIR: 0 = conv1, 1 = conv2
 
   // One strip per workgroup.  (Walking several strips with the next one register-prefetched under the MFMAs was
   // measured slower -- spills, and the strips of a workgroup serialise -- and is gone.)
@@ -205,15 +201,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
   const int flip = p.mode;
   constexpr int OCH = COUT / 8;
 
-#pragma unroll
-  for (stage = 0; stage < (PAIR ? 2 : 1); ++stage) {
-    if (PAIR && stage == 1) {
-      wgt = reinterpret_cast<const bf16_t*>(p.w2);
-      out = reinterpret_cast<bf16_t*>(p.out2);
-    }
+  {
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) wrow[j] = wgt + (size_t)(ncol0 + n0 + j * 16 + fr) * 9 * CIN + fq * 8;
-    const int epi = PAIR && stage == 0 ? (int)FR_EPI_STORE : p.epi;
+    const int epi = p.epi;
     const bool stats = epi == FR_EPI_STATS || epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD;
     const int b = NIMG > 1 ? s * NIMG : s / C::NS;  // first image of the strip
     const int row0 = NIMG > 1 ? 0 : (s - b * C::NS) * ROWS;
@@ -227,7 +218,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
     // ---------------------------------------------------------------- strip -> LDS (prologue applied once)
     __syncthreads();  // the previous strip's output tile has left LDS / the previous channel stage has been consumed
     FR_STAMP(0);
-    if (!PAIR || stage == 0) load_now(s);  // pair, stage 1: the image was rebuilt from stage 0's output tile
+    load_now(s);
     FR_STAMP(1);
     __syncthreads();
     FR_STAMP(2);
@@ -317,7 +308,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
     // barrier that ends the K loop: as a load -> wait -> LDS-store loop it cost one HBM round trip per 16 bytes of a
     // thread (13 of them, ~7 us of a 55-us 14x14 launch); the registers are those of the dead fragment rings.
     constexpr int NAUX = (C::M * OCH + NTH - 1) / NTH;
-    const bool has_aux = !PAIR && (epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD || epi == FR_EPI_BIAS_RES);  // pair: STORE / STATS only
+    const bool has_aux = epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD || epi == FR_EPI_BIAS_RES;
     U128 av[NAUX];
     if (has_aux) {
       const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
@@ -418,10 +409,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
           }
       }
     };
-    if (PAIR) {
-      if (epi == FR_EPI_STATS) cells(std::integral_constant<int, FR_EPI_STATS>{});
-      else cells(std::integral_constant<int, FR_EPI_STORE>{});
-    } else
     switch (epi) {
       case FR_EPI_STATS: cells(std::integral_constant<int, FR_EPI_STATS>{}); break;
       case FR_EPI_PRELU_BWD: cells(std::integral_constant<int, FR_EPI_PRELU_BWD>{}); break;
@@ -448,45 +435,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
           st16(out + (rowbase + r) * (size_t)p.ldc + ncol0 + c8 * 8, ov[u]);
         }
       }
-      if (PAIR && stage == 0) {
-        // the tile (in registers) becomes the input image of stage 1: PReLU in fp32 on the bf16 values, one rounding back --
-        // the prologue arithmetic of load_now on the same bits; halo pixels (overwritten by the tile) are zeroed again
-        static_assert(!PAIR || NTH % OCH == 0, "a thread keeps its channel chunk");
-        float sl[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sl[j] = p.slope2[(tid % OCH) * 8 + j];
-        __syncthreads();  // every thread holds its part of the tile
-#pragma unroll
-        for (int u = 0; u < NAUX; ++u) {
-          const int idx = u * NTH + tid;
-          if (idx < C::M * OCH) {
-            const int r = idx / OCH, c8 = idx - r * OCH;
-            const int h = r / W, w = r - h * W;
-            float f[8];
-            unpack16<bf16_t>(ov[u], f);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = f[j] > 0.f ? f[j] : f[j] * sl[j];
-            st16(smem + (h + 1) * C::RSTR + (w + 1) * C::PSTR + c8 * 16, pack16<bf16_t>(f));
-          }
-        }
-        constexpr int HALO = 2 * (W + 2) + 2 * W;  // pixels of the border
-        for (int idx = tid; idx < HALO * C::CH; idx += NTH) {
-          const int hp = idx / C::CH, c8 = idx - hp * C::CH;
-          int gh, gw;
-          if (hp < W + 2) {
-            gh = 0;
-            gw = hp;
-          } else if (hp < 2 * (W + 2)) {
-            gh = W + 1;
-            gw = hp - (W + 2);
-          } else {
-            const int q = hp - 2 * (W + 2);
-            gh = 1 + (q >> 1);
-            gw = (q & 1) ? W + 1 : 0;
-          }
-          st16(smem + gh * C::RSTR + gw * C::PSTR + c8 * 16, zero16());
-        }
-      }
     }
     FR_STAMP(6);
 #ifdef FRHIP_STAMPS
@@ -504,8 +452,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
         float t = 0.f;
 #pragma unroll
         for (int g = 0; g < C::WM; ++g) t += red[(g * 2 + k) * COUT + n];
-        p.part[((size_t)sblk * 2 + k) * (COUT * NSPL) + ncol0 + n] = t;
+        st_part(p.part + ((size_t)sblk * 2 + k) * (COUT * NSPL) + ncol0 + n, t);
       }
+      // in-launch reduction of the rows (tail.h); everything in LDS is dead by now
+      fr_tail<NTH>(p.tail, p.part, (int)(gridDim.x / NSPL), gridDim.x, smem, tid);
     }
   }
 }
@@ -520,20 +470,21 @@ static int xcd_order() {
   return v;
 }
 
-template <int CIN, int COUT, int W, int ROWS, int WN, int NW, int NSPL, int PRO, int NIMG = 1, int KSPL = 1,
-          bool PAIR = false>
+template <int CIN, int COUT, int W, int ROWS, int WN, int NW, int NSPL, int PRO, int NIMG = 1, int KSPL = 1>
 int launch(const FrConvArgs& a, hipStream_t st) {
   using C = SC<CIN, COUT, W, ROWS, WN, NW, NIMG, KSPL>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, NSPL, PRO, NIMG, KSPL, PAIR>),
+        reinterpret_cast<const void*>(&conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, NSPL, PRO, NIMG, KSPL>),
         hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    attr_done = true;
   }
   const int strips = a.B * C::NS / NIMG;
-  hipLaunchKernelGGL((conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, NSPL, PRO, NIMG, KSPL, PAIR>),
-                     dim3(strips * NSPL), dim3(C::NTH), C::LDS, st, a, xcd_order());
+  FrConvArgs k = a;
+  const bool sums = a.part && (a.epi == FR_EPI_STATS || a.epi == FR_EPI_PRELU_BWD || a.epi == FR_EPI_BNBWD);
+  if (fr_tail_prepare(a.tail, 2, a.N, C::NTH / FR_RT, &k.tail, sums)) return -1;
+  hipLaunchKernelGGL((conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, NSPL, PRO, NIMG, KSPL>),
+                     dim3(strips * NSPL), dim3(C::NTH), C::LDS, st, k, xcd_order());
   FR_LAUNCH_CHECK();
 }
 
@@ -607,30 +558,6 @@ extern "C" int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi) 
   if (Cin == 512 && Cout == 512 && W == 7 && strip_variant() >= 3 && B % 4 == 0) return B / 4;  // four images per strip
   if (Cin == 512 && Cout == 512 && W == 7 && strip_variant() >= 2 && B % 2 == 0) return B / 2;  // two images per strip
   return rows ? B * (W / rows) : 0;
-}
-
-// The pair instance exists for (256 channels, 14x14, batches above the split-channel threshold).  Measured at B = 256
-// (tools/pair_bench.py, one box): 0.1156-0.1215 ms against 0.1114-0.1259 for the two launches it replaces, and the training
-// step 0.1-0.2 ms SLOWER with it (15.18-15.28 against 15.07-15.09 ms): the strip load it saves (4.5 us) is paid back by the
-// tile -> image pass through registers (PReLU on 100 KB per workgroup, halo re-zeroed, two more barriers), and with two
-// launches the workgroups of conv2 start on the CUs that finish conv1 first, which a fused workgroup cannot.  So the engine
-// uses it only with FRHIP_PAIR=1 (read when a plan is built); the entry point itself serves the shape whenever asked.
-static bool pair_shape(int B, int C, int W) { return strip_variant() >= 1 && C == 256 && W == 14 && B >= 1 && !small_batch(B); }
-
-extern "C" int fr_conv3x3_pair_supported(int B, int C, int W) { return pair_shape(B, C, W) ? 1 : 0; }
-
-extern "C" int fr_conv3x3_pair(const FrConvArgs* args, void* stream) {
-  const FrConvArgs& a = *args;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.RH != a.SH || a.RW != a.SW || a.SH != a.SW || a.mode != 0 ||
-      a.out_f32 || a.splitk > 1 || a.bias || a.SC != a.N || a.pro != FR_PRO_BN ||
-      (a.epi != FR_EPI_STORE && a.epi != FR_EPI_STATS))
-    FR_UNSUPPORTED("fr_conv3x3_pair: two square stride-1 3x3 bf16 convolutions, Cin == Cout, BN prologue, STORE / STATS epilogue");
-  if (!a.w2 || !a.out2 || !a.slope2 || !a.out || (a.epi == FR_EPI_STATS && !a.part))
-    FR_UNSUPPORTED("fr_conv3x3_pair: w2 / out2 / slope2 / out (/ part) must be given");
-  if (a.lda % 8 || a.ldc % 8) FR_UNSUPPORTED("fr_conv3x3_pair: strides must be 16-byte multiples");
-  if (!pair_shape(a.B, a.SC, a.SW)) FR_UNSUPPORTED("fr_conv3x3_pair: shape not served (fr_conv3x3_pair_supported)");
-  return launch<256, 256, 14, 14, 8, 8, 1, FR_PRO_BN, 1, 1, true>(a, st);
 }
 
 extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {

@@ -22,6 +22,7 @@
 // back through LDS so that global stores and the fused column reductions are row-contiguous 16-B accesses.
 #include "common.h"
 #include "frhip_internal.h"
+#include "tail.h"
 
 namespace {
 
@@ -448,9 +449,11 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
       if (n0 + col < p.N) {
         float s = 0.f;
         for (int g = 0; g < nred; ++g) s += Red[(k * 16 + g) * BN + col];
-        p.part[(((size_t)blockIdx.y * mb_count + mb) * 2 + k) * (size_t)p.N + n0 + col] = s;
+        st_part(p.part + (((size_t)blockIdx.y * mb_count + mb) * 2 + k) * (size_t)p.N + n0 + col, s);
       }
     }
+    // in-launch reduction of the [class][M tile] rows (tail.h)
+    fr_tail<NT>(p.tail, p.part, (int)gridDim.y * mb_count, gridDim.x * gridDim.y * gridDim.z, Red, tid);
   }
 }
 
@@ -460,13 +463,15 @@ int launch(const FrConvArgs& a, hipStream_t st) {
   const int M = a.mode == 2 ? a.B * (a.RH / 2) * (a.RW / 2) : a.B * a.RH * a.RW;
   const int mbs = (M + BM - 1) / BM, nbs = (a.N + BN - 1) / BN;
   dim3 grid(mbs * nbs, a.mode == 2 && a.par_h < 0 ? 4 : 1, a.splitk > 1 ? a.splitk : 1);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BN, PRO>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, PRO>), grid, dim3(NT), C::LDS_BYTES, st, a);
+  FrConvArgs k = a;
+  const bool sums = a.part && (a.epi == FR_EPI_STATS || a.epi == FR_EPI_PRELU_BWD || a.epi == FR_EPI_BNBWD);
+  if (fr_tail_prepare(a.tail, 2, a.N, NT / FR_RT, &k.tail, sums)) return -1;
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, PRO>), grid, dim3(NT), C::LDS_BYTES, st, k);
   FR_LAUNCH_CHECK();
 }
 

@@ -233,11 +233,10 @@ int launch(const FrWgradArgs& a, hipStream_t st) {
   const int co_tiles = (a.Cout + BCO - 1) / BCO, ci_tiles = (a.SC + BCI - 1) / BCI;
   dim3 grid(co_tiles * ci_tiles * a.KH * a.KW, a.nsplit, 1);
   constexpr int LDS = lds_bytes<T, BCO, BCI>();
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, BCO, BCI, PRO>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
   }
   hipLaunchKernelGGL((conv_wgrad_kernel<T, BCO, BCI, PRO>), grid, dim3(NT), LDS, st, a);
   if (a.slab) {  // reproducible mode: every pixel slice wrote its own slab; add them in a fixed order into dw

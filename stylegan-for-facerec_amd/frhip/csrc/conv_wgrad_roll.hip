@@ -1155,11 +1155,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_s2roll_kernel(const FrWgrad
 template <int WL, int PRO>
 int launch_s2(const FrWgradArgs& a, hipStream_t st) {
   using L = SL2<WL>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_s2roll_kernel<WL, PRO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS);
-    attr_done = true;
   }
   const int tiles = (a.Cout / CT) * (a.SC / CT);
   hipLaunchKernelGGL((conv_wgrad_s2roll_kernel<WL, PRO>), dim3(tiles * a.nsplit), dim3(512), L::LDS, st, a);
@@ -1185,11 +1184,10 @@ int by_pro_s2(const FrWgradArgs& a, hipStream_t st) {
 template <int W, int PRO>
 int launch_vr(const FrWgradArgs& a, hipStream_t st) {
   using C = VC<W>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_vr_kernel<W, PRO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    attr_done = true;
   }
   const int tiles = (a.Cout / CT) * (a.SC / CT);
   hipLaunchKernelGGL((conv_wgrad_vr_kernel<W, PRO>), dim3(tiles * a.nsplit), dim3(512), C::LDS, st, a);
@@ -1215,11 +1213,10 @@ int by_pro_vr(const FrWgradArgs& a, hipStream_t st) {
 template <int W, int PRO>
 int launch(const FrWgradArgs& a, hipStream_t st) {
   using L = RL<W>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_roll_kernel<W, PRO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS);
-    attr_done = true;
   }
   const int tiles = (a.Cout / CT) * (a.SC / CT);
   hipLaunchKernelGGL((conv_wgrad_roll_kernel<W, PRO>), dim3(tiles * a.nsplit), dim3(512), L::LDS, st, a);

@@ -389,11 +389,10 @@ namespace {
 template <int W, int ROWS, int NIMG, int NW, int PRO, bool S2 = false, bool RK = false>
 int launch(const FrWgradArgs& a, hipStream_t st) {
   using C = WC<W, ROWS, NIMG, NW, S2, RK>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<W, ROWS, NIMG, NW, PRO, S2, RK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    attr_done = true;
   }
   const int tiles = (a.Cout / CT) * (a.SC / CT);
   hipLaunchKernelGGL((conv_wgrad_strip_kernel<W, ROWS, NIMG, NW, PRO, S2, RK>), dim3(tiles * a.nsplit), dim3(C::NTH), C::LDS,

@@ -16,6 +16,7 @@
 
 #include "common.h"
 #include "frhip_internal.h"
+#include "tail.h"
 
 namespace {
 
@@ -38,7 +39,7 @@ __device__ __forceinline__ void block_col_reduce(float (&acc)[K][VEC], float* re
     float s = 0.f;
     for (int r = 0; r < rt_count; ++r) s += red[(r * cpr + cc) * (K * VEC) + kj];
     const int k = kj / VEC, j = kj - k * VEC;
-    part_blk[(size_t)k * C + cc * VEC + j] = s;
+    st_part(part_blk + (size_t)k * C + cc * VEC + j, s);  // write-through: a tail of the same launch may read it
   }
 }
 
@@ -106,107 +107,20 @@ __global__ __launch_bounds__(256) void stem_im2col_rows_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------ partial-row reduction
-// part is [nparts][KC] fp32.  A block of RT threads owns 8 consecutive columns (per column set): thread (row-lane
-// rl = tid/8, column cl = tid%8) strides over the rows (32-B coalesced segments), accumulates in double, and the
-// row-lanes are combined with wave shuffles + one LDS step.  The totals are valid in the threads with tid < 8
-// (column tid).  Fixed summation order: deterministic for a given nparts.
-constexpr int RT = 256;  // threads of the partial-sum reduction kernels: small workgroups, so that they still find
-                         // a slot on CUs that hold a resident strip workgroup of the side stream (512: +0.1 ms / step)
-
-template <int NCOLSETS>
-__device__ __forceinline__ void reduce_rows8(const float* __restrict__ part, int nparts, int KC,
-                                             const int (&col0)[NCOLSETS], double (&out)[NCOLSETS],
-                                             double* lds /* [NCOLSETS][RW][8] */) {
-  // RT threads = RT/8 row-lanes x 8 columns; NCOLSETS column groups are reduced in the same sweep so that all their
-  // loads are in flight together (the kernels below are pure latency: a few hundred KB per workgroup)
-  const int tid = threadIdx.x, cl = tid & 7, rl = tid >> 3;
-  constexpr int RL = RT / 8, RW = RT / 64;
-  double s[NCOLSETS];
-  const float* colp[NCOLSETS];  // out-of-range columns read the last valid one (branch-free loads) and are zeroed below
-#pragma unroll
-  for (int k = 0; k < NCOLSETS; ++k) {
-    s[k] = 0.0;
-    const int c = col0[k] + cl;
-    colp[k] = part + (c < KC ? c : KC - 1);
-  }
-  int r = rl;
-  auto trip = [&](auto utag) {  // U x NCOLSETS independent loads per trip
-    constexpr int U = decltype(utag)::value;
-    for (; r + (U - 1) * RL < nparts; r += U * RL) {
-      float v[NCOLSETS][U];
-#pragma unroll
-      for (int k = 0; k < NCOLSETS; ++k)
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[k][u] = colp[k][(size_t)(r + u * RL) * KC];
-#pragma unroll
-      for (int k = 0; k < NCOLSETS; ++k) {
-        double t = 0.0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) t += (double)v[k][u];
-        s[k] += t;
-      }
-    }
-  };
-  trip(std::integral_constant<int, 8>{});
-  trip(std::integral_constant<int, 4>{});
-  trip(std::integral_constant<int, 2>{});
-  for (; r < nparts; r += RL)
-#pragma unroll
-    for (int k = 0; k < NCOLSETS; ++k) s[k] += (double)colp[k][(size_t)r * KC];
-#pragma unroll
-  for (int k = 0; k < NCOLSETS; ++k)
-    if (col0[k] + cl >= KC) s[k] = 0.0;
-  // lanes of a wave: 8 row-lanes x 8 columns -> fold the row-lane bits (lane bits 3..5)
-  const int wave = tid >> 6;
-#pragma unroll
-  for (int k = 0; k < NCOLSETS; ++k) {
-    double t = s[k];
-    t += __shfl_xor(t, 8, 64);
-    t += __shfl_xor(t, 16, 64);
-    t += __shfl_xor(t, 32, 64);
-    if ((tid & 63) < 8) lds[(k * RW + wave) * 8 + cl] = t;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NCOLSETS; ++k) {
-    double t = 0.0;
-    if (tid < 8)
-      for (int w = 0; w < RW; ++w) t += lds[(k * RW + w) * 8 + tid];
-    out[k] = t;
-  }
-}
+// fr_reduce_rows8 (tail.h) is shared with the in-launch tails of the producing kernels: one summation order everywhere.
+constexpr int RT = FR_RT;  // threads of the partial-sum reduction kernels: small workgroups, so that they still find
+                           // a slot on CUs that hold a resident strip workgroup of the side stream (512: +0.1 ms / step)
 
 // ------------------------------------------------------------------------------------------ BN finalize
-__global__ __launch_bounds__(RT) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C,
-                                                         double count, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float eps, float momentum,
-                                                         float* running_mean, float* running_var, long long* nbt,
-                                                         float* mean, float* invstd, float* scale, float* shift) {
+__global__ __launch_bounds__(RT) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, FrBnFin f) {
   __shared__ double lds[2 * (RT / 64) * 8];
   // part row layout [2][C]: columns c (sum) and C + c (sum of squares); a block finalises 8 channels
   const int c0 = blockIdx.x * 8;
   const int cols[2] = {c0, C + c0};
   double sq[2];
-  reduce_rows8<2>(part, nparts, 2 * C, cols, sq, lds);
-  const double s = sq[0], q = sq[1];
+  fr_reduce_rows8<2>(part, nparts, 2 * C, cols, sq, lds, threadIdx.x);
   const int c = c0 + threadIdx.x;
-  if (threadIdx.x < 8 && c < C) {
-    const double m = s / count;
-    double var = q / count - m * m;
-    if (var < 0.0) var = 0.0;
-    const float is = (float)(1.0 / sqrt(var + (double)eps));
-    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
-    mean[c] = (float)m;
-    invstd[c] = is;
-    scale[c] = g * is;
-    shift[c] = bt - (float)m * g * is;
-    if (running_mean) {
-      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-    }
-    if (nbt && c == 0) *nbt += 1;
-  }
+  if (threadIdx.x < 8 && c < C) fr_bn_finalize_channel(f, c, sq[0], sq[1]);
 }
 
 // eval-mode coefficients from running statistics
@@ -227,7 +141,7 @@ __global__ __launch_bounds__(RT) void reduce_parts_kernel(const float* __restric
   const int col0 = blockIdx.x * 8;  // over the K*C columns of a partial row
   const int cols[1] = {col0};
   double tot[1];
-  reduce_rows8<1>(part, nparts, K * C, cols, tot, lds);
+  fr_reduce_rows8<1>(part, nparts, K * C, cols, tot, lds, threadIdx.x);
   const double s = tot[0];
   const int idx = col0 + threadIdx.x;
   if (threadIdx.x < 8 && idx < K * C) {
@@ -240,7 +154,7 @@ __global__ __launch_bounds__(RT) void reduce_parts_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------ channel stats
 template <typename T>
 __global__ __launch_bounds__(NT) void channel_stats_kernel(const T* __restrict__ x, long long rows, int C,
-                                                           float* __restrict__ part) {
+                                                           float* __restrict__ part, const FrTail tail) {
   constexpr int VEC = Elt<T>::VEC;
   __shared__ float red[NT * 2 * VEC];
   const int cpr = C / VEC, tid = threadIdx.x;
@@ -259,6 +173,7 @@ __global__ __launch_bounds__(NT) void channel_stats_kernel(const T* __restrict__
     }
   }
   block_col_reduce<2, VEC>(acc, red, part + (size_t)blockIdx.x * 2 * C, C, cpr, tid);
+  fr_tail<NT>(tail, part, gridDim.x, gridDim.x, red, tid);
 }
 
 // ------------------------------------------------------------------------------------------ BN apply (+SE, +PReLU, +residual)
@@ -327,7 +242,10 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const FrApplyArgs p) {
       }
     }
   }
-  if (p.part) block_col_reduce<2, VEC>(acc, red, p.part + (size_t)blockIdx.x * 2 * C, C, cpr, tid);
+  if (p.part) {
+    block_col_reduce<2, VEC>(acc, red, p.part + (size_t)blockIdx.x * 2 * C, C, cpr, tid);
+    fr_tail<NT>(p.tail, p.part, gridDim.x, gridDim.x, red, tid);
+  }
 }
 
 // ------------------------------------------------------------------------------------------ BN backward
@@ -390,6 +308,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const FrBnBwdArgs p) 
     }
   }
   block_col_reduce<3, VEC>(acc, red, p.part + (size_t)blockIdx.x * 3 * C, C, cpr, tid);
+  fr_tail<NT>(p.tail, p.part, gridDim.x, gridDim.x, red, tid);
 }
 
 template <typename T>
@@ -543,7 +462,10 @@ __global__ __launch_bounds__(NT, 6) void bn_apply_lean_kernel(const FrApplyArgs 
       }
     }
   }
-  if (STATS) block_col_reduce<2, LV>(acc, red, p.part + (size_t)blockIdx.x * 2 * C, C, cpr, tid);
+  if (STATS) {
+    block_col_reduce<2, LV>(acc, red, p.part + (size_t)blockIdx.x * 2 * C, C, cpr, tid);
+    fr_tail<NT>(p.tail, p.part, gridDim.x, gridDim.x, red, tid);
+  }
 }
 
 // SLOPE: BN followed by PReLU (the stem, model_irse.py:141-142): g' = g * prelu'(u), u = x*scale + shift, and the third
@@ -613,11 +535,11 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_reduce_lean_kernel(const FrBnBwd
     }
   }
   block_col_reduce<3, LV>(acc, red, p.part + (size_t)blockIdx.x * 3 * C, C, cpr, tid);
+  fr_tail<NT>(p.tail, p.part, gridDim.x, gridDim.x, red, tid);
 }
 
-template <bool ADD, bool SE = false, bool NEXT = false>
+template <bool ADD, bool SE = false>
 __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdArgs p) {
-  __shared__ float red[NEXT ? NT * 3 * LV : 1];
   const int C = p.C, cpr = C / LV, tid = threadIdx.x;
   const int cc = tid % cpr, rt = tid / cpr, rtc = NT / cpr, c0 = cc * LV;
   const bf16_t* __restrict__ g = reinterpret_cast<const bf16_t*>(p.g) + c0;
@@ -633,19 +555,12 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdA
     a[j] = p.s0[c0 + j] * p.inv_count;
     bb[j] = p.s1[c0 + j] * p.inv_count;
   }
-  // NEXT: the backward sums of the BatchNorm in front (input nx), formed from the rounded gx in the order
-  // bn_bwd_reduce_lean_kernel<false, false> uses (same rows per thread, same block reduction): bit-identical partial rows
-  const bf16_t* __restrict__ nx = NEXT ? reinterpret_cast<const bf16_t*>(p.nx) + c0 : nullptr;
-  float nmu[LV], nis[LV], nacc[3][LV];
-#pragma unroll
-  for (int j = 0; j < LV; ++j) {
-    nmu[j] = NEXT ? p.nmean[c0 + j] : 0.f;
-    nis[j] = NEXT ? p.ninvstd[c0 + j] : 0.f;
-    nacc[0][j] = nacc[1][j] = nacc[2][j] = 0.f;
-  }
+  // (Round 2-3 carried a NEXT variant here that also formed the backward sums of the BatchNorm in front from the rounded
+  // gx -- bit-identical, one pass less, and 0.04-0.6 ms SLOWER per step beside the weight gradients of the side stream: 80
+  // registers, one wave per SIMD where the two separate kernels run two.  Removed in round 4, ABI v4.)
   const int nrows = (int)p.rows, rstep = gridDim.x * rtc * LUNRB;
   for (int r0 = blockIdx.x * rtc * LUNRB + rt; r0 < nrows; r0 += rstep) {
-    uint2 gr[LUNRB], xr[LUNRB], er[LUNRB], nr[LUNRB];
+    uint2 gr[LUNRB], xr[LUNRB], er[LUNRB];
 #pragma unroll
     for (int u = 0; u < LUNRB; ++u) {
       const int r = r0 + u * rtc;
@@ -653,7 +568,6 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdA
         gr[u] = ld8(g + (size_t)r * C);
         xr[u] = ld8(x + (size_t)r * C);
         if (ADD) er[u] = ld8(add + (size_t)r * C);
-        if (NEXT) nr[u] = ld8(nx + (size_t)r * C);
       }
     }
 #pragma unroll
@@ -670,22 +584,10 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdA
           o[j] = coef[j] * (gv[j] - a[j] - (xv[j] - mu[j]) * is[j] * bb[j]);
           if (ADD) o[j] += e[j];
         }
-        const uint2 packed = pack4bf(o);
-        *reinterpret_cast<uint2*>(gx + (size_t)r * C) = packed;
-        if (NEXT) {
-          float ov[LV], nv[LV];
-          unpack4bf(packed, ov);
-          unpack4bf(nr[u], nv);
-#pragma unroll
-          for (int j = 0; j < LV; ++j) {
-            nacc[0][j] += ov[j];
-            nacc[1][j] = fmaf(ov[j], (nv[j] - nmu[j]) * nis[j], nacc[1][j]);
-          }
-        }
+        *reinterpret_cast<uint2*>(gx + (size_t)r * C) = pack4bf(o);
       }
     }
   }
-  if (NEXT) block_col_reduce<3, LV>(nacc, red, p.npart + (size_t)blockIdx.x * 3 * C, C, cpr, tid);
 }
 
 // ------------------------------------------------------------------------------------------ SE
@@ -1217,9 +1119,20 @@ extern "C" int fr_bn_finalize(const float* part, int nparts, int C, double count
                               const float* beta, float eps, float momentum, float* running_mean,
                               float* running_var, int64_t* nbt, float* mean, float* invstd, float* scale,
                               float* shift, void* stream) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(RT), 0, (hipStream_t)stream, part, nparts, C,
-                     count, gamma, beta, eps, momentum, running_mean, running_var, (long long*)nbt, mean, invstd,
-                     scale, shift);
+  FrBnFin f;
+  f.count = count;
+  f.gamma = gamma;
+  f.beta = beta;
+  f.eps = eps;
+  f.momentum = momentum;
+  f.running_mean = running_mean;
+  f.running_var = running_var;
+  f.nbt = (long long*)nbt;
+  f.mean = mean;
+  f.invstd = invstd;
+  f.scale = scale;
+  f.shift = shift;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(RT), 0, (hipStream_t)stream, part, nparts, C, f);
   FR_LAUNCH_CHECK();
 }
 
@@ -1258,22 +1171,27 @@ extern "C" int fr_reduce_parts(const float* part, int nparts, int K, int C, floa
 }
 
 extern "C" int fr_channel_stats(const void* x, long long rows, int C, float* part, int nblocks, int dtype,
-                                void* stream) {
+                                const FrTail* tail, void* stream) {
   if (!chan_ok(C, dtype)) FR_UNSUPPORTED("fr_channel_stats: unsupported channel count");
   hipStream_t st = (hipStream_t)stream;
+  FrTail t;
+  if (fr_tail_prepare(tail ? *tail : FrTail{}, 2, C, NT / FR_RT, &t, part != nullptr)) return -1;
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(channel_stats_kernel<float>, dim3(nblocks), dim3(NT), 0, st, (const float*)x, rows,
-                                C, part),
+                                C, part, t),
              hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, dim3(nblocks), dim3(NT), 0, st, (const bf16_t*)x,
-                                rows, C, part),
+                                rows, C, part, t),
              "fr_channel_stats");
   FR_LAUNCH_CHECK();
 }
 
-extern "C" int fr_bn_apply(const FrApplyArgs* args, int dtype, void* stream) {
-  if (!chan_ok(args->C, dtype)) FR_UNSUPPORTED("fr_bn_apply: unsupported channel count");
-  if (args->nblocks < 1) FR_UNSUPPORTED("fr_bn_apply: nblocks < 1");
+extern "C" int fr_bn_apply(const FrApplyArgs* args_in, int dtype, void* stream) {
+  if (!chan_ok(args_in->C, dtype)) FR_UNSUPPORTED("fr_bn_apply: unsupported channel count");
+  if (args_in->nblocks < 1) FR_UNSUPPORTED("fr_bn_apply: nblocks < 1");
   hipStream_t st = (hipStream_t)stream;
+  FrApplyArgs prepared = *args_in;
+  if (fr_tail_prepare(args_in->tail, 2, args_in->C, NT / FR_RT, &prepared.tail, args_in->part != nullptr)) return -1;
+  const FrApplyArgs* args = &prepared;
   if (dtype == FR_BF16 && lean_ok(args->C) && !args->slope &&
       !(args->res_kind == 1 && args->res_stride > 1) && (long long)args->B * args->H * args->W < (1ll << 31)) {
     const dim3 grid(args->nblocks), blk(NT);
@@ -1300,9 +1218,12 @@ extern "C" int fr_bn_apply(const FrApplyArgs* args, int dtype, void* stream) {
   FR_LAUNCH_CHECK();
 }
 
-extern "C" int fr_bn_bwd_reduce(const FrBnBwdArgs* args, int dtype, void* stream) {
-  if (!chan_ok(args->C, dtype)) FR_UNSUPPORTED("fr_bn_bwd_reduce: unsupported channel count");
+extern "C" int fr_bn_bwd_reduce(const FrBnBwdArgs* args_in, int dtype, void* stream) {
+  if (!chan_ok(args_in->C, dtype)) FR_UNSUPPORTED("fr_bn_bwd_reduce: unsupported channel count");
   hipStream_t st = (hipStream_t)stream;
+  FrBnBwdArgs prepared = *args_in;
+  if (fr_tail_prepare(args_in->tail, 3, args_in->C, NT / FR_RT, &prepared.tail, args_in->part != nullptr)) return -1;
+  const FrBnBwdArgs* args = &prepared;
   if (dtype == FR_BF16 && lean_ok(args->C) && args->rows < (1ll << 31) && !(args->se && args->slope) &&
       (!args->slope || (args->scale && args->shift))) {
     const dim3 grid(args->nblocks), blk(NT);
@@ -1320,13 +1241,6 @@ extern "C" int fr_bn_bwd_reduce(const FrBnBwdArgs* args, int dtype, void* stream
 extern "C" int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream) {
   if (!chan_ok(args->C, dtype)) FR_UNSUPPORTED("fr_bn_bwd_apply: unsupported channel count");
   hipStream_t st = (hipStream_t)stream;
-  if (args->nx) {  // + the backward sums of the BatchNorm in front: the plain bf16 residual case only
-    if (!(dtype == FR_BF16 && lean_ok(args->C) && !args->slope && !args->se && args->add_kind == 1 &&
-          args->rows < (1ll << 31) && args->nmean && args->ninvstd && args->npart))
-      FR_UNSUPPORTED("fr_bn_bwd_apply: nx / nmean / ninvstd / npart need bf16, add_kind 1, no se / slope");
-    hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<true, false, true>), dim3(args->nblocks), dim3(NT), 0, st, *args);
-    FR_LAUNCH_CHECK();
-  }
   if (dtype == FR_BF16 && lean_ok(args->C) && !args->slope && args->add_kind != 2 && args->rows < (1ll << 31)) {
     const dim3 grid(args->nblocks), blk(NT);
     if (args->se) {

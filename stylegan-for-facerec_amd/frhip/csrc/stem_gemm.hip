@@ -8,6 +8,7 @@
 // wave streams 16-row tiles, and both are HBM-bound by construction (forward: 64 B in, 128 B out per row).
 #include "common.h"
 #include "frhip_internal.h"
+#include "tail.h"
 
 namespace {
 
@@ -17,7 +18,8 @@ constexpr int SN = 64;  // output channels of the stem
 // out[m][n] = sum_k X[m][k] W[n][k];  part[blk][0][n] = sum_m out, part[blk][1][n] = sum_m out^2 (of the rounded bf16)
 template <int K>
 __global__ __launch_bounds__(256) void stem_gemm_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wp,
-                                                        bf16_t* __restrict__ out, float* __restrict__ part, int M) {
+                                                        bf16_t* __restrict__ out, float* __restrict__ part, int M,
+                                                        const FrTail tail) {
   constexpr int KS = K / 32;
   constexpr int OSTR = SN * 2 + 16;                    // per-wave transpose tile [16 rows][64 ch], padded rows
   __shared__ __attribute__((aligned(16))) char tiles[4 * 16 * OSTR];
@@ -102,9 +104,10 @@ __global__ __launch_bounds__(256) void stem_gemm_kernel(const bf16_t* __restrict
   __syncthreads();
   if (tid < 2 * SN) {
     const int k = tid / SN, n = tid - k * SN;
-    part[((size_t)blockIdx.x * 2 + k) * SN + n] =
-        red[(0 * 2 + k) * SN + n] + red[(1 * 2 + k) * SN + n] + red[(2 * 2 + k) * SN + n] + red[(3 * 2 + k) * SN + n];
+    st_part(part + ((size_t)blockIdx.x * 2 + k) * SN + n,
+            red[(0 * 2 + k) * SN + n] + red[(1 * 2 + k) * SN + n] + red[(2 * 2 + k) * SN + n] + red[(3 * 2 + k) * SN + n]);
   }
+  fr_tail<256>(tail, part, gridDim.x, gridDim.x, tiles, tid);  // in-launch BatchNorm statistics (tail.h)
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient
@@ -224,16 +227,18 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16_t* __restric
 }  // namespace
 
 extern "C" int fr_stem_gemm(const void* X, const void* Wp, void* out, float* part, long long M, int K, int nblocks,
-                            void* stream) {
+                            const FrTail* tail, void* stream) {
   if ((K != 32 && K != 64) || M < 1 || M >= (1ll << 31) - 64 || nblocks < 1)
     FR_UNSUPPORTED("fr_stem_gemm: K must be 32 or 64, 0 < M < 2^31, nblocks >= 1");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  FrTail t;
+  if (fr_tail_prepare(tail ? *tail : FrTail{}, 2, SN, 1, &t, part != nullptr)) return -1;
   if (K == 32)
     hipLaunchKernelGGL(stem_gemm_kernel<32>, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)X, (const bf16_t*)Wp,
-                       (bf16_t*)out, part, (int)M);
+                       (bf16_t*)out, part, (int)M, t);
   else
     hipLaunchKernelGGL(stem_gemm_kernel<64>, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)X, (const bf16_t*)Wp,
-                       (bf16_t*)out, part, (int)M);
+                       (bf16_t*)out, part, (int)M, t);
   FR_LAUNCH_CHECK();
 }
 

@@ -119,10 +119,11 @@ def ready_order_params(module):
 
 class _BN(object):
     """Device-side coefficients of one BatchNorm: mean, invstd, scale (= gamma*invstd), shift."""
-    __slots__ = ("mod", "C", "mean", "invstd", "scale", "shift")
+    __slots__ = ("mod", "C", "mean", "invstd", "scale", "shift", "tailed")
 
     def __init__(self, mod, pool):
         self.mod, self.C = mod, mod.num_features
+        self.tailed = False  # its statistics are finalised by the tail of the launch that produces them (ops.tail_bn)
         self.mean, self.invstd, self.scale, self.shift = (pool.take(self.C) for _ in range(4))
 
 
@@ -250,14 +251,14 @@ class BackbonePlan(object):
         self.stream2 = ctypes.c_void_p(self.stream2_t.cuda_stream)
         self.S = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
         self.generation = 0
-        # FRHIP_GRAPH=1: the two launch lists are captured into HIP graphs after the first eager step and replayed from then
-        # on (single-process steps only).  Opt-in, because on this stack replay is SLOWER than eager launches at every batch
-        # size (ms per step, eager / graph: B = 8: 6.05 / 6.86, 32: 6.71 / 7.30, 64: 7.67 / 8.11, 128: 10.0 / 10.6, 256: 16.0 /
-        # 16.4).  The small-batch floor of ~6 ms is ~500 dependent dispatches at ~12 us each on the GPU side, and the host's
-        # 6.5 ms of enqueue per step is inside hipLaunchKernel, not in Python: a packed native list executor (one foreign call
-        # per list, built and measured in round 2, then removed) left both the enqueue time and the step time unchanged.
-        self.graph_mode = os.environ.get("FRHIP_GRAPH", "0") == "1"
-        self._graphs = None
+        # (FRHIP_GRAPH, rounds 2-3: the two launch lists captured into HIP graphs.  Replay was SLOWER than eager launches at
+        # every batch size on this stack -- ms per step eager / graph: B = 8: 6.05 / 6.86, 64: 7.67 / 8.11, 256: 16.0 / 16.4 --
+        # and a packed native list executor left both the enqueue time and the step time unchanged; removed in round 4.)
+        # In-launch reductions (csrc/tail.h): the launches that write partial rows also add them (last workgroups to arrive),
+        # instead of a fr_bn_finalize / fr_reduce_parts launch behind each of them.  FRHIP_TAIL=0: the separate launches (A/B
+        # switch; bit-identical results either way).
+        self.use_tail = os.environ.get("FRHIP_TAIL", "1") != "0"
+        self.tickets = ops.Tickets(8 * len(self.units) + 32, device)
         self.use_strip = os.environ.get("FRHIP_NO_STRIP", "0") != "1"
         self.use_stem_gemm = (self.fr == FR_BF16 and os.environ.get("FRHIP_NO_STEM_GEMM", "0") != "1" and
                               not self.body_only)
@@ -266,12 +267,6 @@ class BackbonePlan(object):
         # deferred slab sums (FrWgradArgs.defer / prev_*): a weight-gradient launch that supports it leaves the sum of its
         # slabs to the NEXT such launch of the side stream (two slab buffers alternate); fr_reduce_slabs flushes the last
         self.defer_slabs = os.environ.get("FRHIP_NO_DEFER_SLABS", "0") != "1"
-        # FrBnBwdArgs.nx: the kernel that writes a unit's input gradient also forms the BN2-backward sums of the unit in
-        # front.  Bit-identical, one pass + one launch less per unit -- and SLOWER: 0.04 ms per step when it was written
-        # (16.45 vs 16.41 ms, three A/B pairs on one box: the fused kernel needs 80 registers and runs one wave per SIMD
-        # beside the weight gradients where the two separate kernels run two), 0.6 ms at the end of round 3 (15.8-15.9 vs
-        # 15.2-15.3 beside the 224-workgroup weight gradients and the three-row BN kernels).  Opt-in.
-        self.fuse_bn_sums = os.environ.get("FRHIP_FUSED_BN_SUMS", "0") == "1"
         self.slab2, self._slab2_users, self._slab_flip = None, [], 0
         self._pending = None  # (launch that wrote the slabs, groups, n, dw tensor, parameter)
         self.part_slope = None  # per-buffer-set partial rows of the PReLU slope gradient (side-stream reduction)
@@ -570,11 +565,37 @@ class BackbonePlan(object):
         return done
 
     # ---- forward -----------------------------------------------------------------------------------
+    def _bn_tail(self, bn, count):
+        """The in-launch form of fr_bn_finalize for the launch that produces bn's (sum, sum of squares) rows: pass the result
+        as that launch's `tail`; _bn_train_launches then appends nothing.  None: the separate launch stays."""
+        m = bn.mod
+        if not self.use_tail or self.fold or not m.training:
+            return None
+        bn.tailed = True
+        return ops.tail_bn(self.tickets.take(), bn.C, count, m.weight, m.bias, m.eps,
+                           m.momentum if m.momentum is not None else 0.1,
+                           m.running_mean if m.track_running_stats else None,
+                           m.running_var if m.track_running_stats else None,
+                           m.num_batches_tracked if m.track_running_stats else None, bn.mean, bn.invstd, bn.scale,
+                           bn.shift)
+
+    def _sum_tail(self, K, C, o0, o1=None, o2=None):
+        """The in-launch form of fr_reduce_parts(part, rows, K, C, o0, o1, o2), or None with FRHIP_TAIL=0."""
+        if not self.use_tail:
+            return None
+        return ops.tail_sums(self.tickets.take(), K, C, o0, o1, o2)
+
+    @staticmethod
+    def _tail_kw(tail):
+        return {} if tail is None else {"tail": tail}
+
     def _bn_train_launches(self, L, bn, part, nparts, count):
         m = bn.mod
         st = self.stream
         if self.fold:  # one fr_bn_eval_coeffs_multi launch in front of the weight packing covers every BatchNorm
             self._fold_bns.append(bn)
+            return
+        if bn.tailed:  # the producing launch carries the reduction (ops.tail_bn)
             return
         if m.training:
             L.append(ops.call("fr_bn_finalize", part, nparts, bn.C, float(count), m.weight, m.bias, float(m.eps),
@@ -602,7 +623,8 @@ class BackbonePlan(object):
             C0 = self.units[0].cin
             nb = ops.grid_blocks(self.M0, C0, fr)
             if not fold:
-                L.append(ops.call("fr_channel_stats", self.z0, self.M0, C0, self.part, nb, fr, st))
+                L.append(ops.call("fr_channel_stats", self.z0, self.M0, C0, self.part, nb, fr,
+                                  self._bn_tail(first_bn, self.M0), st))
             self._bn_train_launches(L, first_bn, self.part, nb, self.M0)
         else:
             sc, sb, sp = self.stem
@@ -613,17 +635,18 @@ class BackbonePlan(object):
             self.l_im2col = None  # bound per call (input pointer changes)
             if self.use_stem_gemm:  # 3.2 M rows x 64 columns x K0: the row-streaming kernels of stem_gemm.hip
                 mt0 = int(min(2048, (self.M0 + 63) // 64))
-                L.append(ops.call("fr_stem_gemm", self.X0, self.W0p, self.y0, self.part, self.M0, self.K0, mt0, st))
+                L.append(ops.call("fr_stem_gemm", self.X0, self.W0p, self.y0, self.part, self.M0, self.K0, mt0,
+                                  self._bn_tail(self.bn0, self.M0), st))
             else:
                 mt0 = (self.M0 + 127) // 128
                 L.append(ops.conv(st, fr, src=self.X0, w=self.W0p, out=self.y0, B=self.M0, RH=1, RW=1, SH=1, SW=1,
                                   SC=self.K0, N=64, KH=1, KW=1, stride=1, pad=0, mode=0, lda=self.K0, ldc=64, pro=0,
-                                  epi=ops.EPI_STATS, part=self.part))
+                                  epi=ops.EPI_STATS, part=self.part, **self._tail_kw(self._bn_tail(self.bn0, self.M0))))
             self._bn_train_launches(L, self.bn0, self.part, mt0, self.M0)
             nb = ops.grid_blocks(self.M0, 64, fr)
             L.append(ops.bn_apply(st, fr, x=self.y0, out=self.z0, scale=self.bn0.scale, shift=self.bn0.shift,
                                   slope=sp.weight, part=stats_part, B=B, H=S, W=S, C=64, res_kind=0, res_stride=1,
-                                  nblocks=nb))
+                                  nblocks=nb, **self._tail_kw(self._bn_tail(first_bn, self.M0))))
             self._bn_train_launches(L, first_bn, self.part, nb, self.M0)
         x = self.z0
         for i, u in enumerate(self.units):
@@ -640,22 +663,9 @@ class BackbonePlan(object):
                 wp1, wp2 = w1, w2
             bn1, bn2 = d["bn1"], d["bn2"]
             folded = fold and u.se is None and (u.sc_conv is not None or u.stride == 1)
-            # FRHIP_PAIR=1: conv1 -> PReLU -> conv2 in one launch where the strip table has a pair instance (256 channels at
-            # 14x14): y1 still goes to HBM for the backward pass, but conv2 takes it from LDS (bit-identical to two launches).
-            # Opt-in: measured 0.1-0.2 ms SLOWER per step than the two launches (csrc/conv3x3_strip.hip, tools/pair_bench.py)
-            pair = (fr == FR_BF16 and self.use_strip and not folded and u.cin == u.depth and u.stride == 1 and
-                    os.environ.get("FRHIP_PAIR", "0") == "1" and ops.strip_pair_supported(B, u.depth, u.H))
-            if pair:
-                kw = dict(src=x, w=wp1, out=d["y1"], w2=wp2, out2=d["y2"], slope2=u.prelu.weight, B=B, RH=u.H, RW=u.H,
-                          SH=u.H, SW=u.H, SC=u.cin, N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.cin,
-                          ldc=u.depth, pro=ops.PRO_BN, pro_a=bn1.scale, pro_b=bn1.shift, epi=stats_epi, part=stats_part)
-                L.append(ops.conv_strip_pair(st, **kw))
-                self._last_conv_strips = ops.strip_parts(B, u.depth, u.depth, u.H, stats_epi)
-                np2 = self._check_part(self._last_conv_strips, kw)
-            else:
-                self._conv(L, src=x, w=wp1, out=d["y1"], B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H, SC=u.cin,
-                           N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.cin, ldc=u.depth,
-                           pro=ops.PRO_BN, pro_a=bn1.scale, pro_b=bn1.shift, epi=ops.EPI_STORE)
+            self._conv(L, src=x, w=wp1, out=d["y1"], B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H, SC=u.cin,
+                       N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.cin, ldc=u.depth,
+                       pro=ops.PRO_BN, pro_a=bn1.scale, pro_b=bn1.shift, epi=ops.EPI_STORE)
             if folded:
                 # inference with BN2 (and the shortcut BN) folded into the packed weights: out = conv2'(PReLU(y1)) +
                 # shift2 [+ shiftS] + shortcut straight from conv2's epilogue -- y2 is never written, no BN-apply pass
@@ -679,11 +689,10 @@ class BackbonePlan(object):
                     self._bn_train_launches(L, nxt, None, 0, rout)
                 x = d["out"]
                 continue
-            if not pair:
-                np2 = self._conv(L, src=d["y1"], w=wp2, out=d["y2"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H,
-                                 SC=u.depth, N=u.depth, KH=3, KW=3, stride=u.stride, pad=1, mode=0, lda=u.depth,
-                                 ldc=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight, epi=stats_epi,
-                                 part=stats_part)
+            np2 = self._conv(L, src=d["y1"], w=wp2, out=d["y2"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H,
+                             SC=u.depth, N=u.depth, KH=3, KW=3, stride=u.stride, pad=1, mode=0, lda=u.depth,
+                             ldc=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight, epi=stats_epi,
+                             part=stats_part, **self._tail_kw(self._bn_tail(bn2, rout)))
             self._bn_train_launches(L, bn2, self.part, np2, rout)
             strips2 = self._last_conv_strips if not fold else 0  # conv2's partial rows, if they are whole strips of single images
             if u.sc_conv is not None:
@@ -696,7 +705,7 @@ class BackbonePlan(object):
                     wps = ws
                 L.append(ops.conv(st, fr, src=x, w=wps, out=d["yS"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H, SC=u.cin,
                                   N=u.depth, KH=1, KW=1, stride=u.stride, pad=0, mode=0, lda=u.cin, ldc=u.depth,
-                                  pro=0, epi=stats_epi, part=stats_part))
+                                  pro=0, epi=stats_epi, part=stats_part, **self._tail_kw(self._bn_tail(d["bnS"], rout))))
                 self._bn_train_launches(L, d["bnS"], self.part, (rout + 127) // 128, rout)
             if u.se is not None:
                 R = u.se.fc1.out_channels
@@ -723,6 +732,8 @@ class BackbonePlan(object):
             nxt = self.ubuf[i + 1]["bn1"] if i + 1 < len(self.units) else (None if self.body_only else self.bn_out)
             if nxt is None:
                 kw["part"] = None  # nobody consumes the statistics of a bare stack's output
+            elif not fold:
+                kw.update(self._tail_kw(self._bn_tail(nxt, rout)))
             L.append(ops.bn_apply(st, fr, **kw))
             if nxt is not None:
                 self._bn_train_launches(L, nxt, self.part, nb, rout)
@@ -754,7 +765,7 @@ class BackbonePlan(object):
         L.append(ops.call("fr_reduce_parts", self.lin_slab, self.lin_splitk, 1, B * 512, self.f, None, None, st))
         nbf = ops.grid_blocks(B, 512, FR_F32)
         if not fold:
-            L.append(ops.call("fr_channel_stats", self.f, B, 512, self.part, nbf, FR_F32, st))
+            L.append(ops.call("fr_channel_stats", self.f, B, 512, self.part, nbf, FR_F32, self._bn_tail(self.bn1d, B), st))
         self._bn_train_launches(L, self.bn1d, self.part, nbf, B)
         L.append(ops.bn_apply(st, FR_F32, x=self.f, out=self.feat, scale=self.bn1d.scale, shift=self.bn1d.shift, B=B,
                               H=1, W=1, C=512, res_kind=0, res_stride=1, nblocks=nbf))
@@ -803,8 +814,10 @@ class BackbonePlan(object):
         return ops.Launch("fr_bn_eval_coeffs_multi", [table, len(bns), self.stream], keep=(bns,))
 
     # ---- backward ----------------------------------------------------------------------------------
-    def _reduce(self, L, nparts, K, C, o0, o1, o2=None):
-        L.append(ops.call("fr_reduce_parts", self.part, nparts, K, C, o0, o1, o2, self.stream))
+    def _reduce(self, L, nparts, K, C, o0, o1, o2=None, tail=None):
+        """Add the partial rows the last launch wrote -- unless that launch carried the reduction itself (tail)."""
+        if tail is None:
+            L.append(ops.call("fr_reduce_parts", self.part, nparts, K, C, o0, o1, o2, self.stream))
 
     def _bn_grads(self, bn):
         """(dbeta target, dgamma target): the parameter gradients when they train, scratch otherwise."""
@@ -835,16 +848,18 @@ class BackbonePlan(object):
         db, dg = self._bn_grads(self.bn1d)
         common = dict(g=self.g_feat_in, x=self.f, mean=self.bn1d.mean, invstd=self.bn1d.invstd, rows=B, C=512,
                       rows_per_image=1, nblocks=nbf)
-        L.append(ops.bn_bwd_reduce(st, FR_F32, part=self.part, **common))
-        self._reduce(L, nbf, 3, 512, db, dg)
+        t = self._sum_tail(3, 512, db, dg)
+        L.append(ops.bn_bwd_reduce(st, FR_F32, part=self.part, **self._tail_kw(t), **common))
+        self._reduce(L, nbf, 3, 512, db, dg, tail=t)
         s0, s1 = self._s01(self.bn1d, db, dg)
         L.append(ops.bn_bwd_apply(st, FR_F32, gx=self.g_f32, gamma=ob1.weight, s0=s0, s1=s1, inv_count=1.0 / B,
                                   **common))
         # Linear bias gradient = column sums of g_f
         gbias = self.grad_of(ol.bias)
         if gbias is not None:
-            L.append(ops.call("fr_channel_stats", self.g_f32, B, 512, self.part, nbf, FR_F32, st))
-            self._reduce(L, nbf, 2, 512, gbias, None)
+            t = self._sum_tail(1, 512, gbias)
+            L.append(ops.call("fr_channel_stats", self.g_f32, B, 512, self.part, nbf, FR_F32, t, st))
+            self._reduce(L, nbf, 2, 512, gbias, None, tail=t)
         if fr == FR_BF16:
             L.append(ops.call("fr_cast", self.g_f32, self.g_fT, B * 512, FR_F32, FR_BF16, st))
             gfT = self.g_fT
@@ -870,8 +885,9 @@ class BackbonePlan(object):
         db, dg = self._bn_grads(self.bn_out)
         common = dict(g=g_a, x=x_last, mean=self.bn_out.mean, invstd=self.bn_out.invstd, rows=rows_o, C=C,
                       rows_per_image=self.HWo, nblocks=nb)
-        L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
-        self._reduce(L, nb, 3, C, db, dg)
+        t = self._sum_tail(3, C, db, dg)
+        L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **self._tail_kw(t), **common))
+        self._reduce(L, nb, 3, C, db, dg, tail=t)
         s0, s1 = self._s01(self.bn_out, db, dg)
         cur = 0
         g_out = self.g_pp[cur][:rows_o * C]
@@ -883,7 +899,6 @@ class BackbonePlan(object):
         B, st, fr = self.B, self.stream, self.fr
         # ---- residual units in reverse
         unit_done = {}  # unit index -> event recorded on the side stream after its weight gradients
-        fused_sums = -1  # unit whose BN2-backward partial sums the previous unit's last kernel has already written
         for i in range(len(self.units) - 1, -1, -1):
             u, d = self.units[i], self.ubuf[i]
             x = self.ubuf[i - 1]["out"] if i > 0 else self.z0
@@ -913,9 +928,9 @@ class BackbonePlan(object):
             db, dg = self._bn_grads(bn2)
             common = dict(g=g_out, x=d["y2"], mean=bn2.mean, invstd=bn2.invstd, rows=rout, C=u.depth,
                           rows_per_image=HWo, nblocks=nb, **se_kw)
-            if fused_sums != i:  # else: the kernel that wrote g_out has left these partial rows in self.part already
-                L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
-            self._reduce(L, nb, 3, u.depth, db, dg)
+            t = self._sum_tail(3, u.depth, db, dg)
+            L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **self._tail_kw(t), **common))
+            self._reduce(L, nb, 3, u.depth, db, dg, tail=t)
             s0, s1 = self._s01(bn2, db, dg)
             L.append(ops.bn_bwd_apply(st, fr, gx=g_y2, gamma=u.bn2.weight, s0=s0, s1=s1, inv_count=1.0 / rout,
                                       **common))
@@ -926,8 +941,9 @@ class BackbonePlan(object):
                 db, dg = self._bn_grads(bnS)
                 common = dict(g=g_out, x=d["yS"], mean=bnS.mean, invstd=bnS.invstd, rows=rout, C=u.depth,
                               rows_per_image=HWo, nblocks=nb)
-                L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
-                self._reduce(L, nb, 3, u.depth, db, dg)
+                t = self._sum_tail(3, u.depth, db, dg)
+                L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **self._tail_kw(t), **common))
+                self._reduce(L, nb, 3, u.depth, db, dg, tail=t)
                 s0, s1 = self._s01(bnS, db, dg)
                 L.append(ops.bn_bwd_apply(st, fr, gx=g_yS, gamma=u.sc_bn.weight, s0=s0, s1=s1,
                                           inv_count=1.0 / rout, **common))
@@ -954,17 +970,22 @@ class BackbonePlan(object):
                       epi=ops.EPI_PRELU_BWD, aux=d["y1"], epi_a=u.prelu.weight)
             # The PReLU-slope partial sums of this data gradient feed nothing downstream (a parameter gradient): with the
             # side stream they go to a buffer of their own (one per buffer set) and are added there, off the main chain.
-            part2 = self.part_slope[par] if self.side_slope else self.part
+            gsl = self.grad_of(u.prelu.weight)
+            gsl = gsl if gsl is not None else self.sums[2, :u.depth]
+            # with the in-launch reduction the data gradient adds its own slope partials: nothing for the side stream to do
+            tsl = self._sum_tail(1, u.depth, gsl)
+            part2 = self.part_slope[par] if (self.side_slope and tsl is None) else self.part
             if u.stride == 2 and u.H % 2 == 0:
                 # one launch per output-pixel parity class: 9/4 taps per pixel instead of 9 (3/4 of them misses)
                 # (all four classes in one launch: par = -1; partial rows come back as [class][M tile])
-                mt = self._conv(L, mode=2, par_h=-1, par_w=-1, part=part2, **c2)
+                mt = self._conv(L, mode=2, par_h=-1, par_w=-1, part=part2, **self._tail_kw(tsl), **c2)
             else:
-                mt = self._conv(L, mode=1, part=part2, **c2)
-            gsl = self.grad_of(u.prelu.weight)
-            gsl = gsl if gsl is not None else self.sums[2, :u.depth]
+                mt = self._conv(L, mode=1, part=part2, **self._tail_kw(tsl), **c2)
             gw2 = self.grad_of(u.conv2.weight)
-            if self.side_slope:
+            if tsl is not None:
+                if gw2 is not None:
+                    self._side_after_main(L)  # g_y1, g_y2 (BN2 backward) and y1 are final
+            elif self.side_slope:
                 self._side_after_main(L)  # g_y1 / the slope partials, g_y2 (BN2 backward) and y1 are final
                 r = ops.call("fr_reduce_parts", part2, mt, 2, u.depth, gsl, None, None, self.stream2)
                 r.tstream = self.stream2_t
@@ -973,7 +994,7 @@ class BackbonePlan(object):
                 self._reduce(L, mt, 2, u.depth, gsl, None)
             if gw2 is not None:
                 tiles = ((u.depth + 127) // 128) ** 2 * 9
-                if not self.side_slope:
+                if not self.side_slope and tsl is None:
                     self._side_after_main(L)
                 ready += self._wgrad(L, param=u.conv2.weight, g=g_y2, src=d["y1"], dw=gw2, B=B, GH=u.Ho, GW=u.Ho,
                                      Cout=u.depth, SH=u.H, SW=u.H, SC=u.depth, KH=3, KW=3, stride=u.stride, pad=1,
@@ -983,12 +1004,13 @@ class BackbonePlan(object):
                 ready.append(u.conv2.weight)
             # conv1: data gradient with the BN1-backward sums epilogue, then the weight gradient
             g_xh = self.g_xh[:rin * u.cin]
+            db, dg = self._bn_grads(bn1)
+            t = self._sum_tail(2, u.cin, db, dg)
             mt = self._conv(L, src=g_y1, w=d["wt1"], out=g_xh, B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H,
                             SC=u.depth, N=u.cin, KH=3, KW=3, stride=1, pad=1, mode=1, lda=u.depth, ldc=u.cin,
                             ldaux=u.cin, pro=0, epi=ops.EPI_BNBWD, aux=x, epi_a=bn1.mean, epi_b=bn1.invstd,
-                            part=self.part)
-            db, dg = self._bn_grads(bn1)
-            self._reduce(L, mt, 2, u.cin, db, dg)
+                            part=self.part, **self._tail_kw(t))
+            self._reduce(L, mt, 2, u.cin, db, dg, tail=t)
             gw1 = self.grad_of(u.conv1.weight)
             if gw1 is not None:
                 tiles = ((u.depth + 127) // 128) * ((u.cin + 127) // 128) * 9
@@ -1010,13 +1032,6 @@ class BackbonePlan(object):
                 kw.update(add=g_xS, add_kind=2, H=u.H, W=u.H, add_stride=u.stride)
             elif u.stride == 1:
                 kw.update(add=g_out, add_kind=1)
-                # g_x is the upstream gradient of BN2 of the unit in front: form its backward sums here (one pass over
-                # g_x and one launch less per unit; bit-identical partial rows, FrBnBwdArgs.nx).  bf16, no SE there.
-                if (self.fuse_bn_sums and i > 0 and fr == FR_BF16 and self.units[i - 1].se is None and u.se is None
-                        and u.cin % 4 == 0 and 256 % (u.cin // 4) == 0 and self.units[i - 1].depth == u.cin):
-                    pb = self.ubuf[i - 1]["bn2"]
-                    kw.update(nx=self.ubuf[i - 1]["y2"], nmean=pb.mean, ninvstd=pb.invstd, npart=self.part)
-                    fused_sums = i - 1
             else:
                 kw.update(add=g_out, add_kind=2, H=u.H, W=u.H, add_stride=u.stride)
             L.append(ops.bn_bwd_apply(st, fr, **kw))
@@ -1051,8 +1066,9 @@ class BackbonePlan(object):
         common = dict(g=g_out, x=self.y0, mean=self.bn0.mean, invstd=self.bn0.invstd, scale=self.bn0.scale,
                       shift=self.bn0.shift, slope=sp.weight, rows=self.M0, C=64, rows_per_image=self.S * self.S,
                       nblocks=nb)
-        L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
-        self._reduce(L, nb, 3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64])
+        t = self._sum_tail(3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64])
+        L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **self._tail_kw(t), **common))
+        self._reduce(L, nb, 3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64], tail=t)
         s0, s1 = self._s01(self.bn0, db, dg)
         g_y0 = self.g_y1s[1 if self.dual else 0][:self.M0 * 64]  # unit 0's wgrads (side stream) still read set 0
         if self.dual and 1 in unit_done:
@@ -1138,70 +1154,6 @@ class BackbonePlan(object):
         ops.run(self.bwd_list)
         return self.g_input.view(B, first.H, first.H, first.cin).permute(0, 3, 1, 2).to(torch.float32, copy=True)
 
-    # ---- HIP graphs ---------------------------------------------------------------------------------
-    def _capture(self, launches):
-        """Record a launch list into a HIP graph.  The lists carry the caller's stream (usually the default stream, which
-        cannot capture) as ONE shared ctypes value: it is pointed at a capture stream for the duration, and the event
-        edges to the side stream are re-targeted the same way; the side stream joins the capture through those edges and
-        the lists end with its join, so the graph holds the two-stream schedule as branches."""
-        cap = torch.cuda.Stream(device=self.device)
-        trans = []
-        for l in launches:
-            if isinstance(l, _EvRecord) and l.stream is self.stream1_t:
-                l = _EvRecord(l.ev, cap)
-            elif isinstance(l, _EvWait) and l.stream is self.stream1_t:
-                l = _EvWait(cap, l.ev)
-            trans.append(l)
-        saved = (self.stream.value, self.stream2.value)
-        g = torch.cuda.CUDAGraph()
-        try:
-            self.stream.value = cap.cuda_stream
-            if not self.dual:
-                self.stream2.value = cap.cuda_stream
-            with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
-                ops.run(trans)
-        finally:
-            self.stream.value, self.stream2.value = saved
-        return g
-
-    def _split_at(self, launches, dyn):
-        """[segment | launch with per-step arguments | segment]: the Dropout launches carry the step's seed.  Accepts a
-        plain list or the result of an earlier split."""
-        if launches and not isinstance(launches[0], list) and not any(isinstance(x, list) for x in launches):
-            launches = [launches]
-        out = []
-        for seg in launches:
-            if isinstance(seg, list) and dyn is not None and any(x is dyn for x in seg):
-                k = [x is dyn for x in seg].index(True)
-                out += [seg[:k], dyn, seg[k + 1:]]
-            else:
-                out.append(seg)
-        return out
-
-    def _ensure_graphs(self):
-        if self._graphs is None and self.graph_mode and self.generation >= 1:
-            try:
-                fwd = [seg if isinstance(seg, ops.Launch) else self._capture(seg)
-                       for seg in self._split_at(self.pack_list + self.fwd_list, getattr(self, "l_drop_fwd", None))]
-                bwd = None
-                if not self.infer:
-                    bwd = [seg if isinstance(seg, ops.Launch) else self._capture(seg)
-                           for seg in self._split_at(self.bwd_list, getattr(self, "l_drop_bwd", None))]
-                self._graphs = (fwd, bwd)
-            except Exception as e:  # noqa: BLE001 -- a capture that fails must not take the training run with it
-                import warnings
-                warnings.warn("frhip: HIP graph capture failed (%s); continuing with eager launches" % (e,), RuntimeWarning)
-                self.graph_mode = False
-        return self._graphs is not None
-
-    @staticmethod
-    def _replay(segments):
-        for seg in segments:
-            if isinstance(seg, ops.Launch):
-                seg()
-            else:
-                seg.replay()
-
     def run_forward(self, x, avg_image, seed):
         B, S = self.B, self.S
         st = self.stream
@@ -1214,11 +1166,8 @@ class BackbonePlan(object):
         if not self.infer:
             self.l_drop_bwd.args[4] = p
             self.l_drop_bwd.args[5] = seed
-        if self._ensure_graphs():
-            self._replay(self._graphs[0])
-        else:
-            ops.run(self.pack_list)
-            ops.run(self.fwd_list)
+        ops.run(self.pack_list)
+        ops.run(self.fwd_list)
         self.generation += 1
         return self.feat
 
@@ -1234,10 +1183,7 @@ class BackbonePlan(object):
             if p.grad is not v and p.requires_grad:
                 p.grad = v
         if on_ready is None:
-            if self._ensure_graphs():
-                self._replay(self._graphs[1])
-            else:
-                ops.run(self.bwd_list)
+            ops.run(self.bwd_list)
             return
         # Readiness callbacks (gradient all-reduce) run on their own stream, ordered behind the main stream up to this
         # point and behind the unit's side-stream weight gradients -- the main stream itself never waits for the side

@@ -80,17 +80,6 @@ def conv_strip(stream, **kw):
     return Launch("fr_conv3x3_strip", [ctypes.byref(a), stream], keep=(a, kw))
 
 
-def conv_strip_pair(stream, **kw):
-    """fr_conv3x3_pair: conv1 -> PReLU -> conv2 of a residual unit in one launch (out = y1, out2 / w2 / slope2 = the second
-    convolution).  Same FrConvArgs fields as conv()."""
-    a = _fill(_lib.FrConvArgs(), **kw)
-    return Launch("fr_conv3x3_pair", [ctypes.byref(a), stream], keep=(a, kw))
-
-
-def strip_pair_supported(B, c, w):
-    return bool(lib.fr_conv3x3_pair_supported(int(B), int(c), int(w)))
-
-
 def strip_parts(B, cin, cout, w, epi=EPI_STORE):
     """Workgroups (= partial-sum rows) of the strip kernel for a shape + epilogue; 0 when it is not served."""
     return int(lib.fr_conv3x3_strip_parts(int(B), int(cin), int(cout), int(w), int(epi)))
@@ -137,10 +126,58 @@ def bn_bwd_apply(stream, dtype, **kw):
     return Launch("fr_bn_bwd_apply", [ctypes.byref(a), dtype, stream], keep=(a, kw))
 
 
+class Tickets(object):
+    """Arrival tickets of the in-launch reductions (FrTail.ticket): 4 words each on a cache line of its own, zero when
+    handed out and left zero by every launch that used them (the last reducer resets its ticket)."""
+
+    STRIDE = 32  # uint32 words: 128 bytes
+
+    def __init__(self, n, device):
+        self.buf = torch.zeros(n * self.STRIDE, dtype=torch.int32, device=device)
+        self.n, self.used = n, 0
+
+    def take(self):
+        if self.used >= self.n:
+            raise _lib.FrhipError("frhip: ticket pool exhausted")
+        t = self.buf[self.used * self.STRIDE:self.used * self.STRIDE + 4]
+        self.used += 1
+        return t
+
+    def check_idle(self):
+        """Host-side assertion for tests (synchronises): every ticket is back at zero and no reducer ever gave up."""
+        torch.cuda.synchronize(self.buf.device)
+        bad = self.buf.view(-1, self.STRIDE)[:, :4].ne(0).any(dim=1).nonzero().flatten().tolist()
+        if bad:
+            raise _lib.FrhipError("frhip: tickets %s are not idle: %s" % (
+                bad[:8], self.buf.view(-1, self.STRIDE)[bad[:8], :4].tolist()))
+
+
+def tail_sums(ticket, K, C, o0, o1=None, o2=None, nred=0):
+    """FrTail that adds a launch's partial rows part[row][K][C] into o_k[C] (what fr_reduce_parts would do)."""
+    t = _lib.FrTail()
+    _fill(t, ticket=ticket, o0=o0, o1=o1, o2=o2)
+    t.kind, t.K, t.C, t.nred = _lib.TAIL_SUMS, K, C, nred
+    t._keep = (ticket, o0, o1, o2)
+    return t
+
+
+def tail_bn(ticket, C, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, invstd, scale, shift,
+            nred=0):
+    """FrTail that turns a launch's (sum, sum of squares) rows into BatchNorm coefficients (what fr_bn_finalize would do)."""
+    t = _lib.FrTail()
+    _fill(t, ticket=ticket, gamma=gamma, beta=beta, running_mean=running_mean, running_var=running_var, nbt=nbt,
+          mean=mean, invstd=invstd, scale=scale, shift=shift)
+    t.kind, t.K, t.C, t.nred = _lib.TAIL_BN, 2, C, nred
+    t.count, t.eps, t.momentum = float(count), float(eps), float(momentum)
+    t._keep = (ticket, gamma, beta, running_mean, running_var, nbt, mean, invstd, scale, shift)
+    return t
+
+
 def call(name, *args):
     """Generic positional launch: tensors -> pointers, everything else passed through."""
     keep = args
-    conv_args = [ptr(a) if isinstance(a, torch.Tensor) else a for a in args]
+    conv_args = [ptr(a) if isinstance(a, torch.Tensor) else
+                 (ctypes.byref(a) if isinstance(a, ctypes.Structure) else a) for a in args]
     return Launch(name, conv_args, keep=keep)
 
 

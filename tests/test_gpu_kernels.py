@@ -426,7 +426,7 @@ def test_bn_apply_and_backward(K, name, dtype, tol):
     rows = B * H * H
     nb = K.grid_blocks(rows, C, fr)
     part = torch.zeros(nb, 2, C, device="cuda")
-    K.call("fr_channel_stats", xd, rows, C, part, nb, fr, st)()
+    K.call("fr_channel_stats", xd, rows, C, part, nb, fr, None, st)()
     mean, invstd, scale, shift = (torch.zeros(C, device="cuda") for _ in range(4))
     rmd, rvd, nbt = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.zeros((), dtype=torch.int64,
                                                                                               device="cuda")
@@ -647,42 +647,6 @@ def test_conv3x3_strip(K, cin, cout, W, B):
                                        atol=1e-2 * float((gx * xh).abs().sum() / cin))
 
 
-@pytest.mark.parametrize("B", [161, 200])
-def test_conv3x3_pair_is_bit_identical_to_two_launches(K, B):
-    """fr_conv3x3_pair (conv1 -> PReLU -> conv2 of a residual unit in one launch; the 13 all-256-channel units at 14x14 of an
-    IR-50 / IR-SE step at B > 160) against the two fr_conv3x3_strip launches it replaces: y1, y2 and the BatchNorm partial
-    sums must agree bit for bit (the PReLU between them is the same fp32 arithmetic on the same bf16 tile), and y2 is
-    checked against F.conv2d once."""
-    dtype, C, W = torch.bfloat16, 256, 14
-    if not K.strip_pair_supported(B, C, W):
-        pytest.skip("no pair instance in this strip table (FRHIP_STRIP_VARIANT=0)")
-    st = K.current_stream_ptr()
-    x = q(synth.normal(33, "px", (B, C, W, W)), dtype)
-    w1 = q(synth.normal(33, "pw1", (C, C, 3, 3), std=0.03), dtype)
-    w2 = q(synth.normal(33, "pw2", (C, C, 3, 3), std=0.03), dtype)
-    pa = synth.uniform(33, "ppa", (C,), 0.5, 1.5)
-    pb = synth.uniform(33, "ppb", (C,), -0.5, 0.5)
-    slope = synth.uniform(33, "psl", (C,), 0.05, 0.4)
-    xd, w1d, w2d = nhwc(x, dtype), pack_w(w1, dtype), pack_w(w2, dtype)
-    n = K.strip_parts(B, C, C, W, K.EPI_STATS)
-    common = dict(B=B, RH=W, RW=W, SH=W, SW=W, SC=C, N=C, KH=3, KW=3, stride=1, pad=1, mode=0, lda=C, ldc=C)
-    y1p = torch.zeros(B, W, W, C, device="cuda", dtype=dtype)
-    y2p = torch.zeros_like(y1p)
-    partp = torch.zeros(n, 2, C, device="cuda")
-    K.conv_strip_pair(st, src=xd, w=w1d, out=y1p, w2=w2d, out2=y2p, slope2=slope.cuda(), pro=K.PRO_BN, pro_a=pa.cuda(),
-                      pro_b=pb.cuda(), epi=K.EPI_STATS, part=partp, **common)()
-    y1 = torch.zeros_like(y1p)
-    y2 = torch.zeros_like(y1p)
-    part = torch.zeros(n, 2, C, device="cuda")
-    K.conv_strip(st, src=xd, w=w1d, out=y1, pro=K.PRO_BN, pro_a=pa.cuda(), pro_b=pb.cuda(), epi=K.EPI_STORE, **common)()
-    K.conv_strip(st, src=y1, w=w2d, out=y2, pro=K.PRO_PRELU, pro_a=slope.cuda(), epi=K.EPI_STATS, part=part, **common)()
-    torch.cuda.synchronize()
-    assert torch.equal(y1p, y1) and torch.equal(y2p, y2) and torch.equal(partp, part)
-    if B == 161:  # and the pair against the CPU once (first 3 images)
-        xin = q((x[:3].double() * pa.double().view(1, -1, 1, 1) + pb.double().view(1, -1, 1, 1)).float(), dtype)
-        r1 = q(F.conv2d(xin, w1, padding=1), dtype)
-        r2 = F.conv2d(q(torch.where(r1 > 0, r1, r1 * slope.view(1, -1, 1, 1)), dtype), w2, padding=1)
-        assert relerr(from_nhwc(y2p[:3]), r2) < BF16_TOL * 2
 
 
 @pytest.mark.parametrize("name,dtype,tol", DT)
@@ -1013,7 +977,7 @@ def test_stem_gemm_and_wgrad(K, Kp, M):
     nb = 5
     out = torch.zeros(M, 64, device="cuda", dtype=dtype)
     part = torch.zeros(nb, 2, 64, device="cuda")
-    K.call("fr_stem_gemm", x.to("cuda", dtype), w.to("cuda", dtype), out, part, M, Kp, nb, st)()
+    K.call("fr_stem_gemm", x.to("cuda", dtype), w.to("cuda", dtype), out, part, M, Kp, nb, None, st)()
     torch.cuda.synchronize()
     got = out.float().cpu()
     assert relerr(got, y) < tol
@@ -1193,3 +1157,215 @@ def test_conv_bias_residual_epilogue(K, name, dtype, C, H, stride):
         K.conv_strip(st, **kw)()
     torch.cuda.synchronize()
     assert relerr(from_nhwc(out), ref) < tol
+
+
+# ------------------------------------------------------------------------------------------------ in-launch reductions
+
+
+def _bn_outputs(C):
+    return [torch.zeros(C, device="cuda") for _ in range(4)]
+
+
+@pytest.mark.parametrize("nred", [0, 1, 3, 16])
+@pytest.mark.parametrize("dname,C,rows,nb", [("bf16", 64, 5000, 333), ("bf16", 256, 4099, 1024), ("f32", 512, 777, 97),
+                                             ("bf16", 128, 300, 2)])
+def test_tail_equals_the_stand_alone_reductions(K, dname, C, rows, nb, nred):
+    """FrTail on the channel-wise producers (fr_channel_stats, fr_bn_apply, fr_bn_bwd_reduce): the launch that writes the
+    partial rows also adds them -- BatchNorm coefficients + running statistics (FR_TAIL_BN) and gradient sums
+    (FR_TAIL_SUMS) must be BIT-identical to fr_bn_finalize / fr_reduce_parts on the same rows, for one reducer (the last
+    workgroup alone), several (they wait for the arrival count) and more reducers than workgroups; tickets end at zero."""
+    dtype = torch.float32 if dname == "f32" else torch.bfloat16
+    fr, st = K.fr_dtype(torch.empty(0, dtype=dtype)), K.current_stream_ptr()
+    x = synth.normal(31, "tx", (rows, C)).to("cuda", dtype)
+    g = synth.normal(31, "tg", (rows, C)).to("cuda", dtype)
+    gamma, beta = synth.uniform(31, "tga", (C,), 0.8, 1.2).cuda(), synth.uniform(31, "tbe", (C,), -0.1, 0.1).cuda()
+    tickets = K.Tickets(8, "cuda")
+    # ---- statistics: stand-alone
+    part = torch.zeros(nb, 2, C, device="cuda")
+    K.call("fr_channel_stats", x, rows, C, part, nb, fr, None, st)()
+    ref = _bn_outputs(C)
+    rm0, rv0, nbt0 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.zeros((), dtype=torch.int64, device="cuda")
+    K.call("fr_bn_finalize", part, nb, C, float(rows), gamma, beta, 1e-5, 0.1, rm0, rv0, nbt0, *ref, st)()
+    # ---- statistics: tail
+    part_t = torch.zeros(nb, 2, C, device="cuda")
+    got = _bn_outputs(C)
+    rm1, rv1, nbt1 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.zeros((), dtype=torch.int64, device="cuda")
+    t = K.tail_bn(tickets.take(), C, rows, gamma, beta, 1e-5, 0.1, rm1, rv1, nbt1, *got, nred=nred)
+    K.call("fr_channel_stats", x, rows, C, part_t, nb, fr, t, st)()
+    torch.cuda.synchronize()
+    assert torch.equal(part, part_t)
+    for a, b in zip(ref + [rm0, rv0], got + [rm1, rv1]):
+        assert torch.equal(a, b)
+    assert int(nbt1) == 1
+    # ---- bn_apply with the statistics of its output
+    out0, out1 = torch.zeros(rows, C, device="cuda", dtype=dtype), torch.zeros(rows, C, device="cuda", dtype=dtype)
+    p0, p1 = torch.zeros(nb, 2, C, device="cuda"), torch.zeros(nb, 2, C, device="cuda")
+    kw = dict(x=x, scale=ref[2], shift=ref[3], B=1, H=rows, W=1, C=C, res_kind=0, res_stride=1, nblocks=nb)
+    K.bn_apply(st, fr, out=out0, part=p0, **kw)()
+    ref2, got2 = _bn_outputs(C), _bn_outputs(C)
+    K.call("fr_bn_finalize", p0, nb, C, float(rows), gamma, beta, 1e-5, 0.1, None, None, None, *ref2, st)()
+    t2 = K.tail_bn(tickets.take(), C, rows, gamma, beta, 1e-5, 0.1, None, None, None, *got2, nred=nred)
+    K.bn_apply(st, fr, out=out1, part=p1, tail=t2, **kw)()
+    torch.cuda.synchronize()
+    assert torch.equal(out0, out1) and torch.equal(p0, p1)
+    for a, b in zip(ref2, got2):
+        assert torch.equal(a, b)
+    # ---- backward sums: K = 3 rows, two outputs wanted
+    common = dict(g=g, x=x, mean=ref[0], invstd=ref[1], rows=rows, C=C, rows_per_image=rows, nblocks=nb)
+    q0, q1 = torch.zeros(nb, 3, C, device="cuda"), torch.zeros(nb, 3, C, device="cuda")
+    K.bn_bwd_reduce(st, fr, part=q0, **common)()
+    s_ref = [torch.zeros(C, device="cuda") for _ in range(2)]
+    K.call("fr_reduce_parts", q0, nb, 3, C, s_ref[0], s_ref[1], None, st)()
+    s_got = [torch.zeros(C, device="cuda") for _ in range(2)]
+    t3 = K.tail_sums(tickets.take(), 3, C, s_got[0], s_got[1], None, nred=nred)
+    K.bn_bwd_reduce(st, fr, part=q1, tail=t3, **common)()
+    torch.cuda.synchronize()
+    assert torch.equal(q0, q1)
+    assert torch.equal(s_ref[0], s_got[0]) and torch.equal(s_ref[1], s_got[1])
+    tickets.check_idle()
+
+
+def test_tail_rejects_what_it_cannot_serve(K):
+    """A tail on a launch without partial rows, with the wrong channel count, or without its outputs is refused (rc < 0),
+    never silently dropped."""
+    from frhip import _lib
+    st = K.current_stream_ptr()
+    C, rows, nb = 64, 100, 4
+    x = torch.zeros(rows, C, device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros_like(x)
+    sc = torch.ones(C, device="cuda")
+    tickets = K.Tickets(4, "cuda")
+    o = torch.zeros(C, device="cuda")
+    kw = dict(x=x, out=out, scale=sc, shift=sc, B=1, H=rows, W=1, C=C, res_kind=0, res_stride=1, nblocks=nb)
+    with pytest.raises(_lib.FrhipError, match="no partial rows"):
+        K.bn_apply(st, _lib.FR_BF16, tail=K.tail_sums(tickets.take(), 2, C, o, o), **kw)()
+    part = torch.zeros(nb, 2, C, device="cuda")
+    with pytest.raises(_lib.FrhipError, match="C must equal"):
+        K.bn_apply(st, _lib.FR_BF16, part=part, tail=K.tail_sums(tickets.take(), 2, 2 * C, o, o), **kw)()
+    bad = K.tail_bn(tickets.take(), C, rows, None, None, 1e-5, 0.1, None, None, None, None, o, o, o)
+    with pytest.raises(_lib.FrhipError, match="FR_TAIL_BN needs"):
+        K.bn_apply(st, _lib.FR_BF16, part=part, tail=bad, **kw)()
+    torch.cuda.synchronize()
+    tickets.check_idle()
+
+
+@pytest.mark.parametrize("shape", ["strip_256_14_b162", "strip_128_28_b40", "roll64_56_b130", "s2_128_28_b40",
+                                   "s2grad_128_28_b40", "igemm_f32_1x1", "strip_512_7_b12"])
+def test_conv_epilogue_tails_equal_the_stand_alone_reductions(K, shape):
+    """FrTail on the convolution epilogues that write partial rows (strip, rolling-window, stride-2 parity planes, generic
+    implicit GEMM; STATS / BNBWD / PRELU_BWD): output tensor and partial rows unchanged, reduced vectors bit-identical to
+    fr_bn_finalize / fr_reduce_parts run on those rows; the instances named are the ones the training step launches (B = 162 /
+    130: more strips than CUs; 512 @7: four images per workgroup, output channels over four workgroups)."""
+    from frhip import _lib
+    st = K.current_stream_ptr()
+    bf = torch.bfloat16
+    tickets = K.Tickets(8, "cuda")
+    spec = {"strip_256_14_b162": (162, 256, 256, 14, 1, "strip", ops_epi("BNBWD")),
+            "strip_128_28_b40": (40, 128, 128, 28, 1, "strip", ops_epi("STATS")),
+            "roll64_56_b130": (130, 64, 64, 56, 1, "strip", ops_epi("PRELU_BWD")),
+            "s2_128_28_b40": (40, 128, 128, 28, 2, "s2", ops_epi("STATS")),
+            "s2grad_128_28_b40": (40, 128, 128, 28, 2, "s2grad", ops_epi("PRELU_BWD")),
+            "igemm_f32_1x1": (6, 64, 128, 28, 2, "igemm", ops_epi("STATS")),
+            "strip_512_7_b12": (12, 512, 512, 7, 1, "strip", ops_epi("STATS"))}[shape]
+    B, Cin, Cout, Wd, stride, fam, epi = spec
+    dtype = torch.float32 if fam == "igemm" else bf
+    fr = _lib.FR_F32 if fam == "igemm" else _lib.FR_BF16
+    if fam == "igemm":  # 1x1 stride-2 shortcut convolution, forward with statistics
+        Hs = 2 * Wd
+        src = synth.normal(41, "cs", (B * Hs * Hs, Cin)).to("cuda", dtype)
+        w = (synth.normal(41, "cw", (Cout, 1, Cin)) * 0.1).to("cuda", dtype)
+        kw = dict(src=src, w=w, B=B, RH=Wd, RW=Wd, SH=Hs, SW=Hs, SC=Cin, N=Cout, KH=1, KW=1, stride=2, pad=0, mode=0,
+                  lda=Cin, ldc=Cout, pro=0, epi=epi)
+        rows_out = B * Wd * Wd
+        nparts = (rows_out + 127) // 128
+        mk = lambda **k: K.conv(st, fr, **k)  # noqa: E731
+    else:
+        Hs = Wd * (2 if fam == "s2" else 1)  # source side
+        Ro = Wd * (2 if fam == "s2grad" else 1)  # output side
+        src = synth.normal(41, "cs", (B * Hs * Hs, Cin)).to("cuda", dtype)
+        w = (synth.normal(41, "cw", (Cout, 9, Cin)) * 0.05).to("cuda", dtype)
+        mode = {"strip": 1 if epi != _lib.EPI_STATS else 0, "s2": 0, "s2grad": 2}[fam]
+        kw = dict(src=src, w=w, B=B, RH=Ro, RW=Ro, SH=Hs, SW=Hs, SC=Cin, N=Cout, KH=3, KW=3, stride=stride, pad=1,
+                  mode=mode, lda=Cin, ldc=Cout, ldaux=Cout, pro=0, epi=epi)
+        if fam == "s2grad":
+            kw.update(par_h=-1, par_w=-1)
+        rows_out = B * Ro * Ro
+        if fam == "strip":
+            nparts = K.strip_parts(B, Cin, Cout, Wd, epi)
+            mk = lambda **k: K.conv_strip(st, **k)  # noqa: E731
+        else:
+            nparts = K.s2_strip_parts(B, Cin, Cout, Wd, mode)
+            mk = lambda **k: K.conv_s2_strip(st, **k)  # noqa: E731
+        assert nparts > 0, "shape not served by the kernel family under test"
+    if epi != _lib.EPI_STATS:
+        kw.update(aux=synth.normal(41, "ca", (rows_out, Cout)).to("cuda", dtype),
+                  epi_a=synth.uniform(41, "ea", (Cout,), -0.2, 0.3).cuda(), epi_b=synth.uniform(41, "eb", (Cout,), 0.5, 1.5).cuda())
+    out0 = torch.zeros(rows_out, Cout, device="cuda", dtype=dtype)
+    out1 = torch.zeros(rows_out, Cout, device="cuda", dtype=dtype)
+    p0, p1 = torch.zeros(nparts, 2, Cout, device="cuda"), torch.zeros(nparts, 2, Cout, device="cuda")
+    mk(out=out0, part=p0, **kw)()
+    if epi == _lib.EPI_STATS:
+        ref, got = _bn_outputs(Cout), _bn_outputs(Cout)
+        K.call("fr_bn_finalize", p0, nparts, Cout, float(rows_out), None, None, 1e-5, 0.1, None, None, None, *ref, st)()
+        t = K.tail_bn(tickets.take(), Cout, rows_out, None, None, 1e-5, 0.1, None, None, None, *got)
+    else:
+        want2 = epi == _lib.EPI_BNBWD
+        ref, got = [torch.zeros(Cout, device="cuda") for _ in range(2)], [torch.zeros(Cout, device="cuda") for _ in range(2)]
+        K.call("fr_reduce_parts", p0, nparts, 2, Cout, ref[0], ref[1] if want2 else None, None, st)()
+        t = K.tail_sums(tickets.take(), 2 if want2 else 1, Cout, got[0], got[1] if want2 else None)
+    mk(out=out1, part=p1, tail=t, **kw)()
+    torch.cuda.synchronize()
+    assert torch.equal(out0, out1) and torch.equal(p0, p1)
+    assert float(p0.abs().sum()) > 0
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    tickets.check_idle()
+
+
+def ops_epi(name):
+    from frhip import _lib
+    return getattr(_lib, "EPI_" + name)
+
+
+def test_tail_under_uneven_load_and_warm_caches(K):
+    """The hand-off inside a launch (write-through rows -> arrival count -> acquire -> plain loads) checked the way the
+    CDNA4 guide asks: many back-to-back launches that REUSE the same partial-row buffer with new values every time (so a
+    reducer that trusted a stale L1 / L2 line would return the previous launch's sums), while a second stream keeps a share
+    of the CUs busy with an unrelated streaming kernel (uneven arrival order).  Every launch's sums must equal the
+    stand-alone reduction of a private copy of its rows, bit for bit."""
+    from frhip import _lib
+    st = K.current_stream_ptr()
+    C, rows, nb, iters = 256, 40000, 1024, 60
+    fr = _lib.FR_BF16
+    xs = [(synth.normal(51, "lx%d" % (i % 6), (rows, C)) * (1.0 + i)).to("cuda", torch.bfloat16) for i in range(6)]
+    part = torch.zeros(nb, 2, C, device="cuda")            # shared by every tail launch
+    got = torch.zeros(iters, 4, C, device="cuda")
+    ref = torch.zeros(iters, 4, C, device="cuda")
+    tickets = K.Tickets(2, "cuda")
+    tk = tickets.take()
+    side = torch.cuda.Stream()
+    big = torch.zeros(64 * 1024 * 1024, device="cuda")
+    launches, refs = [], []
+    for i in range(iters):
+        x = xs[i % 6][: rows - 37 * (i % 5)]
+        t = K.tail_bn(tk, C, x.shape[0], None, None, 1e-5, 0.1, None, None, None, *[got[i, k] for k in range(4)],
+                      nred=(1, 4, 16)[i % 3])
+        launches.append(K.call("fr_channel_stats", x, x.shape[0], C, part, nb, fr, t, st))
+        pi = torch.zeros(nb, 2, C, device="cuda")
+        refs.append((K.call("fr_channel_stats", x, x.shape[0], C, pi, nb, fr, None, st),
+                     K.call("fr_bn_finalize", pi, nb, C, float(x.shape[0]), None, None, 1e-5, 0.1, None, None, None,
+                            *[ref[i, k] for k in range(4)], st)))
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(40):
+            big.mul_(1.0001)
+    for l in launches:
+        l()
+    torch.cuda.synchronize()
+    for a, b in refs:
+        a()
+        b()
+    torch.cuda.synchronize()
+    bad = [i for i in range(iters) if not torch.equal(got[i], ref[i])]
+    assert not bad, "launches %s returned other sums than the stand-alone reduction" % bad[:10]
+    tickets.check_idle()

@@ -667,57 +667,6 @@ def test_step_is_reproducible_and_side_stream_is_bit_identical():
     assert not sched, "side-stream and single-stream schedules differ (missing dependency edge?): %s" % sched[:5]
 
 
-def test_hip_graph_replay_is_bit_identical_to_eager_launches():
-    """FRHIP_GRAPH=1: after the first eager step the forward and backward launch lists (two streams, event edges, ~450
-    launches) are captured into HIP graphs and replayed; the Dropout launches, whose seed changes every step, stay eager
-    between the graph segments.  Four bf16 training steps with Dropout(0.5) must leave bit-identical parameters and BN
-    running statistics either way, and the graphs must really have been built."""
-    _need_gpu()
-    import os
-    from backbone.model_irse import IR_50
-    from frhip import synth
-    from frhip.optim import SGD
-    from head.metrics import ArcFace
-    from loss.focal import FocalLoss
-    from util.utils import separate_irse_bn_paras
-
-    def run(graph):
-        os.environ["FRHIP_GRAPH"] = graph
-        try:
-            m = IR_50([112, 112])
-            synth.fill_state_dict(m.state_dict(), 15)
-            m.compute_dtype = torch.bfloat16
-            m = m.cuda().train()
-            head = ArcFace(512, 100, None).cuda()
-            with torch.no_grad():
-                head.weight.copy_(synth.uniform(16, "full.head", (100, 512), -0.1, 0.1))
-            bn, wo = separate_irse_bn_paras(m)
-            opt = SGD([{"params": wo + list(head.parameters()), "weight_decay": 2e-3}, {"params": bn}], lr=0.03,
-                      momentum=0.9)
-            x = synth.uniform(16, "full.x", (6, 3, 112, 112)).cuda()
-            y = synth.labels(16, "full.label", 6, 100).cuda()
-            losses = []
-            for _ in range(4):
-                loss, _ = FocalLoss()(head(m(x), y), y)
-                opt.zero_grad()
-                loss.backward()
-                opt.step()
-                losses.append(float(loss.detach()))
-            torch.cuda.synchronize()
-            out = {n: t.detach().clone() for n, t in m.state_dict().items()}
-            plan = m._runner[0].plan
-            return out, losses, plan._graphs
-        finally:
-            os.environ.pop("FRHIP_GRAPH")
-
-    (a, la, ga), (b, lb, gb) = run("0"), run("1")
-    assert ga is None and gb is not None and gb[1] is not None, "the graph run did not capture"
-    assert sum(not isinstance(seg, type(gb[0][1])) for seg in gb[0]) == 2, "forward = graph | dropout launch | graph"
-    assert la == lb and len(set(la)) == 4, (la, lb)  # four different dropout masks, the same ones in both runs
-    diff = [n for n in a if not torch.equal(a[n], b[n])]
-    assert not diff, "graph replay and eager launches differ: %s" % diff[:5]
-
-
 def test_full_size_step_strip_and_generic_paths_agree():
     """BASELINE configs[1] at its full size (IR-50, batch 256, bf16), as a property (the comparison with the oracle at this
     size is test_bench_size_step_tracks_the_oracle) -- the LDS-strip kernels (stride 1 / stride 2 / stem, incl. the two-images-per-workgroup and side-stream
@@ -1373,87 +1322,63 @@ def test_freeze_then_unfreeze_from_a_stage2_checkpoint(tmp_path, ranks):
     assert list(h.keys()) == ["weight"] and tuple(h["weight"].shape) == (12, 512) and torch.isfinite(h["weight"]).all()
 
 
-def test_fused_bn_backward_sums_are_bit_identical():
-    """FrBnBwdArgs.nx (round 3): the kernel that writes a unit's input gradient also forms the backward sums of the
-    BatchNorm in front of it (BN2 of the previous unit, reference model_irse.py:60) from the ROUNDED gradient, in the order
-    fr_bn_bwd_reduce uses -- one pass and one launch less per residual unit, and every parameter gradient of a bf16
-    IR-50 step bit for bit what the separate launches give.  (Opt-in, FRHIP_FUSED_BN_SUMS=1: measured 0.04-0.6 ms slower per
-    step beside the weight-gradient kernels, engine.py.)"""
+@pytest.mark.parametrize("kind,B", [("IR_50", 6), ("IR_50", 162), ("pSp", 5), ("IR_50_fp32", 4)])
+def test_in_launch_reductions_are_bit_identical_to_separate_launches(kind, B):
+    """FrTail (round 4, csrc/tail.h): every launch that writes partial rows -- BatchNorm statistics, BatchNorm-backward sums,
+    PReLU slope sums -- adds them itself (the last workgroups to arrive, same summation tree as fr_bn_finalize /
+    fr_reduce_parts) instead of leaving them to a second launch.  A training step with FRHIP_TAIL=1 (default) must give bit
+    for bit the loss, features, gradients and BatchNorm running statistics of FRHIP_TAIL=0, have none of the stand-alone
+    reductions left behind its convolutions / channel-wise passes, and leave every ticket at zero.  B = 6 / 5 / 4 run the
+    small-batch kernel instances, B = 162 the ones the bs-256 benchmark runs; pSp adds the squeeze-excite units, the fp32
+    case the generic implicit-GEMM epilogues.  Reference arithmetic: backbone/model_irse.py:57-60,141-148."""
     _need_gpu()
-    from backbone.model_irse import IR_50
     from head.metrics import ArcFace
     from loss.focal import FocalLoss
 
-    def run(fuse):
-        os.environ["FRHIP_FUSED_BN_SUMS"] = fuse
+    def run(tail):
+        os.environ["FRHIP_TAIL"] = tail
         try:
-            m = IR_50([112, 112])
-            synth.fill_state_dict(m.state_dict(), 15)
-            m.output_layer[1].p = 0.0
-            m.compute_dtype = torch.bfloat16
-            m = m.cuda().train()
+            m, _prefix = build(kind.replace("_fp32", ""))
+            inner = m.encoder if hasattr(m, "encoder") else m
+            inner.compute_dtype = torch.float32 if kind.endswith("fp32") else torch.bfloat16
+            m = m.train()
             head = ArcFace(512, 100, None).cuda()
             with torch.no_grad():
                 head.weight.copy_(synth.uniform(16, "full.head", (100, 512), -0.1, 0.1))
-            x = synth.uniform(16, "full.x", (6, 3, 112, 112)).cuda()
-            y = synth.labels(16, "full.label", 6, 100).cuda()
-            loss, _ = FocalLoss()(head(m(x), y), y)
-            loss.backward()
-            torch.cuda.synchronize()
-            plan = m._runner[0].plan
-            n_reduce = sum(getattr(l, "name", "") == "fr_bn_bwd_reduce" for l in plan.bwd_list)
-            return {n: p.grad.detach().clone() for n, p in m.named_parameters()}, n_reduce
+            x = synth.uniform(16, "tail.x", (B, 3, 112, 112)).cuda()
+            y = synth.labels(16, "tail.label", B, 100).cuda()
+            outs = []
+            for _ in range(2):  # twice: the tickets must have been left at zero by the first step
+                for p in list(m.parameters()) + list(head.parameters()):
+                    p.grad = None
+                f = m(x)
+                loss, _ = FocalLoss()(head(f, y), y)
+                loss.backward()
+                torch.cuda.synchronize()
+                outs.append((f.detach().clone(), float(loss.detach()),
+                             {n: p.grad.detach().clone() for n, p in m.named_parameters()},
+                             {n: t.detach().clone() for n, t in m.state_dict().items() if "running" in n or "num_batches" in n}))
+            plan = inner._runner[0].plan
+            plan.tickets.check_idle()
+            names = [getattr(l, "name", "") for l in plan.fwd_list + plan.bwd_list]
+            return outs, names.count("fr_bn_finalize"), names.count("fr_reduce_parts"), plan.tickets.used
         finally:
-            os.environ.pop("FRHIP_FUSED_BN_SUMS")
+            os.environ.pop("FRHIP_TAIL")
 
-    fused, n_fused = run("1")
-    plain, n_plain = run("0")
-    assert n_plain - n_fused == 20, (n_plain, n_fused)  # every unit behind a stride-1 identity unit: 24 - 4 stage heads
-    bad = [n for n in plain if not torch.equal(plain[n], fused[n])]
-    assert not bad, bad[:5]
-
-
-def test_paired_convolutions_are_bit_identical_to_separate_launches():
-    """fr_conv3x3_pair in the engine (round 3, opt-in FRHIP_PAIR=1: measured no faster): at B > 160 the 13 all-256-channel
-    units at 14x14 of IR-50 run conv1 -> PReLU -> conv2 as ONE launch (y1 goes to HBM for the backward pass, conv2 takes it from
-    LDS).  Loss, features and every parameter gradient of a bf16 training step must be bit for bit what the default (two
-    launches per unit) gives."""
-    _need_gpu()
-    from backbone.model_irse import IR_50
-    from head.metrics import ArcFace
-    from loss.focal import FocalLoss
-    B = 162
-
-    def run(pair):
-        os.environ["FRHIP_PAIR"] = pair
-        try:
-            m = IR_50([112, 112])
-            synth.fill_state_dict(m.state_dict(), 15)
-            m.output_layer[1].p = 0.0
-            m.compute_dtype = torch.bfloat16
-            m = m.cuda().train()
-            head = ArcFace(512, 100, None).cuda()
-            with torch.no_grad():
-                head.weight.copy_(synth.uniform(16, "full.head", (100, 512), -0.1, 0.1))
-            x = synth.uniform(16, "pair.x", (B, 3, 112, 112)).cuda()
-            y = synth.labels(16, "pair.label", B, 100).cuda()
-            f = m(x)
-            loss, _ = FocalLoss()(head(f, y), y)
-            loss.backward()
-            torch.cuda.synchronize()
-            plan = m._runner[0].plan
-            n_pair = sum(getattr(l, "name", "") == "fr_conv3x3_pair" for l in plan.fwd_list)
-            grads = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
-            return f.detach().clone(), float(loss.detach()), grads, n_pair
-        finally:
-            os.environ.pop("FRHIP_PAIR")
-
-    f1, l1, g1, n1 = run("1")
-    f0, l0, g0, n0 = run("0")
-    assert (n1, n0) == (13, 0), (n1, n0)
-    assert l1 == l0 and torch.equal(f1, f0)
-    bad = [n for n in g0 if not torch.equal(g0[n], g1[n])]
-    assert not bad, bad[:5]
+    on, fin1, red1, used1 = run("1")
+    off, fin0, red0, used0 = run("0")
+    assert used0 == 0 and used1 > 100, (used0, used1)
+    assert fin1 == 0 and fin0 >= 50, (fin1, fin0)
+    # what stays a launch of its own: the split-K slabs of Linear(25088, 512) and the stem weight-gradient slabs
+    assert red1 <= 2 and red0 >= 78, (red1, red0)
+    for step in range(2):
+        f1, l1, g1, r1 = on[step]
+        f0, l0, g0, r0 = off[step]
+        assert l1 == l0 and torch.equal(f1, f0), (step, l1, l0)
+        bad = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+        assert not bad, (step, bad[:5])
+        bad = [n for n in r0 if not torch.equal(r0[n], r1[n])]
+        assert not bad, (step, bad[:5])
 
 
 BENCH_SIZE = [("configs1_ir50_arc7000_b256", "IR_50", 50, False, "ArcFace", 7000, 256),

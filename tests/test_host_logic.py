@@ -410,8 +410,6 @@ def test_dispatch_geometry_of_the_strip_tables():
     assert s2(256, 512, 512, 7, 0) == 128 and s2(256, 512, 512, 7, 2) == 4 * 128    # image pairs
     assert s2(3, 512, 512, 7, 0) == 3                                               # odd batch: one image
     assert s2(256, 128, 256, 28, 0) == 0                                            # Cin != Cout: generic kernel
-    assert L.fr_conv3x3_pair_supported(256, 256, 14) == 1 and L.fr_conv3x3_pair_supported(128, 256, 14) == 0
-    assert L.fr_conv3x3_pair_supported(256, 128, 28) == 0
     ws = L.fr_conv_wgrad_strip_supported
     assert all(ws(c, c, w) == 1 for c, w in ((64, 112), (64, 56), (128, 28), (256, 14), (512, 7)))
     assert ws(96, 64, 56) == 0 and ws(64, 64, 20) == 0

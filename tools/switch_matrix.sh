@@ -12,8 +12,6 @@ run FRHIP_WGRAD_ROLL7=0 FRHIP_WGRAD_S2ROLL=0
 run FRHIP_WGRAD_S2ROLL56=0 FRHIP_WGRAD_VR=0
 run FRHIP_WGRAD_DEFER=0
 run FRHIP_NO_DEFER_SLABS=1
-run FRHIP_PAIR=1
-run FRHIP_FUSED_BN_SUMS=1
 run FRHIP_SPLIT_STRIPS=1
 run FRHIP_ROLL64=0 FRHIP_S2ROLL=0
 run FRHIP_NO_S2_STRIP=1
