@@ -27,7 +27,16 @@ extern "C" {
 enum { FR_F32 = 0, FR_BF16 = 1 };
 
 /* prologue applied to the gathered A operand */
-enum { FR_PRO_NONE = 0, FR_PRO_BN = 1 /* x*a[c]+b[c] */, FR_PRO_PRELU = 2 /* x>0?x:a[c]*x */ };
+enum {
+  FR_PRO_NONE = 0,
+  FR_PRO_BN = 1,     /* x*a[c]+b[c] */
+  FR_PRO_PRELU = 2,  /* x>0?x:a[c]*x */
+  FR_PRO_BNBWD2 = 3  /* a[c]*x + b[c]*x2 + c[c] with x2 = src2 at the same pixel: the backward of a train-mode BatchNorm applied
+                        while the data gradient of the convolution in front of it gathers its operand (x = gradient at the BN
+                        output, x2 = BN input; a, b, c from FR_TAIL_BNBWD).  The result, rounded to the compute dtype, is what the
+                        kernel multiplies; with pro_out != NULL it is also stored (interior pixels, once each) for the weight
+                        gradient to read.  Served by fr_conv3x3_strip / fr_conv3x3_s2_strip data gradients (bf16). */
+};
 
 /* epilogue of fr_conv_igemm */
 enum {
@@ -50,11 +59,16 @@ enum {
  * `nred` of them add the rows in the order of fr_reduce_parts / fr_bn_finalize (bit-identical results) and write
  *   FR_TAIL_SUMS: o_k[c] = sum_rows part[row][k][c], k < K (NULL outputs skipped)     == fr_reduce_parts(part, rows, K, C, ..)
  *   FR_TAIL_BN  : mean / invstd / scale / shift (+ running statistics)               == fr_bn_finalize(part, rows, C, ..)
+ *   FR_TAIL_BNBWD: FR_TAIL_SUMS of fr_bn_bwd_reduce's rows (o0 = d beta, o1 = d gamma [, o2]) plus the coefficients of the
+ *                 BatchNorm backward as an affine map of (g, x):  gx = ca*g + cb*x + cc  with, per channel,
+ *                 k = gamma*in_invstd, ca = k, cb = -k*in_invstd*s1/count, cc = k*(in_invstd*s1/count*in_mean - s0/count)
+ *                 (bn_eval != 0: the BatchNorm ran on its running statistics -- s0 = s1 = 0 in the coefficients);
+ *                 what FR_PRO_BNBWD2 consumes
  * ticket: 4 x uint32 of device memory, zero before the launch, zero again after it ([0] arrivals, [1] finished reducers,
  * [2] set to 1 if a reducer gave up waiting for a producer -- never in a healthy run); one ticket must not be shared by
  * launches that can run concurrently.  The rows stay in `part` as without a tail.
  * Replaces the separate statistics / gradient-sum launches behind BatchNorm2d / PReLU (backbone/model_irse.py:57-60,141-148). */
-enum { FR_TAIL_NONE = 0, FR_TAIL_SUMS = 1, FR_TAIL_BN = 2 };
+enum { FR_TAIL_NONE = 0, FR_TAIL_SUMS = 1, FR_TAIL_BN = 2, FR_TAIL_BNBWD = 3 };
 typedef struct FrTail {
   uint32_t* ticket;
   int32_t kind;  /* FR_TAIL_* */
@@ -75,6 +89,13 @@ typedef struct FrTail {
   float* invstd;
   float* scale;
   float* shift;
+  const float* in_mean;   /* BNBWD: statistics of the forward pass (inputs) */
+  const float* in_invstd;
+  float* ca;              /* BNBWD outputs [C] */
+  float* cb;
+  float* cc;
+  int32_t bn_eval;
+  int32_t pad_;
 } FrTail;
 
 typedef struct FrConvArgs {
@@ -109,6 +130,10 @@ typedef struct FrConvArgs {
   const int64_t* label; /* [rows] */
   float* cos_t;         /* [rows] */
   FrTail tail;         /* in-launch reduction of `part` (epilogues that write partial rows), see FrTail */
+  /* FR_PRO_BNBWD2 only (ABI v4) */
+  const void* src2;    /* second source, geometry and strides of src */
+  const float* pro_c;  /* [SC] */
+  void* pro_out;       /* NULL or [B*SH*SW][lda]: the prologue result of every source pixel */
 } FrConvArgs;
 
 /* Convolution forward / data gradient / dense GEMM on MFMA.
@@ -125,6 +150,8 @@ int fr_conv_igemm(const FrConvArgs* args, int dtype, void* stream);
  * Replaces Conv2d(c, d, (3,3), (1,1), 1) of bottleneck_IR (backbone/model_irse.py:57-59) fwd + data gradient. */
 int fr_conv3x3_strip(const FrConvArgs* args, void* stream);
 int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi);
+/* 1 when fr_conv3x3_strip serves the FR_PRO_BNBWD2 prologue for the data gradient of a C -> C layer of width W at batch B */
+int fr_conv3x3_strip_serves_bnbwd2(int B, int C, int W);
 
 /* Stride-2 3x3 convolution (bf16, Cin == Cout: the first unit of every IR stage) on LDS-resident parity planes:
  * mode 0 = forward (SH = 2*RH), mode 2 with par_h = par_w = -1 = data gradient of all four output parity classes
@@ -280,6 +307,13 @@ int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream);
  * Used for d gamma (k=1), d beta (k=0), d PReLU slope (k=2) and for the conv-epilogue partials. */
 int fr_reduce_parts(const float* part, int nparts, int K, int C, float* o0, float* o1, float* o2, void* stream);
 
+/* fr_reduce_parts of fr_bn_bwd_reduce's rows part[nparts][3][C] (o0 = d beta, o1 = d gamma; NULL skipped) and, in the same
+ * launch, the BatchNorm backward as an affine map of (g, x) -- gx = ca*g + cb*x + cc, see FR_TAIL_BNBWD -- which the
+ * FR_PRO_BNBWD2 prologue of the following data gradient applies instead of a fr_bn_bwd_apply pass.  The stand-alone form of
+ * the FR_TAIL_BNBWD tail (same arithmetic, same bits).  Replaces the autograd of BatchNorm2d (backbone/model_irse.py:60). */
+int fr_bn_bwd_coeffs(const float* part, int nparts, int C, double count, const float* gamma, const float* mean,
+                     const float* invstd, int bn_eval, float* o0, float* o1, float* ca, float* cb, float* cc, void* stream);
+
 /* eval-mode BatchNorm coefficients from the running statistics */
 int fr_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
                       float eps, int C, float* mean, float* invstd, float* scale, float* shift, void* stream);
@@ -337,6 +371,27 @@ int fr_bn_dropout(const void* x, void* out, const float* scale, const float* shi
                   float p, uint64_t seed, int dtype, void* stream);
 int fr_dropout_bwd(void* g, long long rows, int C, int HW, float p, uint64_t seed, int dtype, void* stream);
 
+/* The same pair with the Linear layer's activation in the reference's own Flatten order (round 4):
+ *   fr_bn_dropout_cm : out[b][c*HW + hw] = dropout(x[b][hw][c]*scale[c] + shift[c])     (x NHWC, out = Flatten of NCHW)
+ *   fr_dropout_bwd_cm: out[b][hw][c] = mask * g_cm[b][c*HW + hw] / (1 - p)              (out of place, back to NHWC)
+ * same counter-hash mask as above.  C % 64 == 0.  With it Linear(512*7*7, 512) (model_irse.py:146-147) runs on the fp32
+ * master weight in its own layout: */
+int fr_bn_dropout_cm(const void* x, void* out, const float* scale, const float* shift, int B, int C, int HW, float p,
+                     uint64_t seed, int dtype, void* stream);
+int fr_dropout_bwd_cm(const void* g_cm, void* out, int B, int C, int HW, float p, uint64_t seed, int dtype, void* stream);
+/* Linear(K, O) as weight-streaming GEMMs on the fp32 master W [O][K] (csrc/linear_gemm.hip; bf16 activations, the weight
+ * rounded to bf16 in registers, fp32 accumulation):
+ *   fr_linear_fwd  : slab[s][b][o] = sum_{k in K-slice s} a[b][k]*W[o][k] (+ bias[o] in slice 0), s < slices; add the slabs
+ *                    with fr_reduce_parts(slab, slices, 1, B*O, out, ..) -- a fixed order, reproducible.  fr_linear_slices
+ *                    returns the slice count the library recommends for (O, K) (0: shape not served); O % 64 == 0, K % 32 == 0
+ *   fr_linear_dgrad: ga[b][k] = sum_o g[b][o]*W[o][k], ga in the compute dtype; O % 128 == 0, K % 128 == 0
+ * The weight gradient dW[o][k] = sum_b g[b][o] a[b][k] is fr_conv_wgrad (taps = 1) on the same a.
+ * Replace nn.Linear(512*7*7, 512) of output_layer (backbone/model_irse.py:147) forward and its autograd data gradient. */
+int fr_linear_slices(int O, int K);
+int fr_linear_fwd(const void* a, const float* W, const float* bias, float* slab, int B, int O, int K, int slices,
+                  void* stream);
+int fr_linear_dgrad(const void* g, const float* W, void* ga, int B, int O, int K, void* stream);
+
 /* ---- weight packing: fp32 master [Cout][taps][Cin] (channels-last storage of the OIHW Parameter)
  *   wp [Cout][taps][Cin] compute dtype (NULL to skip), wt [Cin][taps][Cout] compute dtype (NULL to skip) */
 int fr_pack_weight(const float* w, void* wp, void* wt, int Cout, int taps, int Cin, int dtype, void* stream);
@@ -380,6 +435,10 @@ int fr_ce_rows(const float* logits, const int64_t* label, float* lse, float* ce,
                int ld, void* stream);
 /* rank[m] only (accuracy on arbitrary logits, util/utils.py:343-358) */
 int fr_rank_rows(const float* logits, const int64_t* label, int32_t* rank, int rows, int N, int ld, void* stream);
+/* out[j] = scale * #{m < rows: rank[m] < k_j}, j < nk <= 4: precision@k in percent with scale = 100 / rows rounded to float,
+ * the value correct_k.mul_(100.0 / batch_size) of util/utils.py:343-358 gives (counts are exact in fp32) */
+int fr_topk_precision(const int32_t* rank, int rows, int nk, int k0, int k1, int k2, int k3, float scale, float* out,
+                      void* stream);
 /* scalars[0]=loss, [1]=dloss/dmeanCE, [2]=prec@1, [3]=prec@5, [4]=mean CE */
 int fr_focal_finalize(const float* ce, const int32_t* rank, int rows, float gamma, float* scalars, void* stream);
 /* grad[m][n] = gup[0]*scalars[1]/rows * (exp(z-lse[m]) - [n==label[m]]) */

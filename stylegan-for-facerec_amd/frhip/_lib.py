@@ -89,9 +89,9 @@ FrTail = structs["FrTail"]
 
 # enums of the header
 FR_F32, FR_BF16 = 0, 1
-PRO_NONE, PRO_BN, PRO_PRELU = 0, 1, 2
+PRO_NONE, PRO_BN, PRO_PRELU, PRO_BNBWD2 = 0, 1, 2, 3
 EPI_STORE, EPI_STATS, EPI_PRELU_BWD, EPI_BNBWD, EPI_MARGIN, EPI_ATOMIC, EPI_SLAB, EPI_BIAS_RES = range(8)
-TAIL_NONE, TAIL_SUMS, TAIL_BN = range(3)
+TAIL_NONE, TAIL_SUMS, TAIL_BN, TAIL_BNBWD = range(4)
 
 
 class FrhipError(RuntimeError):

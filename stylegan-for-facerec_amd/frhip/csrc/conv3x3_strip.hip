@@ -119,8 +119,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
   constexpr int WP = W + 2;
   constexpr int TOTAL = NIMG * C::GH * WP * C::CH;
   const int ch = tid % C::CH;  // NTH is a multiple of CH: a thread always handles the same channel chunk
-  float pa[8], pb[8];  // prologue coefficients of this thread's channel chunk: re-read per strip (L1 hits) rather
-                       // than kept live across the MFMA loop
+  float pa[8], pb[8], pc[8];  // prologue coefficients of this thread's channel chunk: re-read per strip (L1 hits) rather
+                              // than kept live across the MFMA loop
   int kc = 0;  // channel stage (KSPL > 1): input channels [kc*CK, (kc+1)*CK) are resident
   auto kco = [&]() -> int { return KSPL > 1 ? kc * CK : 0; };  // literally 0 for the single-stage instances
   auto load_pro = [&]() {
@@ -128,44 +128,59 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         pa[j] = p.pro_a[kco() + ch * 8 + j];
-        pb[j] = PRO == FR_PRO_BN ? p.pro_b[kco() + ch * 8 + j] : 0.f;
+        pb[j] = (PRO == FR_PRO_BN || PRO == FR_PRO_BNBWD2) ? p.pro_b[kco() + ch * 8 + j] : 0.f;
+        pc[j] = PRO == FR_PRO_BNBWD2 ? p.pro_c[kco() + ch * 8 + j] : 0.f;
       }
     }
   };
-  // chunk u of this thread (idx = u*NTH + tid) -> source validity / address / LDS address
-  auto chunk_src = [&](int s, int idx, bool& ok) -> const bf16_t* {
+  // FR_PRO_BNBWD2: the operand is ca*g + cb*x2 + cc of TWO tensors (the backward of the BatchNorm behind this convolution,
+  // applied while its data gradient loads the strip: the pass that used to materialise it -- 75 MB of traffic and a launch per
+  // 14x14 unit -- is gone); the rounded result also goes to p.pro_out, once per pixel, for the weight gradient to read.
+  const bf16_t* __restrict__ src2 = reinterpret_cast<const bf16_t*>(p.src2);
+  bf16_t* __restrict__ pro_out = PRO == FR_PRO_BNBWD2 ? reinterpret_cast<bf16_t*>(p.pro_out) : nullptr;
+  // chunk u of this thread (idx = u*NTH + tid) -> source validity / element offset / LDS address
+  auto chunk_off = [&](int s, int idx, bool& ok, bool& own) -> size_t {
     int b = s / C::NS;
     const int row0 = (s - b * C::NS) * ROWS;
-    int pc = idx / C::CH;
+    int pc_ = idx / C::CH;
     if (NIMG > 1) {
-      const int img = pc / (C::GH * WP);
-      pc -= img * (C::GH * WP);
+      const int img = pc_ / (C::GH * WP);
+      pc_ -= img * (C::GH * WP);
       b = s * NIMG + img;
     }
-    const int gh = pc / WP, gw = pc - gh * WP;
+    const int gh = pc_ / WP, gw = pc_ - gh * WP;
     const int h = row0 + gh - 1, w = gw - 1;
     ok = idx < TOTAL && (unsigned)h < (unsigned)C::H && (unsigned)w < (unsigned)W;
-    return src + ((size_t)(b * C::H + h) * W + w) * (size_t)p.lda + kco() + ch * 8;
+    own = ok && gh >= 1 && gh <= ROWS;  // a pixel of this strip's own rows (halo rows belong to the neighbours)
+    return ((size_t)(b * C::H + h) * W + w) * (size_t)p.lda + kco() + ch * 8;
   };
-  auto chunk_store = [&](int idx, U128 x, bool ok) {
+  auto chunk_store = [&](int idx, U128 x, U128 x2, bool ok, bool own, size_t off) {
     if (idx < TOTAL) {
-      int pc = idx / C::CH;
+      int pc_ = idx / C::CH;
       int ioff = 0;
       if (NIMG > 1) {
-        const int img = pc / (C::GH * WP);
-        pc -= img * (C::GH * WP);
+        const int img = pc_ / (C::GH * WP);
+        pc_ -= img * (C::GH * WP);
         ioff = img * C::ISTR;
       }
-      const int gh = pc / WP, gw = pc - gh * WP;
+      const int gh = pc_ / WP, gw = pc_ - gh * WP;
       if (PRO != FR_PRO_NONE && ok) {
         float f[8];
         unpack16<bf16_t>(x, f);
+        if (PRO == FR_PRO_BNBWD2) {
+          float f2[8];
+          unpack16<bf16_t>(x2, f2);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (PRO == FR_PRO_BN) f[j] = fmaf(f[j], pa[j], pb[j]);
-          else f[j] = f[j] > 0.f ? f[j] : f[j] * pa[j];
+          for (int j = 0; j < 8; ++j) f[j] = fmaf(pa[j], f[j], fmaf(pb[j], f2[j], pc[j]));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (PRO == FR_PRO_BN) f[j] = fmaf(f[j], pa[j], pb[j]);
+            else f[j] = f[j] > 0.f ? f[j] : f[j] * pa[j];
+          }
         }
         x = pack16<bf16_t>(f);
+        if (PRO == FR_PRO_BNBWD2 && own && nh == 0 && pro_out) st16(pro_out + off, x);
       }
       st16(smem + ioff + gh * C::RSTR + gw * C::PSTR + ch * 16, x);
     }
@@ -180,18 +195,22 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
 #endif
     // (channel stages: the accumulators are live across the load -- one batch only beside small accumulator tiles)
     constexpr bool ONE = (NW == 4 && PER <= 18) || (PER <= FRHIP_STRIP_LOAD_BATCH && (KSPL == 1 || C::TM * C::TN * 4 <= 64));
-    constexpr int UNR = ONE ? PER : 8;
+    constexpr int UNR1 = ONE ? PER : 8;
+    constexpr int UNR = (PRO == FR_PRO_BNBWD2 && UNR1 > 10) ? (UNR1 + 1) / 2 : UNR1;  // two sources: half the chunks per batch
     load_pro();
     for (int base = 0; base < TOTAL; base += NTH * UNR) {
-      U128 v[UNR];
-      bool ok[UNR];
+      U128 v[UNR], v2[PRO == FR_PRO_BNBWD2 ? UNR : 1];
+      bool ok[UNR], own[UNR];
+      size_t off[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        const bf16_t* ptr = chunk_src(s, base + u * NTH + tid, ok[u]);
-        v[u] = ok[u] ? ld16(ptr) : zero16();
+        off[u] = chunk_off(s, base + u * NTH + tid, ok[u], own[u]);
+        v[u] = ok[u] ? ld16(src + off[u]) : zero16();
+        if (PRO == FR_PRO_BNBWD2) v2[u] = ok[u] ? ld16(src2 + off[u]) : zero16();
       }
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) chunk_store(base + u * NTH + tid, v[u], ok[u]);
+      for (int u = 0; u < UNR; ++u)
+        chunk_store(base + u * NTH + tid, v[u], PRO == FR_PRO_BNBWD2 ? v2[u] : v[u], ok[u], own[u], off[u]);
     }
   };
 
@@ -494,6 +513,13 @@ int by_pro(const FrConvArgs& a, hipStream_t st) {
     case FR_PRO_NONE: return launch<CIN, COUT, W, ROWS, WN, NW, NSPL, FR_PRO_NONE, NIMG, KSPL>(a, st);
     case FR_PRO_BN: return launch<CIN, COUT, W, ROWS, WN, NW, NSPL, FR_PRO_BN, NIMG, KSPL>(a, st);
     case FR_PRO_PRELU: return launch<CIN, COUT, W, ROWS, WN, NW, NSPL, FR_PRO_PRELU, NIMG, KSPL>(a, st);
+    case FR_PRO_BNBWD2:  // the data gradient of a unit's second convolution: square layers only
+      if constexpr (CIN == COUT * NSPL) {
+        if (!a.src2 || !a.pro_a || !a.pro_b || !a.pro_c) FR_UNSUPPORTED("fr_conv3x3_strip: FR_PRO_BNBWD2 needs src2, pro_a, pro_b, pro_c");
+        return launch<CIN, COUT, W, ROWS, WN, NW, NSPL, FR_PRO_BNBWD2, NIMG, KSPL>(a, st);
+      } else {
+        FR_UNSUPPORTED("fr_conv3x3_strip: FR_PRO_BNBWD2 is served for Cin == Cout only");
+      }
   }
   FR_UNSUPPORTED("fr_conv3x3_strip: unknown prologue");
 }
@@ -547,6 +573,13 @@ static int strip_rows(int Cin, int Cout, int W) {
   SHAPE(512, 512, 7, 7, 7)
 #undef SHAPE
   return 0;
+}
+
+// FR_PRO_BNBWD2 (two-source prologue) exists on the LDS-strip instances of the square layers; the 64-channel layers run on
+// the rolling-window kernel, which does not take it.
+extern "C" int fr_conv3x3_strip_serves_bnbwd2(int B, int C, int W) {
+  if (C == 64 && (W == 112 || W == 56) && fr_roll64_enabled()) return 0;
+  return fr_conv3x3_strip_parts(B, C, C, W, FR_EPI_PRELU_BWD) > 0 ? 1 : 0;
 }
 
 // Number of partial rows the kernel writes into `part` (= workgroups) for a supported shape, 0 if unsupported.

@@ -20,6 +20,8 @@
 // global -> registers (prologue applied) -> LDS, double buffered, one barrier per K step; LDS rows are
 // padded by 16 B so the ds_read_b128 fragment reads are (nearly) conflict free.  The accumulator tile goes
 // back through LDS so that global stores and the fused column reductions are row-contiguous 16-B accesses.
+#include <stdlib.h>
+
 #include "common.h"
 #include "frhip_internal.h"
 #include "tail.h"
@@ -477,14 +479,17 @@ int launch(const FrConvArgs& a, hipStream_t st) {
 
 template <typename T>
 int dispatch(const FrConvArgs& a, hipStream_t st) {
-  // 64-wide tiles for N <= 64, and where 128-wide ones would leave most of the chip idle (the margin head's logits GEMM at
-  // batch 256: 2 x 55 tiles on 256 CUs) -- twice the workgroups at half the width
-  const long long M = a.mode == 2 ? (long long)a.B * (a.RH / 2) * (a.RW / 2) : (long long)a.B * a.RH * a.RW;
-  const long long wgs128 = ((M + BM - 1) / BM) * ((a.N + 127) / 128) * (a.splitk > 1 ? a.splitk : 1) *
-                           (a.mode == 2 && a.par_h < 0 ? 4 : 1);
-  // (only for the margin epilogue: with the rule applied to every small launch six fixture tests of the fp32 path moved past
-  // their bars at batches 4-16 -- the 64-wide instance is not bit-compatible with the 128-wide one there)
-  const bool narrow = a.N <= 64 || (wgs128 < 160 && a.epi == FR_EPI_MARGIN);
+  // 64-wide tiles for N <= 64 and for the margin head's logits GEMM (at batch 256 and 7000 classes 2 x 55 128-wide tiles
+  // leave most of the chip idle; ALWAYS the narrow instance there, so that the logits' bits do not depend on the batch size
+  // or on how the classes are sharded over ranks -- round 3 chose by workgroup count).  Every other launch keeps 128-wide
+  // tiles: the two instances differ only in the ORDER in which a tile's rows enter the per-tile partial sums (and in
+  // nothing else: tests/test_gpu_kernels.py::test_igemm_tile_width_changes_only_the_partial_sum_order), and at batch 4-16 the
+  // fp32 fixture networks amplify that last-bit difference of a BatchNorm statistic past bars that were set from ONE
+  // selection's readings.  FRHIP_IGEMM_BN=64 / 128 forces an instance (read per call: test switch).
+  const char* force = getenv("FRHIP_IGEMM_BN");
+  bool narrow = a.N <= 64 || a.epi == FR_EPI_MARGIN;
+  if (force && force[0] == '6') narrow = true;
+  if (force && force[0] == '1') narrow = a.N <= 64;
   switch (a.pro) {
     case FR_PRO_NONE:
       return narrow ? launch<T, 64, FR_PRO_NONE>(a, st) : launch<T, 128, FR_PRO_NONE>(a, st);

@@ -196,6 +196,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_roll_kernel(const FrWgradAr
   // ones cost 8.5-9.9 us per launch in situ, tools/stamps_step.py).
   auto fold_prev = [&](bool movers) { fold_prev_share(p, movers, tid); };
 
+#ifdef ROLL_ALL_PRIO  // experiment: the weight-gradient waves win every issue arbitration against co-resident channel-wise kernels
+  __builtin_amdgcn_s_setprio(ROLL_ALL_PRIO);
+#endif
   if (wave >= 4) {
     // ------------------------------------------------------------------------------------------- data-moving waves
 #ifdef ROLL_LOADER_PRIO
@@ -627,6 +630,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_vr_kernel(const FrWgradArgs
   // deferred slab sum of the previous launch, split between the wave roles (see conv_wgrad_roll_kernel)
   auto fold_prev = [&](bool movers) { fold_prev_share(p, movers, tid); };
 
+#ifdef ROLL_ALL_PRIO  // experiment: the weight-gradient waves win every issue arbitration against co-resident channel-wise kernels
+  __builtin_amdgcn_s_setprio(ROLL_ALL_PRIO);
+#endif
   if (wave >= 4) {
     // ------------------------------------------------------------------------------------------- data-moving waves
 #ifdef ROLL_LOADER_PRIO
@@ -945,6 +951,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_s2roll_kernel(const FrWgrad
 
   auto fold_prev = [&](bool movers) { fold_prev_share(p, movers, tid); };
 
+#ifdef ROLL_ALL_PRIO  // experiment: the weight-gradient waves win every issue arbitration against co-resident channel-wise kernels
+  __builtin_amdgcn_s_setprio(ROLL_ALL_PRIO);
+#endif
   if (wave >= 4) {
     // ------------------------------------------------------------------------------------------- data-moving waves
     if (nph == 0) {

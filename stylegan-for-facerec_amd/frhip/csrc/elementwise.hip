@@ -123,6 +123,17 @@ __global__ __launch_bounds__(RT) void bn_finalize_kernel(const float* __restrict
   if (threadIdx.x < 8 && c < C) fr_bn_finalize_channel(f, c, sq[0], sq[1]);
 }
 
+// fr_reduce_parts of fr_bn_bwd_reduce's rows (vectors 0 and 1) + the coefficients FR_PRO_BNBWD2 applies, in one launch
+__global__ __launch_bounds__(RT) void bn_bwd_coeffs_kernel(const float* __restrict__ part, int nparts, int C, FrBnBwdCo f) {
+  __shared__ double lds[2 * (RT / 64) * 8];
+  const int c0 = blockIdx.x * 8;
+  const int cols[2] = {c0, C + c0};
+  double sq[2];
+  fr_reduce_rows8<2>(part, nparts, 3 * C, cols, sq, lds, threadIdx.x);
+  const int c = c0 + threadIdx.x;
+  if (threadIdx.x < 8 && c < C) fr_bnbwd_channel(f, c, sq[0], sq[1]);
+}
+
 // eval-mode coefficients from running statistics
 __global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, const float* gamma, const float* beta,
                                       float eps, int C, float* mean, float* invstd, float* scale, float* shift) {
@@ -538,7 +549,11 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_reduce_lean_kernel(const FrBnBwd
   fr_tail<NT>(p.tail, p.part, gridDim.x, gridDim.x, red, tid);
 }
 
-template <bool ADD, bool SE = false>
+// ADD: 0 none, 1 a tensor of the same geometry, 2 (round 4) the strided scatter of a stride-2 shortcut gradient -- add[b, h/2,
+// w/2, c] lands on the pixels with even h and w (MaxPool2d(1, 2) / the 1x1 stride-2 shortcut convolution, model_irse.py:52-56).
+// The four stage-entry units ran the general kernel for it: 387 us at 112x112 (1.2 GB of traffic, 200 us at HBM rate), 45-66
+// us at the other three.
+template <int ADD, bool SE = false>
 __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdArgs p) {
   const int C = p.C, cpr = C / LV, tid = threadIdx.x;
   const int cc = tid % cpr, rt = tid / cpr, rtc = NT / cpr, c0 = cc * LV;
@@ -559,15 +574,26 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdA
   // gx -- bit-identical, one pass less, and 0.04-0.6 ms SLOWER per step beside the weight gradients of the side stream: 80
   // registers, one wave per SIMD where the two separate kernels run two.  Removed in round 4, ABI v4.)
   const int nrows = (int)p.rows, rstep = gridDim.x * rtc * LUNRB;
+  const unsigned W = (unsigned)p.W, HW = (unsigned)p.rows_per_image, Wh = W >> 1, HWq = HW >> 2;  // ADD == 2
+  const float invW = 1.0f / (float)p.W, invHW = 1.0f / (float)p.rows_per_image;
   for (int r0 = blockIdx.x * rtc * LUNRB + rt; r0 < nrows; r0 += rstep) {
     uint2 gr[LUNRB], xr[LUNRB], er[LUNRB];
+    bool hit[LUNRB];
 #pragma unroll
     for (int u = 0; u < LUNRB; ++u) {
       const int r = r0 + u * rtc;
+      hit[u] = false;
       if (r < nrows) {
         gr[u] = ld8(g + (size_t)r * C);
         xr[u] = ld8(x + (size_t)r * C);
-        if (ADD) er[u] = ld8(add + (size_t)r * C);
+        if (ADD == 1) er[u] = ld8(add + (size_t)r * C);
+        if (ADD == 2) {
+          unsigned b, rem, h, w;
+          fast_divmod((unsigned)r, HW, invHW, b, rem);  // rows < 2^24 per launch is checked by the launcher
+          fast_divmod(rem, W, invW, h, w);
+          hit[u] = ((h | w) & 1u) == 0u;
+          if (hit[u]) er[u] = ld8(add + ((size_t)b * HWq + (h >> 1) * Wh + (w >> 1)) * C);
+        }
       }
     }
 #pragma unroll
@@ -577,12 +603,12 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdA
         float gv[LV], xv[LV], e[LV], o[LV];
         unpack4bf(gr[u], gv);
         unpack4bf(xr[u], xv);
-        if (ADD) unpack4bf(er[u], e);
+        if (ADD == 1 || (ADD == 2 && hit[u])) unpack4bf(er[u], e);
         if (SE) se_gprime(p, r, c0, gv);
 #pragma unroll
         for (int j = 0; j < LV; ++j) {
           o[j] = coef[j] * (gv[j] - a[j] - (xv[j] - mu[j]) * is[j] * bb[j]);
-          if (ADD) o[j] += e[j];
+          if (ADD == 1 || (ADD == 2 && hit[u])) o[j] += e[j];
         }
         *reinterpret_cast<uint2*>(gx + (size_t)r * C) = pack4bf(o);
       }
@@ -908,6 +934,72 @@ __global__ void bn_dropout_kernel(const T* __restrict__ x, T* __restrict__ out, 
   }
 }
 
+// The same with the activation of the Linear layer in the REFERENCE's flatten order (round 4): a[b][c*HW + hw], what
+// Flatten() of the NCHW tensor gives (model_irse.py:146), so that Linear(25088, 512) runs on the master weight as it lies
+// (linear_gemm.hip).  One workgroup per (image, 64 channels): the [HW][64] tile goes through LDS and leaves as one contiguous
+// 64*HW-element run (forward), or arrives as one and leaves as HW rows of 128 B (backward, out of place: g_cm -> NHWC).
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void bn_dropout_cm_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int C, int HW, float p,
+                                                            uint64_t seed) {
+  constexpr int VEC = Elt<T>::VEC;
+  constexpr int CPR = 64 / VEC;  // 16-byte chunks per pixel of this workgroup's 64 channels
+  extern __shared__ __attribute__((aligned(16))) char smem_cm[];
+  float* tile = reinterpret_cast<float*>(smem_cm);  // [64][HW + 1]
+  const int LD = HW + 1;
+  const int b = blockIdx.x, cg = blockIdx.y, tid = threadIdx.x;
+  const float keep_scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  const size_t seg = (size_t)b * C * HW + (size_t)cg * 64 * HW;  // first element of the contiguous c-major run
+  if (!BWD) {
+    for (int e = tid; e < HW * CPR; e += 256) {
+      const int hw = e / CPR, ch = e - hw * CPR;
+      const int c0 = cg * 64 + ch * VEC;
+      float f[VEC];
+      unpack16<T>(ld16(in + ((size_t)b * HW + hw) * C + c0), f);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float v = fmaf(f[j], scale[c0 + j], shift[c0 + j]);
+        if (p > 0.f) {
+          const uint64_t idx = (uint64_t)b * (uint64_t)(C * HW) + (uint64_t)(c0 + j) * HW + hw;
+          v = drop_keep(seed, idx, p) ? v * keep_scale : 0.f;
+        }
+        tile[(ch * VEC + j) * LD + hw] = v;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e * VEC < 64 * HW; e += 256) {
+      float f[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const int idx = e * VEC + j, cl = idx / HW;
+        f[j] = tile[cl * LD + (idx - cl * HW)];
+      }
+      st16(out + seg + (size_t)e * VEC, pack16<T>(f));
+    }
+  } else {
+    for (int e = tid; e * VEC < 64 * HW; e += 256) {
+      float f[VEC];
+      unpack16<T>(ld16(in + seg + (size_t)e * VEC), f);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const int idx = e * VEC + j, cl = idx / HW;
+        float v = f[j];
+        if (p > 0.f) v = drop_keep(seed, (uint64_t)seg + (uint64_t)idx, p) ? v * keep_scale : 0.f;
+        tile[cl * LD + (idx - cl * HW)] = v;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < HW * CPR; e += 256) {
+      const int hw = e / CPR, ch = e - hw * CPR;
+      float f[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] = tile[(ch * VEC + j) * LD + hw];
+      st16(out + ((size_t)b * HW + hw) * C + cg * 64 + ch * VEC, pack16<T>(f));
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ weight packing
 // src fp32 [Cout][taps][Cin]; wp [Cout][taps][Cin] (T), wt [Cin][taps][Cout] (T)
 template <typename T>
@@ -1136,6 +1228,26 @@ extern "C" int fr_bn_finalize(const float* part, int nparts, int C, double count
   FR_LAUNCH_CHECK();
 }
 
+extern "C" int fr_bn_bwd_coeffs(const float* part, int nparts, int C, double count, const float* gamma, const float* mean,
+                                const float* invstd, int bn_eval, float* o0, float* o1, float* ca, float* cb, float* cc,
+                                void* stream) {
+  if (!part || nparts < 1 || C < 1 || !(count > 0.0) || !mean || !invstd || !ca || !cb || !cc)
+    FR_UNSUPPORTED("fr_bn_bwd_coeffs: part, count, mean, invstd, ca, cb, cc are required");
+  FrBnBwdCo f;
+  f.count = count;
+  f.gamma = gamma;
+  f.mean = mean;
+  f.invstd = invstd;
+  f.bn_eval = bn_eval;
+  f.o0 = o0;
+  f.o1 = o1;
+  f.ca = ca;
+  f.cb = cb;
+  f.cc = cc;
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + 7) / 8), dim3(RT), 0, (hipStream_t)stream, part, nparts, C, f);
+  FR_LAUNCH_CHECK();
+}
+
 namespace {
 __global__ void bn_eval_coeffs_multi_kernel(const FrBnEvalEntry* __restrict__ table) {
   const FrBnEvalEntry e = table[blockIdx.x];
@@ -1241,14 +1353,18 @@ extern "C" int fr_bn_bwd_reduce(const FrBnBwdArgs* args_in, int dtype, void* str
 extern "C" int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream) {
   if (!chan_ok(args->C, dtype)) FR_UNSUPPORTED("fr_bn_bwd_apply: unsupported channel count");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == FR_BF16 && lean_ok(args->C) && !args->slope && args->add_kind != 2 && args->rows < (1ll << 31)) {
+  // add_kind 2 on the lean kernel: stride 2, even geometry, row indices that the float-reciprocal division handles exactly
+  const bool scatter_ok = args->add_kind != 2 || (args->add_stride == 2 && !args->se && args->H % 2 == 0 && args->W % 2 == 0 &&
+                                                  args->rows_per_image == args->H * args->W && args->rows < (1ll << 24));
+  if (dtype == FR_BF16 && lean_ok(args->C) && !args->slope && scatter_ok && args->rows < (1ll << 31)) {
     const dim3 grid(args->nblocks), blk(NT);
     if (args->se) {
-      if (args->add_kind == 1) hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<true, true>), grid, blk, 0, st, *args);
-      else hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<false, true>), grid, blk, 0, st, *args);
+      if (args->add_kind == 1) hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<1, true>), grid, blk, 0, st, *args);
+      else hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<0, true>), grid, blk, 0, st, *args);
     } else {
-      if (args->add_kind == 1) hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<true, false>), grid, blk, 0, st, *args);
-      else hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<false, false>), grid, blk, 0, st, *args);
+      if (args->add_kind == 1) hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<1, false>), grid, blk, 0, st, *args);
+      else if (args->add_kind == 2) hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<2, false>), grid, blk, 0, st, *args);
+      else hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<0, false>), grid, blk, 0, st, *args);
     }
     FR_LAUNCH_CHECK();
   }
@@ -1372,6 +1488,36 @@ extern "C" int fr_dropout_bwd(void* g, long long rows, int C, int HW, float p, u
              hipLaunchKernelGGL((bn_dropout_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)g,
                                 (bf16_t*)g, (const float*)nullptr, (const float*)nullptr, rows, C, HW, p, seed),
              "fr_dropout_bwd");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_bn_dropout_cm(const void* x, void* out, const float* scale, const float* shift, int B, int C, int HW,
+                                float p, uint64_t seed, int dtype, void* stream) {
+  if (B < 1 || C % 64 || HW < 1 || (64 * (HW + 1) * 4) > 64 * 1024) FR_UNSUPPORTED("fr_bn_dropout_cm: C % 64 == 0, HW <= 255");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(B, C / 64);
+  const size_t lds = (size_t)64 * (HW + 1) * 4;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((bn_dropout_cm_kernel<float, false>), grid, dim3(256), lds, st, (const float*)x, (float*)out,
+                                scale, shift, C, HW, p, seed),
+             hipLaunchKernelGGL((bn_dropout_cm_kernel<bf16_t, false>), grid, dim3(256), lds, st, (const bf16_t*)x,
+                                (bf16_t*)out, scale, shift, C, HW, p, seed),
+             "fr_bn_dropout_cm");
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_dropout_bwd_cm(const void* g_cm, void* out, int B, int C, int HW, float p, uint64_t seed, int dtype,
+                                 void* stream) {
+  if (B < 1 || C % 64 || HW < 1 || (64 * (HW + 1) * 4) > 64 * 1024) FR_UNSUPPORTED("fr_dropout_bwd_cm: C % 64 == 0, HW <= 255");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(B, C / 64);
+  const size_t lds = (size_t)64 * (HW + 1) * 4;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((bn_dropout_cm_kernel<float, true>), grid, dim3(256), lds, st, (const float*)g_cm,
+                                (float*)out, nullptr, nullptr, C, HW, p, seed),
+             hipLaunchKernelGGL((bn_dropout_cm_kernel<bf16_t, true>), grid, dim3(256), lds, st, (const bf16_t*)g_cm,
+                                (bf16_t*)out, nullptr, nullptr, C, HW, p, seed),
+             "fr_dropout_bwd_cm");
   FR_LAUNCH_CHECK();
 }
 

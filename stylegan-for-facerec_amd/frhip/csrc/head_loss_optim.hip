@@ -198,6 +198,28 @@ __global__ __launch_bounds__(256) void rank_rows_kernel(const float* __restrict_
   if (tid == 0) rank[m] = ired[0] + ired[1] + ired[2] + ired[3];
 }
 
+// out[j] = scale * #{m: rank[m] < k_j}: precision@k of util/utils.py:343-358 from the label ranks, one launch instead of
+// four small torch kernels per k
+__global__ __launch_bounds__(256) void topk_precision_kernel(const int* __restrict__ rank, int rows, int nk, int4 ks,
+                                                             float scale, float* __restrict__ out) {
+  __shared__ int ired[4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk[4] = {ks.x, ks.y, ks.z, ks.w};
+  int cnt[4] = {0, 0, 0, 0};
+  for (int m = tid; m < rows; m += 256) {
+    const int r = rank[m];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cnt[j] += (j < nk && r < kk[j]) ? 1 : 0;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float fc = wave_sum((float)cnt[j]);  // exact: counts below 2^24
+    if (lane == 0) ired[j][wave] = (int)fc;
+  }
+  __syncthreads();
+  if (tid < nk) out[tid] = (float)(ired[tid][0] + ired[tid][1] + ired[tid][2] + ired[tid][3]) * scale;
+}
+
 // ------------------------------------------------------------------------------------------ class-sharded softmax
 // One rank holds the logits of its own contiguous class range only.  Per row it contributes (max, sum exp(z - max),
 // label logit or 0); the ranks' triples are gathered and combined in rank order (shard_combine_kernel), which gives every
@@ -362,6 +384,14 @@ extern "C" int fr_rank_rows(const float* logits, const int64_t* label, int32_t* 
                             void* stream) {
   hipLaunchKernelGGL(rank_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
                      (const long long*)label, rank, N, ld);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_topk_precision(const int32_t* rank, int rows, int nk, int k0, int k1, int k2, int k3, float scale,
+                                 float* out, void* stream) {
+  if (nk < 1 || nk > 4 || rows < 0) FR_UNSUPPORTED("fr_topk_precision: 1..4 values of k");
+  hipLaunchKernelGGL(topk_precision_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rank, rows, nk,
+                     make_int4(k0, k1, k2, k3), scale, out);
   FR_LAUNCH_CHECK();
 }
 

@@ -114,22 +114,67 @@ struct FrBnFin {
   float* scale;
   float* shift;
 };
+// Floating-point contraction is OFF in this function, and it uses plain operators only: hipcc fuses a*b+c into an fma or not
+// depending on the code around it, and this function must give the same bits inlined into a producer's tail as in the
+// stand-alone kernel (round 4: the stand-alone kernel fused running_var's update, the tail did not -- last-bit differences).
+// ROCm's __fmul_rn / __fadd_rn do NOT help: they are inline wrappers around * and + compiled with contraction allowed, and
+// fuse with each other after inlining whatever the caller's pragma says.
 __device__ __forceinline__ void fr_bn_finalize_channel(const FrBnFin& f, int c, double s, double q) {
+#pragma clang fp contract(off)
+  // (the fused operations below are the ones rounds 1-3 shipped -- then chosen by the compiler, now written out -- so that
+  // the fp32 parity fixtures see the same bits: batch-4 ... 16 networks at random init amplify a last-bit change of a shift)
   const double m = s / f.count;
-  double var = q / f.count - m * m;
+  double var = __builtin_fma(-m, m, q / f.count);
   if (var < 0.0) var = 0.0;
   const float is = (float)(1.0 / sqrt(var + (double)f.eps));
   const float g = f.gamma ? f.gamma[c] : 1.f, bt = f.beta ? f.beta[c] : 0.f;
-  f.mean[c] = (float)m;
+  const float mf = (float)m;
+  f.mean[c] = mf;
   f.invstd[c] = is;
   f.scale[c] = g * is;
-  f.shift[c] = bt - (float)m * g * is;
+  const float gm = g * mf;
+  f.shift[c] = __builtin_fmaf(-gm, is, bt);
   if (f.running_mean) {
     const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
-    f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)m;
-    f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
+    const float keep = 1.f - f.momentum;
+    const float om = keep * f.running_mean[c], nm = f.momentum * mf;
+    f.running_mean[c] = om + nm;
+    const float ov = keep * f.running_var[c];
+    f.running_var[c] = __builtin_fmaf(f.momentum, (float)unbiased, ov);
   }
   if (f.nbt && c == 0) *f.nbt += 1;
+}
+
+// the per-channel arithmetic behind FR_TAIL_BNBWD / fr_bn_bwd_coeffs: the reduced sums and the BatchNorm backward as an affine
+// map of (g, x):  gx = k*(g - s0/n - xhat*s1/n), xhat = (x - mean)*invstd, k = gamma*invstd  ==  ca*g + cb*x + cc
+struct FrBnBwdCo {
+  double count;
+  const float* gamma;
+  const float* mean;
+  const float* invstd;
+  int bn_eval;
+  float* o0;
+  float* o1;
+  float* ca;
+  float* cb;
+  float* cc;
+};
+__device__ __forceinline__ void fr_bnbwd_channel(const FrBnBwdCo& f, int c, double d0, double d1) {
+#pragma clang fp contract(off)
+  const float s0 = (float)d0, s1 = (float)d1;
+  if (f.o0) f.o0[c] = s0;
+  if (f.o1) f.o1[c] = s1;
+  const float inv_count = (float)(1.0 / f.count);
+  const float is = f.invstd[c], mu = f.mean[c];
+  const float k = (f.gamma ? f.gamma[c] : 1.f) * is;
+  const float a = f.bn_eval ? 0.f : s0 * inv_count, bb = f.bn_eval ? 0.f : s1 * inv_count;
+  const float ib = is * bb;
+  const float kib = k * ib;
+  const float ibm = ib * mu;
+  const float d = ibm - a;
+  f.ca[c] = k;
+  f.cb[c] = -kib;
+  f.cc[c] = k * d;
 }
 
 // bytes of LDS scratch fr_tail needs (it may alias anything that is dead once the partial rows are stored)
@@ -175,49 +220,74 @@ __device__ __forceinline__ void fr_tail(const FrTail& t, const float* part, int 
   constexpr int NVB = NTH / FR_RT;
   const int vb = tid / FR_RT, vt = tid - vb * FR_RT;
   double* lds = reinterpret_cast<double*>(lds_raw) + vb * 2 * (FR_RT / 64) * 8;
-  const bool bn = t.kind == FR_TAIL_BN;
+  const bool bn = t.kind == FR_TAIL_BN, bwd = t.kind == FR_TAIL_BNBWD;
   const int C = t.C;
   const int KC = bn ? 2 * C : t.K * C;
-  // SUMS: only the vectors somebody wants (C % 8 == 0: an 8-column group never straddles two vectors).  Written with
-  // selects, not arrays: hipcc promotes small private arrays to LDS.
-  float* const out0 = t.o0;
-  float* const out1 = t.K > 1 ? t.o1 : nullptr;
-  float* const out2 = t.K > 2 ? t.o2 : nullptr;
   const int cg = (C + 7) / 8;
-  const bool whole = (C & 7) == 0;
-  // active vector number ka -> vector index: km0 <= km1 <= km2 over the non-NULL outputs
-  const int has0 = out0 != nullptr, has1 = out1 != nullptr, has2 = out2 != nullptr;
-  const int nact = has0 + has1 + has2;
-  const int km0 = has0 ? 0 : (has1 ? 1 : 2);
-  const int km1 = has0 ? (has1 ? 1 : 2) : 2;
-  const int G = bn ? cg : (whole ? nact * cg : (KC + 7) / 8);
-  for (int g0 = slice * NVB; g0 < G; g0 += (int)S * NVB) {
-    __syncthreads();  // the previous trip's LDS totals have been read
-    const int g = g0 + vb;
-    const bool valid = g < G;
-    const int gc = valid ? g : G - 1;
-    if (bn) {
+  // ---- pass 1 (BN, BNBWD): 8-channel groups with TWO column sets -- (sum, sum of squares) resp. (sum g', sum g' xhat) --
+  // in one sweep; the thread that holds a channel's two totals writes everything derived from them
+  if (bn || bwd) {
+    for (int g0 = slice * NVB; g0 < cg; g0 += (int)S * NVB) {
+      __syncthreads();  // the previous trip's LDS totals have been read
+      const int g = g0 + vb;
+      const bool valid = g < cg;
+      const int gc = valid ? g : cg - 1;
       const int cols[2] = {gc * 8, C + gc * 8};
       double sq[2];
       fr_reduce_rows8<2>(part, nparts, KC, cols, sq, lds, vt);
       const int c = gc * 8 + vt;
       if (valid && vt < 8 && c < C) {
-        FrBnFin f;
-        f.count = t.count;
-        f.gamma = t.gamma;
-        f.beta = t.beta;
-        f.eps = t.eps;
-        f.momentum = t.momentum;
-        f.running_mean = t.running_mean;
-        f.running_var = t.running_var;
-        f.nbt = reinterpret_cast<long long*>(t.nbt);
-        f.mean = t.mean;
-        f.invstd = t.invstd;
-        f.scale = t.scale;
-        f.shift = t.shift;
-        fr_bn_finalize_channel(f, c, sq[0], sq[1]);
+        if (bn) {
+          FrBnFin f;
+          f.count = t.count;
+          f.gamma = t.gamma;
+          f.beta = t.beta;
+          f.eps = t.eps;
+          f.momentum = t.momentum;
+          f.running_mean = t.running_mean;
+          f.running_var = t.running_var;
+          f.nbt = reinterpret_cast<long long*>(t.nbt);
+          f.mean = t.mean;
+          f.invstd = t.invstd;
+          f.scale = t.scale;
+          f.shift = t.shift;
+          fr_bn_finalize_channel(f, c, sq[0], sq[1]);
+        } else {
+          FrBnBwdCo f;
+          f.count = t.count;
+          f.gamma = t.gamma;
+          f.mean = t.in_mean;
+          f.invstd = t.in_invstd;
+          f.bn_eval = t.bn_eval;
+          f.o0 = t.o0;
+          f.o1 = t.o1;
+          f.ca = t.ca;
+          f.cb = t.cb;
+          f.cc = t.cc;
+          fr_bnbwd_channel(f, c, sq[0], sq[1]);
+        }
       }
-    } else {
+    }
+    __syncthreads();
+  }
+  // ---- pass 2 (SUMS; the third vector of BNBWD): single column sets.  Only the vectors somebody wants (C % 8 == 0: an
+  // 8-column group never straddles two vectors).  Written with selects, not arrays: hipcc promotes small private arrays to LDS.
+  if (!bn) {
+    float* const out0 = bwd ? nullptr : t.o0;
+    float* const out1 = (bwd || t.K < 2) ? nullptr : t.o1;
+    float* const out2 = t.K > 2 ? t.o2 : nullptr;
+    const bool whole = (C & 7) == 0;
+    // active vector number ka -> vector index: km0 <= km1 <= km2 over the non-NULL outputs
+    const int has0 = out0 != nullptr, has1 = out1 != nullptr, has2 = out2 != nullptr;
+    const int nact = has0 + has1 + has2;
+    const int km0 = has0 ? 0 : (has1 ? 1 : 2);
+    const int km1 = has0 ? (has1 ? 1 : 2) : 2;
+    const int G = whole ? nact * cg : (bwd ? 0 : (KC + 7) / 8);
+    for (int g0 = slice * NVB; g0 < G; g0 += (int)S * NVB) {
+      __syncthreads();  // the previous trip's LDS totals have been read
+      const int g = g0 + vb;
+      const bool valid = g < G;
+      const int gc = valid ? g : G - 1;
       int col0 = gc * 8;
       if (whole) {
         const int ka = gc / cg;
@@ -268,6 +338,13 @@ inline int fr_tail_prepare(const FrTail& in, int K, int C, int nvb, FrTail* out,
     if (in.K < 3) out->o2 = nullptr;
     if (in.K < 2) out->o1 = nullptr;
     groups = (K * C + 7) / 8;
+  } else if (in.kind == FR_TAIL_BNBWD) {
+    if (K != 3 || in.K != 3) FR_UNSUPPORTED("tail: FR_TAIL_BNBWD reduces the three-vector rows of fr_bn_bwd_reduce (K = 3)");
+    if ((C & 7) != 0) FR_UNSUPPORTED("tail: FR_TAIL_BNBWD needs C % 8 == 0");
+    if (!in.in_mean || !in.in_invstd || !in.ca || !in.cb || !in.cc || !(in.count > 0.0))
+      FR_UNSUPPORTED("tail: FR_TAIL_BNBWD needs count, in_mean, in_invstd, ca, cb, cc");
+    out->K = 3;
+    groups = (C + 7) / 8;
   } else {
     FR_UNSUPPORTED("tail: unknown kind");
   }

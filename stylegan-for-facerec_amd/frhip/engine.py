@@ -257,8 +257,26 @@ class BackbonePlan(object):
         # In-launch reductions (csrc/tail.h): the launches that write partial rows also add them (last workgroups to arrive),
         # instead of a fr_bn_finalize / fr_reduce_parts launch behind each of them.  FRHIP_TAIL=0: the separate launches (A/B
         # switch; bit-identical results either way).
-        self.use_tail = os.environ.get("FRHIP_TAIL", "1") != "0"
+        # MEASURED SLOWER, so opt-in (FRHIP_TAIL=1; profiles/r04_ab_tail*.txt): 15.97 against 15.22 ms per step with every
+        # reduction in its producer and 16 reducers, 15.68 with 32, 17.8 with 4, 22.9 with the last workgroup alone.  What a tail
+        # adds behind the last workgroup -- drain + ticket (~1.5 us), acquire (1.7), one load round trip per 8 rows and thread
+        # of 256-1024 rows x 512-1536 columns (2.5-8), the double-precision finalize -- is MORE than the 1.5-us launch boundary +
+        # 3-5 us of the stand-alone kernel it removes: a few hundred KB of partial rows is past what a last-arriver reduction
+        # pays for (cdna_hip_programming.md, split-K seam: "a few tens of KB").  FRHIP_TAIL_MASK picks the producers: 1 forward
+        # convolutions, 2 forward channel-wise, 4 backward BatchNorm sums, 8 backward convolution epilogues.
+        self.use_tail = os.environ.get("FRHIP_TAIL", "0") == "1"
+        self.tail_mask = int(os.environ.get("FRHIP_TAIL_MASK", "15"))
         self.tickets = ops.Tickets(8 * len(self.units) + 32, device)
+        # FR_PRO_BNBWD2 (round 4): the backward of BN2 applied by the data gradient of conv2 while it loads its strip (two
+        # sources), which also writes the result once for the weight gradient: no fr_bn_bwd_apply pass for BN2 (28 launches,
+        # 0.57 ms of kernel time alone).  MEASURED: -0.19 ms per step on ONE stream (15.95 against 16.14) and nothing on two
+        # (15.20-15.29 against 15.21-15.22; 14.70 against 14.66-14.67 on a faster box: profiles/r04_ab_fuse_bn2_schedule.txt,
+        # r04_ab_edges.txt).  The pass it deletes ran beside the weight gradients of the side stream, i.e. it was already
+        # hidden; its work moved into the CU-exclusive strip load of the data gradient (0.0627 -> 0.0716 ms warm, 0.0723 ->
+        # 0.0841 ms behind a cache flush: profiles/r04_kbench_warm_cold.txt).  The backward pass is the SUM of its four MFMA
+        # kernels per unit (72 + 72 + 66 + 66 us from cold caches = the 270-280 us a 14x14 unit takes in the timeline);
+        # channel-wise work only matters where nothing runs beside it.  So: opt-in (FRHIP_FUSE_BN2=1), default off.
+        self.fuse_bn2 = os.environ.get("FRHIP_FUSE_BN2", "0") == "1"
         self.use_strip = os.environ.get("FRHIP_NO_STRIP", "0") != "1"
         self.use_stem_gemm = (self.fr == FR_BF16 and os.environ.get("FRHIP_NO_STEM_GEMM", "0") != "1" and
                               not self.body_only)
@@ -342,9 +360,18 @@ class BackbonePlan(object):
             self.a = self._act(B, self.feat_in)
             self.f = torch.empty(B, 512, device=dev)
             self.feat = torch.empty(B, 512, device=dev)
-            self.Wlin = torch.empty(512, self.feat_in, device=dev, dtype=self.tdtype)
-            self.WlinT = torch.empty(self.feat_in, 512, device=dev, dtype=self.tdtype)
-            self.gWlin = torch.zeros(512, self.feat_in, device=dev)
+            # Linear(25088, 512) on the master weight in its own (reference Flatten) layout: the activation `a` is written
+            # c-major instead (csrc/linear_gemm.hip; bf16 path; FRHIP_LINEAR_CM=0: the per-step permuted copies, A/B switch)
+            ol = self.out[2]
+            self.lin_cm = (self.fr == FR_BF16 and os.environ.get("FRHIP_LINEAR_CM", "1") != "0" and last.depth % 64 == 0 and
+                           self.feat_in % 128 == 0 and ol.weight.is_contiguous() and
+                           _lib.lib.fr_linear_slices(512, self.feat_in) > 0)
+            if self.lin_cm:
+                self.g_cm = self._act(B, self.feat_in)
+            else:
+                self.Wlin = torch.empty(512, self.feat_in, device=dev, dtype=self.tdtype)
+                self.WlinT = torch.empty(self.feat_in, 512, device=dev, dtype=self.tdtype)
+                self.gWlin = torch.zeros(512, self.feat_in, device=dev)
         self.zeros_c = torch.zeros(512, device=dev)
         if self.infer:
             self.part = torch.zeros(max(4 * 1024 * 1024, ((M0 + 127) // 128) * 2 * 64 + 4096), device=dev)
@@ -354,7 +381,16 @@ class BackbonePlan(object):
         # gradients consumed by the side-stream wgrads are double-buffered by unit parity (the next unit must not
         # overwrite what a still-running weight gradient reads)
         # FRHIP_WGRAD_SETS: how many units the main stream may run ahead of the side stream's weight gradients
-        nset = max(2, int(os.environ.get("FRHIP_WGRAD_SETS", "2"))) if self.dual else 1
+        # Round 4, measured and rejected (switches kept for the A/B): the two-stream timeline shows a ~6-us gap on the main
+        # stream at every event edge, three per residual unit, so (a) ONE main -> side edge per unit behind the second data
+        # gradient (FRHIP_MERGE_EDGES=1) and (b) four gradient buffer sets with the main stream waiting for the side stream
+        # every second unit (FRHIP_WAIT_EVERY=2 FRHIP_WGRAD_SETS=4) were tried: 14.92-15.02 ms per step against 14.66-14.67
+        # with the round-3 edges on the same box (merge alone +0.26 ms, thinned waits alone +0.05: profiles/r04_ab_edges.txt).
+        # The early edge behind conv2's data gradient is worth more than its gap: the side stream's kernels are queued while
+        # the first data gradient still holds the CUs and take them as its workgroups retire.
+        self.merge_edges = os.environ.get("FRHIP_MERGE_EDGES", "0") == "1"
+        self.wait_every = max(1, int(os.environ.get("FRHIP_WAIT_EVERY", "1")))
+        nset = max(self.wait_every + 1, int(os.environ.get("FRHIP_WGRAD_SETS", "2"))) if self.dual else 1
         self.nset = nset
         self.g_y2s = [self._act(max_out, 1).view(-1) for _ in range(nset)]
         self.g_ySs = [self._act(max_out, 1).view(-1) if max_xs else None for _ in range(nset)]
@@ -565,11 +601,12 @@ class BackbonePlan(object):
         return done
 
     # ---- forward -----------------------------------------------------------------------------------
-    def _bn_tail(self, bn, count):
+    def _bn_tail(self, bn, count, cls=1):
         """The in-launch form of fr_bn_finalize for the launch that produces bn's (sum, sum of squares) rows: pass the result
-        as that launch's `tail`; _bn_train_launches then appends nothing.  None: the separate launch stays."""
+        as that launch's `tail`; _bn_train_launches then appends nothing.  None: the separate launch stays.  cls: the
+        producer class bit of FRHIP_TAIL_MASK."""
         m = bn.mod
-        if not self.use_tail or self.fold or not m.training:
+        if not self.use_tail or not (self.tail_mask & cls) or self.fold or not m.training:
             return None
         bn.tailed = True
         return ops.tail_bn(self.tickets.take(), bn.C, count, m.weight, m.bias, m.eps,
@@ -579,9 +616,9 @@ class BackbonePlan(object):
                            m.num_batches_tracked if m.track_running_stats else None, bn.mean, bn.invstd, bn.scale,
                            bn.shift)
 
-    def _sum_tail(self, K, C, o0, o1=None, o2=None):
-        """The in-launch form of fr_reduce_parts(part, rows, K, C, o0, o1, o2), or None with FRHIP_TAIL=0."""
-        if not self.use_tail:
+    def _sum_tail(self, K, C, o0, o1=None, o2=None, cls=4):
+        """The in-launch form of fr_reduce_parts(part, rows, K, C, o0, o1, o2), or None without FRHIP_TAIL=1."""
+        if not self.use_tail or not (self.tail_mask & cls):
             return None
         return ops.tail_sums(self.tickets.take(), K, C, o0, o1, o2)
 
@@ -624,7 +661,7 @@ class BackbonePlan(object):
             nb = ops.grid_blocks(self.M0, C0, fr)
             if not fold:
                 L.append(ops.call("fr_channel_stats", self.z0, self.M0, C0, self.part, nb, fr,
-                                  self._bn_tail(first_bn, self.M0), st))
+                                  self._bn_tail(first_bn, self.M0, 2), st))
             self._bn_train_launches(L, first_bn, self.part, nb, self.M0)
         else:
             sc, sb, sp = self.stem
@@ -646,7 +683,7 @@ class BackbonePlan(object):
             nb = ops.grid_blocks(self.M0, 64, fr)
             L.append(ops.bn_apply(st, fr, x=self.y0, out=self.z0, scale=self.bn0.scale, shift=self.bn0.shift,
                                   slope=sp.weight, part=stats_part, B=B, H=S, W=S, C=64, res_kind=0, res_stride=1,
-                                  nblocks=nb, **self._tail_kw(self._bn_tail(first_bn, self.M0))))
+                                  nblocks=nb, **self._tail_kw(self._bn_tail(first_bn, self.M0, 2))))
             self._bn_train_launches(L, first_bn, self.part, nb, self.M0)
         x = self.z0
         for i, u in enumerate(self.units):
@@ -733,7 +770,7 @@ class BackbonePlan(object):
             if nxt is None:
                 kw["part"] = None  # nobody consumes the statistics of a bare stack's output
             elif not fold:
-                kw.update(self._tail_kw(self._bn_tail(nxt, rout)))
+                kw.update(self._tail_kw(self._bn_tail(nxt, rout, 2)))
             L.append(ops.bn_apply(st, fr, **kw))
             if nxt is not None:
                 self._bn_train_launches(L, nxt, self.part, nb, rout)
@@ -749,23 +786,33 @@ class BackbonePlan(object):
         ob, od, ol, ob1 = self.out
         last = self.units[-1]
         C = last.depth
-        P.append(ops.call("fr_permute_linear", ol.weight, self.Wlin, self.WlinT, 512, C, self.HWo, 0, fr, st))
-        drop = ops.call("fr_bn_dropout", x, self.a, self.bn_out.scale, self.bn_out.shift, B * self.HWo, C, self.HWo,
-                        0.0, 0, fr, st)
-        L.append(drop)
-        self.l_drop_fwd = drop
-        # split-K over 25088: every K slice stores its [B][512] partial (+ bias in slice 0) to its own slab and the
-        # slabs are added in a fixed order -- reproducible, unlike atomics, and the sums are formed in double
-        nk = self.feat_in // 32
-        self.lin_splitk = max(1, min(64, nk // 16))
-        self.lin_slab = torch.empty(self.lin_splitk * B * 512, device=self.device)
-        L.append(ops.conv(st, fr, src=self.a, w=self.Wlin, out=self.lin_slab, B=B, RH=1, RW=1, SH=1, SW=1,
-                          SC=self.feat_in, N=512, KH=1, KW=1, stride=1, pad=0, mode=0, lda=self.feat_in, ldc=512, pro=0,
-                          epi=ops.EPI_SLAB, out_f32=1, splitk=self.lin_splitk, bias=ol.bias))
+        if self.lin_cm:
+            drop = ops.call("fr_bn_dropout_cm", x, self.a, self.bn_out.scale, self.bn_out.shift, B, C, self.HWo, 0.0, 0, fr,
+                            st)
+            L.append(drop)
+            self.l_drop_fwd = drop
+            self.lin_splitk = int(_lib.lib.fr_linear_slices(512, self.feat_in))
+            self.lin_slab = torch.empty(self.lin_splitk * B * 512, device=self.device)
+            L.append(ops.call("fr_linear_fwd", self.a, ol.weight, ol.bias, self.lin_slab, B, 512, self.feat_in,
+                              self.lin_splitk, st))
+        else:
+            P.append(ops.call("fr_permute_linear", ol.weight, self.Wlin, self.WlinT, 512, C, self.HWo, 0, fr, st))
+            drop = ops.call("fr_bn_dropout", x, self.a, self.bn_out.scale, self.bn_out.shift, B * self.HWo, C, self.HWo,
+                            0.0, 0, fr, st)
+            L.append(drop)
+            self.l_drop_fwd = drop
+            # split-K over 25088: every K slice stores its [B][512] partial (+ bias in slice 0) to its own slab and the
+            # slabs are added in a fixed order -- reproducible, unlike atomics, and the sums are formed in double
+            nk = self.feat_in // 32
+            self.lin_splitk = max(1, min(64, nk // 16))
+            self.lin_slab = torch.empty(self.lin_splitk * B * 512, device=self.device)
+            L.append(ops.conv(st, fr, src=self.a, w=self.Wlin, out=self.lin_slab, B=B, RH=1, RW=1, SH=1, SW=1,
+                              SC=self.feat_in, N=512, KH=1, KW=1, stride=1, pad=0, mode=0, lda=self.feat_in, ldc=512, pro=0,
+                              epi=ops.EPI_SLAB, out_f32=1, splitk=self.lin_splitk, bias=ol.bias))
         L.append(ops.call("fr_reduce_parts", self.lin_slab, self.lin_splitk, 1, B * 512, self.f, None, None, st))
         nbf = ops.grid_blocks(B, 512, FR_F32)
         if not fold:
-            L.append(ops.call("fr_channel_stats", self.f, B, 512, self.part, nbf, FR_F32, self._bn_tail(self.bn1d, B), st))
+            L.append(ops.call("fr_channel_stats", self.f, B, 512, self.part, nbf, FR_F32, self._bn_tail(self.bn1d, B, 2), st))
         self._bn_train_launches(L, self.bn1d, self.part, nbf, B)
         L.append(ops.bn_apply(st, FR_F32, x=self.f, out=self.feat, scale=self.bn1d.scale, shift=self.bn1d.shift, B=B,
                               H=1, W=1, C=512, res_kind=0, res_stride=1, nblocks=nbf))
@@ -867,17 +914,28 @@ class BackbonePlan(object):
             gfT = self.g_f32
         # Linear weight gradient (packed layout) -> torch layout
         glw = self.grad_of(ol.weight)
-        if glw is not None:
-            L.append(ops.call("fr_fill_rows", self.gWlin, None, 512, self.feat_in, st))
-            L.append(ops.wgrad(st, fr, g=gfT, src=self.a, dw=self.gWlin, B=B, GH=1, GW=1, Cout=512, SH=1, SW=1,
-                               SC=self.feat_in, KH=1, KW=1, stride=1, pad=0, ldg=512, lda=self.feat_in, pro=0,
-                               nsplit=1))
-            L.append(ops.call("fr_permute_linear", self.gWlin, glw, None, 512, C, self.HWo, 1, FR_F32, st))
-        # Linear data gradient -> dropout backward -> BN(out) backward
         g_a = self.g_xh[:B * self.feat_in].view(B, self.feat_in)
-        L.append(ops.conv(st, fr, src=gfT, w=self.WlinT, out=g_a, B=B, RH=1, RW=1, SH=1, SW=1, SC=512, N=self.feat_in,
-                          KH=1, KW=1, stride=1, pad=0, mode=0, lda=512, ldc=self.feat_in, pro=0, epi=ops.EPI_STORE))
-        dropb = ops.call("fr_dropout_bwd", g_a, rows_o, C, self.HWo, 0.0, 0, fr, st)
+        if self.lin_cm:
+            if glw is not None:  # straight into the master's layout (one workgroup per element: the add is onto the zeroed arena)
+                L.append(ops.wgrad(st, fr, g=gfT, src=self.a, dw=glw, B=B, GH=1, GW=1, Cout=512, SH=1, SW=1,
+                                   SC=self.feat_in, KH=1, KW=1, stride=1, pad=0, ldg=512, lda=self.feat_in, pro=0,
+                                   nsplit=1))
+            # Linear data gradient (c-major) -> dropout backward + back to NHWC -> BN(out) backward
+            L.append(ops.call("fr_linear_dgrad", gfT, ol.weight, self.g_cm, B, 512, self.feat_in, st))
+            dropb = ops.call("fr_dropout_bwd_cm", self.g_cm, g_a, B, C, self.HWo, 0.0, 0, fr, st)
+            self._drop_bwd_idx = (5, 6)
+        else:
+            if glw is not None:
+                L.append(ops.call("fr_fill_rows", self.gWlin, None, 512, self.feat_in, st))
+                L.append(ops.wgrad(st, fr, g=gfT, src=self.a, dw=self.gWlin, B=B, GH=1, GW=1, Cout=512, SH=1, SW=1,
+                                   SC=self.feat_in, KH=1, KW=1, stride=1, pad=0, ldg=512, lda=self.feat_in, pro=0,
+                                   nsplit=1))
+                L.append(ops.call("fr_permute_linear", self.gWlin, glw, None, 512, C, self.HWo, 1, FR_F32, st))
+            # Linear data gradient -> dropout backward -> BN(out) backward
+            L.append(ops.conv(st, fr, src=gfT, w=self.WlinT, out=g_a, B=B, RH=1, RW=1, SH=1, SW=1, SC=512, N=self.feat_in,
+                              KH=1, KW=1, stride=1, pad=0, mode=0, lda=512, ldc=self.feat_in, pro=0, epi=ops.EPI_STORE))
+            dropb = ops.call("fr_dropout_bwd", g_a, rows_o, C, self.HWo, 0.0, 0, fr, st)
+            self._drop_bwd_idx = (4, 5)
         L.append(dropb)
         self.l_drop_bwd = dropb
         x_last = self.ubuf[-1]["out"]
@@ -907,8 +965,18 @@ class BackbonePlan(object):
             bn1, bn2 = d["bn1"], d["bn2"]
             par = i % self.nset if self.dual else 0
             g_y2 = self.g_y2s[par][:rout * u.depth]
-            if self.dual and i + self.nset in unit_done:
-                L.append(_EvWait(self.stream1_t, unit_done[i + self.nset]))  # that unit's wgrads read this buffer set
+            if self.dual:
+                # unit i + nset's weight gradients read this buffer set.  The side stream is FIFO, so waiting every
+                # wait_every-th unit for a later unit's event covers the units in between.
+                tgt = i + self.nset - (self.wait_every - 1) if i % self.wait_every == 0 else None
+                if tgt is not None and tgt in unit_done:
+                    L.append(_EvWait(self.stream1_t, unit_done[tgt]))
+            merged = self.dual and self.merge_edges
+            S = [] if merged else L  # side-stream launches of this unit (merged: enqueued behind ONE edge)
+
+            def edge():
+                if not merged:
+                    self._side_after_main(L)
             nb = ops.grid_blocks(rout, u.depth, fr)
             ready = [u.bn2.weight, u.bn2.bias]
             se_kw = {}
@@ -928,12 +996,27 @@ class BackbonePlan(object):
             db, dg = self._bn_grads(bn2)
             common = dict(g=g_out, x=d["y2"], mean=bn2.mean, invstd=bn2.invstd, rows=rout, C=u.depth,
                           rows_per_image=HWo, nblocks=nb, **se_kw)
-            t = self._sum_tail(3, u.depth, db, dg)
-            L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **self._tail_kw(t), **common))
-            self._reduce(L, nb, 3, u.depth, db, dg, tail=t)
-            s0, s1 = self._s01(bn2, db, dg)
-            L.append(ops.bn_bwd_apply(st, fr, gx=g_y2, gamma=u.bn2.weight, s0=s0, s1=s1, inv_count=1.0 / rout,
-                                      **common))
+            # BN2 backward inside the data gradient of conv2 (FR_PRO_BNBWD2): bf16 strip instances of the stride-1 units
+            fuse2 = (self.fuse_bn2 and fr == FR_BF16 and self.use_strip and u.stride == 1 and u.se is None and
+                     bool(_lib.lib.fr_conv3x3_strip_serves_bnbwd2(B, u.depth, u.H)))
+            if fuse2:
+                co = [self.pool.take(u.depth) for _ in range(3)]
+                ev = not bn2.mod.training
+                if self.use_tail and (self.tail_mask & 4):
+                    t = ops.tail_bnbwd(self.tickets.take(), 3, u.depth, db, dg, None, rout, u.bn2.weight, bn2.mean,
+                                       bn2.invstd, co[0], co[1], co[2], bn_eval=ev)
+                    L.append(ops.bn_bwd_reduce(st, fr, part=self.part, tail=t, **common))
+                else:
+                    L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
+                    L.append(ops.call("fr_bn_bwd_coeffs", self.part, nb, u.depth, float(rout), u.bn2.weight, bn2.mean,
+                                      bn2.invstd, 1 if ev else 0, db, dg, co[0], co[1], co[2], st))
+            else:
+                t = self._sum_tail(3, u.depth, db, dg)
+                L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **self._tail_kw(t), **common))
+                self._reduce(L, nb, 3, u.depth, db, dg, tail=t)
+                s0, s1 = self._s01(bn2, db, dg)
+                L.append(ops.bn_bwd_apply(st, fr, gx=g_y2, gamma=u.bn2.weight, s0=s0, s1=s1, inv_count=1.0 / rout,
+                                          **common))
             g_xS = None
             if u.sc_conv is not None:
                 bnS = d["bnS"]
@@ -956,8 +1039,8 @@ class BackbonePlan(object):
                 gws = self.grad_of(u.sc_conv.weight)
                 if gws is not None:
                     tiles = ((u.depth + 127) // 128) * ((u.cin + 127) // 128)
-                    self._side_after_main(L)
-                    ready += self._wgrad(L, param=u.sc_conv.weight, g=g_yS, src=x, dw=gws, B=B, GH=u.Ho, GW=u.Ho,
+                    edge()
+                    ready += self._wgrad(S, param=u.sc_conv.weight, g=g_yS, src=x, dw=gws, B=B, GH=u.Ho, GW=u.Ho,
                                          Cout=u.depth, SH=u.H, SW=u.H, SC=u.cin, KH=1, KW=1, stride=u.stride, pad=0,
                                          ldg=u.depth, lda=u.cin, pro=0, nsplit=_wgrad_slices(rout, tiles))
                 else:
@@ -968,12 +1051,15 @@ class BackbonePlan(object):
             c2 = dict(src=g_y2, w=d["wt2"], out=g_y1, B=B, RH=u.H, RW=u.H, SH=u.Ho, SW=u.Ho, SC=u.depth, N=u.depth,
                       KH=3, KW=3, stride=u.stride, pad=1, lda=u.depth, ldc=u.depth, ldaux=u.depth, pro=0,
                       epi=ops.EPI_PRELU_BWD, aux=d["y1"], epi_a=u.prelu.weight)
+            if fuse2:  # the operand is ca*g_out + cb*y2 + cc; g_y2 is written on the way for the weight gradient
+                c2.update(src=g_out, src2=d["y2"], pro=ops.PRO_BNBWD2, pro_a=co[0], pro_b=co[1], pro_c=co[2],
+                          pro_out=g_y2 if self.grad_of(u.conv2.weight) is not None else None)
             # The PReLU-slope partial sums of this data gradient feed nothing downstream (a parameter gradient): with the
             # side stream they go to a buffer of their own (one per buffer set) and are added there, off the main chain.
             gsl = self.grad_of(u.prelu.weight)
             gsl = gsl if gsl is not None else self.sums[2, :u.depth]
             # with the in-launch reduction the data gradient adds its own slope partials: nothing for the side stream to do
-            tsl = self._sum_tail(1, u.depth, gsl)
+            tsl = self._sum_tail(1, u.depth, gsl, cls=8)
             part2 = self.part_slope[par] if (self.side_slope and tsl is None) else self.part
             if u.stride == 2 and u.H % 2 == 0:
                 # one launch per output-pixel parity class: 9/4 taps per pixel instead of 9 (3/4 of them misses)
@@ -984,19 +1070,19 @@ class BackbonePlan(object):
             gw2 = self.grad_of(u.conv2.weight)
             if tsl is not None:
                 if gw2 is not None:
-                    self._side_after_main(L)  # g_y1, g_y2 (BN2 backward) and y1 are final
+                    edge()  # g_y1, g_y2 (BN2 backward) and y1 are final
             elif self.side_slope:
-                self._side_after_main(L)  # g_y1 / the slope partials, g_y2 (BN2 backward) and y1 are final
+                edge()  # g_y1 / the slope partials, g_y2 (BN2 backward) and y1 are final
                 r = ops.call("fr_reduce_parts", part2, mt, 2, u.depth, gsl, None, None, self.stream2)
                 r.tstream = self.stream2_t
-                L.append(r)
+                S.append(r)
             else:
                 self._reduce(L, mt, 2, u.depth, gsl, None)
             if gw2 is not None:
                 tiles = ((u.depth + 127) // 128) ** 2 * 9
                 if not self.side_slope and tsl is None:
-                    self._side_after_main(L)
-                ready += self._wgrad(L, param=u.conv2.weight, g=g_y2, src=d["y1"], dw=gw2, B=B, GH=u.Ho, GW=u.Ho,
+                    edge()
+                ready += self._wgrad(S, param=u.conv2.weight, g=g_y2, src=d["y1"], dw=gw2, B=B, GH=u.Ho, GW=u.Ho,
                                      Cout=u.depth, SH=u.H, SW=u.H, SC=u.depth, KH=3, KW=3, stride=u.stride, pad=1,
                                      ldg=u.depth, lda=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight,
                                      nsplit=_wgrad_slices(rout, tiles))
@@ -1005,7 +1091,7 @@ class BackbonePlan(object):
             # conv1: data gradient with the BN1-backward sums epilogue, then the weight gradient
             g_xh = self.g_xh[:rin * u.cin]
             db, dg = self._bn_grads(bn1)
-            t = self._sum_tail(2, u.cin, db, dg)
+            t = self._sum_tail(2, u.cin, db, dg, cls=8)
             mt = self._conv(L, src=g_y1, w=d["wt1"], out=g_xh, B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H,
                             SC=u.depth, N=u.cin, KH=3, KW=3, stride=1, pad=1, mode=1, lda=u.depth, ldc=u.cin,
                             ldaux=u.cin, pro=0, epi=ops.EPI_BNBWD, aux=x, epi_a=bn1.mean, epi_b=bn1.invstd,
@@ -1014,13 +1100,16 @@ class BackbonePlan(object):
             gw1 = self.grad_of(u.conv1.weight)
             if gw1 is not None:
                 tiles = ((u.depth + 127) // 128) * ((u.cin + 127) // 128) * 9
-                self._side_after_main(L)  # g_y1 (conv2 data gradient) is final on the main stream
-                ready += self._wgrad(L, param=u.conv1.weight, g=g_y1, src=x, dw=gw1, B=B, GH=u.H, GW=u.H, Cout=u.depth,
+                edge()  # g_y1 (conv2 data gradient) is final on the main stream
+                ready += self._wgrad(S, param=u.conv1.weight, g=g_y1, src=x, dw=gw1, B=B, GH=u.H, GW=u.H, Cout=u.depth,
                                      SH=u.H, SW=u.H, SC=u.cin, KH=3, KW=3, stride=1, pad=1, ldg=u.depth, lda=u.cin,
                                      pro=ops.PRO_BN, pro_a=bn1.scale, pro_b=bn1.shift, nsplit=_wgrad_slices(rin, tiles))
             else:
                 ready.append(u.conv1.weight)
             ready += [u.prelu.weight, u.bn1.weight, u.bn1.bias]
+            if merged and S:  # the unit's one edge: everything the side-stream launches read is final on the main stream
+                self._side_after_main(L)
+                L.extend(S)
             # unit input gradient = BN1 backward of g_xh + shortcut gradient
             nxt = 1 - cur
             g_x = self.g_pp[nxt][:rin * u.cin]
@@ -1164,8 +1253,8 @@ class BackbonePlan(object):
         self.l_drop_fwd.args[7] = p
         self.l_drop_fwd.args[8] = seed
         if not self.infer:
-            self.l_drop_bwd.args[4] = p
-            self.l_drop_bwd.args[5] = seed
+            self.l_drop_bwd.args[self._drop_bwd_idx[0]] = p
+            self.l_drop_bwd.args[self._drop_bwd_idx[1]] = seed
         ops.run(self.pack_list)
         ops.run(self.fwd_list)
         self.generation += 1

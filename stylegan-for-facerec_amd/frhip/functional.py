@@ -161,6 +161,16 @@ def focal_loss(logits, target, gamma=2.0):
     return FocalLossFn.apply(logits, target, gamma)
 
 
+def topk_precision(rank, topk):
+    """[precision@k in percent for k in topk] from the label ranks (device float32 [len(topk)]); the arithmetic of
+    ``(rank < k).float().sum().mul_(100.0 / n)`` (reference util/utils.py:343-358) in one launch."""
+    ks = [int(k) for k in topk] + [0] * (4 - len(topk))
+    out = torch.empty(len(topk), device=rank.device, dtype=torch.float32)
+    ops.call("fr_topk_precision", rank, rank.numel(), len(topk), ks[0], ks[1], ks[2], ks[3], 100.0 / rank.numel(), out,
+             ops.current_stream_ptr())()
+    return out
+
+
 def topk_ranks(logits, target):
     """rank[m] = number of classes scoring strictly above the label's logit (device int32 [B])."""
     B, N = logits.shape

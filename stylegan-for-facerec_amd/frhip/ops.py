@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import (EPI_ATOMIC, EPI_BIAS_RES, EPI_BNBWD, EPI_MARGIN, EPI_PRELU_BWD, EPI_SLAB, EPI_STATS, EPI_STORE, FR_BF16,  # noqa: F401
                    FR_F32,
-                   PRO_BN, PRO_NONE, PRO_PRELU, lib)
+                   PRO_BN, PRO_BNBWD2, PRO_NONE, PRO_PRELU, lib)
 
 TORCH_DTYPE = {FR_F32: torch.float32, FR_BF16: torch.bfloat16}
 
@@ -158,6 +158,17 @@ def tail_sums(ticket, K, C, o0, o1=None, o2=None, nred=0):
     _fill(t, ticket=ticket, o0=o0, o1=o1, o2=o2)
     t.kind, t.K, t.C, t.nred = _lib.TAIL_SUMS, K, C, nred
     t._keep = (ticket, o0, o1, o2)
+    return t
+
+
+def tail_bnbwd(ticket, K, C, o0, o1, o2, count, gamma, mean, invstd, ca, cb, cc, bn_eval=False, nred=0):
+    """tail_sums of fr_bn_bwd_reduce's rows + the coefficients of the BatchNorm backward as gx = ca*g + cb*x + cc (what the
+    FR_PRO_BNBWD2 prologue of the following data gradient applies)."""
+    t = _lib.FrTail()
+    _fill(t, ticket=ticket, o0=o0, o1=o1, o2=o2, gamma=gamma, in_mean=mean, in_invstd=invstd, ca=ca, cb=cb, cc=cc)
+    t.kind, t.K, t.C, t.nred = _lib.TAIL_BNBWD, K, C, nred
+    t.count, t.bn_eval = float(count), 1 if bn_eval else 0
+    t._keep = (ticket, o0, o1, o2, gamma, mean, invstd, ca, cb, cc)
     return t
 
 

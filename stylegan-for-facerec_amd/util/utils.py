@@ -112,7 +112,9 @@ def accuracy(output, target, topk=(1,)):
     from frhip import functional as FRF
     rank = FRF.topk_ranks(output, target)
     n = target.size(0)
-    return [(rank < k).float().sum().mul_(100.0 / n) for k in topk]
+    if n == 0 or len(topk) > 4 or not rank.is_cuda:
+        return [(rank < k).float().sum().mul_(100.0 / n) for k in topk]
+    return list(FRF.topk_precision(rank, topk).unbind(0))  # one launch: count(rank < k) * float32(100 / n) per k
 
 
 def collate_fn_ignore_none(batch):
@@ -244,14 +246,24 @@ def perform_val(multi_gpu, device, embedding_size, batch_size, backbone, carray,
 
     ``world > 1`` (one process per GPU; collective -- every rank calls it): batch k of the SAME batch partition goes to
     rank k % world, the embedding sums are combined with one all-reduce (every row is written by exactly one rank and is
-    zero elsewhere, so the sum is exact) and every rank computes the same metrics.  The batches themselves are the ones a
-    single rank would run, so the result equals the single-rank result bit for bit."""
+    zero elsewhere, so the sum is exact) and every rank computes the same metrics.  Data-parallel training keeps the
+    BatchNorm running statistics per rank (as nn.DataParallel keeps them per replica and the reference evaluates replica 0,
+    train.py:219-222), so the ranks hold slightly different eval models: for the evaluation every rank takes rank 0's
+    buffers (one broadcast per buffer) and gets its own back afterwards.  The model evaluated is then the one rank 0 saves
+    as the checkpoint, the batches are the ones a single rank would run, and the result equals rank 0 evaluating alone bit
+    for bit."""
     import numpy as np
     from util.verification import evaluate
     if multi_gpu:
         backbone = backbone.module
     backbone = backbone.to(device)
     backbone.eval()
+    own_buffers = None
+    if world > 1:
+        import torch.distributed as dist
+        own_buffers = [b.detach().clone() for b in backbone.buffers()]
+        for b in backbone.buffers():
+            dist.broadcast(b.data, src=0, group=group)
     n = len(carray)
     is_dev = torch.device(device).type == "cuda"
     sums = torch.zeros(n, embedding_size, device=device, dtype=torch.float32)  # f(img) [+ f(hflip(img))], on the device
@@ -281,8 +293,10 @@ def perform_val(multi_gpu, device, embedding_size, batch_size, backbone, carray,
                 emb = emb + backbone(hflip_batch(cropped))  # fp32 add: same bits as on the host
             sums[idx:idx + batch.shape[0]] = emb
     if world > 1:
-        import torch.distributed as dist
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        with torch.no_grad():  # training continues with this rank's own running statistics
+            for b, mine in zip(backbone.buffers(), own_buffers):
+                b.data.copy_(mine)
     embeddings = np.zeros([n, embedding_size])
     embeddings[:] = l2_norm(sums.cpu()).numpy()  # one copy back; normalisation on the host, as in the reference
     tpr, fpr, acc, best_thresholds = evaluate(embeddings, issame, nrof_folds)

@@ -1381,10 +1381,54 @@ def test_in_launch_reductions_are_bit_identical_to_separate_launches(kind, B):
         assert not bad, (step, bad[:5])
 
 
+def test_bn2_backward_inside_the_data_gradient_tracks_the_two_pass_path():
+    """FR_PRO_BNBWD2 in the engine (round 4, opt-in FRHIP_FUSE_BN2=1: measured no faster on two streams): the 18 stride-1 strip units of IR-50
+    form dy2 = BN2-backward(g_out, y2) inside conv2's data gradient instead of in a fr_bn_bwd_apply pass.  Same arithmetic up to
+    one re-associated fp32 expression before the bf16 rounding: the loss and features are identical (forward untouched), every
+    parameter gradient agrees in direction (cos >= 0.9995) and norm (2e-3), and the apply launches are gone."""
+    _need_gpu()
+    from head.metrics import ArcFace
+    from loss.focal import FocalLoss
+
+    def run(fuse):
+        os.environ["FRHIP_FUSE_BN2"] = fuse
+        try:
+            m, _ = build("IR_50")
+            m.compute_dtype = torch.bfloat16
+            m = m.train()
+            head = ArcFace(512, 100, None).cuda()
+            with torch.no_grad():
+                head.weight.copy_(synth.uniform(16, "full.head", (100, 512), -0.1, 0.1))
+            x = synth.uniform(16, "fuse.x", (12, 3, 112, 112)).cuda()
+            y = synth.labels(16, "fuse.label", 12, 100).cuda()
+            f = m(x)
+            loss, _ = FocalLoss()(head(f, y), y)
+            loss.backward()
+            torch.cuda.synchronize()
+            names = [getattr(l, "name", "") for l in m._runner[0].plan.bwd_list]
+            return (f.detach().clone(), float(loss.detach()), {n: p.grad.detach().clone() for n, p in m.named_parameters()},
+                    names.count("fr_bn_bwd_apply"), names.count("fr_bn_bwd_coeffs"))
+        finally:
+            os.environ.pop("FRHIP_FUSE_BN2")
+
+    f1, l1, g1, a1, c1 = run("1")
+    f0, l0, g0, a0, c0 = run("0")
+    assert l1 == l0 and torch.equal(f1, f0)
+    assert (c1, c0) == (18, 0) and a0 - a1 == 18, (a1, a0, c1, c0)
+    for n in g0:
+        a, b = g1[n].float().flatten(), g0[n].float().flatten()
+        cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+        # (measured: cos 0.99989 at the stem weight, the end of 24 units of re-rounded bf16 gradients; >= 0.99995 elsewhere)
+        assert cos >= 0.9995 and abs(float(a.norm() / b.norm()) - 1.0) < 2e-3, (n, cos, float(a.norm() / b.norm()))
+
+
 BENCH_SIZE = [("configs1_ir50_arc7000_b256", "IR_50", 50, False, "ArcFace", 7000, 256),
               ("configs2_ir50_arc28000_b256", "IR_50", 50, False, "ArcFace", 28000, 256),
               ("configs3_irse101_cos28000_b128", "IR_SE_101", 100, True, "CosFace", 28000, 128),
-              ("configs4_psp_arc28000_b256", "pSp", 50, True, "ArcFace", 28000, 256)]
+              ("configs4_psp_arc28000_b256", "pSp", 50, True, "ArcFace", 28000, 256),
+              # BASELINE configs[0] at ITS size (configs/config_BUPT_IR_50_baseline.py:20,33: pSp, BATCH_SIZE = 100; the synthetic
+              # set has 100 identities): 100 images select the small-batch strip instances, another table than 128 / 256
+              ("configs0_psp_arc100_b100", "pSp", 50, True, "ArcFace", 100, 100)]
 
 
 @pytest.mark.parametrize("tag,kind,layers,se,head_name,N,B", BENCH_SIZE, ids=[c[0] for c in BENCH_SIZE])
@@ -1454,3 +1498,52 @@ def test_bench_size_step_tracks_the_oracle(tag, kind, layers, se, head_name, N, 
         assert c > 0.975 and abs(r - 1) < 0.02, (n, c, r)
     c = float(cosf(head.weight.grad.detach().cpu().double().reshape(1, -1), rg["head.weight"].double().reshape(1, -1)))
     assert c > 0.999, c
+
+
+def test_configs0_fp32_step_at_its_own_size():
+    """BASELINE configs[0] on the fp32 parity path at its own size -- pSp (IR-SE-50 trunk, 6-channel stem, average image) +
+    ArcFace over 100 identities, batch 100 (reference configs/config_BUPT_IR_50_baseline.py:20,33), Focal loss -- against the
+    fp32 CPU oracle: logits within north_star's 1e-3 (max |dlogit|), loss, and every parameter gradient norm.  The fixture
+    tests run this network at batch 8 and the train driver at batch 20; 100 images is the size the reference's own config
+    names."""
+    _need_gpu()
+    from head.metrics import ArcFace
+    from loss.focal import FocalLoss
+    from oracle import irse_ref as O
+    B, N = 100, 100
+    x = synth.uniform(35, "c0.x", (B, 3, 112, 112))
+    y = synth.labels(35, "c0.y", B, N)
+    m, prefix = build("pSp")
+    m.encoder.compute_dtype = torch.float32
+    m.train()
+    head = ArcFace(512, N, None).cuda()
+    with torch.no_grad():
+        head.weight.copy_(synth.uniform(35, "c0.head", (N, 512), -0.05, 0.05))
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running_" not in k and "avg_image" not in k:
+            v.requires_grad_(True)
+    hw = head.weight.detach().cpu().clone().requires_grad_(True)
+    feats = m(x.cuda())
+    logits = head(feats, y.cuda())
+    loss, _ = FocalLoss()(logits, y.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert m.encoder._runner[0].plan.tdtype == torch.float32
+    avg = synth.uniform(15, "avg_image", (3, 112, 112))
+    rf, rl, rloss, rg = O.train_step(sd, x, y, hw, num_layers=50, se=True, prefix=prefix, avg_image=avg, head="ArcFace",
+                                     s=64.0, m=0.5)
+    dlogit = float((logits.detach().cpu() - rl.detach()).abs().max())
+    loss_rel = abs(float(loss.detach()) - float(rloss.detach())) / abs(float(rloss.detach()))
+    named = dict(m.named_parameters())
+    names = [n for n in named if n in rg and named[n].grad is not None and not n.endswith(ZERO_GRAD_SUFFIXES)]
+    got = np.array([float(named[n].grad.double().norm()) for n in names])
+    ref = np.array([float(rg[n].double().norm()) for n in names])
+    ratio = np.abs(got - ref) / np.maximum(ref, 1e-12)
+    worst = int(np.argmax(ratio))
+    rep = dict(max_dlogit=dlogit, loss_rel=loss_rel, norms_median=float(np.median(ratio)),
+               norms_p95=float(np.percentile(ratio, 95)), norms_worst=float(ratio[worst]), worst_name=names[worst],
+               tensors=len(names))
+    print("\nfp32 configs[0] step (pSp, ArcFace(100), bs 100) vs oracle: %s" % json.dumps(rep))
+    assert dlogit < 1e-3 and loss_rel < 1e-4, rep
+    assert rep["norms_median"] < 1e-3 and rep["norms_p95"] < 5e-3 and rep["norms_worst"] < 2.5e-2, rep

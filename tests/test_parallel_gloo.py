@@ -167,6 +167,25 @@ def _val_worker(rank, world, port, q):
         one = perform_val(False, "cpu", 32, 8, net, carray, issame, nrof_folds=5, ccrop=False)
         two = perform_val(False, "cpu", 32, 8, net, carray, issame, nrof_folds=5, ccrop=False, rank=rank, world=world)
         assert one[0] == two[0] and one[1] == two[1], (one[:2], two[:2])  # bit-equal metrics on every rank
+        # Data-parallel training leaves every rank with its OWN BatchNorm running statistics: the sharded evaluation must
+        # still be the evaluation of ONE model -- rank 0's, the one the checkpoint holds -- and must hand every rank its
+        # own statistics back.
+        torch.manual_seed(11)
+        bnet = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(3 * 112 * 112, 32), torch.nn.BatchNorm1d(32))
+        with torch.no_grad():
+            bnet[2].running_mean.copy_(torch.linspace(-0.5, 0.5, 32) * (1 + rank))
+            bnet[2].running_var.copy_(torch.linspace(0.5, 2.0, 32) * (1 + 0.3 * rank))
+        mine = [b.clone() for b in bnet.buffers()]
+        ref = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(3 * 112 * 112, 32), torch.nn.BatchNorm1d(32))
+        ref.load_state_dict(bnet.state_dict())
+        with torch.no_grad():  # rank 0's statistics
+            ref[2].running_mean.copy_(torch.linspace(-0.5, 0.5, 32))
+            ref[2].running_var.copy_(torch.linspace(0.5, 2.0, 32))
+        alone = perform_val(False, "cpu", 32, 8, ref, carray, issame, nrof_folds=5, ccrop=False)
+        shared = perform_val(False, "cpu", 32, 8, bnet, carray, issame, nrof_folds=5, ccrop=False, rank=rank, world=world)
+        assert alone[0] == shared[0] and alone[1] == shared[1], (rank, alone[:2], shared[:2])
+        for a, b in zip(bnet.buffers(), mine):
+            assert torch.equal(a, b), "rank %d did not get its own running statistics back" % rank
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
