@@ -404,6 +404,13 @@ class ClockSampler(threading.Thread):
 
     def run(self):
         self.t0 = time.perf_counter()
+        if self.freq_file is None and self.dpm_file is None:
+            # no sysfs node: the only source is a `rocm-smi` child, and forking one every 100 ms from this multi-GB process
+            # would perturb the host-side launch loop being timed -- one snapshot when the loop starts, one when it stops
+            self._read()
+            self._stop_ev.wait()
+            self._read()
+            return
         while not self._stop_ev.is_set():
             self._read()
             self._stop_ev.wait(self.period)
@@ -475,7 +482,7 @@ def run_other_config(label, spec, args, device, rank, world, peak, steps=10, war
     inner = model.encoder if hasattr(model, "encoder") else model
     inner._runner[0].plans.clear()
     inner._runner[0].plan = None
-    del model, head, opt, xs, ys, step, dp
+    del model, head, opt, xs, ys, step, dp, inner
     gc.collect()
     torch.cuda.empty_cache()
     return rec
@@ -632,7 +639,7 @@ def main():
         import gc
         inner._runner[0].plans.clear()
         inner._runner[0].plan = None
-        del model, head, opt, xs, ys, x, y, step, dp
+        del model, head, opt, xs, ys, x, y, step, dp, inner
         gc.collect()
         torch.cuda.empty_cache()
         others = []

@@ -232,6 +232,17 @@ int fr_stem_wgrad_bn(const void* G, const void* Y, const void* X, const float* m
                      const float* scale, const float* shift, const float* slope, const float* gamma, const float* s0,
                      const float* s1, float inv_count, float* slab, long long M, int K, int nblocks, void* stream);
 
+/* Round 4: the same two GEMMs WITHOUT materialised im2col rows -- the kernels build their row chunks from the fp32 NCHW
+ * batch x [B][C][H][W] (and the constant average image avg [Cavg][H][W] of pSp, restyle_psp.py:445-447) in registers: the
+ * values of fr_stem_im2col, rounded to bf16 the same way, so the results equal fr_stem_gemm / fr_stem_wgrad_bn on the rows
+ * bit for bit, and the 205-MB row tensor is neither written nor read.  (C, Cavg, K) = (3, 0, 32) or C + Cavg = 6, K = 64. */
+int fr_stem_gemm_x(const float* x, const float* avg, const void* Wp, void* out, float* part, int B, int H, int W, int C,
+                   int Cavg, int K, int nblocks, const FrTail* tail, void* stream);
+int fr_stem_wgrad_bn_x(const void* G, const void* Y, const float* x, const float* avg, const float* mean,
+                       const float* invstd, const float* scale, const float* shift, const float* slope, const float* gamma,
+                       const float* s0, const float* s1, float inv_count, float* slab, int B, int H, int W, int C, int Cavg,
+                       int K, int nblocks, void* stream);
+
 /* ---- BatchNorm statistics (train mode; torch defaults eps 1e-5, momentum 0.1 -- SURVEY App. B 13)
  * part: [nparts][2][C] partial (sum, sum of squares) rows; count = elements per channel.
  * Writes mean, invstd, scale = gamma*invstd, shift = beta - mean*scale; updates running stats (unbiased var)
@@ -363,6 +374,20 @@ int fr_se_gscale_mlp_bwd(const void* g, const void* x, const float* scale, const
                          const float* hidden, const float* pooled, const float* w1, const float* w2, float* gpooled,
                          float* dw1, float* dw2, float* gz, float* gh, int B, int C, int R, int HW, int dtype,
                          void* stream);
+
+/* Round 4: fr_se_gscale_mlp_bwd that ALSO leaves the per-image sums the backward of the BatchNorm in front of the excite
+ * needs -- sums[b][0][c] = sum_hw g, [1] = sum_hw g*xhat, [2] = sum_hw xhat, xhat = (x - mean)*invstd -- and
+ * fr_se_bn_bwd_sums, which turns them into that BatchNorm's backward sums without another pass over (g, x):
+ *   o0[c] = sum_{b,hw} g' = sum_b (s*sums0 + HW*gse),   o1[c] = sum_{b,hw} g'*xhat = sum_b (s*sums1 + gse*sums2),
+ *   g' = g*s[b][c] + gse[b][c]  (gse = gpooled of the first call)   == fr_bn_bwd_reduce(se, gse) + fr_reduce_parts.
+ * The squeeze is re-associated (gs = scale*sum(g*x) + shift*sum(g)): equal to fr_se_gscale_mlp_bwd to fp32 rounding, not
+ * bit for bit.  Replaces the autograd of BatchNorm2d -> SEModule in bottleneck_IR_SE (model_irse.py:84-87). */
+int fr_se_gscale_mlp_bwd_sums(const void* g, const void* x, const float* scale, const float* shift, const float* mean,
+                              const float* invstd, const float* s, const float* hidden, const float* pooled,
+                              const float* w1, const float* w2, float* gpooled, float* dw1, float* dw2, float* gz, float* gh,
+                              float* sums, int B, int C, int R, int HW, int dtype, void* stream);
+int fr_se_bn_bwd_sums(const float* sums, const float* s, const float* gse, int B, int C, int HW, float* o0, float* o1,
+                      void* stream);
 
 /* ---- output layer pieces (model_irse.py:144-148) */
 /* a[b][(h*7+w)*C + c] = dropout(x*scale+shift): mask from a counter hash of (seed, element index in the

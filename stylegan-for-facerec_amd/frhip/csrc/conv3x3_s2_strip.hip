@@ -568,30 +568,21 @@ int by_pro(const FrConvArgs& a, hipStream_t st) {
   FR_UNSUPPORTED("fr_conv3x3_s2_strip: unknown prologue");
 }
 
-// FRHIP_S2_VARIANT=0: the round-2 table (A/B switch, tools/kbench.py).  Default 1 (round 3): instances in which ONE weight
-// fragment feeds as many M tiles as the registers allow -- a wave's cost per MFMA is its private weight stream from L2
-// (conv3x3_strip.hip, variant 4):
+// The table (round 3; its round-2 predecessor behind FRHIP_S2_VARIANT=0 was removed in round 4): instances in which ONE
+// weight fragment feeds as many M tiles as the registers allow -- a wave's cost per MFMA is its private weight stream from L2
+// (conv3x3_strip.hip):
 //   128 @28: 8 waves x (13 tiles x 1 column) instead of 4 x 2 waves x (7 x 2): 0.139 -> 0.116 ms forward, 0.193 -> 0.168 gradient
 //   256 @14 forward: the whole image (13 tiles) x 1 column, output channels over two workgroups (123 KB plane);
 //            the gradient keeps 7-row strips: its g strip stays resident beside the output tile (178 KB otherwise)
 //   512 @7:  two images per workgroup (7 tiles x 1 column), output channels over four workgroups; odd batches keep the
 //            one-image instance
-int s2_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FRHIP_S2_VARIANT");
-    v = e ? atoi(e) : 1;
-  }
-  return v;
-}
 
 // strips (= partial-sum rows per output class) of a served shape, 0 = not served: the four IR stage transitions
 int s2_strips(int B, int C, int WL, int mode) {
-  const bool v1 = s2_variant() >= 1;
   if (C == 64 && WL == 56) return B * 28;   // 2 low-res rows per workgroup
   if (C == 128 && WL == 28) return B * 4;   // 7 rows
-  if (C == 256 && WL == 14) return (v1 && mode == 0) ? B : B * 2;
-  if (C == 512 && WL == 7) return (v1 && B % 2 == 0) ? B / 2 : B;
+  if (C == 256 && WL == 14) return mode == 0 ? B : B * 2;
+  if (C == 512 && WL == 7) return B % 2 == 0 ? B / 2 : B;
   return 0;
 }
 
@@ -639,15 +630,12 @@ extern "C" int fr_conv3x3_s2_strip(const FrConvArgs* args, void* stream) {
   SHAPE(64, 56, 2, 2, 4)
   // 128 -> 128: 7-row strips (196 pixels per weight pass) although only one workgroup then fits a CU: 0.166 -> 0.140 ms
   // forward, 0.221 -> 0.206 ms gradient against the 4-row strips (the kernel is bound by the weight stream)
-  if (s2_variant() >= 1) {
-    SHAPE(128, 28, 7, 8, 8)
-    if (a.SC == 256 && WLo == 14 && a.mode == 0) return by_pro<256, 128, 14, 14, 8, 8, 0, 2, 1>(a, st);
-    if (a.SC == 512 && WLo == 7 && a.B % 2 == 0) {
-      if (a.mode == 0) return by_pro<512, 128, 7, 7, 8, 8, 0, 4, 2>(a, st);
-      return by_pro<512, 128, 7, 7, 8, 8, 1, 4, 2>(a, st);
-    }
+  SHAPE(128, 28, 7, 8, 8)
+  if (a.SC == 256 && WLo == 14 && a.mode == 0) return by_pro<256, 128, 14, 14, 8, 8, 0, 2, 1>(a, st);
+  if (a.SC == 512 && WLo == 7 && a.B % 2 == 0) {
+    if (a.mode == 0) return by_pro<512, 128, 7, 7, 8, 8, 0, 4, 2>(a, st);
+    return by_pro<512, 128, 7, 7, 8, 8, 1, 4, 2>(a, st);
   }
-  SHAPE(128, 28, 7, 4, 8)
   SHAPE(256, 14, 7, 8, 8)
   SHAPE(512, 7, 7, 8, 8)
 #undef SHAPE

@@ -475,6 +475,67 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
       }
       // in-launch reduction of the rows (tail.h); everything in LDS is dead by now
       fr_tail<NTH>(p.tail, p.part, (int)(gridDim.x / NSPL), gridDim.x, smem, tid);
+#ifdef FRHIP_EXP_GRIDBAR
+      // EXPERIMENT (never in the product library): what the grid-wide synchronisation of a fused
+      // conv2 -> BatchNorm statistics -> apply epilogue would cost inside this launch.  Two counter barriers (release /
+      // relaxed sc1 poll / acquire, MI355X_MICROARCH.md "barrier-counter") around a distributed finalize: workgroup w adds
+      // column w of the partial rows and publishes (scale, shift) of channel w, then every thread reads its channels'
+      // coefficients back.  The counters live in p.cos_t (unused by this kernel): [0] arrivals, [1] exits.
+      if (p.cos_t && NSPL == 1 && (int)gridDim.x >= COUT) {
+        unsigned* cnt = reinterpret_cast<unsigned*>(p.cos_t);
+        float* coef = reinterpret_cast<float*>(cnt + 16);  // [2][COUT]
+        auto grid_barrier = [&](unsigned target) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 22))
+              __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          __syncthreads();
+        };
+        grid_barrier(gridDim.x);
+        if ((int)blockIdx.x < COUT) {  // channel blockIdx.x: sums over all rows (256 rows x 2 floats, one round trip)
+          float a = 0.f, c = 0.f;
+          for (int r = tid; r < (int)gridDim.x; r += NTH) {
+            a += p.part[((size_t)r * 2 + 0) * COUT + blockIdx.x];
+            c += p.part[((size_t)r * 2 + 1) * COUT + blockIdx.x];
+          }
+          float* red2 = reinterpret_cast<float*>(smem);
+          red2[tid] = a;
+          red2[NTH + tid] = c;
+          __syncthreads();
+          if (tid == 0) {
+            float sa = 0.f, sc = 0.f;
+            for (int t = 0; t < NTH; ++t) {
+              sa += red2[t];
+              sc += red2[NTH + t];
+            }
+            const float m = sa / (float)(gridDim.x * C::M), var = sc / (float)(gridDim.x * C::M) - m * m;
+            const float is = rsqrtf(fmaxf(var, 0.f) + 1e-5f);
+            __hip_atomic_store(coef + blockIdx.x, is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(coef + COUT + blockIdx.x, -m * is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        grid_barrier(2u * gridDim.x);
+        float acc2 = 0.f;
+        for (int c = tid; c < 2 * COUT; c += NTH) acc2 += coef[c];
+        if (acc2 == 123456.789f) p.part[0] = acc2;  // keep the reads
+        __syncthreads();
+        if (tid == 0) {
+          const unsigned done = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (done + 1 == gridDim.x) {
+            __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+#endif
     }
   }
 }
@@ -526,20 +587,12 @@ int by_pro(const FrConvArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// Shape table.  Variant >= 1 serves the 64- and 128-channel layers with 4-wave workgroups on shorter strips so
-// that two workgroups are resident per CU and overlap each other's load / epilogue phases; variant 2 adds the
-// two-images-per-workgroup instance of the 7x7 stage, variant 3 the four-images one, variant 4 (default) the
-// one-output-tile-column-per-wave instances of the stage-entry shapes; FRHIP_STRIP_VARIANT=0 is the one-workgroup-per-CU
-// table (A/B switch for tools/kbench.py, tools/ab_variant.sh and bench.py).
-static int strip_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FRHIP_STRIP_VARIANT");
-    v = e ? atoi(e) : 4;
-  }
-  return v;
-}
-
+// Shape table.  (Rounds 1-3 carried five generations of it behind FRHIP_STRIP_VARIANT=0..4 for same-box A/B runs: the
+// one-workgroup-per-CU instances of the 64- and 128-channel layers, the 7 x 2 tile instances of the stage-entry shapes and
+// the one- / two-image 7x7 instances as the DEFAULT.  Table 4 -- 4-wave workgroups, two resident per CU, at 64 / 128
+// channels; one tile column per wave at the stage entries; 2 - 4 images per workgroup at 7x7 -- ran 0.8 ms per step faster
+// than table 0 and has a round of green tests behind it; the older generations were removed in round 4, their measurements
+// stay in the comments below and in DESIGN.md section 3.)
 // fewer whole-image workgroups than ~3/4 of the CUs: prefer the instances that split an image over two workgroups
 // FRHIP_SPLIT_STRIPS=1 forces them at any batch: 2 x B workgroups of half the output channels instead of B whole-image
 // ones, so that CUs taken by another resident kernel (RCCL's all-reduce under data parallelism) cost a proportional
@@ -550,27 +603,24 @@ static bool small_batch(int B) {
     const char* e = getenv("FRHIP_SPLIT_STRIPS");
     force = (e && e[0] == '1') ? 1 : 0;
   }
-  return (B <= 160 || force) && strip_variant() >= 2;
+  return B <= 160 || force;
 }
 
 // rows per strip for a shape (0 = not served)
 static int strip_rows(int Cin, int Cout, int W) {
-  const bool v1 = strip_variant() >= 1;
-#define SHAPE(ci, co, w, rows0, rows1) \
-  if (Cin == ci && Cout == co && W == w) return v1 ? rows1 : rows0;
-  SHAPE(64, 64, 112, 4, 2)
-  SHAPE(64, 64, 56, 7, 7)
-  if (Cin == 64 && Cout == 128 && W == 56 && strip_variant() >= 4) return 4;
-  SHAPE(64, 128, 56, 7, 7)
-  SHAPE(128, 64, 56, 7, 7)
-  SHAPE(128, 128, 28, 14, 7)
-  SHAPE(128, 256, 28, 7, 7)
-  SHAPE(256, 128, 28, 7, 7)
-  SHAPE(256, 256, 14, 14, 14)
-  SHAPE(256, 512, 14, 14, 14)
-  if (Cin == 512 && Cout == 256 && W == 14 && strip_variant() >= 4) return 14;
-  SHAPE(512, 256, 14, 7, 7)
-  SHAPE(512, 512, 7, 7, 7)
+#define SHAPE(ci, co, w, rows) \
+  if (Cin == ci && Cout == co && W == w) return rows;
+  SHAPE(64, 64, 112, 2)
+  SHAPE(64, 64, 56, 7)
+  SHAPE(64, 128, 56, 4)
+  SHAPE(128, 64, 56, 7)
+  SHAPE(128, 128, 28, 7)
+  SHAPE(128, 256, 28, 7)
+  SHAPE(256, 128, 28, 7)
+  SHAPE(256, 256, 14, 14)
+  SHAPE(256, 512, 14, 14)
+  SHAPE(512, 256, 14, 14)
+  SHAPE(512, 512, 7, 7)
 #undef SHAPE
   return 0;
 }
@@ -587,9 +637,9 @@ extern "C" int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi) 
   if (Cin == 256 && Cout == 512 && W == 14 && epi != FR_EPI_STORE) return 0;
   if (Cin == 64 && Cout == 64 && (W == 112 || W == 56) && fr_roll64_enabled()) return fr_roll64_parts(B, W);
   const int rows = strip_rows(Cin, Cout, W);
-  if (Cin == 512 && Cout == 512 && W == 7 && strip_variant() >= 3 && B % 2 == 0 && small_batch(B)) return B / 2;
-  if (Cin == 512 && Cout == 512 && W == 7 && strip_variant() >= 3 && B % 4 == 0) return B / 4;  // four images per strip
-  if (Cin == 512 && Cout == 512 && W == 7 && strip_variant() >= 2 && B % 2 == 0) return B / 2;  // two images per strip
+  if (Cin == 512 && Cout == 512 && W == 7 && B % 2 == 0 && small_batch(B)) return B / 2;
+  if (Cin == 512 && Cout == 512 && W == 7 && B % 4 == 0) return B / 4;  // four images per strip
+  if (Cin == 512 && Cout == 512 && W == 7 && B % 2 == 0) return B / 2;  // two images per strip
   return rows ? B * (W / rows) : 0;
 }
 
@@ -601,20 +651,15 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
     FR_UNSUPPORTED("fr_conv3x3_strip: only square stride-1 3x3 bf16 convolutions");
   if (a.lda % 8 || a.ldc % 8 || (a.aux && a.ldaux % 8)) FR_UNSUPPORTED("fr_conv3x3_strip: strides must be 16-byte multiples");
   if (a.SC == 64 && a.N == 64 && (a.SW == 112 || a.SW == 56) && fr_roll64_enabled()) return fr_roll64_launch(a, st);
-  const bool v1 = strip_variant() >= 1;
 #define SHAPE(ci, co, w, rows, wn, nw) \
   if (a.SC == ci && a.N == co && a.SW == w) return by_pro<ci, co, w, rows, wn, nw>(a, st);
   // (round 3: 128 -> 128 @28 as 8 waves x (25 tiles x 1 column) on half images, one workgroup per CU, half the weight stream:
   // 0.143 / 0.151 ms forward / data gradient against 0.068 / 0.070 for the two resident 4-wave workgroups below)
-  if (v1) {  // measured (tools/kbench.py, B=256): 1.1-1.45x over the 8-wave instances at these three shapes
-    SHAPE(64, 64, 112, 2, 2, 4)
-    SHAPE(64, 64, 56, 7, 2, 4)
-    SHAPE(128, 128, 28, 7, 4, 4)
-  } else {
-    SHAPE(64, 64, 112, 4, 2, 8)
-    SHAPE(64, 64, 56, 7, 2, 8)
-    SHAPE(128, 128, 28, 14, 4, 8)
-  }
+  // 4-wave workgroups, two resident per CU -- measured (tools/kbench.py, B=256) 1.1-1.45x over the 8-wave one-per-CU
+  // instances <64,64,112,4,2,8>, <64,64,56,7,2,8>, <128,128,28,14,4,8> of round 1 (removed in round 4)
+  SHAPE(64, 64, 112, 2, 2, 4)
+  SHAPE(64, 64, 56, 7, 2, 4)
+  SHAPE(128, 128, 28, 7, 4, 4)
   // 256 -> 256 @14 (half of all FLOPs): 8 waves x (13 x 2) accumulator tiles on the whole image.  Measured and rejected
   // at B=256 (tools/kbench.py): 4-wave half-height strips 0.101 ms, the same with the channels split over two
   // workgroups (NSPL = 2, no spills) 0.093 ms, 8 waves x (7 x 4) tiles 0.114 ms (spills) -- against 0.062 ms here.
@@ -629,25 +674,18 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
   if (a.SC == 256 && a.N == 256 && a.SW == 14 && small_batch(a.B)) return by_pro<256, 128, 14, 14, 8, 8, 2>(a, st);
   SHAPE(256, 256, 14, 14, 8, 8)
   // 64 -> 128 @56 (one forward launch per step): 4-row strips, two resident 4-wave workgroups per CU: 0.170-0.174 -> 0.159-0.160 ms
-  if (strip_variant() >= 4) {
-    SHAPE(64, 128, 56, 4, 4, 4)
-  }
-  SHAPE(64, 128, 56, 7, 4, 8)
+  // against the 7-row 8-wave instance <64,128,56,7,4,8> (removed)
+  SHAPE(64, 128, 56, 4, 4, 4)
   // Round 3: what a wave pays per MFMA is its private weight stream (16 B per lane from L2 for every (tap, 32 channels,
   // 16 output channels)): an instance is fast when one weight fragment feeds ~13 M tiles.  The data gradients of the three
-  // stage-entry convolutions ran 7 tiles x 2 columns per wave; with ONE 16-channel column per wave and 13 tiles (128 -> 64:
-  // 4 x 2 waves; 256 -> 128: 8 x 1; 512 -> 256: the whole image in two channel stages, output channels over two workgroups)
-  // the same launches take 0.254 -> 0.202, 0.202 -> 0.150 and 0.177 -> 0.132 ms (tools/ab_variant.sh, same box), the step
-  // 0.2 ms less.
-  if (strip_variant() >= 4) {
-    SHAPE(128, 64, 56, 7, 4, 8)
-    SHAPE(256, 128, 28, 7, 8, 8)
-    if (a.SC == 512 && a.N == 256 && a.SW == 14) return by_pro<512, 128, 14, 14, 8, 8, 2, 1, 2>(a, st);
-  }
-  SHAPE(128, 64, 56, 7, 2, 8)
+  // stage-entry convolutions ran 7 tiles x 2 columns per wave (<128,64,56,7,2,8>, <256,128,28,7,4,8>, <512,256,14,7,8,8>:
+  // removed in round 4); with ONE 16-channel column per wave and 13 tiles (128 -> 64: 4 x 2 waves; 256 -> 128: 8 x 1;
+  // 512 -> 256: the whole image in two channel stages, output channels over two workgroups) the same launches take
+  // 0.254 -> 0.202, 0.202 -> 0.150 and 0.177 -> 0.132 ms (same box), the step 0.2 ms less.
+  SHAPE(128, 64, 56, 7, 4, 8)
+  SHAPE(256, 128, 28, 7, 8, 8)
+  if (a.SC == 512 && a.N == 256 && a.SW == 14) return by_pro<512, 128, 14, 14, 8, 8, 2, 1, 2>(a, st);
   SHAPE(128, 256, 28, 7, 8, 8)
-  SHAPE(256, 128, 28, 7, 4, 8)
-  SHAPE(512, 256, 14, 7, 8, 8)
   // 512 -> 512 @7: two images per workgroup, 256 resident input channels at a time, output channels split over two
   // workgroups: every weight fragment now feeds 98 pixels instead of 49 and the M tiles are 12 % instead of 23 % padding
   // Round 3: FOUR images per workgroup, 128 resident input channels at a time (four stages of the strip), output channels
@@ -656,10 +694,10 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
   // data gradient at B = 256 (tools/kbench.py, same box), no scratch, 100 KB of LDS.
   // ... at small batches (IR-SE-101 trains at 128 images per GPU: 32 four-image strips x 4 = 128 workgroups would leave half
   // the CUs idle) two images per workgroup with the same split: B / 2 x 4 workgroups
-  if (a.SC == 512 && a.N == 512 && a.SW == 7 && strip_variant() >= 3 && a.B % 2 == 0 && small_batch(a.B))
+  if (a.SC == 512 && a.N == 512 && a.SW == 7 && a.B % 2 == 0 && small_batch(a.B))
     return by_pro<512, 128, 7, 7, 8, 8, 4, 2, 2>(a, st);
-  if (a.SC == 512 && a.N == 512 && a.SW == 7 && strip_variant() >= 3 && a.B % 4 == 0) return by_pro<512, 128, 7, 7, 8, 8, 4, 4, 4>(a, st);
-  if (a.SC == 512 && a.N == 512 && a.SW == 7 && strip_variant() >= 2 && a.B % 2 == 0) return by_pro<512, 256, 7, 7, 8, 8, 2, 2, 2>(a, st);
+  if (a.SC == 512 && a.N == 512 && a.SW == 7 && a.B % 4 == 0) return by_pro<512, 128, 7, 7, 8, 8, 4, 4, 4>(a, st);
+  if (a.SC == 512 && a.N == 512 && a.SW == 7 && a.B % 2 == 0) return by_pro<512, 256, 7, 7, 8, 8, 2, 2, 2>(a, st);
   SHAPE(512, 512, 7, 7, 8, 8)
 #undef SHAPE
   if (a.SC == 256 && a.N == 512 && a.SW == 14 && a.epi == FR_EPI_STORE) {

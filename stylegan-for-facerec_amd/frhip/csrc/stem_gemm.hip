@@ -14,12 +14,48 @@ namespace {
 
 constexpr int SN = 64;  // output channels of the stem
 
+// Round 4: the im2col rows need not exist.  X0 [B*112*112][K] is 205 MB written by fr_stem_im2col and read back by both
+// GEMMs (410 MB + a launch per step in the forward pass, 205 MB more in the backward pass) to carry 38.5 MB of image.  With a
+// StemSrc the two kernels build their 16-byte row chunks from the fp32 NCHW batch (and pSp's constant average image) in
+// registers -- the same values, rounded to bf16 the same way, so the results are bit-identical to the X0 path.
+struct StemSrc {
+  const float* x;    // [B][C][H][W] fp32, or NULL: read the materialised rows
+  const float* avg;  // [Cavg][H][W] or NULL
+  int H, W, C, Cavg;
+  float inv_w, inv_hw;
+};
+
+// im2col row `row` = pixel (b, h, w), elements k0 .. k0 + 7 (k = tap*CT + c, zero beyond 9*CT and outside the image)
+template <int CT>
+__device__ __forceinline__ U128 stem_row_chunk(const StemSrc& s, int row, int k0) {
+  uint32_t b, rem, h, w;
+  fast_divmod((uint32_t)row, (uint32_t)(s.H * s.W), s.inv_hw, b, rem);
+  fast_divmod(rem, (uint32_t)s.W, s.inv_w, h, w);
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = k0 + j;
+    const int tap = k / CT, c = k - tap * CT;
+    const int th = tap / 3;
+    const int sh = (int)h + th - 1, sw = (int)w + (tap - th * 3) - 1;
+    const bool ok = k < 9 * CT && (unsigned)sh < (unsigned)s.H && (unsigned)sw < (unsigned)s.W;
+    const int shc = ok ? sh : (int)h, swc = ok ? sw : (int)w;  // always a valid address; the value is dropped
+    const int cc = k < 9 * CT ? c : 0;
+    const float* p = (CT > 3 && cc >= s.C) ? s.avg + ((size_t)(cc - s.C) * s.H + shc) * s.W + swc
+                                           : s.x + (((size_t)b * s.C + cc) * s.H + shc) * s.W + swc;
+    const float v = *p;
+    f[j] = ok ? v : 0.f;
+  }
+  return pack16<bf16_t>(f);
+}
+
 // ------------------------------------------------------------------------------------------ forward + BN statistics
 // out[m][n] = sum_k X[m][k] W[n][k];  part[blk][0][n] = sum_m out, part[blk][1][n] = sum_m out^2 (of the rounded bf16)
-template <int K>
+template <int K, bool IMPL>
 __global__ __launch_bounds__(256) void stem_gemm_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wp,
                                                         bf16_t* __restrict__ out, float* __restrict__ part, int M,
-                                                        const FrTail tail) {
+                                                        const FrTail tail, const StemSrc src) {
+  constexpr int CT = K == 32 ? 3 : 6;
   constexpr int KS = K / 32;
   constexpr int OSTR = SN * 2 + 16;                    // per-wave transpose tile [16 rows][64 ch], padded rows
   __shared__ __attribute__((aligned(16))) char tiles[4 * 16 * OSTR];
@@ -52,7 +88,10 @@ __global__ __launch_bounds__(256) void stem_gemm_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       s16x8 af = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (ok) af = *reinterpret_cast<const s16x8*>(X + (size_t)row * K + kk * 32 + fq * 8);
+      if (ok) {
+        if (IMPL) af = __builtin_bit_cast(s16x8, stem_row_chunk<CT>(src, row, kk * 32 + fq * 8));
+        else af = *reinterpret_cast<const s16x8*>(X + (size_t)row * K + kk * 32 + fq * 8);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], af, acc[j], 0, 0, 0);
     }
@@ -131,9 +170,11 @@ struct StemBn {
   float inv_count;
 };
 
-template <int K, bool BN>
+template <int K, bool BN, bool IMPL = false>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
-                                                         float* __restrict__ slab, int M, const StemBn bn) {
+                                                         float* __restrict__ slab, int M, const StemBn bn,
+                                                         const StemSrc src) {
+  constexpr int CT = K == 32 ? 3 : 6;
   constexpr int RB = 64;                     // rows staged per trip (two 32-deep MFMA steps)
   constexpr int GSTR = SN * 2 + 32;          // conflict-free row strides for the transposing reads
   constexpr int XSTR = K * 2 + 32;
@@ -191,7 +232,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16_t* __restric
         }
       } else if (idx < NCH) {
         const int a = idx - GCH, r = a / (K / 8), c = a - r * (K / 8);
-        if (row0 + r < M) v[u] = ld16(X + (size_t)(row0 + r) * K + c * 8);
+        if (row0 + r < M) v[u] = IMPL ? stem_row_chunk<CT>(src, row0 + r, c * 8) : ld16(X + (size_t)(row0 + r) * K + c * 8);
       }
     }
     __syncthreads();  // the previous trip's fragments have been read
@@ -226,6 +267,25 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16_t* __restric
 
 }  // namespace
 
+namespace {
+int stem_src(const float* x, const float* avg, int B, int H, int W, int C, int Cavg, int K, StemSrc* s, long long* M) {
+  if (!x || B < 1 || H < 1 || W < 1) FR_UNSUPPORTED("stem (implicit im2col): x and a positive geometry are required");
+  if (!((K == 32 && C == 3 && Cavg == 0) || (K == 64 && C + Cavg == 6 && C >= 1 && (Cavg == 0 || avg))))
+    FR_UNSUPPORTED("stem (implicit im2col): 3 image channels (K = 32) or 6 channels in all, image + average image (K = 64)");
+  *M = (long long)B * H * W;
+  if (*M >= (1ll << 24)) FR_UNSUPPORTED("stem (implicit im2col): fewer than 2^24 pixels per launch");
+  s->x = x;
+  s->avg = avg;
+  s->H = H;
+  s->W = W;
+  s->C = C;
+  s->Cavg = Cavg;
+  s->inv_w = 1.0f / (float)W;
+  s->inv_hw = 1.0f / (float)(H * W);
+  return 0;
+}
+}  // namespace
+
 extern "C" int fr_stem_gemm(const void* X, const void* Wp, void* out, float* part, long long M, int K, int nblocks,
                             const FrTail* tail, void* stream) {
   if ((K != 32 && K != 64) || M < 1 || M >= (1ll << 31) - 64 || nblocks < 1)
@@ -233,12 +293,31 @@ extern "C" int fr_stem_gemm(const void* X, const void* Wp, void* out, float* par
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   FrTail t;
   if (fr_tail_prepare(tail ? *tail : FrTail{}, 2, SN, 1, &t, part != nullptr)) return -1;
+  const StemSrc none = {};
   if (K == 32)
-    hipLaunchKernelGGL(stem_gemm_kernel<32>, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)X, (const bf16_t*)Wp,
-                       (bf16_t*)out, part, (int)M, t);
+    hipLaunchKernelGGL((stem_gemm_kernel<32, false>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)X, (const bf16_t*)Wp,
+                       (bf16_t*)out, part, (int)M, t, none);
   else
-    hipLaunchKernelGGL(stem_gemm_kernel<64>, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)X, (const bf16_t*)Wp,
-                       (bf16_t*)out, part, (int)M, t);
+    hipLaunchKernelGGL((stem_gemm_kernel<64, false>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)X, (const bf16_t*)Wp,
+                       (bf16_t*)out, part, (int)M, t, none);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_stem_gemm_x(const float* x, const float* avg, const void* Wp, void* out, float* part, int B, int H, int W,
+                              int C, int Cavg, int K, int nblocks, const FrTail* tail, void* stream) {
+  StemSrc src;
+  long long M;
+  if (stem_src(x, avg, B, H, W, C, Cavg, K, &src, &M)) return -1;
+  if (nblocks < 1) FR_UNSUPPORTED("fr_stem_gemm_x: nblocks >= 1");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  FrTail t;
+  if (fr_tail_prepare(tail ? *tail : FrTail{}, 2, SN, 1, &t, part != nullptr)) return -1;
+  if (K == 32)
+    hipLaunchKernelGGL((stem_gemm_kernel<32, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)nullptr,
+                       (const bf16_t*)Wp, (bf16_t*)out, part, (int)M, t, src);
+  else
+    hipLaunchKernelGGL((stem_gemm_kernel<64, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)nullptr,
+                       (const bf16_t*)Wp, (bf16_t*)out, part, (int)M, t, src);
   FR_LAUNCH_CHECK();
 }
 
@@ -247,12 +326,13 @@ extern "C" int fr_stem_wgrad(const void* G, const void* X, float* slab, long lon
     FR_UNSUPPORTED("fr_stem_wgrad: K must be 32 or 64, 0 < M < 2^31, nblocks >= 1");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const StemBn none = {};
+  const StemSrc nosrc = {};
   if (K == 32)
     hipLaunchKernelGGL((stem_wgrad_kernel<32, false>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X,
-                       slab, (int)M, none);
+                       slab, (int)M, none, nosrc);
   else
     hipLaunchKernelGGL((stem_wgrad_kernel<64, false>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X,
-                       slab, (int)M, none);
+                       slab, (int)M, none, nosrc);
   FR_LAUNCH_CHECK();
 }
 
@@ -266,11 +346,33 @@ extern "C" int fr_stem_wgrad_bn(const void* G, const void* Y, const void* X, con
     FR_UNSUPPORTED("fr_stem_wgrad_bn: every BatchNorm / PReLU coefficient vector is required");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const StemBn bn = {(const bf16_t*)Y, mean, invstd, scale, shift, slope, gamma, s0, s1, inv_count};
+  const StemSrc nosrc = {};
   if (K == 32)
     hipLaunchKernelGGL((stem_wgrad_kernel<32, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X,
-                       slab, (int)M, bn);
+                       slab, (int)M, bn, nosrc);
   else
     hipLaunchKernelGGL((stem_wgrad_kernel<64, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X,
-                       slab, (int)M, bn);
+                       slab, (int)M, bn, nosrc);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_stem_wgrad_bn_x(const void* G, const void* Y, const float* x, const float* avg, const float* mean,
+                                  const float* invstd, const float* scale, const float* shift, const float* slope,
+                                  const float* gamma, const float* s0, const float* s1, float inv_count, float* slab, int B,
+                                  int H, int W, int C, int Cavg, int K, int nblocks, void* stream) {
+  StemSrc src;
+  long long M;
+  if (stem_src(x, avg, B, H, W, C, Cavg, K, &src, &M)) return -1;
+  if (nblocks < 1) FR_UNSUPPORTED("fr_stem_wgrad_bn_x: nblocks >= 1");
+  if (!Y || !mean || !invstd || !scale || !shift || !slope || !gamma || !s0 || !s1)
+    FR_UNSUPPORTED("fr_stem_wgrad_bn_x: every BatchNorm / PReLU coefficient vector is required");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const StemBn bn = {(const bf16_t*)Y, mean, invstd, scale, shift, slope, gamma, s0, s1, inv_count};
+  if (K == 32)
+    hipLaunchKernelGGL((stem_wgrad_kernel<32, true, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G,
+                       (const bf16_t*)nullptr, slab, (int)M, bn, src);
+  else
+    hipLaunchKernelGGL((stem_wgrad_kernel<64, true, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G,
+                       (const bf16_t*)nullptr, slab, (int)M, bn, src);
   FR_LAUNCH_CHECK();
 }

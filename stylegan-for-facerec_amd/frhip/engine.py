@@ -247,7 +247,7 @@ class BackbonePlan(object):
         # 224-workgroup 256x256@14 launch 0.069 ms against 0.068 with 256: 12 % fewer slabs to write and sum), and the 32 CUs
         # without a persistent weight-gradient workgroup take the channel-wise kernels of the main stream at full speed:
         # 15.06-15.10 against 15.13-15.16 ms per step (192: 15.09, 240: 15.25, 160: 15.15; FRHIP_WGRAD_WGS, one box).
-        self.wgrad_wgs = max(64, int(os.environ.get("FRHIP_WGRAD_WGS", "224")))
+        self.wgrad_wgs = min(256, max(64, int(os.environ.get("FRHIP_WGRAD_WGS", "224"))))  # the slab sum takes <= 256 groups
         self.stream2 = ctypes.c_void_p(self.stream2_t.cuda_stream)
         self.S = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
         self.generation = 0
@@ -310,7 +310,14 @@ class BackbonePlan(object):
         C0 = self.units[0].cin if self.body_only else 64  # channels of the first unit's input
         self.z0 = self._act(M0, C0)
         if not self.body_only:
-            self.X0 = self._act(M0, self.K0)
+            # Round 4: the two stem GEMMs build their im2col rows from the fp32 batch in registers (fr_stem_gemm_x /
+            # fr_stem_wgrad_bn_x: bit-identical to the materialised rows) -- X0, 205 MB at batch 256, is neither written nor read
+            # and fr_stem_im2col is gone from the step (FRHIP_STEM_IMPLICIT=0: A/B switch)
+            self.stem_x = (self.use_stem_gemm and os.environ.get("FRHIP_STEM_IMPLICIT", "1") != "0" and
+                           os.environ.get("FRHIP_NO_STEM_BNFUSE", "0") != "1" and M0 < (1 << 24) and
+                           ((self.K0 == 32 and self.in_channels == 3 and self.avg_channels == 0) or
+                            (self.K0 == 64 and self.in_channels + self.avg_channels == 6)))
+            self.X0 = None if self.stem_x else self._act(M0, self.K0)
             self.y0 = self._act(M0, 64)
             self.W0p = torch.empty(64, self.K0, device=dev, dtype=self.tdtype)
             self.gW0p = torch.zeros(64, self.K0, device=dev)
@@ -672,8 +679,14 @@ class BackbonePlan(object):
             self.l_im2col = None  # bound per call (input pointer changes)
             if self.use_stem_gemm:  # 3.2 M rows x 64 columns x K0: the row-streaming kernels of stem_gemm.hip
                 mt0 = int(min(2048, (self.M0 + 63) // 64))
-                L.append(ops.call("fr_stem_gemm", self.X0, self.W0p, self.y0, self.part, self.M0, self.K0, mt0,
-                                  self._bn_tail(self.bn0, self.M0), st))
+                if self.stem_x:  # x / avg pointers are bound per call (run_forward)
+                    self.l_stem_fwd = ops.call("fr_stem_gemm_x", None, None, self.W0p, self.y0, self.part, B, S, S,
+                                               self.in_channels, self.avg_channels, self.K0, mt0,
+                                               self._bn_tail(self.bn0, self.M0), st)
+                    L.append(self.l_stem_fwd)
+                else:
+                    L.append(ops.call("fr_stem_gemm", self.X0, self.W0p, self.y0, self.part, self.M0, self.K0, mt0,
+                                      self._bn_tail(self.bn0, self.M0), st))
             else:
                 mt0 = (self.M0 + 127) // 128
                 L.append(ops.conv(st, fr, src=self.X0, w=self.W0p, out=self.y0, B=self.M0, RH=1, RW=1, SH=1, SW=1,
@@ -973,6 +986,11 @@ class BackbonePlan(object):
                     L.append(_EvWait(self.stream1_t, unit_done[tgt]))
             merged = self.dual and self.merge_edges
             S = [] if merged else L  # side-stream launches of this unit (merged: enqueued behind ONE edge)
+            # (Round 4, measured and removed again -- profiles/r04_ab_edge2_wgrad_order.txt: without the second main -> side edge
+            # in front of conv1's weight gradient, which is redundant on a FIFO side stream, 15.13-15.18 against 15.18-15.19 ms:
+            # nothing; conv1's weight gradient BEFORE conv2's, i.e. right behind the data gradient it shares both operands with:
+            # 15.57 against 15.18 ms, slower.)
+            S2 = S
 
             def edge():
                 if not merged:
@@ -987,10 +1005,21 @@ class BackbonePlan(object):
                     g1 = self.se_scratch[0, :R * u.depth]
                 if g2 is None:
                     g2 = self.se_scratch[1, :R * u.depth]
-                # gradient wrt the excite scale (a pass over g and y2) + the MLP backward of the same image in one launch
-                L.append(ops.call("fr_se_gscale_mlp_bwd", g_out, d["y2"], bn2.scale, bn2.shift, d["s"], d["hidden"],
-                                  d["pooled"], u.se.fc1.weight, u.se.fc2.weight, d["gpooled"], g1, g2, d["gz"], d["gh"],
-                                  B, u.depth, R, HWo, fr, st))
+                # gradient wrt the excite scale (a pass over g and y2) + the MLP backward of the same image in one launch;
+                # round 4: the same pass leaves the per-image sums BN2's backward needs (FRHIP_SE_SUMS=0: the round-3 pair)
+                # MEASURED SLOWER (IR-SE-101 + CosFace(28000), bs 128: 19.50-19.52 against 19.22-19.30 ms per step; pSp bs 256:
+                # 17.31 against 17.22; profiles/r04_ab_se_sums.txt): the pass it deletes ran beside the weight gradients of the
+                # side stream, the extra work sits in a 128-workgroup launch that half the chip idles through.  Opt-in.
+                se_sums = os.environ.get("FRHIP_SE_SUMS", "0") == "1" and bn2.mod.training
+                if se_sums:
+                    d["sesums"] = torch.zeros(B, 3, u.depth, device=self.device)
+                    L.append(ops.call("fr_se_gscale_mlp_bwd_sums", g_out, d["y2"], bn2.scale, bn2.shift, bn2.mean,
+                                      bn2.invstd, d["s"], d["hidden"], d["pooled"], u.se.fc1.weight, u.se.fc2.weight,
+                                      d["gpooled"], g1, g2, d["gz"], d["gh"], d["sesums"], B, u.depth, R, HWo, fr, st))
+                else:
+                    L.append(ops.call("fr_se_gscale_mlp_bwd", g_out, d["y2"], bn2.scale, bn2.shift, d["s"], d["hidden"],
+                                      d["pooled"], u.se.fc1.weight, u.se.fc2.weight, d["gpooled"], g1, g2, d["gz"],
+                                      d["gh"], B, u.depth, R, HWo, fr, st))
                 se_kw = dict(se=d["s"], gse=d["gpooled"])
                 ready += [u.se.fc1.weight, u.se.fc2.weight]
             db, dg = self._bn_grads(bn2)
@@ -1011,9 +1040,12 @@ class BackbonePlan(object):
                     L.append(ops.call("fr_bn_bwd_coeffs", self.part, nb, u.depth, float(rout), u.bn2.weight, bn2.mean,
                                       bn2.invstd, 1 if ev else 0, db, dg, co[0], co[1], co[2], st))
             else:
-                t = self._sum_tail(3, u.depth, db, dg)
-                L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **self._tail_kw(t), **common))
-                self._reduce(L, nb, 3, u.depth, db, dg, tail=t)
+                if u.se is not None and se_sums:  # the sums come from the squeeze's per-image sums: no pass, no partial rows
+                    L.append(ops.call("fr_se_bn_bwd_sums", d["sesums"], d["s"], d["gpooled"], B, u.depth, HWo, db, dg, st))
+                else:
+                    t = self._sum_tail(3, u.depth, db, dg)
+                    L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **self._tail_kw(t), **common))
+                    self._reduce(L, nb, 3, u.depth, db, dg, tail=t)
                 s0, s1 = self._s01(bn2, db, dg)
                 L.append(ops.bn_bwd_apply(st, fr, gx=g_y2, gamma=u.bn2.weight, s0=s0, s1=s1, inv_count=1.0 / rout,
                                           **common))
@@ -1075,17 +1107,18 @@ class BackbonePlan(object):
                 edge()  # g_y1 / the slope partials, g_y2 (BN2 backward) and y1 are final
                 r = ops.call("fr_reduce_parts", part2, mt, 2, u.depth, gsl, None, None, self.stream2)
                 r.tstream = self.stream2_t
-                S.append(r)
+                S2.append(r)
             else:
                 self._reduce(L, mt, 2, u.depth, gsl, None)
             if gw2 is not None:
                 tiles = ((u.depth + 127) // 128) ** 2 * 9
                 if not self.side_slope and tsl is None:
                     edge()
-                ready += self._wgrad(S, param=u.conv2.weight, g=g_y2, src=d["y1"], dw=gw2, B=B, GH=u.Ho, GW=u.Ho,
-                                     Cout=u.depth, SH=u.H, SW=u.H, SC=u.depth, KH=3, KW=3, stride=u.stride, pad=1,
-                                     ldg=u.depth, lda=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight,
-                                     nsplit=_wgrad_slices(rout, tiles))
+                kw2 = dict(param=u.conv2.weight, g=g_y2, src=d["y1"], dw=gw2, B=B, GH=u.Ho, GW=u.Ho,
+                           Cout=u.depth, SH=u.H, SW=u.H, SC=u.depth, KH=3, KW=3, stride=u.stride, pad=1,
+                           ldg=u.depth, lda=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight,
+                           nsplit=_wgrad_slices(rout, tiles))
+                ready += self._wgrad(S2, **kw2)
             else:
                 ready.append(u.conv2.weight)
             # conv1: data gradient with the BN1-backward sums epilogue, then the weight gradient
@@ -1175,9 +1208,16 @@ class BackbonePlan(object):
             elif fuse:
                 # BN0 backward is applied while the gradient rows are staged: g_y0 is never materialised
                 nsl = int(min(1024 if self.K0 == 32 else 512, (self.M0 + 63) // 64))  # partials live in self.part
-                L.append(ops.call("fr_stem_wgrad_bn", g_out, self.y0, self.X0, self.bn0.mean, self.bn0.invstd,
-                                  self.bn0.scale, self.bn0.shift, sp.weight, sb.weight, s0, s1, 1.0 / self.M0,
-                                  self.part, self.M0, self.K0, nsl, st))
+                if self.stem_x:
+                    self.l_stem_bwd = ops.call("fr_stem_wgrad_bn_x", g_out, self.y0, None, None, self.bn0.mean,
+                                               self.bn0.invstd, self.bn0.scale, self.bn0.shift, sp.weight, sb.weight, s0,
+                                               s1, 1.0 / self.M0, self.part, B, self.S, self.S, self.in_channels,
+                                               self.avg_channels, self.K0, nsl, st)
+                    L.append(self.l_stem_bwd)
+                else:
+                    L.append(ops.call("fr_stem_wgrad_bn", g_out, self.y0, self.X0, self.bn0.mean, self.bn0.invstd,
+                                      self.bn0.scale, self.bn0.shift, sp.weight, sb.weight, s0, s1, 1.0 / self.M0,
+                                      self.part, self.M0, self.K0, nsl, st))
                 L.append(ops.call("fr_reduce_parts", self.part, nsl, 1, 64 * self.K0, self.gW0p, None, None, st))
             else:
                 nsl = int(min(_wgrad_slices(self.M0, 1), self.part.numel() // (64 * self.K0)))
@@ -1247,7 +1287,15 @@ class BackbonePlan(object):
         B, S = self.B, self.S
         st = self.stream
         avg = avg_image
-        ops.call("fr_stem_im2col", x, avg, self.X0, B, S, S, self.in_channels, self.avg_channels, self.K0, self.fr, st)()
+        if self.stem_x:
+            # the stem kernels read the batch itself: bind its address (and keep it alive until the backward pass has run)
+            self._x_ref = (x, avg)
+            self.l_stem_fwd.args[0], self.l_stem_fwd.args[1] = ops.ptr(x), ops.ptr(avg)
+            if getattr(self, "l_stem_bwd", None) is not None:
+                self.l_stem_bwd.args[2], self.l_stem_bwd.args[3] = ops.ptr(x), ops.ptr(avg)
+        else:
+            ops.call("fr_stem_im2col", x, avg, self.X0, B, S, S, self.in_channels, self.avg_channels, self.K0, self.fr,
+                     st)()
         od = self.out[1]
         p = float(od.p) if od.training else 0.0
         self.l_drop_fwd.args[7] = p

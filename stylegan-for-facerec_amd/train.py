@@ -219,10 +219,12 @@ def main():
     BACKBONE = DataParallel(backbone, None if crit is not None else head)
     ce = torch.nn.CrossEntropyLoss()
 
+    optimizer_loaded = False
     if opt_resume:  # reference train.py:227-232: before the first step (momentum buffers and the groups' LR come back)
         if os.path.isfile(opt_resume):
             print("Loading Optimizer Checkpoint '{}'".format(opt_resume))
             load_optimizer_checkpoint(optimizer, crit, torch.load(opt_resume, map_location=device))
+            optimizer_loaded = True
         else:
             print("No Checkpoint Found at '{}'. Please Have a Check or Continue to Train from Scratch".format(opt_resume))
     runner = (backbone.encoder if hasattr(backbone, "encoder") else backbone)._runner[0]
@@ -231,7 +233,12 @@ def main():
     if state_resume and os.path.isfile(state_resume):
         state = torch.load(state_resume, map_location="cpu")
         start_epoch, batch, runner.step_seed = int(state["epoch"]), int(state["batch"]), int(state["dropout_stream"])
-        lr_stage_done = state.get("lr_stage_applied")  # an unfinished epoch whose LR stage is already in the optimizer file
+        # an unfinished epoch whose LR stage is already in the optimizer file -- honoured only if that file was really
+        # loaded: a State_* file alone carries no learning rate, and skipping schedule_lr then would lose the division
+        lr_stage_done = state.get("lr_stage_applied") if optimizer_loaded else None
+        if state.get("lr_stage_applied") is not None and not optimizer_loaded:
+            print("State file marks the LR stage of epoch {} as applied, but no optimizer checkpoint was loaded: "
+                  "the stage is applied again".format(state.get("lr_stage_applied")))
         if "torch_rng" in state:
             torch.set_rng_state(state["torch_rng"])
             n = state["numpy_rng"]

@@ -1480,7 +1480,7 @@ def test_dropout_in_flatten_order_equals_the_nhwc_kernels(K, dname, B, C, HW, p)
     assert torch.equal(g0, out)
 
 
-@pytest.mark.parametrize("B,O,Kd", [(256, 512, 25088), (5, 512, 25088), (300, 128, 2048), (17, 64, 128)])
+@pytest.mark.parametrize("B,O,Kd", [(256, 512, 25088), (5, 512, 25088), (300, 128, 2048), (17, 128, 128)])
 def test_linear_on_the_master_weight(K, B, O, Kd):
     """fr_linear_fwd / fr_linear_dgrad (csrc/linear_gemm.hip): Linear(K, O) with the fp32 master weight as the GEMM operand
     (rounded to bf16 in registers), bf16 activations, fp32 accumulation -- against torch on the same rounded operands.
@@ -1570,3 +1570,103 @@ def test_igemm_tile_width_changes_only_the_partial_sum_order(K, dname, mode, N, 
     if mode == 0 and epi == _lib.EPI_STORE:
         ref = F.conv2d(src_t, w_t, padding=1)
         assert relerr(from_nhwc(o64.view(B, H, H, N)), ref) < tol
+
+
+# ------------------------------------------------------------------------------------------------ SE backward sums
+
+
+@pytest.mark.parametrize("dname,B,C,H", [("bf16", 6, 256, 14), ("bf16", 128, 256, 14), ("f32", 5, 64, 9), ("bf16", 4, 512, 7)])
+def test_se_backward_sums_equal_the_reduce_pass(K, dname, B, C, H):
+    """fr_se_gscale_mlp_bwd_sums + fr_se_bn_bwd_sums (round 4): the squeeze of the SE backward leaves per-image sums from which
+    the BN2-backward sums of an IR-SE unit follow WITHOUT another pass over (g, y2).  Against the pair it replaces
+    (fr_se_gscale_mlp_bwd, then fr_bn_bwd_reduce with the excite terms + fr_reduce_parts): the MLP gradients, gpooled and the two
+    BatchNorm sums agree to fp32 rounding (the squeeze is re-associated; inputs are identical bf16 / fp32 tensors).
+    Reference: bottleneck_IR_SE, backbone/model_irse.py:84-87 and its autograd."""
+    from frhip import _lib
+    dtype = torch.float32 if dname == "f32" else torch.bfloat16
+    fr, st = K.fr_dtype(torch.empty(0, dtype=dtype)), K.current_stream_ptr()
+    HW, R = H * H, C // 16
+    rows = B * HW
+    g = synth.normal(95, "se.g", (rows, C)).to("cuda", dtype)
+    y2 = (synth.normal(95, "se.y", (rows, C)) * 1.3 + 0.4).to("cuda", dtype)
+    y64 = y2.double().cpu()
+    mean = y64.mean(0).float().cuda()
+    invstd = (1.0 / torch.sqrt(y64.var(0, unbiased=False) + 1e-5)).float().cuda()
+    gamma, beta = synth.uniform(95, "se.ga", (C,), 0.5, 1.5).cuda(), synth.uniform(95, "se.be", (C,), -0.3, 0.3).cuda()
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    sgate = torch.sigmoid(synth.normal(95, "se.s", (B, C))).cuda()
+    hidden = torch.relu(synth.normal(95, "se.h", (B, R))).cuda()
+    pooled = synth.normal(95, "se.p", (B, C)).cuda()
+    w1, w2 = (synth.normal(95, "se.w1", (R, C)) * 0.1).cuda(), (synth.normal(95, "se.w2", (C, R)) * 0.1).cuda()
+
+    def bufs():
+        return dict(gpooled=torch.zeros(B, C, device="cuda"), dw1=torch.zeros(R, C, device="cuda"),
+                    dw2=torch.zeros(C, R, device="cuda"), gz=torch.zeros(B, C, device="cuda"), gh=torch.zeros(B, R, device="cuda"))
+    a, b = bufs(), bufs()
+    K.call("fr_se_gscale_mlp_bwd", g, y2, scale, shift, sgate, hidden, pooled, w1, w2, a["gpooled"], a["dw1"], a["dw2"],
+           a["gz"], a["gh"], B, C, R, HW, fr, st)()
+    nb = K.grid_blocks(rows, C, fr)
+    part = torch.zeros(nb, 3, C, device="cuda")
+    K.bn_bwd_reduce(st, fr, part=part, g=g, x=y2, mean=mean, invstd=invstd, rows=rows, C=C, rows_per_image=HW, nblocks=nb,
+                    se=sgate, gse=a["gpooled"])()
+    s0, s1 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    K.call("fr_reduce_parts", part, nb, 3, C, s0, s1, None, st)()
+    sums = torch.zeros(B, 3, C, device="cuda")
+    K.call("fr_se_gscale_mlp_bwd_sums", g, y2, scale, shift, mean, invstd, sgate, hidden, pooled, w1, w2, b["gpooled"],
+           b["dw1"], b["dw2"], b["gz"], b["gh"], sums, B, C, R, HW, fr, st)()
+    t0, t1 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    K.call("fr_se_bn_bwd_sums", sums, sgate, b["gpooled"], B, C, HW, t0, t1, st)()
+    torch.cuda.synchronize()
+    for k in ("gpooled", "dw1", "dw2"):
+        assert relerr(b[k].cpu(), a[k].cpu()) < 2e-5, k
+    # the sums: fp32 accumulation of ~HW*B terms in another order; scale = the size of the terms, not of the (cancelling) sum
+    tscale = float((g.float().abs().mean() * rows))
+    assert float((t0 - s0).abs().max()) < 2e-6 * tscale and float((t1 - s1).abs().max()) < 2e-6 * tscale, (
+        float((t0 - s0).abs().max()), float((t1 - s1).abs().max()), tscale)
+    # and against float64 on the host
+    gp = g.double().cpu().view(B, HW, C) * sgate.double().cpu().view(B, 1, C) + b["gpooled"].double().cpu().view(B, 1, C)
+    xh = (y64.view(B, HW, C) - mean.double().cpu()) * invstd.double().cpu()
+    assert float((t0.double().cpu() - gp.sum((0, 1))).abs().max()) < 2e-6 * tscale
+    assert float((t1.double().cpu() - (gp * xh).sum((0, 1))).abs().max()) < 2e-6 * tscale
+
+
+# ------------------------------------------------------------------------------------------------ stem without im2col rows
+
+
+@pytest.mark.parametrize("Cavg,Kp", [(0, 32), (3, 64)])
+@pytest.mark.parametrize("B,S", [(3, 10), (2, 37), (5, 112)])
+def test_stem_gemms_without_materialised_rows(K, Cavg, Kp, B, S):
+    """fr_stem_gemm_x / fr_stem_wgrad_bn_x (round 4): the input-layer GEMM and its weight gradient build the im2col rows of
+    Conv2d(3|6, 64, 3, 1, 1) from the fp32 NCHW batch (+ pSp's average image) in registers.  Same values, same rounding:
+    output, BatchNorm partial rows and weight-gradient slabs must equal fr_stem_im2col + fr_stem_gemm / fr_stem_wgrad_bn
+    BIT FOR BIT (image borders, the zero tail of K, row counts that end inside a 16-row tile / a 64-row staging chunk).
+    Reference: input_layer of backbone/model_irse.py:140, restyle_psp.py:137,445-447."""
+    st, bf = K.current_stream_ptr(), torch.bfloat16
+    fr = K.fr_dtype(torch.empty(0, dtype=bf))
+    M = B * S * S
+    x = synth.normal(77, "sx", (B, 3, S, S)).cuda()
+    avg = synth.normal(77, "sa", (Cavg, S, S)).cuda() if Cavg else None
+    w = (synth.normal(77, "sw", (64, Kp)) * 0.2).to("cuda", bf)
+    rows = torch.zeros(M, Kp, device="cuda", dtype=bf)
+    K.call("fr_stem_im2col", x, avg, rows, B, S, S, 3, Cavg, Kp, fr, st)()
+    nb = 7
+    out0, out1 = torch.zeros(M, 64, device="cuda", dtype=bf), torch.zeros(M, 64, device="cuda", dtype=bf)
+    p0, p1 = torch.zeros(nb, 2, 64, device="cuda"), torch.zeros(nb, 2, 64, device="cuda")
+    K.call("fr_stem_gemm", rows, w, out0, p0, M, Kp, nb, None, st)()
+    K.call("fr_stem_gemm_x", x, avg, w, out1, p1, B, S, S, 3, Cavg, Kp, nb, None, st)()
+    torch.cuda.synchronize()
+    assert torch.equal(out0, out1) and torch.equal(p0, p1) and float(out0.float().abs().max()) > 0
+    g = synth.normal(77, "sg", (M, 64)).to("cuda", bf)
+    vec = lambda n, lo, hi: synth.uniform(77, n, (64,), lo, hi).cuda()  # noqa: E731
+    mean, invstd, gamma, slope = vec("m", -0.3, 0.3), vec("i", 0.5, 2.0), vec("g", 0.8, 1.2), vec("s", 0.1, 0.4)
+    s0, s1 = vec("s0", -50.0, 50.0), vec("s1", -50.0, 50.0)
+    scale = gamma * invstd
+    shift = vec("b", -0.2, 0.2) - mean * scale
+    ns = 5
+    slab0, slab1 = torch.zeros(ns, 64, Kp, device="cuda"), torch.zeros(ns, 64, Kp, device="cuda")
+    K.call("fr_stem_wgrad_bn", g, out0, rows, mean, invstd, scale, shift, slope, gamma, s0, s1, 1.0 / M, slab0, M, Kp, ns,
+           st)()
+    K.call("fr_stem_wgrad_bn_x", g, out0, x, avg, mean, invstd, scale, shift, slope, gamma, s0, s1, 1.0 / M, slab1, B, S, S,
+           3, Cavg, Kp, ns, st)()
+    torch.cuda.synchronize()
+    assert torch.equal(slab0, slab1) and float(slab0.abs().max()) > 0

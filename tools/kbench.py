@@ -84,6 +84,8 @@ def conv_case(kind, cin, cout, W, B, stride=1, pro=1, epi=1, mode=0, iters=20):
               mode=mode, lda=SC, ldc=N, ldaux=N, pro=pro, pro_a=va, pro_b=vb, epi=epi, epi_a=va, epi_b=vb, aux=aux,
               part=part)
     flops = 2.0 * B * Ho * Ho * N * 9 * SC  # stride 2: both directions do 9 taps per LOW-res pixel
+    if os.environ.get("KBENCH_GRIDBAR", "0") == "1":  # libfrhip_gridbar.so: counters + coefficient scratch behind cos_t
+        kw["cos_t"] = torch.zeros(16 + 2 * 512, device="cuda")
     if pro == 3:  # FR_PRO_BNBWD2: two sources, three coefficient vectors, the operand stored on the way
         kw.update(src2=rnd(*src.shape), pro_c=vb, pro_out=torch.empty_like(src))
     if kind == "s2":  # stride-2 parity-plane kernel: mode 0 forward (W = input side), mode 2 all-class data gradient

@@ -4,9 +4,6 @@ R=$GRAFT_REPO_ROOT; cd $R
 run() { printf "%-48s " "$*"; env "$@" python bench.py --steps 20 --warmup 5 --no-roofline --no-cpu-baseline --no-other-configs 2>/tmp/sw.err | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('%.3f ms  loss %.3f' % (d['ms_per_step'], d['config']['final_loss']))" || tail -3 /tmp/sw.err; }
 run FRHIP_DEFAULT=1
 run FRHIP_SINGLE_STREAM=1
-run FRHIP_STRIP_VARIANT=0
-run FRHIP_STRIP_VARIANT=2
-run FRHIP_S2_VARIANT=0
 run FRHIP_WGRAD_ROLL=0
 run FRHIP_WGRAD_ROLL7=0 FRHIP_WGRAD_S2ROLL=0
 run FRHIP_WGRAD_S2ROLL56=0 FRHIP_WGRAD_VR=0
@@ -18,3 +15,11 @@ run FRHIP_NO_S2_STRIP=1
 run FRHIP_NO_STRIP=1
 run FRHIP_SLOPE_ON_MAIN=1
 run FRHIP_XCD_ORDER=0
+run FRHIP_TAIL=1
+run FRHIP_TAIL=1 FRHIP_TAIL_NRED=32
+run FRHIP_FUSE_BN2=1
+run FRHIP_FUSE_BN2=1 FRHIP_TAIL=1
+run FRHIP_LINEAR_CM=0
+run FRHIP_MERGE_EDGES=1
+run FRHIP_WAIT_EVERY=2 FRHIP_WGRAD_SETS=4
+run FRHIP_SE_SUMS=1
