@@ -36,6 +36,14 @@ enum {
                         output, x2 = BN input; a, b, c from FR_TAIL_BNBWD).  The result, rounded to the compute dtype, is what the
                         kernel multiplies; with pro_out != NULL it is also stored (interior pixels, once each) for the weight
                         gradient to read.  Served by fr_conv3x3_strip / fr_conv3x3_s2_strip data gradients (bf16). */
+  ,
+  FR_PRO_RESBN = 4   /* BN1 of a residual unit applied to the OUTPUT of the unit in front of it, formed on the way:
+                        o = round(a[c]*x + b[c] + x2)  (x = conv2 output of the previous unit, a / b = its BN2 coefficients, x2 =
+                        src2 = that unit's input: bottleneck_IR's `res + shortcut`, backbone/model_irse.py:64-66 with the
+                        MaxPool2d(1, 1) shortcut), operand = c[c]*o + d[c] (pro_c / pro_d: this unit's BN1).  o is stored to
+                        pro_out (interior pixels, once each): the residual stream is materialised by its consumer and the
+                        BN-apply pass behind conv2 is gone.  The batch statistics of o come from fr_bn_finalize_res.
+                        Served by fr_conv3x3_strip forward launches of square layers (bf16). */
 };
 
 /* epilogue of fr_conv_igemm */
@@ -49,6 +57,8 @@ enum {
   FR_EPI_BIAS_RES = 7,  /* out = acc + epi_a[n] + epi_b[n] + aux[m][n]: inference with BatchNorm folded into the weights
                            (util/utils.py:254-307 runs the backbone in eval mode): epi_a / epi_b = the folded BN shifts of
                            the residual branch and of the conv shortcut (both required; pass zeros), aux = the shortcut */
+  FR_EPI_STATS_X = 8,   /* FR_EPI_STATS + part[.][2][n] = sum_rows out*aux: the cross moment with the residual input (aux), from
+                           which fr_bn_finalize_res derives the statistics of a*out + b + aux; part rows are [3][N] */
   FR_EPI_SLAB = 6       /* split-K slice z stores its fp32 partial (+bias in slice 0) to out[z][rows][ldc]: the caller
                            adds the splitk slabs with fr_reduce_parts(out, splitk, 1, rows*ldc, ...) -- reproducible */
 };
@@ -134,6 +144,7 @@ typedef struct FrConvArgs {
   const void* src2;    /* second source, geometry and strides of src */
   const float* pro_c;  /* [SC] */
   void* pro_out;       /* NULL or [B*SH*SW][lda]: the prologue result of every source pixel */
+  const float* pro_d;  /* [SC], FR_PRO_RESBN only */
 } FrConvArgs;
 
 /* Convolution forward / data gradient / dense GEMM on MFMA.
@@ -251,6 +262,16 @@ int fr_stem_wgrad_bn_x(const void* G, const void* Y, const float* x, const float
 int fr_bn_finalize(const float* part, int nparts, int C, double count, const float* gamma, const float* beta,
                    float eps, float momentum, float* running_mean, float* running_var, int64_t* nbt,
                    float* mean, float* invstd, float* scale, float* shift, void* stream);
+
+/* Statistics of a residual sum without a pass over it (round 4): part = [nparts][3][C] rows of a FR_EPI_STATS_X launch
+ * (sum y, sum y^2, sum y*o over the conv2 output y and the unit's input o).  One launch finalises `bn` (the BatchNorm behind
+ * conv2: exactly what fr_bn_finalize(part rows 0..1) writes; bn->count = elements per channel) AND `next`, the BatchNorm that
+ * normalises the unit's output o' = scale*y + shift + o:  mean' = scale*my + shift + mo,  var' = scale^2*vy + vo +
+ * 2*scale*cov(y, o), with (mo, vo) from in_mean / in_invstd / in_eps -- the statistics the unit's own BN1 used for o.
+ * Of the two FrTail arguments only the BatchNorm fields are read (count, gamma ... shift); ticket / kind are ignored.
+ * Replaces the statistics pass behind `res + shortcut` of bottleneck_IR (backbone/model_irse.py:64-66) for identity units. */
+int fr_bn_finalize_res(const float* part, int nparts, int C, const FrTail* bn, const float* in_mean, const float* in_invstd,
+                       float in_eps, const FrTail* next, void* stream);
 
 /* per-channel (sum, sumsq) partials of an NHWC tensor: part[blk][2][C], blk < nblocks (= grid size) */
 int fr_channel_stats(const void* x, long long rows, int C, float* part, int nblocks, int dtype,

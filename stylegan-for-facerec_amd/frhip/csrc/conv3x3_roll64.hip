@@ -508,6 +508,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
 
 template <int W>
 int by_pro(const FrConvArgs& a, hipStream_t st) {
+  if (a.epi == FR_EPI_STATS_X) FR_UNSUPPORTED("rolling-window convolution: FR_EPI_STATS_X is served by the LDS-strip instances only");
   if (a.epi == FR_EPI_PRELU_BWD || a.epi == FR_EPI_BNBWD) {
     // the fused backward epilogues come with the data gradients, which have no prologue
     if (a.pro != FR_PRO_NONE || !a.aux) FR_UNSUPPORTED("rolling-window convolution: data-gradient epilogues take no prologue and need aux");

@@ -78,7 +78,7 @@ struct SC {
   static constexpr int TM = (MT + WM - 1) / WM;
   static constexpr int OSTR = COUT * 2 + 16;               // out-tile row stride, bytes
   static constexpr int OUT_BYTES = (M * OSTR + 15) / 16 * 16;
-  static constexpr int RED_BYTES = WM * 2 * COUT * 4;
+  static constexpr int RED_BYTES = WM * 3 * COUT * 4;        // [WM][<= 3][COUT] column sums
   static constexpr int LDS = IMG_BYTES > OUT_BYTES + RED_BYTES ? IMG_BYTES : OUT_BYTES + RED_BYTES;
   static constexpr int NS = H / ROWS;                      // strips per image
   static_assert(H % ROWS == 0, "strip rows must divide the image");
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: keeps the tile loops branch-free
   const int wn = wave % WN, wm = wave / WN;
+  constexpr bool TWO = PRO == FR_PRO_BNBWD2 || PRO == FR_PRO_RESBN;  // two-source prologues
   const bf16_t* __restrict__ src = reinterpret_cast<const bf16_t*>(p.src);
   const bf16_t* __restrict__ wgt = reinterpret_cast<const bf16_t*>(p.w);
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
   constexpr int WP = W + 2;
   constexpr int TOTAL = NIMG * C::GH * WP * C::CH;
   const int ch = tid % C::CH;  // NTH is a multiple of CH: a thread always handles the same channel chunk
-  float pa[8], pb[8], pc[8];  // prologue coefficients of this thread's channel chunk: re-read per strip (L1 hits) rather
+  float pa[8], pb[8], pc[8], pd[PRO == FR_PRO_RESBN ? 8 : 1];  // prologue coefficients of this thread's channel chunk: re-read per strip (L1 hits) rather
                               // than kept live across the MFMA loop
   int kc = 0;  // channel stage (KSPL > 1): input channels [kc*CK, (kc+1)*CK) are resident
   auto kco = [&]() -> int { return KSPL > 1 ? kc * CK : 0; };  // literally 0 for the single-stage instances
@@ -128,16 +129,19 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         pa[j] = p.pro_a[kco() + ch * 8 + j];
-        pb[j] = (PRO == FR_PRO_BN || PRO == FR_PRO_BNBWD2) ? p.pro_b[kco() + ch * 8 + j] : 0.f;
-        pc[j] = PRO == FR_PRO_BNBWD2 ? p.pro_c[kco() + ch * 8 + j] : 0.f;
+        pb[j] = (PRO == FR_PRO_BN || TWO) ? p.pro_b[kco() + ch * 8 + j] : 0.f;
+        pc[j] = TWO ? p.pro_c[kco() + ch * 8 + j] : 0.f;
+        if (PRO == FR_PRO_RESBN) pd[j] = p.pro_d[kco() + ch * 8 + j];
       }
     }
   };
   // FR_PRO_BNBWD2: the operand is ca*g + cb*x2 + cc of TWO tensors (the backward of the BatchNorm behind this convolution,
   // applied while its data gradient loads the strip: the pass that used to materialise it -- 75 MB of traffic and a launch per
   // 14x14 unit -- is gone); the rounded result also goes to p.pro_out, once per pixel, for the weight gradient to read.
+  // FR_PRO_RESBN (forward): the operand is BN1 of o = round(a*y + b + x2) -- the output of the unit in front, formed here from
+  // its conv2 output y and its input x2 instead of by a BN-apply pass; o goes to p.pro_out, the residual stream.
   const bf16_t* __restrict__ src2 = reinterpret_cast<const bf16_t*>(p.src2);
-  bf16_t* __restrict__ pro_out = PRO == FR_PRO_BNBWD2 ? reinterpret_cast<bf16_t*>(p.pro_out) : nullptr;
+  bf16_t* __restrict__ pro_out = TWO ? reinterpret_cast<bf16_t*>(p.pro_out) : nullptr;
   // chunk u of this thread (idx = u*NTH + tid) -> source validity / element offset / LDS address
   auto chunk_off = [&](int s, int idx, bool& ok, bool& own) -> size_t {
     int b = s / C::NS;
@@ -172,6 +176,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
           unpack16<bf16_t>(x2, f2);
 #pragma unroll
           for (int j = 0; j < 8; ++j) f[j] = fmaf(pa[j], f[j], fmaf(pb[j], f2[j], pc[j]));
+        } else if (PRO == FR_PRO_RESBN) {
+          float f2[8];
+          unpack16<bf16_t>(x2, f2);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = fmaf(f[j], pa[j], pb[j]) + f2[j];  // the arithmetic of fr_bn_apply (res_kind 1)
+          x = pack16<bf16_t>(f);
+          if (own && nh == 0 && pro_out) st16(pro_out + off, x);
+          unpack16<bf16_t>(x, f);  // BN1 normalises what the residual stream holds
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = fmaf(f[j], pc[j], pd[j]);
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -196,21 +210,21 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
     // (channel stages: the accumulators are live across the load -- one batch only beside small accumulator tiles)
     constexpr bool ONE = (NW == 4 && PER <= 18) || (PER <= FRHIP_STRIP_LOAD_BATCH && (KSPL == 1 || C::TM * C::TN * 4 <= 64));
     constexpr int UNR1 = ONE ? PER : 8;
-    constexpr int UNR = (PRO == FR_PRO_BNBWD2 && UNR1 > 10) ? (UNR1 + 1) / 2 : UNR1;  // two sources: half the chunks per batch
+    constexpr int UNR = (TWO && UNR1 > 10) ? (UNR1 + 1) / 2 : UNR1;  // two sources: half the chunks per batch
     load_pro();
     for (int base = 0; base < TOTAL; base += NTH * UNR) {
-      U128 v[UNR], v2[PRO == FR_PRO_BNBWD2 ? UNR : 1];
+      U128 v[UNR], v2[TWO ? UNR : 1];
       bool ok[UNR], own[UNR];
       size_t off[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         off[u] = chunk_off(s, base + u * NTH + tid, ok[u], own[u]);
         v[u] = ok[u] ? ld16(src + off[u]) : zero16();
-        if (PRO == FR_PRO_BNBWD2) v2[u] = ok[u] ? ld16(src2 + off[u]) : zero16();
+        if (TWO) v2[u] = ok[u] ? ld16(src2 + off[u]) : zero16();
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u)
-        chunk_store(base + u * NTH + tid, v[u], PRO == FR_PRO_BNBWD2 ? v2[u] : v[u], ok[u], own[u], off[u]);
+        chunk_store(base + u * NTH + tid, v[u], TWO ? v2[u] : v[u], ok[u], own[u], off[u]);
     }
   };
 
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) wrow[j] = wgt + (size_t)(ncol0 + n0 + j * 16 + fr) * 9 * CIN + fq * 8;
     const int epi = p.epi;
-    const bool stats = epi == FR_EPI_STATS || epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD;
+    const bool stats = epi == FR_EPI_STATS || epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD || epi == FR_EPI_STATS_X;
     const int b = NIMG > 1 ? s * NIMG : s / C::NS;  // first image of the strip
     const int row0 = NIMG > 1 ? 0 : (s - b * C::NS) * ROWS;
     f32x4 acc[C::TM][C::TN];
@@ -327,7 +341,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
     // barrier that ends the K loop: as a load -> wait -> LDS-store loop it cost one HBM round trip per 16 bytes of a
     // thread (13 of them, ~7 us of a 55-us 14x14 launch); the registers are those of the dead fragment rings.
     constexpr int NAUX = (C::M * OCH + NTH - 1) / NTH;
-    const bool has_aux = epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD || epi == FR_EPI_BIAS_RES;
+    const bool has_aux = epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD || epi == FR_EPI_BIAS_RES || epi == FR_EPI_STATS_X;
     U128 av[NAUX];
     if (has_aux) {
       const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
@@ -355,12 +369,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
     // The MFMAs ran with the weights as the A operand, so a lane holds, per 16x16 tile, FOUR CONSECUTIVE CHANNELS
     // (n = fq*4 + r) of ONE pixel (m = fr): one 8-byte LDS access per tile instead of four 2-byte ones, and the
     // 16 lanes of a ds_write_b64 lane group hit 16 different rows on disjoint banks (row stride = 4 banks mod 64).
-    float* red = reinterpret_cast<float*>(smem + C::OUT_BYTES);  // [WM][2][COUT] column sums, behind the output tile
+    float* red = reinterpret_cast<float*>(smem + C::OUT_BYTES);  // [WM][NV][COUT] column sums, behind the output tile
+    const int NV = epi == FR_EPI_STATS_X ? 3 : 2;
     // The epilogue kind is a run-time argument, but inside the per-element loops it must be a compile-time constant:
     // with `epi` tested per element the compiler emitted a scalar branch per accumulator (8000 instructions, ~10 us).
     auto cells = [&](auto tag) {
       constexpr int E = decltype(tag)::value;
-      float ea[C::TN][4], eb[C::TN][4], s0[C::TN][4], s1[C::TN][4];
+      constexpr bool AUX = E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD || E == FR_EPI_BIAS_RES || E == FR_EPI_STATS_X;
+      float ea[C::TN][4], eb[C::TN][4], s0[C::TN][4], s1[C::TN][4], s2[E == FR_EPI_STATS_X ? C::TN : 1][4];
   #pragma unroll
       for (int j = 0; j < C::TN; ++j)
   #pragma unroll
@@ -369,6 +385,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
           ea[j][r] = (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD || E == FR_EPI_BIAS_RES) ? p.epi_a[n] : 0.f;
           eb[j][r] = (E == FR_EPI_BNBWD || E == FR_EPI_BIAS_RES) ? p.epi_b[n] : 0.f;
           s0[j][r] = s1[j][r] = 0.f;
+          if (E == FR_EPI_STATS_X) s2[j][r] = 0.f;
         }
   #pragma unroll
       for (int i = 0; i < C::TM; ++i) {
@@ -380,7 +397,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
           float v[4], x[4];
   #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-          if (E == FR_EPI_PRELU_BWD || E == FR_EPI_BNBWD || E == FR_EPI_BIAS_RES) {
+          if (AUX) {
             const uint2 u = *cell;
             x[0] = __uint_as_float(u.x << 16);
             x[1] = __uint_as_float(u.x & 0xFFFF0000u);
@@ -392,6 +409,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
             if (E == FR_EPI_STATS) {
               s0[j][r] += v[r];
               s1[j][r] = fmaf(v[r], v[r], s1[j][r]);
+            } else if (E == FR_EPI_STATS_X) {  // + the cross moment with the residual input (fr_bn_finalize_res)
+              s0[j][r] += v[r];
+              s1[j][r] = fmaf(v[r], v[r], s1[j][r]);
+              s2[j][r] = fmaf(v[r], x[r], s2[j][r]);
             } else if (E == FR_EPI_PRELU_BWD) {
               const bool pos = x[r] > 0.f;
               s0[j][r] += pos ? 0.f : v[r] * x[r];
@@ -415,21 +436,25 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
         for (int j = 0; j < C::TN; ++j)
   #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float a = s0[j][r], c = s1[j][r];
+            constexpr int V = E == FR_EPI_STATS_X ? 3 : 2;
+            float a = s0[j][r], c = s1[j][r], d = E == FR_EPI_STATS_X ? s2[j][r] : 0.f;
   #pragma unroll
             for (int o = 1; o < 16; o <<= 1) {
               a += __shfl_xor(a, o, 64);
               c += __shfl_xor(c, o, 64);
+              if (E == FR_EPI_STATS_X) d += __shfl_xor(d, o, 64);
             }
             if (fr == 0) {
-              red[(wm * 2 + 0) * COUT + n0 + j * 16 + fq * 4 + r] = a;
-              red[(wm * 2 + 1) * COUT + n0 + j * 16 + fq * 4 + r] = c;
+              red[(wm * V + 0) * COUT + n0 + j * 16 + fq * 4 + r] = a;
+              red[(wm * V + 1) * COUT + n0 + j * 16 + fq * 4 + r] = c;
+              if (E == FR_EPI_STATS_X) red[(wm * V + 2) * COUT + n0 + j * 16 + fq * 4 + r] = d;
             }
           }
       }
     };
     switch (epi) {
       case FR_EPI_STATS: cells(std::integral_constant<int, FR_EPI_STATS>{}); break;
+      case FR_EPI_STATS_X: cells(std::integral_constant<int, FR_EPI_STATS_X>{}); break;
       case FR_EPI_PRELU_BWD: cells(std::integral_constant<int, FR_EPI_PRELU_BWD>{}); break;
       case FR_EPI_BNBWD: cells(std::integral_constant<int, FR_EPI_BNBWD>{}); break;
       case FR_EPI_BIAS_RES: cells(std::integral_constant<int, FR_EPI_BIAS_RES>{}); break;
@@ -466,12 +491,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
     }
 #endif
     if (stats) {
-      for (int c = tid; c < 2 * COUT; c += NTH) {
+      for (int c = tid; c < NV * COUT; c += NTH) {
         const int k = c / COUT, n = c - k * COUT;
         float t = 0.f;
 #pragma unroll
-        for (int g = 0; g < C::WM; ++g) t += red[(g * 2 + k) * COUT + n];
-        st_part(p.part + ((size_t)sblk * 2 + k) * (COUT * NSPL) + ncol0 + n, t);
+        for (int g = 0; g < C::WM; ++g) t += red[(g * NV + k) * COUT + n];
+        st_part(p.part + ((size_t)sblk * NV + k) * (COUT * NSPL) + ncol0 + n, t);
       }
       // in-launch reduction of the rows (tail.h); everything in LDS is dead by now
       fr_tail<NTH>(p.tail, p.part, (int)(gridDim.x / NSPL), gridDim.x, smem, tid);
@@ -562,6 +587,8 @@ int launch(const FrConvArgs& a, hipStream_t st) {
   const int strips = a.B * C::NS / NIMG;
   FrConvArgs k = a;
   const bool sums = a.part && (a.epi == FR_EPI_STATS || a.epi == FR_EPI_PRELU_BWD || a.epi == FR_EPI_BNBWD);
+  if (a.epi == FR_EPI_STATS_X && (!a.part || !a.aux || a.tail.ticket))
+    FR_UNSUPPORTED("fr_conv3x3_strip: FR_EPI_STATS_X needs part and aux and takes no tail (its rows go to fr_bn_finalize_res)");
   if (fr_tail_prepare(a.tail, 2, a.N, C::NTH / FR_RT, &k.tail, sums)) return -1;
   hipLaunchKernelGGL((conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, NSPL, PRO, NIMG, KSPL>),
                      dim3(strips * NSPL), dim3(C::NTH), C::LDS, st, k, xcd_order());
@@ -581,6 +608,10 @@ int by_pro(const FrConvArgs& a, hipStream_t st) {
       } else {
         FR_UNSUPPORTED("fr_conv3x3_strip: FR_PRO_BNBWD2 is served for Cin == Cout only");
       }
+    case FR_PRO_RESBN:  // conv1 of a unit behind an identity unit (both sources have this layer's input channels)
+      if (!a.src2 || !a.pro_a || !a.pro_b || !a.pro_c || !a.pro_d || !a.pro_out || a.mode != 0)
+        FR_UNSUPPORTED("fr_conv3x3_strip: FR_PRO_RESBN needs src2, pro_a ... pro_d, pro_out and mode 0");
+      return launch<CIN, COUT, W, ROWS, WN, NW, NSPL, FR_PRO_RESBN, NIMG, KSPL>(a, st);
   }
   FR_UNSUPPORTED("fr_conv3x3_strip: unknown prologue");
 }
@@ -708,6 +739,12 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
     for (int half = 0; half < 2; ++half) {
       h.w = reinterpret_cast<const bf16_t*>(a.w) + (size_t)half * 256 * 9 * 256;
       h.out = reinterpret_cast<bf16_t*>(a.out) + half * 256;
+      if (a.pro == FR_PRO_RESBN && half == 1) {  // the first pass has materialised the residual sum: plain BN1 on it
+        h.pro = FR_PRO_BN;
+        h.src = a.pro_out;
+        h.pro_a = a.pro_c;
+        h.pro_b = a.pro_d;
+      }
       const int rc = small_batch(a.B) ? by_pro<256, 128, 14, 14, 8, 8, 2>(h, st) : by_pro<256, 256, 14, 14, 8, 8>(h, st);
       if (rc) return rc;
     }

@@ -123,6 +123,54 @@ __global__ __launch_bounds__(RT) void bn_finalize_kernel(const float* __restrict
   if (threadIdx.x < 8 && c < C) fr_bn_finalize_channel(f, c, sq[0], sq[1]);
 }
 
+// Statistics of a residual sum without a pass over it (round 4).  A unit's output is  o' = a*y + b + o  per channel (y =
+// conv2's output, (a, b) = BN2's coefficients, o = the unit's input).  Its batch moments follow from the moments of y (the
+// rows conv2 writes anyway), the moments of o (the statistics BN1 of this unit normalised with) and ONE cross moment
+// sum(y*o) (third row vector, FR_EPI_STATS_X):  mean' = a*my + b + mo,  var' = a^2*vy + vo + 2a*(E[y*o] - my*mo).
+// So BN2's coefficients and the next unit's BN1 coefficients come out of the same launch, and the BN-apply pass that
+// materialised o' only to measure it is gone (its consumer forms o' itself: FR_PRO_RESBN).  Centred form in double: the
+// variances add, no difference of large sums beyond the ones fr_bn_finalize already takes.
+static FrBnFin fin_of(const FrTail& t) {
+  FrBnFin f;
+  f.count = t.count;
+  f.gamma = t.gamma;
+  f.beta = t.beta;
+  f.eps = t.eps;
+  f.momentum = t.momentum;
+  f.running_mean = t.running_mean;
+  f.running_var = t.running_var;
+  f.nbt = reinterpret_cast<long long*>(t.nbt);
+  f.mean = t.mean;
+  f.invstd = t.invstd;
+  f.scale = t.scale;
+  f.shift = t.shift;
+  return f;
+}
+__global__ __launch_bounds__(RT) void bn_finalize_res_kernel(const float* __restrict__ part, int nparts, int C, FrBnFin f,
+                                                             const float* __restrict__ in_mean,
+                                                             const float* __restrict__ in_invstd, float in_eps, FrBnFin fn) {
+  __shared__ double lds[3 * (RT / 64) * 8];
+  const int c0 = blockIdx.x * 8;
+  const int cols[3] = {c0, C + c0, 2 * C + c0};
+  double sq[3];
+  fr_reduce_rows8<3>(part, nparts, 3 * C, cols, sq, lds, threadIdx.x);
+  const int c = c0 + threadIdx.x;
+  if (threadIdx.x < 8 && c < C) {
+    const double my = sq[0] / f.count;
+    double vy = __builtin_fma(-my, my, sq[1] / f.count);
+    if (vy < 0.0) vy = 0.0;
+    fr_bn_from_moments(f, c, my, vy);  // BN2 exactly as fr_bn_finalize leaves it
+    const double a = (double)f.scale[c], b = (double)f.shift[c];  // the rounded coefficients the prologue multiplies with
+    const double mo = (double)in_mean[c], io = (double)in_invstd[c];
+    double vo = 1.0 / (io * io) - (double)in_eps;
+    if (vo < 0.0) vo = 0.0;
+    const double cov = sq[2] / f.count - my * mo;
+    double vn = a * a * vy + vo + 2.0 * a * cov;
+    if (vn < 0.0) vn = 0.0;
+    fr_bn_from_moments(fn, c, a * my + b + mo, vn);
+  }
+}
+
 // fr_reduce_parts of fr_bn_bwd_reduce's rows (vectors 0 and 1) + the coefficients FR_PRO_BNBWD2 applies, in one launch
 __global__ __launch_bounds__(RT) void bn_bwd_coeffs_kernel(const float* __restrict__ part, int nparts, int C, FrBnBwdCo f) {
   __shared__ double lds[2 * (RT / 64) * 8];
@@ -1334,6 +1382,20 @@ extern "C" int fr_bn_finalize(const float* part, int nparts, int C, double count
   f.scale = scale;
   f.shift = shift;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(RT), 0, (hipStream_t)stream, part, nparts, C, f);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_bn_finalize_res(const float* part, int nparts, int C, const FrTail* bn, const float* in_mean,
+                                  const float* in_invstd, float in_eps, const FrTail* next, void* stream) {
+  if (!part || nparts < 1 || C < 1 || !bn || !next || !in_mean || !in_invstd)
+    FR_UNSUPPORTED("fr_bn_finalize_res: part, bn, next, in_mean, in_invstd are required");
+  if (!(bn->count > 0.0) || !bn->mean || !bn->invstd || !bn->scale || !bn->shift || !next->mean || !next->invstd ||
+      !next->scale || !next->shift)
+    FR_UNSUPPORTED("fr_bn_finalize_res: count and the four coefficient vectors of both BatchNorms are required");
+  FrBnFin f = fin_of(*bn), fn = fin_of(*next);
+  fn.count = bn->count;  // same pixels
+  hipLaunchKernelGGL(bn_finalize_res_kernel, dim3((C + 7) / 8), dim3(RT), 0, (hipStream_t)stream, part, nparts, C, f,
+                     in_mean, in_invstd, in_eps, fn);
   FR_LAUNCH_CHECK();
 }
 

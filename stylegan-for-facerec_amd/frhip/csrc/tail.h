@@ -119,13 +119,9 @@ struct FrBnFin {
 // stand-alone kernel (round 4: the stand-alone kernel fused running_var's update, the tail did not -- last-bit differences).
 // ROCm's __fmul_rn / __fadd_rn do NOT help: they are inline wrappers around * and + compiled with contraction allowed, and
 // fuse with each other after inlining whatever the caller's pragma says.
-__device__ __forceinline__ void fr_bn_finalize_channel(const FrBnFin& f, int c, double s, double q) {
+// (mean, biased variance) of a channel -> everything fr_bn_finalize writes for it
+__device__ __forceinline__ void fr_bn_from_moments(const FrBnFin& f, int c, double m, double var) {
 #pragma clang fp contract(off)
-  // (the fused operations below are the ones rounds 1-3 shipped -- then chosen by the compiler, now written out -- so that
-  // the fp32 parity fixtures see the same bits: batch-4 ... 16 networks at random init amplify a last-bit change of a shift)
-  const double m = s / f.count;
-  double var = __builtin_fma(-m, m, q / f.count);
-  if (var < 0.0) var = 0.0;
   const float is = (float)(1.0 / sqrt(var + (double)f.eps));
   const float g = f.gamma ? f.gamma[c] : 1.f, bt = f.beta ? f.beta[c] : 0.f;
   const float mf = (float)m;
@@ -143,6 +139,16 @@ __device__ __forceinline__ void fr_bn_finalize_channel(const FrBnFin& f, int c, 
     f.running_var[c] = __builtin_fmaf(f.momentum, (float)unbiased, ov);
   }
   if (f.nbt && c == 0) *f.nbt += 1;
+}
+__device__ __forceinline__ void fr_bn_finalize_channel(const FrBnFin& f, int c, double s, double q) {
+#pragma clang fp contract(off)
+  // (the fused operations here and in fr_bn_from_moments are the ones rounds 1-3 shipped -- then chosen by the compiler, now
+  // written out -- so that the fp32 parity fixtures see the same bits: batch-4 ... 16 networks at random init amplify a
+  // last-bit change of a shift)
+  const double m = s / f.count;
+  double var = __builtin_fma(-m, m, q / f.count);
+  if (var < 0.0) var = 0.0;
+  fr_bn_from_moments(f, c, m, var);
 }
 
 // the per-channel arithmetic behind FR_TAIL_BNBWD / fr_bn_bwd_coeffs: the reduced sums and the BatchNorm backward as an affine

@@ -278,6 +278,18 @@ class BackbonePlan(object):
         # channel-wise work only matters where nothing runs beside it.  So: opt-in (FRHIP_FUSE_BN2=1), default off.
         self.fuse_bn2 = os.environ.get("FRHIP_FUSE_BN2", "0") == "1"
         self.use_strip = os.environ.get("FRHIP_NO_STRIP", "0") != "1"
+        # Residual-sum statistics from moments (round 4).  In the FORWARD pass nothing runs beside the channel-wise passes, and
+        # per identity unit the pass `out = BN2(y2) + x` (fr_bn_apply: 75 MB of traffic at 14x14) existed for two reasons: the
+        # next unit's conv1 reads `out`, and its train-mode BN1 needs the batch statistics of `out` first.  The statistics do
+        # not need the pass: mean / variance of a*y2 + b + x follow from the moments of y2 (conv2's rows), the statistics of
+        # x (this unit's BN1) and one cross moment sum(y2*x) that conv2's epilogue adds while it has y2 in registers
+        # (FR_EPI_STATS_X, fr_bn_finalize_res: BN2's and the next BN1's coefficients from one launch).  And `out` is formed by
+        # its consumer: the next conv1 loads y2 and x, writes out = a*y2 + b + x (same bits as fr_bn_apply) on the way and
+        # applies BN1 to it (FR_PRO_RESBN).  Per fused edge: bn_apply + one finalize launch gone.  Identity units without SE
+        # whose conv2 and whose successor's conv1 run on LDS-strip instances (IR-50: 17 of 24 units).  FRHIP_RES_MOMENTS=0:
+        # A/B switch.
+        self.res_moments = (os.environ.get("FRHIP_RES_MOMENTS", "1") != "0" and self.fr == FR_BF16 and self.use_strip
+                            and not self.fold)
         self.use_stem_gemm = (self.fr == FR_BF16 and os.environ.get("FRHIP_NO_STEM_GEMM", "0") != "1" and
                               not self.body_only)
         self.use_s2 = os.environ.get("FRHIP_NO_S2_STRIP", "0") != "1"  # stride-2 strip kernels (A/B switch)
@@ -481,7 +493,8 @@ class BackbonePlan(object):
     def _check_part(self, n, kw):
         """Fail loudly (instead of a GPU memory fault) if an epilogue's partial rows would not fit their buffer."""
         part = kw.get("part")
-        if part is not None and n * 2 * kw["N"] > part.numel():
+        nv = 3 if kw.get("epi") == ops.EPI_STATS_X else 2
+        if part is not None and n * nv * kw["N"] > part.numel():
             raise _lib.FrhipError("frhip: %d partial rows x 2 x %d channels exceed the %d-float partial-sum buffer "
                                   "(batch %d)" % (n, kw["N"], part.numel(), kw["B"]))
         return n
@@ -623,6 +636,32 @@ class BackbonePlan(object):
                            m.num_batches_tracked if m.track_running_stats else None, bn.mean, bn.invstd, bn.scale,
                            bn.shift)
 
+    def _bn_fields(self, bn, count):
+        """The BatchNorm arguments of fr_bn_finalize as a struct (fr_bn_finalize_res takes two)."""
+        m = bn.mod
+        return ops.tail_bn(None, bn.C, count, m.weight, m.bias, m.eps, m.momentum if m.momentum is not None else 0.1,
+                           m.running_mean if m.track_running_stats else None,
+                           m.running_var if m.track_running_stats else None,
+                           m.num_batches_tracked if m.track_running_stats else None, bn.mean, bn.invstd, bn.scale,
+                           bn.shift)
+
+    def _res_edge(self, i):
+        """True when unit i's output is formed by unit i+1's conv1 (FR_PRO_RESBN) and its statistics come from moments."""
+        if not self.res_moments or i < 0 or i + 1 >= len(self.units):
+            return False
+        u, n = self.units[i], self.units[i + 1]
+        if u.se is not None or u.sc_conv is not None or u.stride != 1 or n.cin != u.depth:
+            return False
+        bns = (self.ubuf[i]["bn1"], self.ubuf[i]["bn2"], self.ubuf[i + 1]["bn1"])
+        if not all(b.mod.training for b in bns):
+            return False
+        # conv2 of unit i and conv1 of unit i + 1 on LDS-strip instances (the 64 -> 64 rolling-window kernel takes neither)
+        if not _lib.lib.fr_conv3x3_strip_serves_bnbwd2(self.B, u.depth, u.Ho):
+            return False
+        if n.cin == n.depth:
+            return True
+        return ops.strip_parts(self.B, n.cin, n.depth, n.H, ops.EPI_STORE) > 0
+
     def _sum_tail(self, K, C, o0, o1=None, o2=None, cls=4):
         """The in-launch form of fr_reduce_parts(part, rows, K, C, o0, o1, o2), or None without FRHIP_TAIL=1."""
         if not self.use_tail or not (self.tail_mask & cls):
@@ -713,9 +752,19 @@ class BackbonePlan(object):
                 wp1, wp2 = w1, w2
             bn1, bn2 = d["bn1"], d["bn2"]
             folded = fold and u.se is None and (u.sc_conv is not None or u.stride == 1)
-            self._conv(L, src=x, w=wp1, out=d["y1"], B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H, SC=u.cin,
-                       N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.cin, ldc=u.depth,
-                       pro=ops.PRO_BN, pro_a=bn1.scale, pro_b=bn1.shift, epi=ops.EPI_STORE)
+            if self._res_edge(i - 1):
+                # x (the previous unit's output) does not exist yet: this launch forms it from that unit's y2 and input,
+                # stores it, and applies BN1 to it
+                pd = self.ubuf[i - 1]
+                self._conv(L, src=pd["y2"], src2=x_in, pro_out=x, w=wp1, out=d["y1"], B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H,
+                           SC=u.cin, N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.cin, ldc=u.depth,
+                           pro=ops.PRO_RESBN, pro_a=pd["bn2"].scale, pro_b=pd["bn2"].shift, pro_c=bn1.scale,
+                           pro_d=bn1.shift, epi=ops.EPI_STORE)
+            else:
+                self._conv(L, src=x, w=wp1, out=d["y1"], B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H, SC=u.cin,
+                           N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.cin, ldc=u.depth,
+                           pro=ops.PRO_BN, pro_a=bn1.scale, pro_b=bn1.shift, epi=ops.EPI_STORE)
+            x_in = x  # this unit's input (the residual term of its output)
             if folded:
                 # inference with BN2 (and the shortcut BN) folded into the packed weights: out = conv2'(PReLU(y1)) +
                 # shift2 [+ shiftS] + shortcut straight from conv2's epilogue -- y2 is never written, no BN-apply pass
@@ -738,6 +787,15 @@ class BackbonePlan(object):
                 if nxt is not None:
                     self._bn_train_launches(L, nxt, None, 0, rout)
                 x = d["out"]
+                continue
+            if self._res_edge(i):
+                np2 = self._conv(L, src=d["y1"], w=wp2, out=d["y2"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H, SC=u.depth,
+                                 N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.depth, ldc=u.depth, ldaux=u.depth,
+                                 pro=ops.PRO_PRELU, pro_a=u.prelu.weight, epi=ops.EPI_STATS_X, aux=x_in, part=self.part)
+                nxt = self.ubuf[i + 1]["bn1"]
+                L.append(ops.call("fr_bn_finalize_res", self.part, np2, u.depth, self._bn_fields(bn2, rout), bn1.mean,
+                                  bn1.invstd, float(bn1.mod.eps), self._bn_fields(nxt, rout), st))
+                x = d["out"]  # written by the next unit's conv1
                 continue
             np2 = self._conv(L, src=d["y1"], w=wp2, out=d["y2"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H,
                              SC=u.depth, N=u.depth, KH=3, KW=3, stride=u.stride, pad=1, mode=0, lda=u.depth,

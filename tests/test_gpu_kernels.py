@@ -1448,6 +1448,113 @@ def test_bnbwd2_prologue_equals_apply_then_data_gradient(K, B, C, W):
     assert torch.equal(out1, out2) and torch.equal(p1, p2)
 
 
+# ------------------------------------------------------------------------------------------------ residual sum formed by its consumer
+
+
+@pytest.mark.parametrize("B,C,W,Cn", [(162, 256, 14, 256), (6, 256, 14, 256), (40, 128, 28, 128), (12, 512, 7, 512),
+                                      (16, 512, 7, 512), (3, 512, 7, 512), (40, 128, 28, 256), (162, 256, 14, 512),
+                                      (6, 256, 14, 512)])
+def test_residual_sum_by_its_consumer_and_statistics_from_moments(K, B, C, W, Cn):
+    """Round 4: the forward pass of an identity unit without the BN-apply pass behind conv2.
+    (1) FR_EPI_STATS_X: conv2 stores y2 and the (sum, sum of squares) rows exactly as FR_EPI_STATS does, plus the cross
+        moment sum(y2 * x) with the unit's input x.
+    (2) fr_bn_finalize_res: BN2's coefficients and running statistics bit-identical to fr_bn_finalize on the same rows; the
+        statistics of out = a*y2 + b + x (the NEXT unit's BN1) derived from the moments agree with the statistics fr_bn_apply
+        measures on the materialised tensor.
+    (3) FR_PRO_RESBN: the next conv1 forms out from (y2, x), stores it once per pixel -- bit-identical to fr_bn_apply's
+        tensor -- and its own result is bit-identical to conv1 with the FR_PRO_BN prologue on that tensor.
+    Instances as in the BNBWD2 test (whole images, channel-split workgroups, 7-row strips, multi-image 7x7 workgroups), and
+    Cn != C: the consumer is the first convolution of the next stage (128 -> 256 @28; 256 -> 512 @14 = two passes over 256
+    output channels, the second one reading the tensor the first one stored).
+    Reference: bottleneck_IR.forward, backbone/model_irse.py:57-66 (BN -> conv -> PReLU -> conv -> BN, res + shortcut)."""
+    from frhip import _lib
+    if not _lib.lib.fr_conv3x3_strip_serves_bnbwd2(B, C, W):
+        pytest.skip("not served")
+    st, bf, fr = K.current_stream_ptr(), torch.bfloat16, _lib.FR_BF16
+    rows = B * W * W
+    dev = lambda t: t.cuda()  # noqa: E731
+    x = dev((synth.normal(67, "x", (rows, C)) * 1.3 + 0.2).to(bf))       # the unit's input (residual term)
+    y1 = dev(synth.normal(67, "y1", (rows, C)).to(bf))
+    w2 = dev((synth.normal(67, "w2", (C, 9, C)) * 0.03).to(bf))
+    w1n = dev((synth.normal(67, "w1n", (Cn, 9, C)) * 0.03).to(bf))
+    slope = dev(synth.uniform(67, "sl", (C,), 0.1, 0.4))
+    vec = lambda n, lo, hi: dev(synth.uniform(67, n, (C,), lo, hi))  # noqa: E731
+    g2, b2, g1n, b1n = vec("g2", 0.5, 1.5), vec("b2", -0.3, 0.3), vec("g1n", 0.5, 1.5), vec("b1n", -0.3, 0.3)
+    # statistics of x as the unit's own BN1 holds them
+    nb = K.grid_blocks(rows, C, fr)
+    px = torch.zeros(nb, 2, C, device="cuda")
+    K.call("fr_channel_stats", x, rows, C, px, nb, fr, None, st)()
+    bnx = [torch.zeros(C, device="cuda") for _ in range(4)]
+    K.call("fr_bn_finalize", px, nb, C, float(rows), None, None, 1e-5, 0.1, None, None, None, *bnx, st)()
+    conv2 = dict(src=y1, w=w2, B=B, RH=W, RW=W, SH=W, SW=W, SC=C, N=C, KH=3, KW=3, stride=1, pad=1, mode=0, lda=C, ldc=C,
+                 ldaux=C, pro=_lib.PRO_PRELU, pro_a=slope)
+    nparts = K.strip_parts(B, C, C, W, _lib.EPI_STATS_X)
+    assert nparts == K.strip_parts(B, C, C, W, _lib.EPI_STATS)
+    # ---- (1)
+    y2a, pa = torch.zeros(rows, C, device="cuda", dtype=bf), torch.zeros(nparts, 2, C, device="cuda")
+    y2b, pb = torch.zeros(rows, C, device="cuda", dtype=bf), torch.zeros(nparts, 3, C, device="cuda")
+    K.conv_strip(st, out=y2a, part=pa, epi=_lib.EPI_STATS, **conv2)()
+    K.conv_strip(st, out=y2b, part=pb, epi=_lib.EPI_STATS_X, aux=x, **conv2)()
+    torch.cuda.synchronize()
+    assert torch.equal(y2a, y2b) and torch.equal(pa, pb[:, :2].contiguous())
+    cross_ref = (y2b.double() * x.double()).sum(0)
+    sq_ref = (y2b.double() ** 2).sum(0)
+    cross = pb[:, 2].double().sum(0)
+    # (the kernel multiplies the fp32 accumulators, the reference their bf16 roundings: 2^-9 relative per term, random sign)
+    assert float((cross - cross_ref).abs().max()) < 2e-3 * float(torch.sqrt(sq_ref * (x.double() ** 2).sum(0)).max())
+    # ---- (2)
+    rm = [torch.zeros(C, device="cuda") for _ in range(4)]
+    rv = [torch.ones(C, device="cuda") for _ in range(4)]
+    nbt = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(4)]
+    bn2a = [torch.zeros(C, device="cuda") for _ in range(4)]
+    bn2b = [torch.zeros(C, device="cuda") for _ in range(4)]
+    bn1a = [torch.zeros(C, device="cuda") for _ in range(4)]
+    bn1b = [torch.zeros(C, device="cuda") for _ in range(4)]
+    K.call("fr_bn_finalize", pa, nparts, C, float(rows), g2, b2, 1e-5, 0.1, rm[0], rv[0], nbt[0], *bn2a, st)()
+    K.call("fr_bn_finalize_res", pb, nparts, C,
+           K.tail_bn(None, C, rows, g2, b2, 1e-5, 0.1, rm[1], rv[1], nbt[1], *bn2b), bnx[0], bnx[1], 1e-5,
+           K.tail_bn(None, C, rows, g1n, b1n, 1e-5, 0.1, rm[3], rv[3], nbt[3], *bn1b), st)()
+    # the two-pass path: out = BN2(y2) + x with the statistics of what was stored, then their finalize
+    out_ref = torch.zeros(rows, C, device="cuda", dtype=bf)
+    po = torch.zeros(nb, 2, C, device="cuda")
+    K.bn_apply(st, fr, x=y2a, out=out_ref, scale=bn2a[2], shift=bn2a[3], part=po, B=B, H=W, W=W, C=C, nblocks=nb, res=x,
+               res_kind=1, res_stride=1)()
+    K.call("fr_bn_finalize", po, nb, C, float(rows), g1n, b1n, 1e-5, 0.1, rm[2], rv[2], nbt[2], *bn1a, st)()
+    torch.cuda.synchronize()
+    for a, b in zip(bn2a, bn2b):
+        assert torch.equal(a, b)
+    assert torch.equal(rm[0], rm[1]) and torch.equal(rv[0], rv[1]) and int(nbt[1]) == 1 and int(nbt[3]) == 1
+    std = 1.0 / bn1a[1]
+    # the moments see conv2's fp32 accumulators, the pass over the tensor their bf16 roundings (2^-9 relative per element,
+    # random sign): the two means differ by that noise averaged over the pixels of a channel (3.4e-4 sigma at 588 pixels)
+    noise = 8 * 2.0 ** -9 / rows ** 0.5
+    assert float(((bn1b[0] - bn1a[0]).abs() / std).max()) < 1e-4 + noise, "mean of the residual sum from moments"
+    assert float((bn1b[1] / bn1a[1] - 1).abs().max()) < 3e-4 + noise, "invstd of the residual sum from moments"
+    assert float((bn1b[2] / bn1a[2] - 1).abs().max()) < 3e-4 + noise
+    assert float((bn1b[3] - bn1a[3]).abs().max()) < (1e-3 + noise) * float(bn1a[3].abs().max() + 1)
+    # (running_var moves by momentum x the difference of the variances: measured 1.4e-4 at 1176 pixels per channel)
+    assert float((rm[3] - rm[2]).abs().max()) < (1e-4 + noise) * float(std.max())
+    assert float((rv[3] / rv[2] - 1).abs().max()) < 2e-4 + noise
+    # ---- (3)
+    conv1 = dict(w=w1n, B=B, RH=W, RW=W, SH=W, SW=W, SC=C, N=Cn, KH=3, KW=3, stride=1, pad=1, mode=0, lda=C, ldc=Cn,
+                 epi=_lib.EPI_STORE)
+    z0, z1 = torch.zeros(rows, Cn, device="cuda", dtype=bf), torch.zeros(rows, Cn, device="cuda", dtype=bf)
+    K.conv_strip(st, src=out_ref, out=z0, pro=_lib.PRO_BN, pro_a=bn1a[2], pro_b=bn1a[3], **conv1)()
+    out1 = torch.full((rows, C), float("nan"), device="cuda", dtype=bf)
+    K.conv_strip(st, src=y2a, src2=x, pro_out=out1, out=z1, pro=_lib.PRO_RESBN, pro_a=bn2a[2], pro_b=bn2a[3],
+                 pro_c=bn1a[2], pro_d=bn1a[3], **conv1)()
+    torch.cuda.synchronize()
+    assert not torch.isnan(out1.float()).any(), "pro_out has pixels nobody wrote"
+    assert torch.equal(out1, out_ref), "the residual stream formed by conv1 differs from fr_bn_apply's"
+    assert torch.equal(z1, z0)
+    # refused: without the second source / the output pointer, as a data gradient, with a tail on the cross-moment rows
+    with pytest.raises(_lib.FrhipError):
+        K.conv_strip(st, src=y2a, out=z1, pro=_lib.PRO_RESBN, pro_a=bn2a[2], pro_b=bn2a[3], pro_c=bn1a[2], pro_d=bn1a[3],
+                     **conv1)()
+    with pytest.raises(_lib.FrhipError):
+        K.conv_strip(st, out=y2b, part=pb, epi=_lib.EPI_STATS_X, **conv2)()
+
+
 # ------------------------------------------------------------------------------------------------ Linear on the master weight
 
 

@@ -38,6 +38,7 @@ def timeit(launch, iters, flops):
 
 
 _FLUSH = None
+TOUCH = []  # operands of the case being timed (KBENCH_TOUCH)
 COLD = os.environ.get("KBENCH_COLD", "0") == "1"
 
 
@@ -51,8 +52,14 @@ def timeit_cold(launch, iters, flops):
     launch()
     torch.cuda.synchronize()
     tot = 0.0
+    mb = int(os.environ.get("KBENCH_FLUSH_MB", "1024"))  # 48: evicts the eight 4-MB L2s only, not the memory-side cache
+    touch = os.environ.get("KBENCH_TOUCH", "0") == "1"  # after the full flush READ the operands again, then evict L2 only
     for _ in range(iters):
-        _FLUSH.fill_(1.0)
+        _FLUSH[:mb * 262144].fill_(1.0)
+        if touch:
+            for t in TOUCH:
+                t.view(torch.int16).bitwise_and(1).sum() if t.dtype == BF else t.sum()
+            _FLUSH[:48 * 262144].fill_(1.0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         launch()
@@ -83,6 +90,7 @@ def conv_case(kind, cin, cout, W, B, stride=1, pro=1, epi=1, mode=0, iters=20):
     kw = dict(src=src, w=w, out=out, B=B, RH=RH, RW=RH, SH=SH, SW=SH, SC=SC, N=N, KH=3, KW=3, stride=stride, pad=1,
               mode=mode, lda=SC, ldc=N, ldaux=N, pro=pro, pro_a=va, pro_b=vb, epi=epi, epi_a=va, epi_b=vb, aux=aux,
               part=part)
+    TOUCH[:] = [src, aux]
     flops = 2.0 * B * Ho * Ho * N * 9 * SC  # stride 2: both directions do 9 taps per LOW-res pixel
     if os.environ.get("KBENCH_GRIDBAR", "0") == "1":  # libfrhip_gridbar.so: counters + coefficient scratch behind cos_t
         kw["cos_t"] = torch.zeros(16 + 2 * 512, device="cuda")
@@ -107,6 +115,7 @@ def wgrad_case(kind, cout, cin, W, B, stride=1, pro=1, iters=20):
     va, vb = torch.rand(512, device="cuda") + 0.5, torch.rand(512, device="cuda") - 0.5
     kw = dict(g=g, src=x, dw=dw, B=B, GH=Ho, GW=Ho, Cout=cout, SH=W, SW=W, SC=cin, KH=3, KW=3, stride=stride, pad=1,
               ldg=cout, lda=cin, pro=pro, pro_a=va, pro_b=vb)
+    TOUCH[:] = [g, x]
     flops = 2.0 * B * Ho * Ho * cout * cin * 9
     if kind == "wgs":
         tiles = (cout // 64) * (cin // 64)
