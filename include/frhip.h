@@ -43,7 +43,11 @@ enum {
                         MaxPool2d(1, 1) shortcut), operand = c[c]*o + d[c] (pro_c / pro_d: this unit's BN1).  o is stored to
                         pro_out (interior pixels, once each): the residual stream is materialised by its consumer and the
                         BN-apply pass behind conv2 is gone.  The batch statistics of o come from fr_bn_finalize_res.
-                        Served by fr_conv3x3_strip forward launches of square layers (bf16). */
+                        Served by fr_conv3x3_strip forward launches (bf16). */
+  ,
+  FR_PRO_RESBN_SE = 5 /* FR_PRO_RESBN behind a squeeze-excite unit (bottleneck_IR_SE, backbone/model_irse.py:84-91):
+                         o = round((a[c]*x + b[c]) * g[image][c] + x2) with the excite gates pro_g = [B][SC] fp32.  Instances
+                         whose workgroups hold strips of ONE image. */
 };
 
 /* epilogue of fr_conv_igemm */
@@ -144,7 +148,8 @@ typedef struct FrConvArgs {
   const void* src2;    /* second source, geometry and strides of src */
   const float* pro_c;  /* [SC] */
   void* pro_out;       /* NULL or [B*SH*SW][lda]: the prologue result of every source pixel */
-  const float* pro_d;  /* [SC], FR_PRO_RESBN only */
+  const float* pro_d;  /* [SC], FR_PRO_RESBN / FR_PRO_RESBN_SE only */
+  const float* pro_g;  /* [B][SC] excite gates, FR_PRO_RESBN_SE only */
 } FrConvArgs;
 
 /* Convolution forward / data gradient / dense GEMM on MFMA.
@@ -269,6 +274,8 @@ int fr_bn_finalize(const float* part, int nparts, int C, double count, const flo
  * normalises the unit's output o' = scale*y + shift + o:  mean' = scale*my + shift + mo,  var' = scale^2*vy + vo +
  * 2*scale*cov(y, o), with (mo, vo) from in_mean / in_invstd / in_eps -- the statistics the unit's own BN1 used for o.
  * Of the two FrTail arguments only the BatchNorm fields are read (count, gamma ... shift); ticket / kind are ignored.
+ * next == NULL: only `bn` is finalised (rows of three vectors; squeeze-excite units, whose output statistics need the
+ * gates: fr_se_pool_parts_mlp_fwd_res).
  * Replaces the statistics pass behind `res + shortcut` of bottleneck_IR (backbone/model_irse.py:64-66) for identity units. */
 int fr_bn_finalize_res(const float* part, int nparts, int C, const FrTail* bn, const float* in_mean, const float* in_invstd,
                        float in_eps, const FrTail* next, void* stream);
@@ -381,6 +388,18 @@ int fr_se_mlp_fwd(const float* pooled, const float* w1, const float* w2, float* 
 int fr_se_pool_parts_mlp_fwd(const float* part, int rows_per_image, const float* scale, const float* shift,
                              const float* w1, const float* w2, float* pooled, float* hidden, float* s, int B, int HW,
                              int C, int R, void* stream);
+/* fr_se_pool_parts_mlp_fwd on rows of `nv` vectors (3: FR_EPI_STATS_X rows -- sum y, sum y^2, sum y*x per strip) that also
+ * derives, per IMAGE, the moments of the unit's output  o = (scale*y + shift)*s[b][c] + x  without a pass over it:
+ *   om[b][0][c] = sum_hw o = s*(scale*Sy + shift*HW) + Sx
+ *   om[b][1][c] = sum_hw o^2 = s^2*(scale^2*Syy + 2*scale*shift*Sy + shift^2*HW) + 2*s*(scale*Syx + shift*Sx) + Sxx
+ * with (Sx, Sxx) = xm[b][0..1][c], the same per-image moments of the unit's INPUT (the om of the unit in front, or
+ * fr_image_moments at the head of a chain).  fr_bn_finalize(om, B, C, B*HW, ..) then gives the next unit's BN1.
+ * Replaces the statistics pass behind `res + shortcut` of bottleneck_IR_SE (backbone/model_irse.py:84-91). */
+int fr_se_pool_parts_mlp_fwd_res(const float* part, int rows_per_image, int nv, const float* scale, const float* shift,
+                                 const float* w1, const float* w2, float* pooled, float* hidden, float* s, int B, int HW,
+                                 int C, int R, const float* xm, float* om, void* stream);
+/* out[b][0][c] = sum_hw x, out[b][1][c] = sum_hw x^2 of an NHWC bf16 tensor [B][HW][C] (C / 8 a divisor of 256) */
+int fr_image_moments(const void* x, int B, int HW, int C, float* out, void* stream);
 /* gs[b][c] = sum_hw g * (x*scale+shift)  (gradient wrt the excite scale) */
 int fr_se_gscale(const void* g, const void* x, const float* scale, const float* shift, float* gs, int B, int HW,
                  int C, int dtype, void* stream);

@@ -89,7 +89,7 @@ FrTail = structs["FrTail"]
 
 # enums of the header
 FR_F32, FR_BF16 = 0, 1
-PRO_NONE, PRO_BN, PRO_PRELU, PRO_BNBWD2, PRO_RESBN = 0, 1, 2, 3, 4
+PRO_NONE, PRO_BN, PRO_PRELU, PRO_BNBWD2, PRO_RESBN, PRO_RESBN_SE = 0, 1, 2, 3, 4, 5
 EPI_STORE, EPI_STATS, EPI_PRELU_BWD, EPI_BNBWD, EPI_MARGIN, EPI_ATOMIC, EPI_SLAB, EPI_BIAS_RES, EPI_STATS_X = range(9)
 TAIL_NONE, TAIL_SUMS, TAIL_BN, TAIL_BNBWD = range(4)
 

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: keeps the tile loops branch-free
   const int wn = wave % WN, wm = wave / WN;
-  constexpr bool TWO = PRO == FR_PRO_BNBWD2 || PRO == FR_PRO_RESBN;  // two-source prologues
+  constexpr bool TWO = PRO == FR_PRO_BNBWD2 || PRO == FR_PRO_RESBN || PRO == FR_PRO_RESBN_SE;  // two-source prologues
   const bf16_t* __restrict__ src = reinterpret_cast<const bf16_t*>(p.src);
   const bf16_t* __restrict__ wgt = reinterpret_cast<const bf16_t*>(p.w);
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
@@ -120,18 +120,20 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
   constexpr int WP = W + 2;
   constexpr int TOTAL = NIMG * C::GH * WP * C::CH;
   const int ch = tid % C::CH;  // NTH is a multiple of CH: a thread always handles the same channel chunk
-  float pa[8], pb[8], pc[8], pd[PRO == FR_PRO_RESBN ? 8 : 1];  // prologue coefficients of this thread's channel chunk: re-read per strip (L1 hits) rather
+  constexpr bool RES = PRO == FR_PRO_RESBN || PRO == FR_PRO_RESBN_SE;
+  float pa[8], pb[8], pc[8], pd[RES ? 8 : 1], pg[PRO == FR_PRO_RESBN_SE ? 8 : 1];  // prologue coefficients of this thread's channel chunk: re-read per strip (L1 hits) rather
                               // than kept live across the MFMA loop
   int kc = 0;  // channel stage (KSPL > 1): input channels [kc*CK, (kc+1)*CK) are resident
   auto kco = [&]() -> int { return KSPL > 1 ? kc * CK : 0; };  // literally 0 for the single-stage instances
-  auto load_pro = [&]() {
+  auto load_pro = [&](int s) {
     if (PRO != FR_PRO_NONE) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         pa[j] = p.pro_a[kco() + ch * 8 + j];
         pb[j] = (PRO == FR_PRO_BN || TWO) ? p.pro_b[kco() + ch * 8 + j] : 0.f;
         pc[j] = TWO ? p.pro_c[kco() + ch * 8 + j] : 0.f;
-        if (PRO == FR_PRO_RESBN) pd[j] = p.pro_d[kco() + ch * 8 + j];
+        if (RES) pd[j] = p.pro_d[kco() + ch * 8 + j];
+        if (PRO == FR_PRO_RESBN_SE) pg[j] = p.pro_g[(size_t)(s / C::NS) * p.SC + kco() + ch * 8 + j];  // this image's gates
       }
     }
   };
@@ -176,11 +178,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
           unpack16<bf16_t>(x2, f2);
 #pragma unroll
           for (int j = 0; j < 8; ++j) f[j] = fmaf(pa[j], f[j], fmaf(pb[j], f2[j], pc[j]));
-        } else if (PRO == FR_PRO_RESBN) {
+        } else if (RES) {
           float f2[8];
           unpack16<bf16_t>(x2, f2);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] = fmaf(f[j], pa[j], pb[j]) + f2[j];  // the arithmetic of fr_bn_apply (res_kind 1)
+          for (int j = 0; j < 8; ++j) {  // the arithmetic of fr_bn_apply (res_kind 1 [, se])
+            f[j] = fmaf(f[j], pa[j], pb[j]);
+            f[j] = PRO == FR_PRO_RESBN_SE ? fmaf(f[j], pg[j], f2[j]) : f[j] + f2[j];
+          }
           x = pack16<bf16_t>(f);
           if (own && nh == 0 && pro_out) st16(pro_out + off, x);
           unpack16<bf16_t>(x, f);  // BN1 normalises what the residual stream holds
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
     constexpr bool ONE = (NW == 4 && PER <= 18) || (PER <= FRHIP_STRIP_LOAD_BATCH && (KSPL == 1 || C::TM * C::TN * 4 <= 64));
     constexpr int UNR1 = ONE ? PER : 8;
     constexpr int UNR = (TWO && UNR1 > 10) ? (UNR1 + 1) / 2 : UNR1;  // two sources: half the chunks per batch
-    load_pro();
+    load_pro(s);
     for (int base = 0; base < TOTAL; base += NTH * UNR) {
       U128 v[UNR], v2[TWO ? UNR : 1];
       bool ok[UNR], own[UNR];
@@ -612,6 +617,14 @@ int by_pro(const FrConvArgs& a, hipStream_t st) {
       if (!a.src2 || !a.pro_a || !a.pro_b || !a.pro_c || !a.pro_d || !a.pro_out || a.mode != 0)
         FR_UNSUPPORTED("fr_conv3x3_strip: FR_PRO_RESBN needs src2, pro_a ... pro_d, pro_out and mode 0");
       return launch<CIN, COUT, W, ROWS, WN, NW, NSPL, FR_PRO_RESBN, NIMG, KSPL>(a, st);
+    case FR_PRO_RESBN_SE:
+      if constexpr (NIMG == 1) {
+        if (!a.src2 || !a.pro_a || !a.pro_b || !a.pro_c || !a.pro_d || !a.pro_g || !a.pro_out || a.mode != 0)
+          FR_UNSUPPORTED("fr_conv3x3_strip: FR_PRO_RESBN_SE needs src2, pro_a ... pro_d, pro_g, pro_out and mode 0");
+        return launch<CIN, COUT, W, ROWS, WN, NW, NSPL, FR_PRO_RESBN_SE, NIMG, KSPL>(a, st);
+      } else {
+        FR_UNSUPPORTED("fr_conv3x3_strip: FR_PRO_RESBN_SE is served by the one-image-per-workgroup instances only");
+      }
   }
   FR_UNSUPPORTED("fr_conv3x3_strip: unknown prologue");
 }
@@ -739,7 +752,7 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
     for (int half = 0; half < 2; ++half) {
       h.w = reinterpret_cast<const bf16_t*>(a.w) + (size_t)half * 256 * 9 * 256;
       h.out = reinterpret_cast<bf16_t*>(a.out) + half * 256;
-      if (a.pro == FR_PRO_RESBN && half == 1) {  // the first pass has materialised the residual sum: plain BN1 on it
+      if ((a.pro == FR_PRO_RESBN || a.pro == FR_PRO_RESBN_SE) && half == 1) {  // the first pass has materialised the residual sum: plain BN1 on it
         h.pro = FR_PRO_BN;
         h.src = a.pro_out;
         h.pro_a = a.pro_c;

@@ -148,7 +148,8 @@ static FrBnFin fin_of(const FrTail& t) {
 }
 __global__ __launch_bounds__(RT) void bn_finalize_res_kernel(const float* __restrict__ part, int nparts, int C, FrBnFin f,
                                                              const float* __restrict__ in_mean,
-                                                             const float* __restrict__ in_invstd, float in_eps, FrBnFin fn) {
+                                                             const float* __restrict__ in_invstd, float in_eps, FrBnFin fn,
+                                                             bool has_next) {
   __shared__ double lds[3 * (RT / 64) * 8];
   const int c0 = blockIdx.x * 8;
   const int cols[3] = {c0, C + c0, 2 * C + c0};
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(RT) void bn_finalize_res_kernel(const float* __rest
     double vy = __builtin_fma(-my, my, sq[1] / f.count);
     if (vy < 0.0) vy = 0.0;
     fr_bn_from_moments(f, c, my, vy);  // BN2 exactly as fr_bn_finalize leaves it
+    if (!has_next) return;
     const double a = (double)f.scale[c], b = (double)f.shift[c];  // the rounded coefficients the prologue multiplies with
     const double mo = (double)in_mean[c], io = (double)in_invstd[c];
     double vo = 1.0 / (io * io) - (double)in_eps;
@@ -504,8 +506,11 @@ __global__ __launch_bounds__(NT, 6) void bn_apply_lean_kernel(const FrApplyArgs 
 #pragma unroll
         for (int j = 0; j < LV; ++j) {
           f[j] = fmaf(f[j], sc[j], sh[j]);
-          if (SE) f[j] *= gt[j];
-          if (RES != 0) f[j] += fmaf(g[j], rs[j], rh[j]);
+          // (gate and residual as ONE fused multiply-add, written out: FR_PRO_RESBN_SE forms the same tensor elsewhere and
+          // must round the same way whatever the compiler contracts)
+          if (SE && RES != 0) f[j] = fmaf(f[j], gt[j], fmaf(g[j], rs[j], rh[j]));
+          else if (SE) f[j] *= gt[j];
+          else if (RES != 0) f[j] += fmaf(g[j], rs[j], rh[j]);
         }
         const uint2 o = pack4bf(f);
         *reinterpret_cast<uint2*>(out + (size_t)r * C) = o;
@@ -758,7 +763,8 @@ __global__ void se_mlp_fwd_kernel(const float* __restrict__ pooled_in, const flo
                                   const float* __restrict__ w2, float* __restrict__ hidden, float* __restrict__ s,
                                   int C, int R, const float* __restrict__ part, int NS,
                                   const float* __restrict__ scale, const float* __restrict__ shift, float inv_hw,
-                                  float* __restrict__ pooled_out) {
+                                  float* __restrict__ pooled_out, int NV = 2, const float* __restrict__ xm = nullptr,
+                                  float* __restrict__ om = nullptr) {
   extern __shared__ float sm[];  // [C] pooled, [R] hidden
   float* pv = sm;
   float* hv = sm + C;
@@ -766,7 +772,7 @@ __global__ void se_mlp_fwd_kernel(const float* __restrict__ pooled_in, const flo
   for (int c = tid; c < C; c += blockDim.x) {
     if (PARTS) {
       float t = 0.f;
-      for (int k = 0; k < NS; ++k) t += part[((size_t)(b * NS + k) * 2) * C + c];
+      for (int k = 0; k < NS; ++k) t += part[((size_t)(b * NS + k) * NV) * C + c];
       const float v = fmaf(t * inv_hw, scale[c], shift[c]);
       pv[c] = v;
       pooled_out[(size_t)b * C + c] = v;
@@ -790,7 +796,57 @@ __global__ void se_mlp_fwd_kernel(const float* __restrict__ pooled_in, const flo
   for (int c = tid; c < C; c += blockDim.x) {
     float acc = 0.f;
     for (int r = 0; r < R; ++r) acc = fmaf(w2[(size_t)c * R + r], hv[r], acc);
-    s[(size_t)b * C + c] = 1.0f / (1.0f + __expf(-acc));
+    const float gate = 1.0f / (1.0f + __expf(-acc));
+    s[(size_t)b * C + c] = gate;
+    if (PARTS && om) {
+      // per-image moments of the unit's output o = (a*y + bb)*g + x from the moments of y (this image's strip rows), the
+      // cross moment sum(y*x) and the moments of x: no pass over o (fr_se_pool_parts_mlp_fwd_res)
+      double Sy = 0.0, Syy = 0.0, Syx = 0.0;
+      for (int k = 0; k < NS; ++k) {
+        const float* row = part + ((size_t)(b * NS + k) * NV) * C + c;
+        Sy += (double)row[0];
+        Syy += (double)row[C];
+        Syx += (double)row[2 * (size_t)C];
+      }
+      const double a = (double)scale[c], bb = (double)shift[c], g = (double)gate, hw = 1.0 / (double)inv_hw;
+      const double Sx = (double)xm[((size_t)b * 2 + 0) * C + c], Sxx = (double)xm[((size_t)b * 2 + 1) * C + c];
+      om[((size_t)b * 2 + 0) * C + c] = (float)(g * (a * Sy + bb * hw) + Sx);
+      om[((size_t)b * 2 + 1) * C + c] =
+          (float)(g * g * (a * a * Syy + 2.0 * a * bb * Sy + bb * bb * hw) + 2.0 * g * (a * Syx + bb * Sx) + Sxx);
+    }
+  }
+}
+
+// per-image (sum, sum of squares) of an NHWC bf16 tensor: the head of a chain of fr_se_pool_parts_mlp_fwd_res launches.
+// One block per image; thread = (row group, 8-channel chunk).
+__global__ __launch_bounds__(256) void image_moments_kernel(const bf16_t* __restrict__ x, int HW, int C,
+                                                            float* __restrict__ out) {
+  __shared__ float red[256 * 16];
+  const int b = blockIdx.x, tid = threadIdx.x, cpr = C / 8, cc = tid % cpr, rt = tid / cpr, rtc = 256 / cpr;
+  float a0[8], a1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a0[j] = a1[j] = 0.f;
+  const bf16_t* base = x + (size_t)b * HW * C + cc * 8;
+  for (int r = rt; r < HW; r += rtc) {
+    float f[8];
+    unpack16<bf16_t>(ld16(base + (size_t)r * C), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a0[j] += f[j];
+      a1[j] = fmaf(f[j], f[j], a1[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[tid * 16 + j] = a0[j];
+    red[tid * 16 + 8 + j] = a1[j];
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * C; i += 256) {
+    const int k = i / C, c = i - k * C;
+    float t = 0.f;
+    for (int g = 0; g < rtc; ++g) t += red[(g * cpr + c / 8) * 16 + k * 8 + (c & 7)];
+    out[((size_t)b * 2 + k) * C + c] = t;
   }
 }
 
@@ -1387,15 +1443,15 @@ extern "C" int fr_bn_finalize(const float* part, int nparts, int C, double count
 
 extern "C" int fr_bn_finalize_res(const float* part, int nparts, int C, const FrTail* bn, const float* in_mean,
                                   const float* in_invstd, float in_eps, const FrTail* next, void* stream) {
-  if (!part || nparts < 1 || C < 1 || !bn || !next || !in_mean || !in_invstd)
-    FR_UNSUPPORTED("fr_bn_finalize_res: part, bn, next, in_mean, in_invstd are required");
-  if (!(bn->count > 0.0) || !bn->mean || !bn->invstd || !bn->scale || !bn->shift || !next->mean || !next->invstd ||
-      !next->scale || !next->shift)
+  if (!part || nparts < 1 || C < 1 || !bn || (next && (!in_mean || !in_invstd)))
+    FR_UNSUPPORTED("fr_bn_finalize_res: part and bn are required, in_mean / in_invstd with next");
+  if (!(bn->count > 0.0) || !bn->mean || !bn->invstd || !bn->scale || !bn->shift ||
+      (next && (!next->mean || !next->invstd || !next->scale || !next->shift)))
     FR_UNSUPPORTED("fr_bn_finalize_res: count and the four coefficient vectors of both BatchNorms are required");
-  FrBnFin f = fin_of(*bn), fn = fin_of(*next);
+  FrBnFin f = fin_of(*bn), fn = next ? fin_of(*next) : f;
   fn.count = bn->count;  // same pixels
   hipLaunchKernelGGL(bn_finalize_res_kernel, dim3((C + 7) / 8), dim3(RT), 0, (hipStream_t)stream, part, nparts, C, f,
-                     in_mean, in_invstd, in_eps, fn);
+                     in_mean, in_invstd, in_eps, fn, next != nullptr);
   FR_LAUNCH_CHECK();
 }
 
@@ -1594,6 +1650,25 @@ extern "C" int fr_se_pool_parts_mlp_fwd(const float* part, int rows_per_image, c
   hipLaunchKernelGGL(se_mlp_fwd_kernel<true>, dim3(B), dim3(256), (C + R) * sizeof(float), (hipStream_t)stream,
                      (const float*)nullptr, w1, w2, hidden, s, C, R, part, rows_per_image, scale, shift,
                      1.0f / (float)HW, pooled);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_se_pool_parts_mlp_fwd_res(const float* part, int rows_per_image, int nv, const float* scale,
+                                            const float* shift, const float* w1, const float* w2, float* pooled,
+                                            float* hidden, float* s, int B, int HW, int C, int R, const float* xm, float* om,
+                                            void* stream) {
+  if (rows_per_image < 1 || B < 1 || C < 1 || R < 1 || !part || !pooled || nv != 3 || !xm || !om)
+    FR_UNSUPPORTED("fr_se_pool_parts_mlp_fwd_res: rows of 3 vectors (FR_EPI_STATS_X), xm and om are required");
+  hipLaunchKernelGGL(se_mlp_fwd_kernel<true>, dim3(B), dim3(256), (C + R) * sizeof(float), (hipStream_t)stream,
+                     (const float*)nullptr, w1, w2, hidden, s, C, R, part, rows_per_image, scale, shift,
+                     1.0f / (float)HW, pooled, nv, xm, om);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_image_moments(const void* x, int B, int HW, int C, float* out, void* stream) {
+  if (!x || !out || B < 1 || HW < 1 || C < 8 || C % 8 || C / 8 > 256 || 256 % (C / 8))
+    FR_UNSUPPORTED("fr_image_moments: bf16 [B][HW][C] with C / 8 a divisor of 256");
+  hipLaunchKernelGGL(image_moments_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, HW, C, out);
   FR_LAUNCH_CHECK();
 }
 

@@ -290,6 +290,10 @@ class BackbonePlan(object):
         # A/B switch.
         self.res_moments = (os.environ.get("FRHIP_RES_MOMENTS", "1") != "0" and self.fr == FR_BF16 and self.use_strip
                             and not self.fold)
+        # ... and behind squeeze-excite units (out = gate[image][c] * BN2(y2) + x): the same moments PER IMAGE, combined with
+        # the gates by the launch that computes them (fr_se_pool_parts_mlp_fwd_res); the moments of x are carried from unit to
+        # unit (one fr_image_moments pass at the head of a stage).  FRHIP_RES_MOMENTS_SE=0: A/B switch for this half.
+        self.res_moments_se = self.res_moments and os.environ.get("FRHIP_RES_MOMENTS_SE", "1") != "0"
         self.use_stem_gemm = (self.fr == FR_BF16 and os.environ.get("FRHIP_NO_STEM_GEMM", "0") != "1" and
                               not self.body_only)
         self.use_s2 = os.environ.get("FRHIP_NO_S2_STRIP", "0") != "1"  # stride-2 strip kernels (A/B switch)
@@ -322,10 +326,15 @@ class BackbonePlan(object):
         C0 = self.units[0].cin if self.body_only else 64  # channels of the first unit's input
         self.z0 = self._act(M0, C0)
         if not self.body_only:
-            # Round 4: the two stem GEMMs build their im2col rows from the fp32 batch in registers (fr_stem_gemm_x /
-            # fr_stem_wgrad_bn_x: bit-identical to the materialised rows) -- X0, 205 MB at batch 256, is neither written nor read
-            # and fr_stem_im2col is gone from the step (FRHIP_STEM_IMPLICIT=0: A/B switch)
-            self.stem_x = (self.use_stem_gemm and os.environ.get("FRHIP_STEM_IMPLICIT", "1") != "0" and
+            # Round 4: the stem GEMMs can build their im2col rows from the fp32 batch in registers (fr_stem_gemm_x /
+            # fr_stem_wgrad_bn_x: bit-identical to the materialised rows).  Per launch at batch 256 (event table): forward 171
+            # us against 93 (fr_stem_im2col) + 122; weight gradient 299 against 180 -- 27 scalar gathers per row cost more in
+            # the weight gradient than the 205 MB of rows they save: +0.05-0.09 ms per step (profiles/r04_ab_stem_implicit.txt;
+            # also measured there: forward implicit + the weight gradient's rows built on the side stream during the forward
+            # pass, +0.1 ms against materialised rows -- removed).  So: opt-in, FRHIP_STEM_IMPLICIT=1 (no X0: 205 MB less
+            # memory at batch 256); default = rows materialised in front of the forward GEMM.
+            mode = os.environ.get("FRHIP_STEM_IMPLICIT", "0")
+            self.stem_x = (self.use_stem_gemm and mode != "0" and
                            os.environ.get("FRHIP_NO_STEM_BNFUSE", "0") != "1" and M0 < (1 << 24) and
                            ((self.K0 == 32 and self.in_channels == 3 and self.avg_channels == 0) or
                             (self.K0 == 64 and self.in_channels + self.avg_channels == 6)))
@@ -646,21 +655,33 @@ class BackbonePlan(object):
                            bn.shift)
 
     def _res_edge(self, i):
-        """True when unit i's output is formed by unit i+1's conv1 (FR_PRO_RESBN) and its statistics come from moments."""
+        """Non-zero when unit i's output is formed by unit i+1's conv1 and its statistics come from moments: 1 = plain unit
+        (FR_PRO_RESBN, fr_bn_finalize_res), 2 = squeeze-excite unit (FR_PRO_RESBN_SE, per-image moments through
+        fr_se_pool_parts_mlp_fwd_res)."""
         if not self.res_moments or i < 0 or i + 1 >= len(self.units):
-            return False
+            return 0
         u, n = self.units[i], self.units[i + 1]
-        if u.se is not None or u.sc_conv is not None or u.stride != 1 or n.cin != u.depth:
-            return False
+        if u.sc_conv is not None or u.stride != 1 or n.cin != u.depth:
+            return 0
         bns = (self.ubuf[i]["bn1"], self.ubuf[i]["bn2"], self.ubuf[i + 1]["bn1"])
         if not all(b.mod.training for b in bns):
-            return False
+            return 0
         # conv2 of unit i and conv1 of unit i + 1 on LDS-strip instances (the 64 -> 64 rolling-window kernel takes neither)
         if not _lib.lib.fr_conv3x3_strip_serves_bnbwd2(self.B, u.depth, u.Ho):
-            return False
-        if n.cin == n.depth:
-            return True
-        return ops.strip_parts(self.B, n.cin, n.depth, n.H, ops.EPI_STORE) > 0
+            return 0
+        if n.cin != n.depth and ops.strip_parts(self.B, n.cin, n.depth, n.H, ops.EPI_STORE) <= 0:
+            return 0
+        if u.se is None:
+            return 1
+        # squeeze-excite: the gates weigh every image differently, so the moments are kept per image -- conv2's partial rows
+        # must be strips of single images (not the multi-image 7x7 workgroups) and so must the consumer's workgroups
+        if not self.res_moments_se or self.B > 65535:
+            return 0
+        rows2 = ops.strip_parts(self.B, u.depth, u.depth, u.Ho, ops.EPI_STATS_X)
+        rows1 = ops.strip_parts(self.B, n.cin, n.depth, n.H, ops.EPI_STORE) if n.cin != n.depth else rows2
+        if rows2 <= 0 or rows2 % self.B or rows1 <= 0 or rows1 % self.B or (u.depth // 8) > 256 or 256 % (u.depth // 8):
+            return 0
+        return 2
 
     def _sum_tail(self, K, C, o0, o1=None, o2=None, cls=4):
         """The in-launch form of fr_reduce_parts(part, rows, K, C, o0, o1, o2), or None without FRHIP_TAIL=1."""
@@ -752,14 +773,16 @@ class BackbonePlan(object):
                 wp1, wp2 = w1, w2
             bn1, bn2 = d["bn1"], d["bn2"]
             folded = fold and u.se is None and (u.sc_conv is not None or u.stride == 1)
-            if self._res_edge(i - 1):
+            edge_in, edge_out = self._res_edge(i - 1), self._res_edge(i)
+            if edge_in:
                 # x (the previous unit's output) does not exist yet: this launch forms it from that unit's y2 and input,
                 # stores it, and applies BN1 to it
                 pd = self.ubuf[i - 1]
+                se_kw = dict(pro=ops.PRO_RESBN_SE, pro_g=pd["s"]) if edge_in == 2 else dict(pro=ops.PRO_RESBN)
                 self._conv(L, src=pd["y2"], src2=x_in, pro_out=x, w=wp1, out=d["y1"], B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H,
                            SC=u.cin, N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.cin, ldc=u.depth,
-                           pro=ops.PRO_RESBN, pro_a=pd["bn2"].scale, pro_b=pd["bn2"].shift, pro_c=bn1.scale,
-                           pro_d=bn1.shift, epi=ops.EPI_STORE)
+                           pro_a=pd["bn2"].scale, pro_b=pd["bn2"].shift, pro_c=bn1.scale, pro_d=bn1.shift,
+                           epi=ops.EPI_STORE, **se_kw)
             else:
                 self._conv(L, src=x, w=wp1, out=d["y1"], B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H, SC=u.cin,
                            N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.cin, ldc=u.depth,
@@ -788,13 +811,26 @@ class BackbonePlan(object):
                     self._bn_train_launches(L, nxt, None, 0, rout)
                 x = d["out"]
                 continue
-            if self._res_edge(i):
+            if edge_out:
+                if edge_out == 2 and edge_in != 2:  # head of a squeeze-excite chain: per-image moments of its input
+                    d["xm"] = torch.empty(B, 2, u.depth, device=self.device)
+                    L.append(ops.call("fr_image_moments", x_in, B, u.H * u.H, u.depth, d["xm"], st))
                 np2 = self._conv(L, src=d["y1"], w=wp2, out=d["y2"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H, SC=u.depth,
                                  N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.depth, ldc=u.depth, ldaux=u.depth,
                                  pro=ops.PRO_PRELU, pro_a=u.prelu.weight, epi=ops.EPI_STATS_X, aux=x_in, part=self.part)
                 nxt = self.ubuf[i + 1]["bn1"]
-                L.append(ops.call("fr_bn_finalize_res", self.part, np2, u.depth, self._bn_fields(bn2, rout), bn1.mean,
-                                  bn1.invstd, float(bn1.mod.eps), self._bn_fields(nxt, rout), st))
+                if edge_out == 1:
+                    L.append(ops.call("fr_bn_finalize_res", self.part, np2, u.depth, self._bn_fields(bn2, rout), bn1.mean,
+                                      bn1.invstd, float(bn1.mod.eps), self._bn_fields(nxt, rout), st))
+                else:
+                    L.append(ops.call("fr_bn_finalize_res", self.part, np2, u.depth, self._bn_fields(bn2, rout), None, None,
+                                      0.0, None, st))
+                    d["om"] = torch.empty(B, 2, u.depth, device=self.device)
+                    xm = self.ubuf[i - 1]["om"] if edge_in == 2 else d["xm"]
+                    L.append(ops.call("fr_se_pool_parts_mlp_fwd_res", self.part, np2 // B, 3, bn2.scale, bn2.shift,
+                                      u.se.fc1.weight, u.se.fc2.weight, d["pooled"], d["hidden"], d["s"], B, u.Ho * u.Ho,
+                                      u.depth, u.se.fc1.out_channels, xm, d["om"], st))
+                    self._bn_train_launches(L, nxt, d["om"], B, rout)
                 x = d["out"]  # written by the next unit's conv1
                 continue
             np2 = self._conv(L, src=d["y1"], w=wp2, out=d["y2"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H,

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import (EPI_ATOMIC, EPI_BIAS_RES, EPI_BNBWD, EPI_MARGIN, EPI_PRELU_BWD, EPI_SLAB, EPI_STATS, EPI_STATS_X, EPI_STORE,  # noqa: F401
                    FR_BF16,
                    FR_F32,
-                   PRO_BN, PRO_BNBWD2, PRO_NONE, PRO_PRELU, PRO_RESBN, lib)
+                   PRO_BN, PRO_BNBWD2, PRO_NONE, PRO_PRELU, PRO_RESBN, PRO_RESBN_SE, lib)
 
 TORCH_DTYPE = {FR_F32: torch.float32, FR_BF16: torch.bfloat16}
 

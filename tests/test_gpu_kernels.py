@@ -1555,6 +1555,97 @@ def test_residual_sum_by_its_consumer_and_statistics_from_moments(K, B, C, W, Cn
         K.conv_strip(st, out=y2b, part=pb, epi=_lib.EPI_STATS_X, **conv2)()
 
 
+@pytest.mark.parametrize("B,C,W,Cn", [(162, 256, 14, 256), (6, 256, 14, 256), (40, 128, 28, 128), (40, 128, 28, 256),
+                                      (6, 256, 14, 512)])
+def test_residual_sum_behind_a_squeeze_excite_unit(K, B, C, W, Cn):
+    """The squeeze-excite form of the test above: out = gate[image][c] * BN2(y2) + x.
+    fr_bn_finalize_res(next = NULL) on rows of three vectors == fr_bn_finalize on rows of two; fr_image_moments against torch;
+    fr_se_pool_parts_mlp_fwd_res gives the pooled vector, hidden layer and gates of fr_se_pool_parts_mlp_fwd bit for bit and
+    per-image moments of `out` that agree with the materialised tensor (fr_bn_apply with the gates); the next BatchNorm's
+    statistics from those moments agree with the ones fr_bn_apply measures; FR_PRO_RESBN_SE forms the same tensor bit for bit.
+    Reference: bottleneck_IR_SE.forward, backbone/model_irse.py:84-91, SEModule :23-46."""
+    from frhip import _lib
+    st, bf, fr = K.current_stream_ptr(), torch.bfloat16, _lib.FR_BF16
+    rows, HW, R = B * W * W, W * W, C // 16
+    dev = lambda t: t.cuda()  # noqa: E731
+    x = dev((synth.normal(71, "x", (rows, C)) * 1.3 + 0.2).to(bf))
+    y1 = dev(synth.normal(71, "y1", (rows, C)).to(bf))
+    w2 = dev((synth.normal(71, "w2", (C, 9, C)) * 0.03).to(bf))
+    w1n = dev((synth.normal(71, "w1n", (Cn, 9, C)) * 0.03).to(bf))
+    fc1, fc2 = dev(synth.normal(71, "fc1", (R, C)) * 0.2), dev(synth.normal(71, "fc2", (C, R)) * 0.5)
+    slope = dev(synth.uniform(71, "sl", (C,), 0.1, 0.4))
+    vec = lambda n, lo, hi: dev(synth.uniform(71, n, (C,), lo, hi))  # noqa: E731
+    g2, b2, g1n, b1n = vec("g2", 0.5, 1.5), vec("b2", -0.3, 0.3), vec("g1n", 0.5, 1.5), vec("b1n", -0.3, 0.3)
+    conv2 = dict(src=y1, w=w2, B=B, RH=W, RW=W, SH=W, SW=W, SC=C, N=C, KH=3, KW=3, stride=1, pad=1, mode=0, lda=C, ldc=C,
+                 ldaux=C, pro=_lib.PRO_PRELU, pro_a=slope)
+    nparts = K.strip_parts(B, C, C, W, _lib.EPI_STATS_X)
+    assert nparts % B == 0
+    y2, pa = torch.zeros(rows, C, device="cuda", dtype=bf), torch.zeros(nparts, 2, C, device="cuda")
+    y2b, pb = torch.zeros(rows, C, device="cuda", dtype=bf), torch.zeros(nparts, 3, C, device="cuda")
+    K.conv_strip(st, out=y2, part=pa, epi=_lib.EPI_STATS, **conv2)()
+    K.conv_strip(st, out=y2b, part=pb, epi=_lib.EPI_STATS_X, aux=x, **conv2)()
+    bn2a = [torch.zeros(C, device="cuda") for _ in range(4)]
+    bn2b = [torch.zeros(C, device="cuda") for _ in range(4)]
+    K.call("fr_bn_finalize", pa, nparts, C, float(rows), g2, b2, 1e-5, 0.1, None, None, None, *bn2a, st)()
+    K.call("fr_bn_finalize_res", pb, nparts, C, K.tail_bn(None, C, rows, g2, b2, 1e-5, 0.1, None, None, None, *bn2b), None,
+           None, 0.0, None, st)()
+    xm = torch.zeros(B, 2, C, device="cuda")
+    K.call("fr_image_moments", x, B, HW, C, xm, st)()
+    mk = lambda *sh: torch.zeros(*sh, device="cuda")  # noqa: E731
+    pooled0, hidden0, s0 = mk(B, C), mk(B, R), mk(B, C)
+    pooled1, hidden1, s1, om = mk(B, C), mk(B, R), mk(B, C), mk(B, 2, C)
+    K.call("fr_se_pool_parts_mlp_fwd", pa, nparts // B, bn2a[2], bn2a[3], fc1, fc2, pooled0, hidden0, s0, B, HW, C, R, st)()
+    K.call("fr_se_pool_parts_mlp_fwd_res", pb, nparts // B, 3, bn2b[2], bn2b[3], fc1, fc2, pooled1, hidden1, s1, B, HW, C, R,
+           xm, om, st)()
+    # the two-pass path
+    nb = K.grid_blocks(rows, C, fr)
+    out_ref, po = torch.zeros(rows, C, device="cuda", dtype=bf), torch.zeros(nb, 2, C, device="cuda")
+    K.bn_apply(st, fr, x=y2, out=out_ref, scale=bn2a[2], shift=bn2a[3], part=po, B=B, H=W, W=W, C=C, nblocks=nb, res=x,
+               res_kind=1, res_stride=1, se=s0)()
+    bn1a = [torch.zeros(C, device="cuda") for _ in range(4)]
+    bn1b = [torch.zeros(C, device="cuda") for _ in range(4)]
+    K.call("fr_bn_finalize", po, nb, C, float(rows), g1n, b1n, 1e-5, 0.1, None, None, None, *bn1a, st)()
+    K.call("fr_bn_finalize", om, B, C, float(rows), g1n, b1n, 1e-5, 0.1, None, None, None, *bn1b, st)()
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y2b)
+    for a, b in zip(bn2a, bn2b):
+        assert torch.equal(a, b)
+    assert torch.equal(pooled0, pooled1) and torch.equal(hidden0, hidden1) and torch.equal(s0, s1)
+    assert float(s0.min()) > 0.002 and float(s0.max()) < 0.998 and float(s0.std()) > 0.05  # gates that differ per image
+    xd = x.double().view(B, HW, C)
+    assert float((xm[:, 0].double() - xd.sum(1)).abs().max()) < 1e-4 * float(xd.abs().sum(1).max())
+    assert float((xm[:, 1].double() / (xd ** 2).sum(1) - 1).abs().max()) < 1e-5
+    od = out_ref.double().view(B, HW, C)
+    sq = (od ** 2).sum(1)
+    # per image: the moments see conv2's fp32 accumulators and the unrounded sum, the tensor their bf16 roundings
+    assert float(((om[:, 0].double() - od.sum(1)).abs() / torch.sqrt(sq * HW)).max()) < 2e-3
+    assert float((om[:, 1].double() / sq - 1).abs().max()) < 4e-3
+    noise = 8 * 2.0 ** -9 / rows ** 0.5
+    std = 1.0 / bn1a[1]
+    assert float(((bn1b[0] - bn1a[0]).abs() / std).max()) < 1e-4 + noise
+    assert float((bn1b[1] / bn1a[1] - 1).abs().max()) < 3e-4 + noise
+    # FR_PRO_RESBN_SE
+    conv1 = dict(w=w1n, B=B, RH=W, RW=W, SH=W, SW=W, SC=C, N=Cn, KH=3, KW=3, stride=1, pad=1, mode=0, lda=C, ldc=Cn,
+                 epi=_lib.EPI_STORE)
+    z0, z1 = torch.zeros(rows, Cn, device="cuda", dtype=bf), torch.zeros(rows, Cn, device="cuda", dtype=bf)
+    K.conv_strip(st, src=out_ref, out=z0, pro=_lib.PRO_BN, pro_a=bn1a[2], pro_b=bn1a[3], **conv1)()
+    out1 = torch.full((rows, C), float("nan"), device="cuda", dtype=bf)
+    K.conv_strip(st, src=y2, src2=x, pro_out=out1, out=z1, pro=_lib.PRO_RESBN_SE, pro_a=bn2a[2], pro_b=bn2a[3],
+                 pro_c=bn1a[2], pro_d=bn1a[3], pro_g=s0, **conv1)()
+    torch.cuda.synchronize()
+    assert not torch.isnan(out1.float()).any(), "pro_out has pixels nobody wrote"
+    assert torch.equal(out1, out_ref), "the residual stream formed by conv1 differs from fr_bn_apply's"
+    assert torch.equal(z1, z0)
+    # refused: the multi-image 7x7 workgroups do not take per-image gates
+    t = lambda *sh: torch.zeros(*sh, device="cuda", dtype=bf)  # noqa: E731
+    one = torch.ones(512, device="cuda")
+    with pytest.raises(_lib.FrhipError):
+        K.conv_strip(st, src=t(196, 512), src2=t(196, 512), pro_out=t(196, 512), out=t(196, 512), pro=_lib.PRO_RESBN_SE,
+                     pro_a=one, pro_b=one, pro_c=one, pro_d=one, pro_g=torch.ones(4, 512, device="cuda"), w=t(512, 9, 512),
+                     B=4, RH=7, RW=7, SH=7, SW=7, SC=512, N=512, KH=3, KW=3, stride=1, pad=1, mode=0, lda=512, ldc=512,
+                     epi=_lib.EPI_STORE)()
+
+
 # ------------------------------------------------------------------------------------------------ Linear on the master weight
 
 

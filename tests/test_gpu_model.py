@@ -1379,14 +1379,18 @@ def test_in_launch_reductions_are_bit_identical_to_separate_launches(kind, B):
             plan = inner._runner[0].plan
             plan.tickets.check_idle()
             names = [getattr(l, "name", "") for l in plan.fwd_list + plan.bwd_list]
-            return outs, names.count("fr_bn_finalize"), names.count("fr_reduce_parts"), plan.tickets.used
+            # (behind a squeeze-excite unit whose statistics come from per-image moments the finalize of those moments stays
+            # a launch: its rows are written by the gate launch, not by a kernel that carries a tail)
+            return (outs, names.count("fr_bn_finalize") - names.count("fr_se_pool_parts_mlp_fwd_res"),
+                    names.count("fr_reduce_parts"), plan.tickets.used)
         finally:
             os.environ.pop("FRHIP_TAIL")
 
     on, fin1, red1, used1 = run("1")
     off, fin0, red0, used0 = run("0")
-    assert used0 == 0 and used1 > 100, (used0, used1)
-    assert fin1 == 0 and fin0 >= 50, (fin1, fin0)
+    # (the identity -> identity edges of IR-50 take their statistics from moments -- fr_bn_finalize_res -- with or without tails)
+    assert used0 == 0 and used1 > 60, (used0, used1)
+    assert fin1 == 0 and fin0 >= 18, (fin1, fin0)
     # what stays a launch of its own: the split-K slabs of Linear(25088, 512) and the stem weight-gradient slabs
     assert red1 <= 2 and red0 >= 78, (red1, red0)
     for step in range(2):
@@ -1442,21 +1446,25 @@ def test_bn2_backward_inside_the_data_gradient_tracks_the_two_pass_path():
         assert cos >= 0.9995 and abs(float(a.norm() / b.norm()) - 1.0) < 5e-3, (n, cos, float(a.norm() / b.norm()))
 
 
-def test_residual_sums_formed_by_their_consumer_track_the_two_pass_path():
-    """Round 4 (FRHIP_RES_MOMENTS, default on): 15 of IR-50's 24 units hand their output to the next conv1 unmaterialised
+@pytest.mark.parametrize("kind,min_edges", [("IR_50", 12), ("pSp", 12)])
+def test_residual_sums_formed_by_their_consumer_track_the_two_pass_path(kind, min_edges):
+    """Round 4 (FRHIP_RES_MOMENTS, default on): 17 of IR-50's 24 units hand their output to the next conv1 unmaterialised
     (FR_PRO_RESBN) and the next BN1's batch statistics come from moments (FR_EPI_STATS_X + fr_bn_finalize_res) instead of a
-    pass over the residual sum.  Against the path with fr_bn_apply behind every conv2: the residual stream holds the same bf16
-    values up to the effect of the (1e-4-level) differences in the derived statistics, so features, loss, every running
-    statistic and every parameter gradient agree far inside the bf16 bars; the apply launches of the fused edges are gone."""
+    pass over the residual sum; in pSp's IR-SE-50 trunk the squeeze-excite form (FR_PRO_RESBN_SE, per-image moments weighted with the
+    gates by fr_se_pool_parts_mlp_fwd_res).  Against the path with fr_bn_apply behind every conv2: the residual stream holds
+    the same bf16 values up to the effect of the (1e-4-level) differences in the derived statistics, so features, loss,
+    running statistics and parameter gradients agree at the level of two bf16 runs; the apply launches of the fused edges
+    are gone."""
     _need_gpu()
     from head.metrics import ArcFace
     from loss.focal import FocalLoss
 
-    def run(on):
+    def run(on, dtype=torch.bfloat16):
         os.environ["FRHIP_RES_MOMENTS"] = on
         try:
-            m, _ = build("IR_50")
-            m.compute_dtype = torch.bfloat16
+            m, _ = build(kind)
+            inner = m.encoder if hasattr(m, "encoder") else m
+            inner.compute_dtype = dtype
             m = m.train()
             head = ArcFace(512, 100, None).cuda()
             with torch.no_grad():
@@ -1467,10 +1475,11 @@ def test_residual_sums_formed_by_their_consumer_track_the_two_pass_path():
             loss, _ = FocalLoss()(head(f, y), y)
             loss.backward()
             torch.cuda.synchronize()
-            names = [getattr(l, "name", "") for l in m._runner[0].plan.fwd_list]
-            return (f.detach().clone(), float(loss.detach()), {n: p.grad.detach().clone() for n, p in m.named_parameters()},
+            names = [getattr(l, "name", "") for l in inner._runner[0].plan.fwd_list]
+            return (f.detach().clone(), float(loss.detach()),
+                    {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None},
                     {n: b.detach().clone() for n, b in m.named_buffers()}, names.count("fr_bn_apply"),
-                    names.count("fr_bn_finalize_res"))
+                    names.count("fr_bn_finalize_res"))  # (one per fused edge, plain or squeeze-excite)
         finally:
             os.environ.pop("FRHIP_RES_MOMENTS")
 
@@ -1478,7 +1487,7 @@ def test_residual_sums_formed_by_their_consumer_track_the_two_pass_path():
     f0, l0, g0, r0, a0, c0 = run("0")
     # IR-50 at 112x112: identity -> identity edges on the LDS-strip instances: 3 at 28x28, 12 at 14x14, 1 at 7x7 -- wait for
     # the count from the plan rather than hard-coding the table: every fused edge removes exactly one fr_bn_apply
-    assert c0 == 0 and c1 >= 12 and a0 - a1 == c1, (a0, a1, c0, c1)
+    assert c0 == 0 and c1 >= min_edges and a0 - a1 == c1, (a0, a1, c0, c1)
     # (batch 12, 24 units of bf16 activations: a 1e-4 difference in a variance flips bf16 roundings downstream; measured
     # 2.7e-4 on the loss -- the bar of the bf16 golden tests is 1e-3)
     assert abs(l1 - l0) <= 1e-3 * abs(l0), (l1, l0)
@@ -1492,12 +1501,39 @@ def test_residual_sums_formed_by_their_consumer_track_the_two_pass_path():
             # largest one -- output_layer.4, the BatchNorm1d over 12 feature vectors, measured 0.85 %)
             tol = (2e-2 if n.endswith("running_mean") else 5e-3) * float(r0[n].abs().max()) + 1e-5
             assert float((r1[n] - r0[n]).abs().max()) <= tol, (n, float((r1[n] - r0[n]).abs().max()), tol)
+    # Gradients: two bf16 runs whose activations differ by re-roundings.  The differences grow towards the stem and are largest
+    # on BatchNorm biases (sums of signed gradients; measured: stem weight cos 0.994, body.21.res_layer.0.bias cos 0.9875 /
+    # norm 2.9 % -- the level at which the bf16 golden test sees such tensors against the fp32 reference); the typical
+    # parameter agrees to 3e-3 in norm.
+    coss, devs = {}, {}
     for n in g0:
         if n.endswith(ZERO_GRAD_SUFFIXES):
             continue
         a, b = g1[n].float().flatten(), g0[n].float().flatten()
-        cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
-        assert cos >= 0.9995 and abs(float(a.norm() / b.norm()) - 1.0) < 5e-3, (n, cos, float(a.norm() / b.norm()))
+        coss[n] = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+        devs[n] = abs(float(a.norm() / b.norm()) - 1.0)
+    # (squeeze-excite MLP weights: the ReLU gates of 4 hidden units on pooled means flip with any re-rounding, see SE_FC1_BARS:
+    # measured 13 % in norm on body.0's fc1 -- they stay in the fp32 comparison below)
+    plain = [n for n in coss if ".fc1." not in n and ".fc2." not in n]
+    worst = min(plain, key=coss.get)
+    assert coss[worst] >= 0.97 and max(devs[n] for n in plain) < 6e-2, (worst, coss[worst], max(devs[n] for n in plain))
+    med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
+    # (median cos 0.9946: two independent realisations of the bf16 rounding noise, each 13 % from the fp32 gradients -- 12
+    # images at random init, loss 39)
+    assert med(coss.values()) >= 0.99 and med(devs.values()) < 5e-3, (med(coss.values()), med(devs.values()))
+    # ... and neither run is closer to the truth than the other: both against the fp32 path of the same network (which takes
+    # neither route: no strip kernels), error = |g - g_fp32| / |g_fp32| per parameter
+    fr_, lr_, gr_, _, _, _ = run("0", torch.float32)
+    e1, e0 = [], []
+    for n in coss:
+        ref = gr_[n].float().flatten()
+        e1.append(float((g1[n].float().flatten() - ref).norm() / ref.norm()))
+        e0.append(float((g0[n].float().flatten() - ref).norm() / ref.norm()))
+    p95 = lambda v: sorted(v)[int(0.95 * len(v))]  # noqa: E731
+    print("gradient error against fp32: moments path median %.2e p95 %.2e max %.2e | two-pass path median %.2e p95 %.2e max %.2e"
+          % (med(e1), p95(e1), max(e1), med(e0), p95(e0), max(e0)))
+    assert med(e1) < 1.2 * med(e0) + 1e-4 and p95(e1) < 1.3 * p95(e0) + 1e-3 and max(e1) < 1.5 * max(e0) + 1e-3
+    assert abs(l1 - lr_) <= max(1e-3 * abs(lr_), 2.0 * abs(l0 - lr_)), (l1, l0, lr_)
 
 
 BENCH_SIZE = [("configs1_ir50_arc7000_b256", "IR_50", 50, False, "ArcFace", 7000, 256),
