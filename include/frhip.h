@@ -415,20 +415,6 @@ int fr_se_gscale_mlp_bwd(const void* g, const void* x, const float* scale, const
                          float* dw1, float* dw2, float* gz, float* gh, int B, int C, int R, int HW, int dtype,
                          void* stream);
 
-/* Round 4: fr_se_gscale_mlp_bwd that ALSO leaves the per-image sums the backward of the BatchNorm in front of the excite
- * needs -- sums[b][0][c] = sum_hw g, [1] = sum_hw g*xhat, [2] = sum_hw xhat, xhat = (x - mean)*invstd -- and
- * fr_se_bn_bwd_sums, which turns them into that BatchNorm's backward sums without another pass over (g, x):
- *   o0[c] = sum_{b,hw} g' = sum_b (s*sums0 + HW*gse),   o1[c] = sum_{b,hw} g'*xhat = sum_b (s*sums1 + gse*sums2),
- *   g' = g*s[b][c] + gse[b][c]  (gse = gpooled of the first call)   == fr_bn_bwd_reduce(se, gse) + fr_reduce_parts.
- * The squeeze is re-associated (gs = scale*sum(g*x) + shift*sum(g)): equal to fr_se_gscale_mlp_bwd to fp32 rounding, not
- * bit for bit.  Replaces the autograd of BatchNorm2d -> SEModule in bottleneck_IR_SE (model_irse.py:84-87). */
-int fr_se_gscale_mlp_bwd_sums(const void* g, const void* x, const float* scale, const float* shift, const float* mean,
-                              const float* invstd, const float* s, const float* hidden, const float* pooled,
-                              const float* w1, const float* w2, float* gpooled, float* dw1, float* dw2, float* gz, float* gh,
-                              float* sums, int B, int C, int R, int HW, int dtype, void* stream);
-int fr_se_bn_bwd_sums(const float* sums, const float* s, const float* gse, int B, int C, int HW, float* o0, float* o1,
-                      void* stream);
-
 /* ---- output layer pieces (model_irse.py:144-148) */
 /* a[b][(h*7+w)*C + c] = dropout(x*scale+shift): mask from a counter hash of (seed, element index in the
  * reference's C-major flatten order), keep prob 1-p, scaled 1/(1-p); p = 0 disables. */

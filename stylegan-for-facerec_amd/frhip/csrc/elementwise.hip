@@ -956,115 +956,6 @@ __global__ __launch_bounds__(SNT_GS) void se_gscale_mlp_bwd_kernel(const T* __re
   se_mlp_bwd_body(sm, s, hidden, w1, w2, gpooled, gz_out, gh_out, C, R, inv_hw, sm + C, sm + 2 * C);
 }
 
-// Round 4: the same launch ALSO leaves, per (image, channel), the three sums the backward of BN2 needs --
-//   sums[b][0][c] = sum_hw g,  sums[b][1][c] = sum_hw g*xhat,  sums[b][2][c] = sum_hw xhat,  xhat = (y2 - mean)*invstd --
-// because the gradient at the BatchNorm output is g' = g*s[b][c] + gse[b][c] (constant over an image), so
-//   sum g' = sum_b (s*sums0 + HW*gse),  sum g'*xhat = sum_b (s*sums1 + gse*sums2)          (se_bn_bwd_sums_kernel)
-// and the separate pass over (g, y2) that formed them (bn_bwd_reduce, 10.7 us + a 4.9-us reduction per IR-SE unit at 128
-// images: three passes over the same two tensors per unit) is gone.  The loop accumulates sum g, sum g*y2, sum y2 -- as many
-// registers as the squeeze's own accumulator + its two coefficient vectors took -- and everything else is derived per
-// (image, channel): gs = scale*sum(g*y2) + shift*sum(g) (re-associated against the stand-alone squeeze: not bit-identical).
-template <typename T>
-__global__ __launch_bounds__(SNT_GS) void se_gscale_mlp_bwd_sums_kernel(
-    const T* __restrict__ x, const T* __restrict__ g, const float* __restrict__ scale, const float* __restrict__ shift,
-    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ s,
-    const float* __restrict__ hidden, const float* __restrict__ w1, const float* __restrict__ w2,
-    float* __restrict__ gpooled, float* __restrict__ gz_out, float* __restrict__ gh_out, float* __restrict__ sums, int HW,
-    int C, int R, float inv_hw) {
-  constexpr int VEC = Elt<T>::VEC;
-  __shared__ float red[SNT_GS * VEC];
-  extern __shared__ float sm[];  // [C] gs, [C] gz, [R] gh
-  const int cpr = C / VEC, tid = threadIdx.x, b = blockIdx.x;
-  const int cc = tid % cpr, rtc = SNT_GS / cpr, rt = tid / cpr, c0 = cc * VEC;
-  float ag[VEC], agy[VEC], ay[VEC];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) ag[j] = agy[j] = ay[j] = 0.f;
-  constexpr int UN = 8;
-  for (int r0 = rt; r0 < HW; r0 += rtc * UN) {
-    U128 xv[UN], gq[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int r = r0 + u * rtc;
-      if (r < HW) {
-        xv[u] = ld16(x + ((size_t)b * HW + r) * C + c0);
-        gq[u] = ld16(g + ((size_t)b * HW + r) * C + c0);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int r = r0 + u * rtc;
-      if (r < HW) {
-        float f[VEC], gv[VEC];
-        unpack16<T>(xv[u], f);
-        unpack16<T>(gq[u], gv);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          ag[j] += gv[j];
-          agy[j] = fmaf(gv[j], f[j], agy[j]);
-          ay[j] += f[j];
-        }
-      }
-    }
-  }
-  float tot[3][VEC];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) red[tid * VEC + j] = k == 0 ? ag[j] : (k == 1 ? agy[j] : ay[j]);
-    __syncthreads();
-    if (rt == 0) {
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        float t = 0.f;
-        for (int r = 0; r < rtc; ++r) t += red[(r * cpr + cc) * VEC + j];
-        tot[k][j] = t;
-      }
-    }
-    __syncthreads();
-  }
-  if (rt == 0) {
-    float* sb = sums + (size_t)b * 3 * C;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const int c = c0 + j;
-      const float mu = mean[c], is = invstd[c];
-      sm[c] = fmaf(scale[c], tot[1][j], shift[c] * tot[0][j]);  // = sum_hw g * (y2*scale + shift)
-      sb[c] = tot[0][j];
-      sb[C + c] = is * (tot[1][j] - mu * tot[0][j]);
-      sb[2 * C + c] = is * (tot[2][j] - (float)HW * mu);
-    }
-  }
-  __syncthreads();
-  se_mlp_bwd_body(sm, s, hidden, w1, w2, gpooled, gz_out, gh_out, C, R, inv_hw, sm + C, sm + 2 * C);
-}
-
-// s0[c] = sum_b (s*sums0 + HW*gse), s1[c] = sum_b (s*sums1 + gse*sums2): the BN2-backward sums of an IR-SE unit from the
-// per-image sums above (double accumulation, images in order, four batch quarters combined in quarter order)
-__global__ __launch_bounds__(256) void se_bn_bwd_sums_kernel(const float* __restrict__ sums, const float* __restrict__ s,
-                                                             const float* __restrict__ gse, int B, int C, float hw,
-                                                             float* __restrict__ o0, float* __restrict__ o1) {
-  __shared__ double part[2][4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-  const int per = (B + 3) / 4, b0 = q * per, b1 = b0 + per < B ? b0 + per : B;
-  double a0 = 0.0, a1 = 0.0;
-  if (c < C) {
-    for (int b = b0; b < b1; ++b) {
-      const float sv = s[(size_t)b * C + c], gv = gse[(size_t)b * C + c];
-      const float* sb = sums + (size_t)b * 3 * C;
-      a0 += (double)fmaf(sv, sb[c], hw * gv);
-      a1 += (double)fmaf(sv, sb[C + c], gv * sb[2 * C + c]);
-    }
-  }
-  part[0][q][threadIdx.x & 63] = a0;
-  part[1][q][threadIdx.x & 63] = a1;
-  __syncthreads();
-  if (q == 0 && c < C) {
-    const int t = threadIdx.x;
-    if (o0) o0[c] = (float)(((part[0][0][t] + part[0][1][t]) + part[0][2][t]) + part[0][3][t]);
-    if (o1) o1[c] = (float)(((part[1][0][t] + part[1][1][t]) + part[1][2][t]) + part[1][3][t]);
-  }
-}
-
 // weight part: dW1[r][c] = sum_b gh[b][r] * pooled[b][c],  dW2[c][r] = sum_b gz[b][c] * hidden[b][r].  Block = 64
 // channels x 4 batch quarters of one r; each thread walks its quarter with 8 independent loads in flight, the four
 // partial sums are added in quarter order through LDS (reproducible); overwrites.
@@ -1704,38 +1595,6 @@ extern "C" int fr_se_gscale_mlp_bwd(const void* g, const void* x, const float* s
              "fr_se_gscale_mlp_bwd");
   hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, gz, gh, hidden, pooled, dw1, dw2, B,
                      C, R);
-  FR_LAUNCH_CHECK();
-}
-
-extern "C" int fr_se_gscale_mlp_bwd_sums(const void* g, const void* x, const float* scale, const float* shift,
-                                         const float* mean, const float* invstd, const float* s, const float* hidden,
-                                         const float* pooled, const float* w1, const float* w2, float* gpooled, float* dw1,
-                                         float* dw2, float* gz, float* gh, float* sums, int B, int C, int R, int HW,
-                                         int dtype, void* stream) {
-  if (!gz || !gh || !sums || !mean || !invstd) FR_UNSUPPORTED("fr_se_gscale_mlp_bwd_sums: gz, gh, sums, mean, invstd are required");
-  if (!chan_ok(C, dtype)) FR_UNSUPPORTED("fr_se_gscale_mlp_bwd_sums: unsupported channel count");
-  const int vec = dtype == FR_BF16 ? 8 : 4;
-  if (C % vec || C / vec > SNT_GS || SNT_GS % (C / vec)) FR_UNSUPPORTED("fr_se_gscale_mlp_bwd_sums: C / vector width must divide the block");
-  hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)(2 * C + R) * sizeof(float);
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(se_gscale_mlp_bwd_sums_kernel<float>, dim3(B), dim3(SNT_GS), lds, st, (const float*)x,
-                                (const float*)g, scale, shift, mean, invstd, s, hidden, w1, w2, gpooled, gz, gh, sums, HW,
-                                C, R, 1.0f / (float)HW),
-             hipLaunchKernelGGL(se_gscale_mlp_bwd_sums_kernel<bf16_t>, dim3(B), dim3(SNT_GS), lds, st, (const bf16_t*)x,
-                                (const bf16_t*)g, scale, shift, mean, invstd, s, hidden, w1, w2, gpooled, gz, gh, sums, HW,
-                                C, R, 1.0f / (float)HW),
-             "fr_se_gscale_mlp_bwd_sums");
-  hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, gz, gh, hidden, pooled, dw1, dw2, B,
-                     C, R);
-  FR_LAUNCH_CHECK();
-}
-
-extern "C" int fr_se_bn_bwd_sums(const float* sums, const float* s, const float* gse, int B, int C, int HW, float* o0,
-                                 float* o1, void* stream) {
-  if (!sums || !s || !gse || B < 1 || C < 1) FR_UNSUPPORTED("fr_se_bn_bwd_sums: sums, s, gse are required");
-  hipLaunchKernelGGL(se_bn_bwd_sums_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, sums, s, gse, B, C,
-                     (float)HW, o0, o1);
   FR_LAUNCH_CHECK();
 }
 

@@ -409,16 +409,13 @@ class BackbonePlan(object):
         # gradients consumed by the side-stream wgrads are double-buffered by unit parity (the next unit must not
         # overwrite what a still-running weight gradient reads)
         # FRHIP_WGRAD_SETS: how many units the main stream may run ahead of the side stream's weight gradients
-        # Round 4, measured and rejected (switches kept for the A/B): the two-stream timeline shows a ~6-us gap on the main
-        # stream at every event edge, three per residual unit, so (a) ONE main -> side edge per unit behind the second data
-        # gradient (FRHIP_MERGE_EDGES=1) and (b) four gradient buffer sets with the main stream waiting for the side stream
-        # every second unit (FRHIP_WAIT_EVERY=2 FRHIP_WGRAD_SETS=4) were tried: 14.92-15.02 ms per step against 14.66-14.67
-        # with the round-3 edges on the same box (merge alone +0.26 ms, thinned waits alone +0.05: profiles/r04_ab_edges.txt).
-        # The early edge behind conv2's data gradient is worth more than its gap: the side stream's kernels are queued while
-        # the first data gradient still holds the CUs and take them as its workgroups retire.
-        self.merge_edges = os.environ.get("FRHIP_MERGE_EDGES", "0") == "1"
-        self.wait_every = max(1, int(os.environ.get("FRHIP_WAIT_EVERY", "1")))
-        nset = max(self.wait_every + 1, int(os.environ.get("FRHIP_WGRAD_SETS", "2"))) if self.dual else 1
+        # (Round 4, measured and removed: the two-stream timeline shows a ~6-us gap on the main stream at every event edge,
+        # three per residual unit; ONE main -> side edge per unit behind the second data gradient and four buffer sets with
+        # the main stream waiting every second unit ran 14.92-15.02 ms per step against 14.66-14.67 with the round-3 edges on
+        # the same box -- profiles/r04_ab_edges.txt.  The early edge behind conv2's data gradient is worth more than its gap:
+        # the side stream's kernels are queued while the first data gradient still holds the CUs and take them as its
+        # workgroups retire.)
+        nset = max(2, int(os.environ.get("FRHIP_WGRAD_SETS", "2"))) if self.dual else 1
         self.nset = nset
         self.g_y2s = [self._act(max_out, 1).view(-1) for _ in range(nset)]
         self.g_ySs = [self._act(max_out, 1).view(-1) if max_xs else None for _ in range(nset)]
@@ -1073,22 +1070,18 @@ class BackbonePlan(object):
             par = i % self.nset if self.dual else 0
             g_y2 = self.g_y2s[par][:rout * u.depth]
             if self.dual:
-                # unit i + nset's weight gradients read this buffer set.  The side stream is FIFO, so waiting every
-                # wait_every-th unit for a later unit's event covers the units in between.
-                tgt = i + self.nset - (self.wait_every - 1) if i % self.wait_every == 0 else None
-                if tgt is not None and tgt in unit_done:
-                    L.append(_EvWait(self.stream1_t, unit_done[tgt]))
-            merged = self.dual and self.merge_edges
-            S = [] if merged else L  # side-stream launches of this unit (merged: enqueued behind ONE edge)
-            # (Round 4, measured and removed again -- profiles/r04_ab_edge2_wgrad_order.txt: without the second main -> side edge
-            # in front of conv1's weight gradient, which is redundant on a FIFO side stream, 15.13-15.18 against 15.18-15.19 ms:
-            # nothing; conv1's weight gradient BEFORE conv2's, i.e. right behind the data gradient it shares both operands with:
-            # 15.57 against 15.18 ms, slower.)
-            S2 = S
+                # unit i + nset's weight gradients read this buffer set
+                if i + self.nset in unit_done:
+                    L.append(_EvWait(self.stream1_t, unit_done[i + self.nset]))
+            # (Round 4, schedule experiments measured and removed again -- profiles/r04_ab_edges.txt, r04_ab_edge2_wgrad_order.txt:
+            # ONE main -> side edge per unit with both weight gradients behind it: +0.26 ms (the first weight gradient then
+            # starts a data gradient later); the main stream waiting for the side stream every second unit with four buffer
+            # sets: +0.05; no second edge in front of conv1's weight gradient: nothing; conv1's weight gradient before
+            # conv2's: +0.39 ms.)
+            S = S2 = L
 
             def edge():
-                if not merged:
-                    self._side_after_main(L)
+                self._side_after_main(L)
             nb = ops.grid_blocks(rout, u.depth, fr)
             ready = [u.bn2.weight, u.bn2.bias]
             se_kw = {}
@@ -1099,21 +1092,14 @@ class BackbonePlan(object):
                     g1 = self.se_scratch[0, :R * u.depth]
                 if g2 is None:
                     g2 = self.se_scratch[1, :R * u.depth]
-                # gradient wrt the excite scale (a pass over g and y2) + the MLP backward of the same image in one launch;
-                # round 4: the same pass leaves the per-image sums BN2's backward needs (FRHIP_SE_SUMS=0: the round-3 pair)
-                # MEASURED SLOWER (IR-SE-101 + CosFace(28000), bs 128: 19.50-19.52 against 19.22-19.30 ms per step; pSp bs 256:
-                # 17.31 against 17.22; profiles/r04_ab_se_sums.txt): the pass it deletes ran beside the weight gradients of the
-                # side stream, the extra work sits in a 128-workgroup launch that half the chip idles through.  Opt-in.
-                se_sums = os.environ.get("FRHIP_SE_SUMS", "0") == "1" and bn2.mod.training
-                if se_sums:
-                    d["sesums"] = torch.zeros(B, 3, u.depth, device=self.device)
-                    L.append(ops.call("fr_se_gscale_mlp_bwd_sums", g_out, d["y2"], bn2.scale, bn2.shift, bn2.mean,
-                                      bn2.invstd, d["s"], d["hidden"], d["pooled"], u.se.fc1.weight, u.se.fc2.weight,
-                                      d["gpooled"], g1, g2, d["gz"], d["gh"], d["sesums"], B, u.depth, R, HWo, fr, st))
-                else:
-                    L.append(ops.call("fr_se_gscale_mlp_bwd", g_out, d["y2"], bn2.scale, bn2.shift, d["s"], d["hidden"],
-                                      d["pooled"], u.se.fc1.weight, u.se.fc2.weight, d["gpooled"], g1, g2, d["gz"],
-                                      d["gh"], B, u.depth, R, HWo, fr, st))
+                # gradient wrt the excite scale (a pass over g and y2) + the MLP backward of the same image in one launch.
+                # (Round 4, measured and removed: the same pass also leaving the per-image sums BN2's backward needs, so that
+                # fr_bn_bwd_reduce disappears from the IR-SE units -- IR-SE-101 + CosFace(28000), bs 128: 19.50-19.52 against
+                # 19.22-19.30 ms per step; pSp bs 256: 17.31 against 17.22; profiles/r04_ab_se_sums.txt: the pass it deleted ran
+                # beside the weight gradients of the side stream, the extra work sat in a 128-workgroup launch.)
+                L.append(ops.call("fr_se_gscale_mlp_bwd", g_out, d["y2"], bn2.scale, bn2.shift, d["s"], d["hidden"],
+                                  d["pooled"], u.se.fc1.weight, u.se.fc2.weight, d["gpooled"], g1, g2, d["gz"],
+                                  d["gh"], B, u.depth, R, HWo, fr, st))
                 se_kw = dict(se=d["s"], gse=d["gpooled"])
                 ready += [u.se.fc1.weight, u.se.fc2.weight]
             db, dg = self._bn_grads(bn2)
@@ -1134,12 +1120,9 @@ class BackbonePlan(object):
                     L.append(ops.call("fr_bn_bwd_coeffs", self.part, nb, u.depth, float(rout), u.bn2.weight, bn2.mean,
                                       bn2.invstd, 1 if ev else 0, db, dg, co[0], co[1], co[2], st))
             else:
-                if u.se is not None and se_sums:  # the sums come from the squeeze's per-image sums: no pass, no partial rows
-                    L.append(ops.call("fr_se_bn_bwd_sums", d["sesums"], d["s"], d["gpooled"], B, u.depth, HWo, db, dg, st))
-                else:
-                    t = self._sum_tail(3, u.depth, db, dg)
-                    L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **self._tail_kw(t), **common))
-                    self._reduce(L, nb, 3, u.depth, db, dg, tail=t)
+                t = self._sum_tail(3, u.depth, db, dg)
+                L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **self._tail_kw(t), **common))
+                self._reduce(L, nb, 3, u.depth, db, dg, tail=t)
                 s0, s1 = self._s01(bn2, db, dg)
                 L.append(ops.bn_bwd_apply(st, fr, gx=g_y2, gamma=u.bn2.weight, s0=s0, s1=s1, inv_count=1.0 / rout,
                                           **common))
@@ -1234,9 +1217,6 @@ class BackbonePlan(object):
             else:
                 ready.append(u.conv1.weight)
             ready += [u.prelu.weight, u.bn1.weight, u.bn1.bias]
-            if merged and S:  # the unit's one edge: everything the side-stream launches read is final on the main stream
-                self._side_after_main(L)
-                L.extend(S)
             # unit input gradient = BN1 backward of g_xh + shortcut gradient
             nxt = 1 - cur
             g_x = self.g_pp[nxt][:rin * u.cin]

@@ -20,6 +20,6 @@ run FRHIP_TAIL=1 FRHIP_TAIL_NRED=32
 run FRHIP_FUSE_BN2=1
 run FRHIP_FUSE_BN2=1 FRHIP_TAIL=1
 run FRHIP_LINEAR_CM=0
-run FRHIP_MERGE_EDGES=1
-run FRHIP_WAIT_EVERY=2 FRHIP_WGRAD_SETS=4
-run FRHIP_SE_SUMS=1
+run FRHIP_RES_MOMENTS=0
+run FRHIP_STEM_IMPLICIT=1
+run FRHIP_IGEMM_BN=64
