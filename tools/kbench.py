@@ -96,6 +96,8 @@ def conv_case(kind, cin, cout, W, B, stride=1, pro=1, epi=1, mode=0, iters=20):
         kw["cos_t"] = torch.zeros(16 + 2 * 512, device="cuda")
     if pro == 3:  # FR_PRO_BNBWD2: two sources, three coefficient vectors, the operand stored on the way
         kw.update(src2=rnd(*src.shape), pro_c=vb, pro_out=torch.empty_like(src))
+    if pro == 4:  # FR_PRO_RESBN: the residual sum formed by its consumer (two sources, two coefficient pairs, stored once)
+        kw.update(src2=rnd(*src.shape), pro_c=va, pro_d=vb, pro_out=torch.empty_like(src))
     if kind == "s2":  # stride-2 parity-plane kernel: mode 0 forward (W = input side), mode 2 all-class data gradient
         if mode == 2:
             kw.update(par_h=-1, par_w=-1)
@@ -157,6 +159,8 @@ def suite_cases(B):
         ("strip_128_128_28_fwd", lambda it: conv_case("strip", 128, 128, 28, B, pro=1, epi=0, iters=it)),
         ("strip_256_256_14_fwd_bn", lambda it: conv_case("strip", 256, 256, 14, B, pro=1, epi=0, iters=it)),
         ("strip_256_256_14_fwd_prelu", lambda it: conv_case("strip", 256, 256, 14, B, pro=2, epi=1, iters=it)),
+        ("strip_256_256_14_fwd_resbn", lambda it: conv_case("strip", 256, 256, 14, B, pro=4, epi=0, iters=it)),
+        ("strip_256_256_14_fwd_stats_x", lambda it: conv_case("strip", 256, 256, 14, B, pro=2, epi=8, iters=it)),
         ("strip_256_256_14_dgrad", lambda it: conv_case("strip", 256, 256, 14, B, pro=0, epi=2, mode=1, iters=it)),
         ("strip_256_256_14_dgrad_bnbwd2", lambda it: conv_case("strip", 256, 256, 14, B, pro=3, epi=2, mode=1, iters=it)),
         ("strip_128_128_28_dgrad", lambda it: conv_case("strip", 128, 128, 28, B, pro=0, epi=2, mode=1, iters=it)),

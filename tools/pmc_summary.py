@@ -50,6 +50,8 @@ def table():
         "strip_128_128_28_fwd": (r"conv3x3_strip_kernel<128, 128, 28, \d+, \d+, \d+, 1, 1,", 2 * act(28, 128) + w3(128, 128), f3(28, 128, 128)),
         "strip_256_256_14_fwd_bn": (r"conv3x3_strip_kernel<256, 256, 14, \d+, \d+, \d+, 1, 1,", 2 * act(14, 256) + w3(256, 256), f3(14, 256, 256)),
         "strip_256_256_14_fwd_prelu": (r"conv3x3_strip_kernel<256, 256, 14, \d+, \d+, \d+, 1, 2,", 2 * act(14, 256) + w3(256, 256), f3(14, 256, 256)),
+        # FR_PRO_RESBN: two sources in, the residual sum + the convolution output out
+        "strip_256_256_14_fwd_resbn": (r"conv3x3_strip_kernel<256, 256, 14, \d+, \d+, \d+, 1, 4,", 4 * act(14, 256) + w3(256, 256), f3(14, 256, 256)),
         "strip_256_256_14_dgrad": (r"conv3x3_strip_kernel<256, 256, 14, \d+, \d+, \d+, 1, 0,", 3 * act(14, 256) + w3(256, 256), f3(14, 256, 256)),
         "wgs_256_256_14": (r"conv_wgrad_roll_kernel<14, 2>|conv_wgrad_strip_kernel<14,", 2 * act(14, 256) + dw(256, 256), f3(14, 256, 256)),
         "wgs_256_256_14_bn": (r"conv_wgrad_roll_kernel<14, 1>", 2 * act(14, 256) + dw(256, 256), f3(14, 256, 256)),
