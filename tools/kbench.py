@@ -160,7 +160,8 @@ def suite_cases(B):
         ("strip_256_256_14_fwd_bn", lambda it: conv_case("strip", 256, 256, 14, B, pro=1, epi=0, iters=it)),
         ("strip_256_256_14_fwd_prelu", lambda it: conv_case("strip", 256, 256, 14, B, pro=2, epi=1, iters=it)),
         ("strip_256_256_14_fwd_resbn", lambda it: conv_case("strip", 256, 256, 14, B, pro=4, epi=0, iters=it)),
-        ("strip_256_256_14_fwd_stats_x", lambda it: conv_case("strip", 256, 256, 14, B, pro=2, epi=8, iters=it)),
+        # (FR_EPI_STATS_X -- `strip 256 256 14 --pro 2 --epi 8` -- shares its kernel name with the case above: not in the suite,
+        # whose PMC rows are matched by name)
         ("strip_256_256_14_dgrad", lambda it: conv_case("strip", 256, 256, 14, B, pro=0, epi=2, mode=1, iters=it)),
         ("strip_256_256_14_dgrad_bnbwd2", lambda it: conv_case("strip", 256, 256, 14, B, pro=3, epi=2, mode=1, iters=it)),
         ("strip_128_128_28_dgrad", lambda it: conv_case("strip", 128, 128, 28, B, pro=0, epi=2, mode=1, iters=it)),
