@@ -785,6 +785,10 @@ class BackbonePlan(object):
                            N=u.depth, KH=3, KW=3, stride=1, pad=1, mode=0, lda=u.cin, ldc=u.depth,
                            pro=ops.PRO_BN, pro_a=bn1.scale, pro_b=bn1.shift, epi=ops.EPI_STORE)
             x_in = x  # this unit's input (the residual term of its output)
+            # (Round 4, measured and removed: the convolved shortcut of a stage entry + its statistics launch on the side stream
+            # beside conv2 -- the side stream idles during the forward pass and the three launches take 24-51 us each on the
+            # generic GEMM: 15.01-15.05 against 14.98-15.00 ms per step, profiles/r04_ab_shortcut_on_side_stream.txt: the two
+            # event edges cost what the overlap saves.)
             if folded:
                 # inference with BN2 (and the shortcut BN) folded into the packed weights: out = conv2'(PReLU(y1)) +
                 # shift2 [+ shiftS] + shortcut straight from conv2's epilogue -- y2 is never written, no BN-apply pass
