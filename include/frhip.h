@@ -240,6 +240,23 @@ int fr_stem_im2col(const float* x, const float* avg, void* out, int B, int H, in
  * Replace the GEMM half of input_layer Conv2d(3|6,64,3,1,1) (model_irse.py:140) forward and its weight gradient. */
 int fr_stem_gemm(const void* X, const void* Wp, void* out, float* part, long long M, int K, int nblocks,
                  const FrTail* tail /* NULL or an in-launch reduction of part (FR_TAIL_BN, C = 64) */, void* stream);
+/* Round 4: the stem forward as TWO passes over the rows instead of GEMM + a BN-apply pass over its 411-MB output:
+ * fr_stem_gemm(out = NULL) leaves only the statistics of y = X * Wp^T (nothing stored), and after fr_bn_finalize
+ * fr_stem_gemm_bn_prelu recomputes y, stores z = PReLU(BN(y)) -- fr_bn_apply(slope) on the rounded y, element for element -- and
+ * y itself (y may be NULL when nothing reads it) and leaves the statistics of the rounded z in part (for the BatchNorm of the
+ * first residual unit).  Replaces input_layer = Conv2d -> BatchNorm2d -> PReLU (backbone/model_irse.py:140-142). */
+int fr_stem_gemm_bn_prelu(const void* X, const void* Wp, const float* scale, const float* shift, const float* slope, void* y,
+                          void* z, float* part, long long M, int K, int nblocks, const FrTail* tail, void* stream);
+/* ... and its backward WITHOUT the stored y (y = NULL above: 411 MB less memory and traffic at batch 256): both kernels
+ * recompute y = X * Wp^T from the rows, rounded as the forward pass rounded it.
+ * fr_stem_bwd_sums  : part[nblocks][3][64] = the rows of fr_bn_bwd_reduce(slope) over (G, y) -- sum g', sum g'*xhat, sum g*u*[u<=0];
+ * fr_stem_wgrad_bn_r: fr_stem_wgrad_bn with y recomputed per 64-row trip (bit-identical slabs).
+ * Replace the autograd of Conv2d -> BatchNorm2d -> PReLU of input_layer (backbone/model_irse.py:140-142). */
+int fr_stem_bwd_sums(const void* X, const void* Wp, const void* G, const float* mean, const float* invstd, const float* scale,
+                     const float* shift, const float* slope, float* part, long long M, int K, int nblocks, void* stream);
+int fr_stem_wgrad_bn_r(const void* G, const void* X, const void* Wp, const float* mean, const float* invstd,
+                       const float* scale, const float* shift, const float* slope, const float* gamma, const float* s0,
+                       const float* s1, float inv_count, float* slab, long long M, int K, int nblocks, void* stream);
 int fr_stem_wgrad(const void* G, const void* X, float* slab, long long M, int K, int nblocks, void* stream);
 /* As fr_stem_wgrad, with the backward of BatchNorm2d(64) -> PReLU(64) (model_irse.py:141-142) applied to the rows of G
  * while they are staged: G = gradient at the PReLU output, Y = BN input (the stem GEMM output), s0/s1 = the reduced
@@ -447,7 +464,9 @@ int fr_linear_dgrad(const void* g, const float* W, void* ga, int B, int O, int K
  *   wp [Cout][taps][Cin] compute dtype (NULL to skip), wt [Cin][taps][Cout] compute dtype (NULL to skip) */
 int fr_pack_weight(const float* w, void* wp, void* wt, int Cout, int taps, int Cin, int dtype, void* stream);
 /* the same for every convolution of the network in one launch: table_dev = device array of records, chunks_dev =
- * device array of (tensor index, tile index) pairs, tile index over taps x ceil(Cout/32) x ceil(Cin/32) */
+ * device array of (tensor index, tile index) pairs, tile index over taps x ceil(Cout/32) x ceil(Cin/32); bf16 tensors with
+ * Cout % 64 == 0 and Cin % 64 == 0 may use 64 x 64 tiles instead (16-byte accesses): tile index -(1 + index over taps x
+ * Cout/64 x Cin/64); one tensor's chunks are all of one kind */
 typedef struct FrPackTensor {
   const float* w;
   void* wp; /* may be NULL */

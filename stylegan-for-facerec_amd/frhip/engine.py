@@ -339,7 +339,15 @@ class BackbonePlan(object):
                            ((self.K0 == 32 and self.in_channels == 3 and self.avg_channels == 0) or
                             (self.K0 == 64 and self.in_channels + self.avg_channels == 6)))
             self.X0 = None if self.stem_x else self._act(M0, self.K0)
-            self.y0 = self._act(M0, 64)
+            # Round 4: the stem forward as two passes over the rows (statistics, then GEMM + BN + PReLU in one kernel) and its
+            # backward on a RECOMPUTED y0: the GEMM is 13 GFLOP at batch 256, its output 411 MB -- y0 is never written or
+            # read, the fr_bn_apply pass over it is gone.  FRHIP_STEM_TWO_PASS=0 / FRHIP_STEM_RECOMPUTE=0: A/B switches
+            # (the second one keeps y0 for the backward kernels of round 3).
+            self.stem_two_pass = (self.use_stem_gemm and not self.stem_x and not self.fold and
+                                  os.environ.get("FRHIP_STEM_TWO_PASS", "1") != "0")
+            self.stem_recompute = (self.stem_two_pass and os.environ.get("FRHIP_NO_STEM_BNFUSE", "0") != "1" and
+                                   os.environ.get("FRHIP_STEM_RECOMPUTE", "1") != "0")
+            self.y0 = None if (self.stem_recompute or (self.stem_two_pass and self.infer)) else self._act(M0, 64)
             self.W0p = torch.empty(64, self.K0, device=dev, dtype=self.tdtype)
             self.gW0p = torch.zeros(64, self.K0, device=dev)
             self.bn0 = _BN(self.stem[1], self.pool)
@@ -734,7 +742,21 @@ class BackbonePlan(object):
             P.append(ops.call("fr_pack_stem", w0, w0.stride(0), w0.stride(1), w0.stride(2), w0.stride(3), self.W0p, 64,
                               w0.shape[1], self.K0, fr, st))
             self.l_im2col = None  # bound per call (input pointer changes)
-            if self.use_stem_gemm:  # 3.2 M rows x 64 columns x K0: the row-streaming kernels of stem_gemm.hip
+            two_pass = self.stem_two_pass
+            if two_pass:
+                # Round 4: the GEMM is 13 GFLOP, its output 411 MB.  Pass 1 leaves only the statistics of y0; pass 2 recomputes
+                # y0 and writes z0 = PReLU(BN0(y0)) (+ y0 for the backward pass) with the statistics of z0 in its epilogue:
+                # the fr_bn_apply pass over the stem output (822 MB of traffic, 161 us at batch 256) is gone.
+                mt0 = int(min(2048, (self.M0 + 63) // 64))
+                if self.bn0.mod.training:
+                    L.append(ops.call("fr_stem_gemm", self.X0, self.W0p, None, self.part, self.M0, self.K0, mt0,
+                                      self._bn_tail(self.bn0, self.M0), st))
+                self._bn_train_launches(L, self.bn0, self.part, mt0, self.M0)
+                L.append(ops.call("fr_stem_gemm_bn_prelu", self.X0, self.W0p, self.bn0.scale, self.bn0.shift, sp.weight,
+                                  self.y0, self.z0, stats_part, self.M0, self.K0, mt0,
+                                  self._bn_tail(first_bn, self.M0, 2), st))
+                self._bn_train_launches(L, first_bn, self.part, mt0, self.M0)
+            elif self.use_stem_gemm:  # 3.2 M rows x 64 columns x K0: the row-streaming kernels of stem_gemm.hip
                 mt0 = int(min(2048, (self.M0 + 63) // 64))
                 if self.stem_x:  # x / avg pointers are bound per call (run_forward)
                     self.l_stem_fwd = ops.call("fr_stem_gemm_x", None, None, self.W0p, self.y0, self.part, B, S, S,
@@ -749,12 +771,13 @@ class BackbonePlan(object):
                 L.append(ops.conv(st, fr, src=self.X0, w=self.W0p, out=self.y0, B=self.M0, RH=1, RW=1, SH=1, SW=1,
                                   SC=self.K0, N=64, KH=1, KW=1, stride=1, pad=0, mode=0, lda=self.K0, ldc=64, pro=0,
                                   epi=ops.EPI_STATS, part=self.part, **self._tail_kw(self._bn_tail(self.bn0, self.M0))))
-            self._bn_train_launches(L, self.bn0, self.part, mt0, self.M0)
-            nb = ops.grid_blocks(self.M0, 64, fr)
-            L.append(ops.bn_apply(st, fr, x=self.y0, out=self.z0, scale=self.bn0.scale, shift=self.bn0.shift,
-                                  slope=sp.weight, part=stats_part, B=B, H=S, W=S, C=64, res_kind=0, res_stride=1,
-                                  nblocks=nb, **self._tail_kw(self._bn_tail(first_bn, self.M0, 2))))
-            self._bn_train_launches(L, first_bn, self.part, nb, self.M0)
+            if not two_pass:
+                self._bn_train_launches(L, self.bn0, self.part, mt0, self.M0)
+                nb = ops.grid_blocks(self.M0, 64, fr)
+                L.append(ops.bn_apply(st, fr, x=self.y0, out=self.z0, scale=self.bn0.scale, shift=self.bn0.shift,
+                                      slope=sp.weight, part=stats_part, B=B, H=S, W=S, C=64, res_kind=0, res_stride=1,
+                                      nblocks=nb, **self._tail_kw(self._bn_tail(first_bn, self.M0, 2))))
+                self._bn_train_launches(L, first_bn, self.part, nb, self.M0)
         x = self.z0
         for i, u in enumerate(self.units):
             d = self.ubuf[i]
@@ -941,6 +964,10 @@ class BackbonePlan(object):
             arr[i].wt = wt.data_ptr() if wt is not None else None
             arr[i].oscale = req[6].data_ptr() if len(req) > 6 else None
             arr[i].Cout, arr[i].taps, arr[i].Cin = cout, taps, cin
+            if self.fr == FR_BF16 and cout % 64 == 0 and cin % 64 == 0 and os.environ.get("FRHIP_PACK64", "1") != "0":
+                # 64 x 64 tiles with 16-byte accesses (chunk index -(tile + 1)): every 3x3 / shortcut convolution of the IR nets
+                chunks.extend((i, -(t + 1)) for t in range(taps * (cout // 64) * (cin // 64)))
+                continue
             tiles = taps * ((cout + 31) // 32) * ((cin + 31) // 32)
             chunks.extend((i, t) for t in range(tiles))
         self._pack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
@@ -1266,9 +1293,15 @@ class BackbonePlan(object):
         common = dict(g=g_out, x=self.y0, mean=self.bn0.mean, invstd=self.bn0.invstd, scale=self.bn0.scale,
                       shift=self.bn0.shift, slope=sp.weight, rows=self.M0, C=64, rows_per_image=self.S * self.S,
                       nblocks=nb)
-        t = self._sum_tail(3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64])
-        L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **self._tail_kw(t), **common))
-        self._reduce(L, nb, 3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64], tail=t)
+        if self.stem_recompute:  # the sums of fr_bn_bwd_reduce over (g, y0) with y0 recomputed from the rows
+            nb = int(min(2048, (self.M0 + 63) // 64))
+            L.append(ops.call("fr_stem_bwd_sums", self.X0, self.W0p, g_out, self.bn0.mean, self.bn0.invstd, self.bn0.scale,
+                              self.bn0.shift, sp.weight, self.part, self.M0, self.K0, nb, st))
+            self._reduce(L, nb, 3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64])
+        else:
+            t = self._sum_tail(3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64])
+            L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **self._tail_kw(t), **common))
+            self._reduce(L, nb, 3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64], tail=t)
         s0, s1 = self._s01(self.bn0, db, dg)
         g_y0 = self.g_y1s[1 if self.dual else 0][:self.M0 * 64]  # unit 0's wgrads (side stream) still read set 0
         if self.dual and 1 in unit_done:
@@ -1292,6 +1325,10 @@ class BackbonePlan(object):
                                                s1, 1.0 / self.M0, self.part, B, self.S, self.S, self.in_channels,
                                                self.avg_channels, self.K0, nsl, st)
                     L.append(self.l_stem_bwd)
+                elif self.stem_recompute:
+                    L.append(ops.call("fr_stem_wgrad_bn_r", g_out, self.X0, self.W0p, self.bn0.mean, self.bn0.invstd,
+                                      self.bn0.scale, self.bn0.shift, sp.weight, sb.weight, s0, s1, 1.0 / self.M0,
+                                      self.part, self.M0, self.K0, nsl, st))
                 else:
                     L.append(ops.call("fr_stem_wgrad_bn", g_out, self.y0, self.X0, self.bn0.mean, self.bn0.invstd,
                                       self.bn0.scale, self.bn0.shift, sp.weight, sb.weight, s0, s1, 1.0 / self.M0,

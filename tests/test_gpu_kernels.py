@@ -1861,3 +1861,125 @@ def test_stem_gemms_without_materialised_rows(K, Cavg, Kp, B, S):
            3, Cavg, Kp, ns, st)()
     torch.cuda.synchronize()
     assert torch.equal(slab0, slab1) and float(slab0.abs().max()) > 0
+
+
+@pytest.mark.parametrize("Kp", [32, 64])
+@pytest.mark.parametrize("M", [16 * 37 + 5, 64 * 2048 + 64 * 3 + 9])
+def test_stem_two_pass_forward_equals_gemm_then_bn_apply(K, Kp, M):
+    """Round 4: input_layer = Conv2d -> BatchNorm2d -> PReLU (backbone/model_irse.py:140-142) as two passes over the im2col rows.
+    fr_stem_gemm(out = NULL) leaves the statistics rows of fr_stem_gemm bit for bit and stores nothing; fr_stem_gemm_bn_prelu
+    stores y and z = PReLU(BN(y)) equal to fr_stem_gemm -> fr_bn_apply(slope) bit for bit (also with y = NULL), and statistics
+    of z that agree with fr_bn_apply's to fp32 summation order (ragged last tile; more 16-row tiles than 4 * nblocks)."""
+    st, bf = K.current_stream_ptr(), torch.bfloat16
+    fr = K.fr_dtype(torch.empty(0, dtype=bf))
+    rows = (synth.normal(83, "r", (M, Kp)) * 0.7).to("cuda", bf)
+    w = (synth.normal(83, "w", (64, Kp)) * 0.2).to("cuda", bf)
+    vec = lambda n, lo, hi: synth.uniform(83, n, (64,), lo, hi).cuda()  # noqa: E731
+    scale, shift, slope = vec("sc", 0.5, 1.5), vec("sh", -0.3, 0.3), vec("sl", 0.1, 0.4)
+    nb = 13
+    y0, p0 = torch.zeros(M, 64, device="cuda", dtype=bf), torch.zeros(nb, 2, 64, device="cuda")
+    K.call("fr_stem_gemm", rows, w, y0, p0, M, Kp, nb, None, st)()
+    p1 = torch.zeros(nb, 2, 64, device="cuda")
+    K.call("fr_stem_gemm", rows, w, None, p1, M, Kp, nb, None, st)()
+    nba = K.grid_blocks(M, 64, fr)
+    z0, pz0 = torch.zeros(M, 64, device="cuda", dtype=bf), torch.zeros(nba, 2, 64, device="cuda")
+    K.bn_apply(st, fr, x=y0, out=z0, scale=scale, shift=shift, slope=slope, part=pz0, B=1, H=1, W=M, C=64, res_kind=0,
+               res_stride=1, nblocks=nba)()
+    y1 = torch.full((M, 64), float("nan"), device="cuda", dtype=bf)
+    z1 = torch.full((M, 64), float("nan"), device="cuda", dtype=bf)
+    pz1 = torch.zeros(nb, 2, 64, device="cuda")
+    K.call("fr_stem_gemm_bn_prelu", rows, w, scale, shift, slope, y1, z1, pz1, M, Kp, nb, None, st)()
+    z2, pz2 = torch.full((M, 64), float("nan"), device="cuda", dtype=bf), torch.zeros(nb, 2, 64, device="cuda")
+    K.call("fr_stem_gemm_bn_prelu", rows, w, scale, shift, slope, None, z2, pz2, M, Kp, nb, None, st)()
+    torch.cuda.synchronize()
+    assert torch.equal(p0, p1) and float(p0.abs().max()) > 0
+    assert torch.equal(y1, y0) and torch.equal(z1, z0) and torch.equal(z2, z0) and torch.equal(pz2, pz1)
+    assert float((z0.float() < 0).float().mean()) > 0.1  # both PReLU branches taken
+    ref = pz0.double().sum(0)
+    got = pz1.double().sum(0)
+    assert float((got[0] - ref[0]).abs().max()) < 1e-5 * float(z0.float().abs().sum(0).max())
+    assert float((got[1] / ref[1] - 1).abs().max()) < 1e-5
+    with pytest.raises(K._lib.FrhipError):
+        K.call("fr_stem_gemm", rows, w, None, None, M, Kp, nb, None, st)()
+
+
+@pytest.mark.parametrize("Kp", [32, 64])
+@pytest.mark.parametrize("M", [64 * 5 + 23, 64 * 2048 + 64 * 3 + 9])
+def test_stem_backward_on_recomputed_rows(K, Kp, M):
+    """Round 4: the backward of input_layer (Conv2d -> BatchNorm2d -> PReLU, backbone/model_irse.py:140-142) without the stored
+    GEMM output.  fr_stem_bwd_sums == fr_bn_bwd_reduce(slope) over (g, y) + the same fixed-order row sums (fp32 summation
+    order aside: 1e-5); fr_stem_wgrad_bn_r == fr_stem_wgrad_bn, slab for slab, BIT FOR BIT (y recomputed per 64-row trip and
+    rounded as the forward pass rounded it; ragged last trip, more trips than workgroups)."""
+    st, bf = K.current_stream_ptr(), torch.bfloat16
+    fr = K.fr_dtype(torch.empty(0, dtype=bf))
+    rows = (synth.normal(85, "r", (M, Kp)) * 0.7).to("cuda", bf)
+    w = (synth.normal(85, "w", (64, Kp)) * 0.2).to("cuda", bf)
+    g = synth.normal(85, "g", (M, 64)).to("cuda", bf)
+    vec = lambda n, lo, hi: synth.uniform(85, n, (64,), lo, hi).cuda()  # noqa: E731
+    mean, invstd, gamma, slope = vec("m", -0.3, 0.3), vec("i", 0.5, 2.0), vec("ga", 0.8, 1.2), vec("sl", 0.1, 0.4)
+    scale = gamma * invstd
+    shift = vec("b", -0.2, 0.2) - mean * scale
+    y, p = torch.zeros(M, 64, device="cuda", dtype=bf), torch.zeros(8, 2, 64, device="cuda")
+    K.call("fr_stem_gemm", rows, w, y, p, M, Kp, 8, None, st)()
+    nb = K.grid_blocks(M, 64, fr)
+    pa = torch.zeros(nb, 3, 64, device="cuda")
+    K.bn_bwd_reduce(st, fr, part=pa, g=g, x=y, mean=mean, invstd=invstd, scale=scale, shift=shift, slope=slope, rows=M, C=64,
+                    rows_per_image=M, nblocks=nb)()
+    nbs = 11
+    pb = torch.zeros(nbs, 3, 64, device="cuda")
+    K.call("fr_stem_bwd_sums", rows, w, g, mean, invstd, scale, shift, slope, pb, M, Kp, nbs, st)()
+    torch.cuda.synchronize()
+    a, b = pa.double().sum(0), pb.double().sum(0)
+    mag = (g.double().abs().sum(0) * 4).clamp_min(1.0)
+    assert float(((a - b).abs() / mag).max()) < 1e-5, float(((a - b).abs() / mag).max())
+    assert float(a[2].abs().max()) > 0 and float(a[1].abs().max()) > 0
+    s0, s1 = a[0].float().cuda(), a[1].float().cuda()
+    ns = 9
+    slab0, slab1 = torch.zeros(ns, 64, Kp, device="cuda"), torch.zeros(ns, 64, Kp, device="cuda")
+    K.call("fr_stem_wgrad_bn", g, y, rows, mean, invstd, scale, shift, slope, gamma, s0, s1, 1.0 / M, slab0, M, Kp, ns, st)()
+    K.call("fr_stem_wgrad_bn_r", g, rows, w, mean, invstd, scale, shift, slope, gamma, s0, s1, 1.0 / M, slab1, M, Kp, ns,
+           st)()
+    torch.cuda.synchronize()
+    assert torch.equal(slab0, slab1) and float(slab0.abs().max()) > 0
+
+
+@pytest.mark.parametrize("fold", [False, True])
+def test_pack_weights_64_tiles_equal_32_tiles(K, fold):
+    """fr_pack_weights_multi (round 4): the 64 x 64-tile chunks (16-byte loads and stores; chunk index < 0) write the same bf16
+    copy [Cout][tap][Cin] and transposed copy [Cin][tap][Cout] as the 32 x 32-tile chunks, bit for bit, for 3x3 and 1x1 tensors,
+    with and without the per-output-channel scale of the BN-folded inference path, tensors of both kinds in one launch."""
+    import ctypes
+    from frhip import _lib
+    st, bf = K.current_stream_ptr(), torch.bfloat16
+    shapes = [(128, 9, 64), (64, 1, 128), (256, 9, 256), (96, 9, 32)]  # the last one: 32-tiles only
+    ws = [synth.normal(87, "w%d" % i, sh).cuda() for i, sh in enumerate(shapes)]
+    osc = [synth.uniform(87, "o%d" % i, (sh[0],), 0.5, 1.5).cuda() if fold else None for i, sh in enumerate(shapes)]
+
+    def run(use64):
+        arr = (_lib.FrPackTensor * len(shapes))()
+        outs, chunks = [], []
+        for i, (co, taps, ci) in enumerate(shapes):
+            wp = torch.full((co, taps, ci), float("nan"), device="cuda", dtype=bf)
+            wt = torch.full((ci, taps, co), float("nan"), device="cuda", dtype=bf)
+            outs.append((wp, wt))
+            arr[i].w, arr[i].wp, arr[i].wt = ws[i].data_ptr(), wp.data_ptr(), wt.data_ptr()
+            arr[i].oscale = osc[i].data_ptr() if fold else None
+            arr[i].Cout, arr[i].taps, arr[i].Cin = co, taps, ci
+            if use64 and co % 64 == 0 and ci % 64 == 0:
+                chunks.extend((i, -(t + 1)) for t in range(taps * (co // 64) * (ci // 64)))
+            else:
+                chunks.extend((i, t) for t in range(taps * ((co + 31) // 32) * ((ci + 31) // 32)))
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+        ch = torch.tensor(chunks, dtype=torch.int32).reshape(-1).cuda()
+        K.call("fr_pack_weights_multi", ctypes.cast(ctypes.c_void_p(table.data_ptr()), ctypes.POINTER(_lib.FrPackTensor)), ch,
+               len(chunks), _lib.FR_BF16, st)()
+        torch.cuda.synchronize()
+        return outs
+
+    a, b = run(False), run(True)
+    for i, ((wp0, wt0), (wp1, wt1)) in enumerate(zip(a, b)):
+        assert not torch.isnan(wp1.float()).any() and not torch.isnan(wt1.float()).any(), shapes[i]
+        assert torch.equal(wp0, wp1) and torch.equal(wt0, wt1), shapes[i]
+        ref = ws[i] * (osc[i].view(-1, 1, 1) if fold else 1.0)
+        assert torch.equal(wp0, ref.to(bf)) and torch.equal(wt0, ref.to(bf).permute(2, 1, 0).contiguous())
+
