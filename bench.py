@@ -608,7 +608,7 @@ def main():
                 # rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections) over the same
                 # kernel instances (tools/pmc_round.sh + tools/pmc_summary.py), averaged over this family's launches
                 pmc = None
-                for tag in ("r03", "r02"):
+                for tag in ("r04", "r03", "r02"):
                     cand = os.path.join(REPO, "profiles", "%s_pmc_kernels.json" % tag)
                     if os.path.exists(cand):
                         pmc = cand
@@ -618,7 +618,7 @@ def main():
                     with open(pmc) as f:
                         recs = {r["kernel"]: r for r in json.load(f)["kernels"]}
                     pre = "strip_%s_%s_%s_" % m.groups()
-                    by_pro = {0: pre + "dgrad", 1: pre + "fwd_bn", 2: pre + "fwd_prelu"}
+                    by_pro = {0: pre + "dgrad", 1: pre + "fwd_bn", 2: pre + "fwd_prelu", 4: pre + "fwd_resbn"}
                     num = den = alg = 0.0
                     for member, n in members.items():
                         r = recs.get(by_pro.get(int(member[-2]), ""))
