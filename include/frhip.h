@@ -169,6 +169,14 @@ int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi);
 /* 1 when fr_conv3x3_strip serves the FR_PRO_BNBWD2 prologue for the data gradient of a C -> C layer of width W at batch B */
 int fr_conv3x3_strip_serves_bnbwd2(int B, int C, int W);
 
+/* 1x1 convolution as a row-streaming GEMM (bf16; round 4): the weights stationary in registers, one row per output pixel,
+ * stride 1 or 2 (SH = RH * stride), epilogue STORE or STATS (part[workgroup][2][N]; fr_conv1x1_stream_parts returns the number
+ * of partial rows, 0 when the shape is not served: 64 -> 128, 128 -> 256, 256 -> 512 and their transposes).  Same FrConvArgs
+ * fields as fr_conv_igemm (mode 0, no prologue).  Replaces shortcut_layer's Conv2d(in, depth, (1, 1), stride) of the first unit
+ * of a stage (backbone/model_irse.py:52-56) forward and, with the transposed weight on dense rows, its data gradient. */
+int fr_conv1x1_stream(const FrConvArgs* args, void* stream);
+int fr_conv1x1_stream_parts(int B, int RH, int RW, int K, int N);
+
 /* Stride-2 3x3 convolution (bf16, Cin == Cout: the first unit of every IR stage) on LDS-resident parity planes:
  * mode 0 = forward (SH = 2*RH), mode 2 with par_h = par_w = -1 = data gradient of all four output parity classes
  * (RH = 2*SH, w = [Cin][tap][Cout]).  Same FrConvArgs contract and epilogues as fr_conv_igemm; partial rows:

@@ -81,6 +81,17 @@ def conv_strip(stream, **kw):
     return Launch("fr_conv3x3_strip", [ctypes.byref(a), stream], keep=(a, kw))
 
 
+def conv1x1_stream(stream, **kw):
+    """fr_conv1x1_stream (bf16 1x1 convolution as a row-streaming GEMM).  Same FrConvArgs fields as conv()."""
+    a = _fill(_lib.FrConvArgs(), **kw)
+    return Launch("fr_conv1x1_stream", [ctypes.byref(a), stream], keep=(a, kw))
+
+
+def conv1x1_stream_parts(B, RH, RW, K, N):
+    """Partial-sum rows of fr_conv1x1_stream for a shape; 0 when it is not served."""
+    return int(lib.fr_conv1x1_stream_parts(int(B), int(RH), int(RW), int(K), int(N)))
+
+
 def strip_parts(B, cin, cout, w, epi=EPI_STORE):
     """Workgroups (= partial-sum rows) of the strip kernel for a shape + epilogue; 0 when it is not served."""
     return int(lib.fr_conv3x3_strip_parts(int(B), int(cin), int(cout), int(w), int(epi)))

@@ -1983,3 +1983,39 @@ def test_pack_weights_64_tiles_equal_32_tiles(K, fold):
         ref = ws[i] * (osc[i].view(-1, 1, 1) if fold else 1.0)
         assert torch.equal(wp0, ref.to(bf)) and torch.equal(wt0, ref.to(bf).permute(2, 1, 0).contiguous())
 
+
+@pytest.mark.parametrize("Kc,N,B,Ho,stride", [(64, 128, 5, 28, 2), (128, 256, 6, 14, 2), (256, 512, 9, 7, 2), (256, 512, 40, 7, 2),
+                                             (128, 64, 5, 28, 1), (256, 128, 6, 14, 1), (512, 256, 9, 7, 1), (64, 128, 3, 9, 1)])
+def test_conv1x1_stream_equals_the_generic_gemm(K, Kc, N, B, Ho, stride):
+    """fr_conv1x1_stream (round 4): shortcut_layer's Conv2d(in, depth, (1, 1), stride) (backbone/model_irse.py:52-56) and its
+    data gradient as row-streaming GEMMs with the weights in registers.  Same MFMA K order as fr_conv_igemm, same rounding:
+    the output is bit-identical; the BatchNorm partial rows (of the fp32 accumulators, as fr_conv_igemm's) agree as sums
+    (another number of rows, fp32 order); against
+    F.conv2d in float64; ragged last tile; refusals."""
+    from frhip import _lib
+    st, bf = K.current_stream_ptr(), torch.bfloat16
+    H = Ho * stride
+    x = synth.normal(89, "x", (B, H, H, Kc)).to("cuda", bf)
+    w = (synth.normal(89, "w", (N, Kc)) * 0.1).to("cuda", bf)
+    rows = B * Ho * Ho
+    kw = dict(src=x, w=w, B=B, RH=Ho, RW=Ho, SH=H, SW=H, SC=Kc, N=N, KH=1, KW=1, stride=stride, pad=0, mode=0, lda=Kc, ldc=N,
+              pro=0)
+    o0, p0 = torch.zeros(rows, N, device="cuda", dtype=bf), torch.zeros((rows + 127) // 128, 2, N, device="cuda")
+    K.conv(st, _lib.FR_BF16, out=o0, epi=_lib.EPI_STATS, part=p0, **kw)()
+    nps = K.conv1x1_stream_parts(B, Ho, Ho, Kc, N)
+    assert nps > 0
+    o1, p1 = torch.full((rows, N), float("nan"), device="cuda", dtype=bf), torch.zeros(nps, 2, N, device="cuda")
+    K.conv1x1_stream(st, out=o1, epi=_lib.EPI_STATS, part=p1, **kw)()
+    o2 = torch.full((rows, N), float("nan"), device="cuda", dtype=bf)
+    K.conv1x1_stream(st, out=o2, epi=_lib.EPI_STORE, **kw)()
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o0) and torch.equal(o2, o0)
+    ref = torch.nn.functional.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu().view(N, Kc, 1, 1), stride=stride)
+    assert relerr(o1.double().cpu().view(B, Ho, Ho, N).permute(0, 3, 1, 2), ref) < BF16_TOL
+    a, b = p0.double().sum(0), p1.double().sum(0)
+    assert float((a[0] - b[0]).abs().max()) < 1e-5 * float(o0.float().abs().sum(0).max()) + 1e-6
+    assert float((a[1] / b[1] - 1).abs().max()) < 1e-5
+    with pytest.raises(_lib.FrhipError):  # not a served shape
+        K.conv1x1_stream(st, out=o2, epi=_lib.EPI_STORE, **dict(kw, N=N // 2))()
+    assert K.conv1x1_stream_parts(B, Ho, Ho, Kc, 96) == 0
+

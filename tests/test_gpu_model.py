@@ -1393,7 +1393,8 @@ def test_in_launch_reductions_are_bit_identical_to_separate_launches(kind, B):
     off, fin0, red0, used0 = run("0")
     # (the identity -> identity edges of IR-50 take their statistics from moments -- fr_bn_finalize_res -- with or without tails)
     assert used0 == 0 and used1 > 60, (used0, used1)
-    assert fin1 == 0 and fin0 >= 18, (fin1, fin0)
+    # (the three streaming shortcut convolutions of a batch >= 32 plan take no tail: their statistics launches stay)
+    assert fin1 <= 3 and fin0 >= 18, (fin1, fin0)
     # what stays a launch of its own: the split-K slabs of Linear(25088, 512), the stem weight-gradient slabs and the rows of
     # the stem's backward sums (fr_stem_bwd_sums takes no tail)
     assert red1 <= 3 and red0 >= 78, (red1, red0)

@@ -1,5 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-bash tools/profile_round.sh r04 > gpurun_out/r4_prof.log 2>&1; tail -12 gpurun_out/r4_prof.log | cut -c1-300
-bash tools/profile_config3.sh > gpurun_out/r4_prof_c3.log 2>&1; tail -2 gpurun_out/r4_prof_c3.log | cut -c1-200
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+( time timeout 2400 python -m pytest tests -x -q -m gpu --durations=6 ) > gpurun_out/r4_full_suite5.log 2>&1; tail -14 gpurun_out/r4_full_suite5.log | cut -c1-200
