@@ -260,6 +260,11 @@ int fr_stem_gemm_bn_prelu(const void* X, const void* Wp, const float* scale, con
  * fr_stem_bwd_sums  : part[nblocks][3][64] = the rows of fr_bn_bwd_reduce(slope) over (G, y) -- sum g', sum g'*xhat, sum g*u*[u<=0];
  * fr_stem_wgrad_bn_r: fr_stem_wgrad_bn with y recomputed per 64-row trip (bit-identical slabs).
  * Replace the autograd of Conv2d -> BatchNorm2d -> PReLU of input_layer (backbone/model_irse.py:140-142). */
+/* ... and the two forward passes on IMPLICIT rows (x / avg as fr_stem_gemm_x: the workgroup stages the image rows it needs
+ * in LDS; W % 16 == 0, W <= 224): fr_stem_gemm_x(out = NULL) = statistics only; fr_stem_gemm_bn_prelu_x = fr_stem_gemm_bn_prelu */
+int fr_stem_gemm_bn_prelu_x(const float* x, const float* avg, const void* Wp, const float* scale, const float* shift,
+                            const float* slope, void* y, void* z, float* part, int B, int H, int W, int C, int Cavg, int K,
+                            int nblocks, const FrTail* tail, void* stream);
 int fr_stem_bwd_sums(const void* X, const void* Wp, const void* G, const float* mean, const float* invstd, const float* scale,
                      const float* shift, const float* slope, float* part, long long M, int K, int nblocks, void* stream);
 int fr_stem_wgrad_bn_r(const void* G, const void* X, const void* Wp, const float* mean, const float* invstd,

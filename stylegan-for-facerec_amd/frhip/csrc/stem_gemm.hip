@@ -49,6 +49,63 @@ __device__ __forceinline__ U128 stem_row_chunk(const StemSrc& s, int row, int k0
   return pack16<bf16_t>(f);
 }
 
+// Round 4, second version of the implicit rows: the 27 / 54 scalar gathers per row above cost more than the rows they save
+// (forward 171 us against 93 + 122, weight gradient 299 against 180).  The workgroup instead STAGES the image rows it needs in
+// LDS as bf16 -- an item = IMG_RB image rows of one image: (IMG_RB + 2) x (W + 2) pixels x CTP channels (3 -> 4, 6 -> 8: the
+// pad channels and the halo columns stay zero) -- and a lane builds its 16-byte chunk of an im2col row with eight ds_read_u16
+// at (pixel base + per-lane constant offsets).  Same values, same rounding: bit-identical to the materialised rows.
+constexpr int IMG_RB = 4;      // image rows per item
+constexpr int IMG_WMAX = 224;  // widest image served
+template <int CT>
+struct StemImg {
+  static constexpr int CTP = CT == 3 ? 4 : 8;
+  static constexpr int ELEMS = (IMG_RB + 2) * (IMG_WMAX + 2) * CTP;
+  // zero everything once: pad channels and halo columns are never written again
+  static __device__ __forceinline__ void clear(unsigned short* img, int tid, int nth) {
+    for (int i = tid; i < ELEMS / 8; i += nth) st16(img + i * 8, zero16());
+  }
+  // rows h0 - 1 .. h0 + IMG_RB of image b (zeros outside the image).  All loads of a batch are requested before the first
+  // conversion (as a load -> convert -> store loop an item cost eight dependent round trips: 74 us for the statistics pass)
+  static __device__ __forceinline__ void stage(unsigned short* img, const StemSrc& s, int b, int h0, int tid, int nth) {
+    const int n = (IMG_RB + 2) * CT * s.W;
+    constexpr int UB = 8;
+    for (int base = 0; base < n; base += UB * nth) {
+      float v[UB];
+      int dst[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int idx = base + u * nth + tid;
+        uint32_t rc, w;
+        fast_divmod((uint32_t)(idx < n ? idx : 0), (uint32_t)s.W, s.inv_w, rc, w);
+        const int r = (int)rc / CT, c = (int)rc - r * CT;
+        const int h = h0 - 1 + r;
+        v[u] = 0.f;
+        dst[u] = idx < n ? (r * (s.W + 2) + (int)w + 1) * CTP + c : -1;
+        if (idx < n && (unsigned)h < (unsigned)s.H)
+          v[u] = (CT > 3 && c >= s.C) ? s.avg[((size_t)(c - s.C) * s.H + h) * s.W + w]
+                                      : s.x[(((size_t)b * s.C + c) * s.H + h) * s.W + w];
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (dst[u] >= 0) img[dst[u]] = f2bf(v[u]);
+    }
+  }
+  // element offsets of the chunk k0 .. k0 + 7 relative to the pixel base (lh * (W + 2) + w) * CTP
+  static __device__ __forceinline__ void offsets(int W, int k0, int (&off)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j, tap = k / CT, c = k - tap * CT, th = tap / 3;
+      off[j] = k < 9 * CT ? (th * (W + 2) + (tap - th * 3)) * CTP + c : CT;  // CT = a pad channel: zero
+    }
+  }
+  static __device__ __forceinline__ s16x8 chunk(const unsigned short* img, int pbase, const int (&off)[8]) {
+    s16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (short)img[pbase + off[j]];
+    return v;
+  }
+};
+
 // ------------------------------------------------------------------------------------------ forward + BN statistics
 // out[m][n] = sum_k X[m][k] W[n][k];  part[blk][0][n] = sum_m out, part[blk][1][n] = sum_m out^2 (of the rounded bf16)
 // MODE 0: out = y, statistics of y.  MODE 1: statistics of y only, nothing stored (the first of two passes over the rows:
@@ -100,30 +157,65 @@ __global__ __launch_bounds__(256) void stem_gemm_kernel(const bf16_t* __restrict
       }
   }
   const int ntiles = (M + 15) / 16;
-  const int tstep = gridDim.x * 4;
-  const int trips = (ntiles + tstep - 1) / tstep;  // same trip count for every wave: the loop body has barriers
+  // IMPL: a workgroup walks ITEMS (IMG_RB image rows of one image, staged in LDS), its four waves the item's 16-row tiles;
+  // otherwise the waves of the whole grid stride over the materialised rows (one pseudo-item)
+  using IM = StemImg<CT>;
+  __shared__ __attribute__((aligned(16))) unsigned short img[IMPL ? IM::ELEMS : 8];
+  int koff[IMPL ? KS : 1][8];
+  if (IMPL) {
+    IM::clear(img, tid, 256);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) IM::offsets(src.W, kk * 32 + fq * 8, koff[kk]);
+  }
+  const int nrg = IMPL ? (src.H + IMG_RB - 1) / IMG_RB : 1;
+  const int nitems = IMPL ? (M / (src.H * src.W)) * nrg : 1;
   // the statistics-only mode has no barrier in the loop: several tiles per trip, all their loads requested before the first MFMA
   constexpr int NT = MODE == 1 ? 4 : 1;
+  for (int item = IMPL ? blockIdx.x : 0; item < nitems; item += IMPL ? gridDim.x : 1) {
+  int tbase, tmul, tlim, trips, pix0 = 0;
+  if (IMPL) {
+    const int b = item / nrg, h0 = (item - b * nrg) * IMG_RB;
+    __syncthreads();  // the previous item's fragments have been read (first item: the image is cleared)
+    IM::stage(img, src, b, h0, tid, 256);
+    __syncthreads();
+    const int rows_valid = src.H - h0 < IMG_RB ? src.H - h0 : IMG_RB;
+    pix0 = (b * src.H + h0) * src.W;  // a multiple of 16 (W % 16 == 0)
+    tbase = pix0 / 16 + wave;
+    tmul = 4;
+    tlim = pix0 / 16 + rows_valid * src.W / 16;
+    trips = (IMG_RB * src.W / 16 + 3) / 4;  // same for every wave and item: the loop body has barriers
+  } else {
+    tbase = blockIdx.x * 4 + wave;
+    tmul = gridDim.x * 4;
+    tlim = ntiles;
+    trips = (ntiles + tmul - 1) / tmul;  // same trip count for every wave: the loop body has barriers
+  }
   for (int it = 0; it < trips; it += NT) {
     s16x8 afs[NT][KS];
     bool oks[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      const int t = (it + u) * tstep + blockIdx.x * 4 + wave;
+      const int t = tbase + (it + u) * tmul;
       const int row = t * 16 + fr;
-      oks[u] = it + u < trips && t < ntiles && row < M;
+      oks[u] = it + u < trips && t < tlim && row < M;
+      int pbase = 0;
+      if (IMPL) {  // pixel (lh, w) of the staged rows
+        uint32_t lh, w;
+        fast_divmod((uint32_t)(oks[u] ? row - pix0 : 0), (uint32_t)src.W, src.inv_w, lh, w);
+        pbase = ((int)lh * (src.W + 2) + (int)w) * IM::CTP;
+      }
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
         afs[u][kk] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
         if (oks[u]) {
-          if (IMPL) afs[u][kk] = __builtin_bit_cast(s16x8, stem_row_chunk<CT>(src, row, kk * 32 + fq * 8));
+          if (IMPL) afs[u][kk] = IM::chunk(img, pbase, koff[kk]);
           else afs[u][kk] = *reinterpret_cast<const s16x8*>(X + (size_t)row * K + kk * 32 + fq * 8);
         }
       }
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-    const int t = (it + u) * tstep + blockIdx.x * 4 + wave;
+    const int t = tbase + (it + u) * tmul;
     const bool ok = oks[u];
     f32x4 acc[4];
 #pragma unroll
@@ -171,7 +263,7 @@ __global__ __launch_bounds__(256) void stem_gemm_kernel(const bf16_t* __restrict
     for (int v = 0; v < 2; ++v) {
       const int c = lane + v * 64, r = c >> 3, c8 = c & 7;
       const int orow = t * 16 + r;
-      if (t < ntiles && orow < M) {
+      if (t < tlim && orow < M) {
         if (MODE != 2 || out) st16(out + (size_t)orow * SN + c8 * 8, ld16(tile + r * OSTR + c8 * 16));
         if (MODE == 2) st16(act.zout + (size_t)orow * SN + c8 * 8, ld16(ztile + r * OSTR + c8 * 16));
       }
@@ -179,6 +271,7 @@ __global__ __launch_bounds__(256) void stem_gemm_kernel(const bf16_t* __restrict
     __syncthreads();
     }
   }
+  }  // items
   // column sums: fold the 16 row lanes, then the 4 waves
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -517,6 +610,7 @@ int stem_src(const float* x, const float* avg, int B, int H, int W, int C, int C
     FR_UNSUPPORTED("stem (implicit im2col): 3 image channels (K = 32) or 6 channels in all, image + average image (K = 64)");
   *M = (long long)B * H * W;
   if (*M >= (1ll << 24)) FR_UNSUPPORTED("stem (implicit im2col): fewer than 2^24 pixels per launch");
+  if (W % 16 || W > IMG_WMAX) FR_UNSUPPORTED("stem (implicit im2col): the image width must be a multiple of 16, at most 224");
   s->x = x;
   s->avg = avg;
   s->H = H;
@@ -616,16 +710,43 @@ extern "C" int fr_stem_gemm_x(const float* x, const float* avg, const void* Wp, 
   long long M;
   if (stem_src(x, avg, B, H, W, C, Cavg, K, &src, &M)) return -1;
   if (nblocks < 1) FR_UNSUPPORTED("fr_stem_gemm_x: nblocks >= 1");
+  if (!out && !part) FR_UNSUPPORTED("fr_stem_gemm_x: out == NULL asks for the statistics only, which need part");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   FrTail t;
   if (fr_tail_prepare(tail ? *tail : FrTail{}, 2, SN, 1, &t, part != nullptr)) return -1;
   const StemAct noact = {};
+#define STEM_FWD_X(KK, MD)                                                                                           \
+  hipLaunchKernelGGL((stem_gemm_kernel<KK, true, MD>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)nullptr,      \
+                     (const bf16_t*)Wp, (bf16_t*)out, part, (int)M, t, src, noact)
+  if (K == 32) {
+    if (out) STEM_FWD_X(32, 0);
+    else STEM_FWD_X(32, 1);
+  } else {
+    if (out) STEM_FWD_X(64, 0);
+    else STEM_FWD_X(64, 1);
+  }
+#undef STEM_FWD_X
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_stem_gemm_bn_prelu_x(const float* x, const float* avg, const void* Wp, const float* scale,
+                                       const float* shift, const float* slope, void* y, void* z, float* part, int B, int H,
+                                       int W, int C, int Cavg, int K, int nblocks, const FrTail* tail, void* stream) {
+  StemSrc src;
+  long long M;
+  if (stem_src(x, avg, B, H, W, C, Cavg, K, &src, &M)) return -1;
+  if (nblocks < 1 || !Wp || !scale || !shift || !slope || !z)
+    FR_UNSUPPORTED("fr_stem_gemm_bn_prelu_x: Wp, scale, shift, slope, z and nblocks >= 1 are required");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  FrTail t;
+  if (fr_tail_prepare(tail ? *tail : FrTail{}, 2, SN, 1, &t, part != nullptr)) return -1;
+  const StemAct act = {scale, shift, slope, (bf16_t*)z};
   if (K == 32)
-    hipLaunchKernelGGL((stem_gemm_kernel<32, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)nullptr,
-                       (const bf16_t*)Wp, (bf16_t*)out, part, (int)M, t, src, noact);
+    hipLaunchKernelGGL((stem_gemm_kernel<32, true, 2>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)nullptr,
+                       (const bf16_t*)Wp, (bf16_t*)y, part, (int)M, t, src, act);
   else
-    hipLaunchKernelGGL((stem_gemm_kernel<64, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)nullptr,
-                       (const bf16_t*)Wp, (bf16_t*)out, part, (int)M, t, src, noact);
+    hipLaunchKernelGGL((stem_gemm_kernel<64, true, 2>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)nullptr,
+                       (const bf16_t*)Wp, (bf16_t*)y, part, (int)M, t, src, act);
   FR_LAUNCH_CHECK();
 }
 

@@ -331,10 +331,12 @@ class BackbonePlan(object):
             # us against 93 (fr_stem_im2col) + 122; weight gradient 299 against 180 -- 27 scalar gathers per row cost more in
             # the weight gradient than the 205 MB of rows they save: +0.05-0.09 ms per step (profiles/r04_ab_stem_implicit.txt;
             # also measured there: forward implicit + the weight gradient's rows built on the side stream during the forward
-            # pass, +0.1 ms against materialised rows -- removed).  So: opt-in, FRHIP_STEM_IMPLICIT=1 (no X0: 205 MB less
-            # memory at batch 256); default = rows materialised in front of the forward GEMM.
+            # pass, +0.1 ms against materialised rows -- removed).  Second version: the forward passes stage the image rows in
+            # LDS (stem_gemm.hip, StemImg): statistics 69 + GEMM/BN/PReLU 133 us against im2col 66 + 43 + 157 on materialised
+            # rows (stand-alone, warm) -- the forward is then the faster one, the weight gradient still gathers from global
+            # memory.  So: opt-in, FRHIP_STEM_IMPLICIT=1 (no X0: 205 MB less memory at batch 256); default = rows materialised.
             mode = os.environ.get("FRHIP_STEM_IMPLICIT", "0")
-            self.stem_x = (self.use_stem_gemm and mode != "0" and
+            self.stem_x = (self.use_stem_gemm and mode != "0" and S % 16 == 0 and S <= 224 and
                            os.environ.get("FRHIP_NO_STEM_BNFUSE", "0") != "1" and M0 < (1 << 24) and
                            ((self.K0 == 32 and self.in_channels == 3 and self.avg_channels == 0) or
                             (self.K0 == 64 and self.in_channels + self.avg_channels == 6)))
@@ -343,9 +345,12 @@ class BackbonePlan(object):
             # backward on a RECOMPUTED y0: the GEMM is 13 GFLOP at batch 256, its output 411 MB -- y0 is never written or
             # read, the fr_bn_apply pass over it is gone.  FRHIP_STEM_TWO_PASS=0 / FRHIP_STEM_RECOMPUTE=0: A/B switches
             # (the second one keeps y0 for the backward kernels of round 3).
-            self.stem_two_pass = (self.use_stem_gemm and not self.stem_x and not self.fold and
+            self.stem_two_pass = (self.use_stem_gemm and not self.fold and
                                   os.environ.get("FRHIP_STEM_TWO_PASS", "1") != "0")
-            self.stem_recompute = (self.stem_two_pass and os.environ.get("FRHIP_NO_STEM_BNFUSE", "0") != "1" and
+            # (on implicit rows -- FRHIP_STEM_IMPLICIT=1 -- the two forward passes stage image rows in LDS; the backward kernels
+            # of that mode read y0)
+            self.stem_recompute = (self.stem_two_pass and not self.stem_x and
+                                   os.environ.get("FRHIP_NO_STEM_BNFUSE", "0") != "1" and
                                    os.environ.get("FRHIP_STEM_RECOMPUTE", "1") != "0")
             self.y0 = None if (self.stem_recompute or (self.stem_two_pass and self.infer)) else self._act(M0, 64)
             self.W0p = torch.empty(64, self.K0, device=dev, dtype=self.tdtype)
@@ -761,13 +766,26 @@ class BackbonePlan(object):
                 # y0 and writes z0 = PReLU(BN0(y0)) (+ y0 for the backward pass) with the statistics of z0 in its epilogue:
                 # the fr_bn_apply pass over the stem output (822 MB of traffic, 161 us at batch 256) is gone.
                 mt0 = int(min(2048, (self.M0 + 63) // 64))
+                self.l_stem_fwd = self.l_stem_fwd2 = None
+                geo = (B, S, S, self.in_channels, self.avg_channels, self.K0, mt0)
                 if self.bn0.mod.training:
-                    L.append(ops.call("fr_stem_gemm", self.X0, self.W0p, None, self.part, self.M0, self.K0, mt0,
-                                      self._bn_tail(self.bn0, self.M0), st))
+                    if self.stem_x:  # x / avg pointers are bound per call (run_forward)
+                        self.l_stem_fwd = ops.call("fr_stem_gemm_x", None, None, self.W0p, None, self.part, *geo,
+                                                   self._bn_tail(self.bn0, self.M0), st)
+                        L.append(self.l_stem_fwd)
+                    else:
+                        L.append(ops.call("fr_stem_gemm", self.X0, self.W0p, None, self.part, self.M0, self.K0, mt0,
+                                          self._bn_tail(self.bn0, self.M0), st))
                 self._bn_train_launches(L, self.bn0, self.part, mt0, self.M0)
-                L.append(ops.call("fr_stem_gemm_bn_prelu", self.X0, self.W0p, self.bn0.scale, self.bn0.shift, sp.weight,
-                                  self.y0, self.z0, stats_part, self.M0, self.K0, mt0,
-                                  self._bn_tail(first_bn, self.M0, 2), st))
+                if self.stem_x:
+                    self.l_stem_fwd2 = ops.call("fr_stem_gemm_bn_prelu_x", None, None, self.W0p, self.bn0.scale,
+                                                self.bn0.shift, sp.weight, self.y0, self.z0, stats_part, *geo,
+                                                self._bn_tail(first_bn, self.M0, 2), st)
+                    L.append(self.l_stem_fwd2)
+                else:
+                    L.append(ops.call("fr_stem_gemm_bn_prelu", self.X0, self.W0p, self.bn0.scale, self.bn0.shift, sp.weight,
+                                      self.y0, self.z0, stats_part, self.M0, self.K0, mt0,
+                                      self._bn_tail(first_bn, self.M0, 2), st))
                 self._bn_train_launches(L, first_bn, self.part, mt0, self.M0)
             elif self.use_stem_gemm:  # 3.2 M rows x 64 columns x K0: the row-streaming kernels of stem_gemm.hip
                 mt0 = int(min(2048, (self.M0 + 63) // 64))
@@ -1427,7 +1445,9 @@ class BackbonePlan(object):
         if self.stem_x:
             # the stem kernels read the batch itself: bind its address (and keep it alive until the backward pass has run)
             self._x_ref = (x, avg)
-            self.l_stem_fwd.args[0], self.l_stem_fwd.args[1] = ops.ptr(x), ops.ptr(avg)
+            for l in (self.l_stem_fwd, getattr(self, "l_stem_fwd2", None)):
+                if l is not None:
+                    l.args[0], l.args[1] = ops.ptr(x), ops.ptr(avg)
             if getattr(self, "l_stem_bwd", None) is not None:
                 self.l_stem_bwd.args[2], self.l_stem_bwd.args[3] = ops.ptr(x), ops.ptr(avg)
         else:

@@ -1825,7 +1825,7 @@ def test_se_branch_against_autograd_with_every_gate_decided(K, B, C, H):
 
 
 @pytest.mark.parametrize("Cavg,Kp", [(0, 32), (3, 64)])
-@pytest.mark.parametrize("B,S", [(3, 10), (2, 37), (5, 112)])
+@pytest.mark.parametrize("B,S", [(3, 16), (2, 48), (5, 112), (1, 224)])
 def test_stem_gemms_without_materialised_rows(K, Cavg, Kp, B, S):
     """fr_stem_gemm_x / fr_stem_wgrad_bn_x (round 4): the input-layer GEMM and its weight gradient build the im2col rows of
     Conv2d(3|6, 64, 3, 1, 1) from the fp32 NCHW batch (+ pSp's average image) in registers.  Same values, same rounding:
@@ -1846,7 +1846,24 @@ def test_stem_gemms_without_materialised_rows(K, Cavg, Kp, B, S):
     K.call("fr_stem_gemm", rows, w, out0, p0, M, Kp, nb, None, st)()
     K.call("fr_stem_gemm_x", x, avg, w, out1, p1, B, S, S, 3, Cavg, Kp, nb, None, st)()
     torch.cuda.synchronize()
-    assert torch.equal(out0, out1) and torch.equal(p0, p1) and float(out0.float().abs().max()) > 0
+    # (second version: the workgroup stages image rows in LDS and walks them item by item -- another assignment of rows to
+    # workgroups than the materialised-rows kernel, so the partial rows agree as sums, the output bit for bit)
+    assert torch.equal(out0, out1) and float(out0.float().abs().max()) > 0
+    assert float((p0.double().sum(0) - p1.double().sum(0)).abs().max()) < 1e-5 * float(p0.double().sum(0).abs().max())
+    # statistics only / GEMM + BN + PReLU on the implicit rows against the same passes on materialised rows
+    vec0 = lambda n, lo, hi: synth.uniform(78, n, (64,), lo, hi).cuda()  # noqa: E731
+    sc_, sh_, sl_ = vec0("sc", 0.5, 1.5), vec0("sh", -0.3, 0.3), vec0("sl", 0.1, 0.4)
+    p2 = torch.zeros(nb, 2, 64, device="cuda")
+    K.call("fr_stem_gemm_x", x, avg, w, None, p2, B, S, S, 3, Cavg, Kp, nb, None, st)()
+    y3, z3, p3 = (torch.full((M, 64), float("nan"), device="cuda", dtype=bf) for _ in range(2)), None, None
+    y3, z3 = y3
+    p3, p4 = torch.zeros(nb, 2, 64, device="cuda"), torch.zeros(nb, 2, 64, device="cuda")
+    z4 = torch.zeros(M, 64, device="cuda", dtype=bf)
+    K.call("fr_stem_gemm_bn_prelu", rows, w, sc_, sh_, sl_, None, z4, p4, M, Kp, nb, None, st)()
+    K.call("fr_stem_gemm_bn_prelu_x", x, avg, w, sc_, sh_, sl_, y3, z3, p3, B, S, S, 3, Cavg, Kp, nb, None, st)()
+    torch.cuda.synchronize()
+    assert torch.equal(p2, p1) and torch.equal(y3, out0) and torch.equal(z3, z4)
+    assert float((p3.double().sum(0) - p4.double().sum(0)).abs().max()) < 1e-5 * float(p4.double().sum(0).abs().max())
     g = synth.normal(77, "sg", (M, 64)).to("cuda", bf)
     vec = lambda n, lo, hi: synth.uniform(77, n, (64,), lo, hi).cuda()  # noqa: E731
     mean, invstd, gamma, slope = vec("m", -0.3, 0.3), vec("i", 0.5, 2.0), vec("g", 0.8, 1.2), vec("s", 0.1, 0.4)
