@@ -353,6 +353,9 @@ class BackbonePlan(object):
                                    os.environ.get("FRHIP_NO_STEM_BNFUSE", "0") != "1" and
                                    os.environ.get("FRHIP_STEM_RECOMPUTE", "1") != "0")
             self.y0 = None if (self.stem_recompute or (self.stem_two_pass and self.infer)) else self._act(M0, 64)
+            # (Measured and removed: the forward passes on LDS-staged image rows while the materialised rows -- which then only
+            # the two backward kernels read -- are built on the side stream at the start of the backward pass: 14.26-14.36
+            # against 14.28-14.34 ms per step, nothing; profiles/r04_ab_stem_implicit.txt.)
             self.W0p = torch.empty(64, self.K0, device=dev, dtype=self.tdtype)
             self.gW0p = torch.zeros(64, self.K0, device=dev)
             self.bn0 = _BN(self.stem[1], self.pool)
