@@ -23,3 +23,8 @@ run FRHIP_LINEAR_CM=0
 run FRHIP_RES_MOMENTS=0
 run FRHIP_STEM_IMPLICIT=1
 run FRHIP_IGEMM_BN=64
+run FRHIP_RES_MOMENTS_SE=0
+run FRHIP_STEM_TWO_PASS=0
+run FRHIP_STEM_RECOMPUTE=0
+run FRHIP_C1_STREAM=0
+run FRHIP_PACK64=0
