@@ -600,6 +600,11 @@ int fr_fill_rows(float* out, const float* bias, long long rows, int C, void* str
  * answers yes / no.  Every entry point additionally returns < 0 for an unsupported argument (text in
  * fr_last_error_string()), never silently computing something else. */
 int fr_abi_version(void);
+/* Run-time switches (kernel-family A/B switches, test hooks; README "Switches"): an int per name, first read from the
+ * environment variable of that name, then cached for the life of the process.  fr_set_option overrides the cached value
+ * (returns the previous one); fr_get_option reads it (dflt when neither set nor in the environment). */
+int fr_set_option(const char* name, int value);
+int fr_get_option(const char* name, int dflt);
 /* sizeof() of the argument structs as compiled, for binding self-checks: 0 FrConvArgs, 1 FrWgradArgs,
  * 2 FrApplyArgs, 3 FrBnBwdArgs, 4 FrSgdTensor, 5 FrPackTensor, 6 FrAdamTensor, 7 FrBnEvalEntry, 8 FrTail */
 int fr_struct_size(int which);

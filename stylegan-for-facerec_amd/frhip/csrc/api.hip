@@ -2,6 +2,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "common.h"
 #include "frhip_internal.h"
 
@@ -27,6 +29,49 @@ extern "C" int fr_struct_size(int which) {
   }
   return -1;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Run-time switches (kernel-family A/B switches and test hooks).  A switch is an int, first read from the environment
+// variable of its name (unset = the default its first reader passes), cached in a slot for the life of the process and
+// overridable through fr_set_option (tests flip kernel families inside one process).  Launchers keep a pointer to the
+// slot: no getenv on the launch path.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct Opt {
+  char name[48];
+  int value;
+};
+Opt g_opts[96];
+int g_nopts = 0;
+std::mutex g_opt_mu;
+Opt* find_opt(const char* name) {
+  for (int i = 0; i < g_nopts; ++i)
+    if (!strcmp(g_opts[i].name, name)) return &g_opts[i];
+  return nullptr;
+}
+}  // namespace
+
+int* fr_option_slot(const char* name, int dflt) {
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  Opt* o = find_opt(name);
+  if (!o) {
+    if (g_nopts >= (int)(sizeof(g_opts) / sizeof(g_opts[0]))) abort();
+    o = &g_opts[g_nopts++];
+    strncpy(o->name, name, sizeof(o->name) - 1);
+    const char* e = getenv(name);
+    o->value = (e && e[0]) ? atoi(e) : dflt;
+  }
+  return &o->value;
+}
+
+extern "C" int fr_set_option(const char* name, int value) {
+  int* slot = fr_option_slot(name, value);
+  const int old = *slot;
+  *slot = value;
+  return old;
+}
+
+extern "C" int fr_get_option(const char* name, int dflt) { return *fr_option_slot(name, dflt); }
 
 // Workgroups that share the in-launch reduction of a launch's partial rows (tail.h) when the caller leaves FrTail.nred 0:
 // enough that every 256-thread reduction block takes one 8-column group, capped here.  FRHIP_TAIL_NRED overrides the cap

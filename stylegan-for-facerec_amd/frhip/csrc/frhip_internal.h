@@ -4,6 +4,9 @@
 
 #include <hip/hip_runtime.h>
 
+// run-time switch `name` (api.hip): pointer to its cached value (environment variable of that name, else dflt)
+int* fr_option_slot(const char* name, int dflt);
+
 // out[i] = sum_g slab[g][i] in the fixed order g = 0, 1, ... (n elements, n % 4 == 0); conv_wgrad_strip.hip
 int fr_launch_reduce_slabs(const float* slab, int groups, long long n, float* out, hipStream_t st);
 
@@ -11,6 +14,12 @@ int fr_launch_reduce_slabs(const float* slab, int groups, long long n, float* ou
 bool fr_roll64_enabled();
 int fr_roll64_parts(int B, int W);
 int fr_roll64_launch(const FrConvArgs& a, hipStream_t st);
+
+// 256 -> 256 @14x14 at whole-image-per-CU batches on the one-wave-per-SIMD kernel (conv3x3_solo.hip); dispatched from
+// fr_conv3x3_strip
+bool fr_solo_enabled();
+bool fr_solo_serves(const FrConvArgs& a);
+int fr_solo_launch(const FrConvArgs& a, hipStream_t st);
 
 // 64-channel stride-2 3x3 layer (112 -> 56) and its data gradient on the rolling-window kernel (conv3x3_s2_roll64.hip);
 // dispatched from fr_conv3x3_s2_strip
