@@ -530,7 +530,7 @@ int by_pro(const FrConvArgs& a, hipStream_t st) {
 
 // FRHIP_SOLO=0: the 8-wave strip instances again (A/B switch)
 bool fr_solo_enabled() {
-  static const int* v = fr_option_slot("FRHIP_SOLO", 1);
+  static const int* v = fr_option_slot("FRHIP_SOLO", 0);
   return *v != 0;
 }
 

@@ -13,6 +13,7 @@ import kbench  # noqa: E402
 from frhip import _lib, ops  # noqa: E402
 
 BF = torch.bfloat16
+OPT = os.environ.get("CHECK_OPT", "FRHIP_SOLO")  # the switch under test (its 0 setting = the 8-wave strip kernel)
 
 
 def setopt(name, v):
@@ -40,7 +41,9 @@ def run(B, pro, epi, mode, solo):
         kw.update(src2=src2, pro_c=vc, pro_d=vd, pro_out=pro_out)
     if pro == 5:
         kw.update(pro_g=vg)
-    setopt("FRHIP_SOLO", solo)
+    for o in ("FRHIP_SOLO", "FRHIP_RELAY"):
+        setopt(o, 0)
+    setopt(OPT, solo)
     ops.conv_strip(st, **kw)()
     torch.cuda.synchronize()
     return out, part, pro_out
@@ -67,7 +70,9 @@ def main():
         kbench.COLD = bool(cold)
         for rep in range(2):
             for solo in (0, 1):
-                setopt("FRHIP_SOLO", solo)
+                for o in ("FRHIP_SOLO", "FRHIP_RELAY"):
+                    setopt(o, 0)
+                setopt(OPT, solo)
                 for label, fn in kbench.suite_cases(256):
                     if label in cases.split(","):
                         ms, tf = fn(20 if cold else 50)

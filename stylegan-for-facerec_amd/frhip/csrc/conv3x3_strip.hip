@@ -695,7 +695,6 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
     FR_UNSUPPORTED("fr_conv3x3_strip: only square stride-1 3x3 bf16 convolutions");
   if (a.lda % 8 || a.ldc % 8 || (a.aux && a.ldaux % 8)) FR_UNSUPPORTED("fr_conv3x3_strip: strides must be 16-byte multiples");
   if (a.SC == 64 && a.N == 64 && (a.SW == 112 || a.SW == 56) && fr_roll64_enabled()) return fr_roll64_launch(a, st);
-  if (!small_batch(a.B) && fr_solo_serves(a)) return fr_solo_launch(a, st);
 #define SHAPE(ci, co, w, rows, wn, nw) \
   if (a.SC == ci && a.N == co && a.SW == w) return by_pro<ci, co, w, rows, wn, nw>(a, st);
   // (round 3: 128 -> 128 @28 as 8 waves x (25 tiles x 1 column) on half images, one workgroup per CU, half the weight stream:
@@ -759,8 +758,7 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
         h.pro_a = a.pro_c;
         h.pro_b = a.pro_d;
       }
-      const int rc = small_batch(a.B) ? by_pro<256, 128, 14, 14, 8, 8, 2>(h, st)
-                     : fr_solo_serves(h) ? fr_solo_launch(h, st) : by_pro<256, 256, 14, 14, 8, 8>(h, st);
+      const int rc = small_batch(a.B) ? by_pro<256, 128, 14, 14, 8, 8, 2>(h, st) : by_pro<256, 256, 14, 14, 8, 8>(h, st);
       if (rc) return rc;
     }
     return 0;

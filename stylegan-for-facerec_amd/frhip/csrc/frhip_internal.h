@@ -15,12 +15,6 @@ bool fr_roll64_enabled();
 int fr_roll64_parts(int B, int W);
 int fr_roll64_launch(const FrConvArgs& a, hipStream_t st);
 
-// 256 -> 256 @14x14 at whole-image-per-CU batches on the one-wave-per-SIMD kernel (conv3x3_solo.hip); dispatched from
-// fr_conv3x3_strip
-bool fr_solo_enabled();
-bool fr_solo_serves(const FrConvArgs& a);
-int fr_solo_launch(const FrConvArgs& a, hipStream_t st);
-
 // 64-channel stride-2 3x3 layer (112 -> 56) and its data gradient on the rolling-window kernel (conv3x3_s2_roll64.hip);
 // dispatched from fr_conv3x3_s2_strip
 bool fr_s2roll_serves(const FrConvArgs& a);
