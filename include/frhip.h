@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 4
+#define FR_ABI_VERSION 5
 
 enum { FR_F32 = 0, FR_BF16 = 1 };
 
@@ -31,12 +31,7 @@ enum {
   FR_PRO_NONE = 0,
   FR_PRO_BN = 1,     /* x*a[c]+b[c] */
   FR_PRO_PRELU = 2,  /* x>0?x:a[c]*x */
-  FR_PRO_BNBWD2 = 3  /* a[c]*x + b[c]*x2 + c[c] with x2 = src2 at the same pixel: the backward of a train-mode BatchNorm applied
-                        while the data gradient of the convolution in front of it gathers its operand (x = gradient at the BN
-                        output, x2 = BN input; a, b, c from FR_TAIL_BNBWD).  The result, rounded to the compute dtype, is what the
-                        kernel multiplies; with pro_out != NULL it is also stored (interior pixels, once each) for the weight
-                        gradient to read.  Served by fr_conv3x3_strip / fr_conv3x3_s2_strip data gradients (bf16). */
-  ,
+  /* 3: FR_PRO_BNBWD2 of ABI v4 (BatchNorm backward inside the data gradient; measured +-0 on two streams, removed in v5) */
   FR_PRO_RESBN = 4   /* BN1 of a residual unit applied to the OUTPUT of the unit in front of it, formed on the way:
                         o = round(a[c]*x + b[c] + x2)  (x = conv2 output of the previous unit, a / b = its BN2 coefficients, x2 =
                         src2 = that unit's input: bottleneck_IR's `res + shortcut`, backbone/model_irse.py:64-66 with the
@@ -67,50 +62,20 @@ enum {
                            adds the splitk slabs with fr_reduce_parts(out, splitk, 1, rows*ldc, ...) -- reproducible */
 };
 
-/* ---- In-launch reduction of the partial rows a launch writes (ABI v4; csrc/tail.h).
- * Every entry point that leaves per-workgroup partial sums (part[row][K][C]) accepts a tail: with tail.ticket != NULL the
- * launch itself adds the rows -- its workgroups count their arrivals on ticket[0] after storing their rows, the last
- * `nred` of them add the rows in the order of fr_reduce_parts / fr_bn_finalize (bit-identical results) and write
- *   FR_TAIL_SUMS: o_k[c] = sum_rows part[row][k][c], k < K (NULL outputs skipped)     == fr_reduce_parts(part, rows, K, C, ..)
- *   FR_TAIL_BN  : mean / invstd / scale / shift (+ running statistics)               == fr_bn_finalize(part, rows, C, ..)
- *   FR_TAIL_BNBWD: FR_TAIL_SUMS of fr_bn_bwd_reduce's rows (o0 = d beta, o1 = d gamma [, o2]) plus the coefficients of the
- *                 BatchNorm backward as an affine map of (g, x):  gx = ca*g + cb*x + cc  with, per channel,
- *                 k = gamma*in_invstd, ca = k, cb = -k*in_invstd*s1/count, cc = k*(in_invstd*s1/count*in_mean - s0/count)
- *                 (bn_eval != 0: the BatchNorm ran on its running statistics -- s0 = s1 = 0 in the coefficients);
- *                 what FR_PRO_BNBWD2 consumes
- * ticket: 4 x uint32 of device memory, zero before the launch, zero again after it ([0] arrivals, [1] finished reducers,
- * [2] set to 1 if a reducer gave up waiting for a producer -- never in a healthy run); one ticket must not be shared by
- * launches that can run concurrently.  The rows stay in `part` as without a tail.
- * Replaces the separate statistics / gradient-sum launches behind BatchNorm2d / PReLU (backbone/model_irse.py:57-60,141-148). */
-enum { FR_TAIL_NONE = 0, FR_TAIL_SUMS = 1, FR_TAIL_BN = 2, FR_TAIL_BNBWD = 3 };
-typedef struct FrTail {
-  uint32_t* ticket;
-  int32_t kind;  /* FR_TAIL_* */
-  int32_t K;     /* SUMS: vectors per partial row (1..3); BN: 2 */
-  int32_t C;     /* channels per vector: must equal the launch's own column count */
-  int32_t nred;  /* workgroups that share the reduction; 0 = library default */
-  float* o0;     /* SUMS outputs [C] */
-  float* o1;
-  float* o2;
-  double count;  /* BN: the arguments of fr_bn_finalize */
+/* The BatchNorm arguments of fr_bn_finalize as a struct (fr_bn_finalize_res takes two of them). */
+typedef struct FrBnFinArgs {
+  double count;            /* elements per channel */
   const float* gamma;
   const float* beta;
   float eps, momentum;
-  float* running_mean;
+  float* running_mean;     /* NULL: no running statistics */
   float* running_var;
   int64_t* nbt;
-  float* mean;
+  float* mean;             /* outputs [C] */
   float* invstd;
   float* scale;
   float* shift;
-  const float* in_mean;   /* BNBWD: statistics of the forward pass (inputs) */
-  const float* in_invstd;
-  float* ca;              /* BNBWD outputs [C] */
-  float* cb;
-  float* cc;
-  int32_t bn_eval;
-  int32_t pad_;
-} FrTail;
+} FrBnFinArgs;
 
 typedef struct FrConvArgs {
   const void* src; /* A operand: NHWC [B,SH,SW,SC], pixel stride lda (elements) */
@@ -143,11 +108,10 @@ typedef struct FrConvArgs {
   float* part;        /* [ceil(rows/128)][2][N] partial column sums */
   const int64_t* label; /* [rows] */
   float* cos_t;         /* [rows] */
-  FrTail tail;         /* in-launch reduction of `part` (epilogues that write partial rows), see FrTail */
-  /* FR_PRO_BNBWD2 only (ABI v4) */
+  /* the two-source prologues FR_PRO_RESBN / FR_PRO_RESBN_SE */
   const void* src2;    /* second source, geometry and strides of src */
   const float* pro_c;  /* [SC] */
-  void* pro_out;       /* NULL or [B*SH*SW][lda]: the prologue result of every source pixel */
+  void* pro_out;       /* NULL or [B*SH*SW][lda]: the residual sum of every source pixel */
   const float* pro_d;  /* [SC], FR_PRO_RESBN / FR_PRO_RESBN_SE only */
   const float* pro_g;  /* [B][SC] excite gates, FR_PRO_RESBN_SE only */
 } FrConvArgs;
@@ -166,8 +130,9 @@ int fr_conv_igemm(const FrConvArgs* args, int dtype, void* stream);
  * Replaces Conv2d(c, d, (3,3), (1,1), 1) of bottleneck_IR (backbone/model_irse.py:57-59) fwd + data gradient. */
 int fr_conv3x3_strip(const FrConvArgs* args, void* stream);
 int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi);
-/* 1 when fr_conv3x3_strip serves the FR_PRO_BNBWD2 prologue for the data gradient of a C -> C layer of width W at batch B */
-int fr_conv3x3_strip_serves_bnbwd2(int B, int C, int W);
+/* 1 when fr_conv3x3_strip serves the two-source prologues (FR_PRO_RESBN[_SE]) and FR_EPI_STATS_X for a C -> C layer of width W
+ * at batch B (the LDS-strip instances; not the 64-channel rolling-window kernel) */
+int fr_conv3x3_strip_serves_resbn(int B, int C, int W);
 
 /* 1x1 convolution as a row-streaming GEMM (bf16; round 4): the weights stationary in registers, one row per output pixel,
  * stride 1 or 2 (SH = RH * stride), epilogue STORE or STATS (part[workgroup][2][N]; fr_conv1x1_stream_parts returns the number
@@ -246,25 +211,19 @@ int fr_stem_im2col(const float* x, const float* avg, void* out, int B, int H, in
  * fr_stem_wgrad: slab[nblocks][64][K] = per-workgroup partial of g[M][64]^T * X[M][K] (add them with fr_reduce_parts,
  *                K = 1, C = 64*K).
  * Replace the GEMM half of input_layer Conv2d(3|6,64,3,1,1) (model_irse.py:140) forward and its weight gradient. */
-int fr_stem_gemm(const void* X, const void* Wp, void* out, float* part, long long M, int K, int nblocks,
-                 const FrTail* tail /* NULL or an in-launch reduction of part (FR_TAIL_BN, C = 64) */, void* stream);
+int fr_stem_gemm(const void* X, const void* Wp, void* out, float* part, long long M, int K, int nblocks, void* stream);
 /* Round 4: the stem forward as TWO passes over the rows instead of GEMM + a BN-apply pass over its 411-MB output:
  * fr_stem_gemm(out = NULL) leaves only the statistics of y = X * Wp^T (nothing stored), and after fr_bn_finalize
  * fr_stem_gemm_bn_prelu recomputes y, stores z = PReLU(BN(y)) -- fr_bn_apply(slope) on the rounded y, element for element -- and
  * y itself (y may be NULL when nothing reads it) and leaves the statistics of the rounded z in part (for the BatchNorm of the
  * first residual unit).  Replaces input_layer = Conv2d -> BatchNorm2d -> PReLU (backbone/model_irse.py:140-142). */
 int fr_stem_gemm_bn_prelu(const void* X, const void* Wp, const float* scale, const float* shift, const float* slope, void* y,
-                          void* z, float* part, long long M, int K, int nblocks, const FrTail* tail, void* stream);
+                          void* z, float* part, long long M, int K, int nblocks, void* stream);
 /* ... and its backward WITHOUT the stored y (y = NULL above: 411 MB less memory and traffic at batch 256): both kernels
  * recompute y = X * Wp^T from the rows, rounded as the forward pass rounded it.
  * fr_stem_bwd_sums  : part[nblocks][3][64] = the rows of fr_bn_bwd_reduce(slope) over (G, y) -- sum g', sum g'*xhat, sum g*u*[u<=0];
  * fr_stem_wgrad_bn_r: fr_stem_wgrad_bn with y recomputed per 64-row trip (bit-identical slabs).
  * Replace the autograd of Conv2d -> BatchNorm2d -> PReLU of input_layer (backbone/model_irse.py:140-142). */
-/* ... and the two forward passes on IMPLICIT rows (x / avg as fr_stem_gemm_x: the workgroup stages the image rows it needs
- * in LDS; W % 16 == 0, W <= 224): fr_stem_gemm_x(out = NULL) = statistics only; fr_stem_gemm_bn_prelu_x = fr_stem_gemm_bn_prelu */
-int fr_stem_gemm_bn_prelu_x(const float* x, const float* avg, const void* Wp, const float* scale, const float* shift,
-                            const float* slope, void* y, void* z, float* part, int B, int H, int W, int C, int Cavg, int K,
-                            int nblocks, const FrTail* tail, void* stream);
 int fr_stem_bwd_sums(const void* X, const void* Wp, const void* G, const float* mean, const float* invstd, const float* scale,
                      const float* shift, const float* slope, float* part, long long M, int K, int nblocks, void* stream);
 int fr_stem_wgrad_bn_r(const void* G, const void* X, const void* Wp, const float* mean, const float* invstd,
@@ -277,17 +236,6 @@ int fr_stem_wgrad(const void* G, const void* X, float* slab, long long M, int K,
 int fr_stem_wgrad_bn(const void* G, const void* Y, const void* X, const float* mean, const float* invstd,
                      const float* scale, const float* shift, const float* slope, const float* gamma, const float* s0,
                      const float* s1, float inv_count, float* slab, long long M, int K, int nblocks, void* stream);
-
-/* Round 4: the same two GEMMs WITHOUT materialised im2col rows -- the kernels build their row chunks from the fp32 NCHW
- * batch x [B][C][H][W] (and the constant average image avg [Cavg][H][W] of pSp, restyle_psp.py:445-447) in registers: the
- * values of fr_stem_im2col, rounded to bf16 the same way, so the results equal fr_stem_gemm / fr_stem_wgrad_bn on the rows
- * bit for bit, and the 205-MB row tensor is neither written nor read.  (C, Cavg, K) = (3, 0, 32) or C + Cavg = 6, K = 64. */
-int fr_stem_gemm_x(const float* x, const float* avg, const void* Wp, void* out, float* part, int B, int H, int W, int C,
-                   int Cavg, int K, int nblocks, const FrTail* tail, void* stream);
-int fr_stem_wgrad_bn_x(const void* G, const void* Y, const float* x, const float* avg, const float* mean,
-                       const float* invstd, const float* scale, const float* shift, const float* slope, const float* gamma,
-                       const float* s0, const float* s1, float inv_count, float* slab, int B, int H, int W, int C, int Cavg,
-                       int K, int nblocks, void* stream);
 
 /* ---- BatchNorm statistics (train mode; torch defaults eps 1e-5, momentum 0.1 -- SURVEY App. B 13)
  * part: [nparts][2][C] partial (sum, sum of squares) rows; count = elements per channel.
@@ -303,16 +251,14 @@ int fr_bn_finalize(const float* part, int nparts, int C, double count, const flo
  * conv2: exactly what fr_bn_finalize(part rows 0..1) writes; bn->count = elements per channel) AND `next`, the BatchNorm that
  * normalises the unit's output o' = scale*y + shift + o:  mean' = scale*my + shift + mo,  var' = scale^2*vy + vo +
  * 2*scale*cov(y, o), with (mo, vo) from in_mean / in_invstd / in_eps -- the statistics the unit's own BN1 used for o.
- * Of the two FrTail arguments only the BatchNorm fields are read (count, gamma ... shift); ticket / kind are ignored.
  * next == NULL: only `bn` is finalised (rows of three vectors; squeeze-excite units, whose output statistics need the
  * gates: fr_se_pool_parts_mlp_fwd_res).
  * Replaces the statistics pass behind `res + shortcut` of bottleneck_IR (backbone/model_irse.py:64-66) for identity units. */
-int fr_bn_finalize_res(const float* part, int nparts, int C, const FrTail* bn, const float* in_mean, const float* in_invstd,
-                       float in_eps, const FrTail* next, void* stream);
+int fr_bn_finalize_res(const float* part, int nparts, int C, const FrBnFinArgs* bn, const float* in_mean,
+                       const float* in_invstd, float in_eps, const FrBnFinArgs* next, void* stream);
 
 /* per-channel (sum, sumsq) partials of an NHWC tensor: part[blk][2][C], blk < nblocks (= grid size) */
-int fr_channel_stats(const void* x, long long rows, int C, float* part, int nblocks, int dtype,
-                     const FrTail* tail /* NULL or an in-launch reduction of part (K = 2) */, void* stream);
+int fr_channel_stats(const void* x, long long rows, int C, float* part, int nblocks, int dtype, void* stream);
 
 /* out = [prelu]( x*scale+shift [* se[b][c]] ) [+ res]  with (sum,sumsq) partials of `out` for the next BN.
  *   res_kind 0 none | 1 identity shortcut x_in[b, h*stride, w*stride, c] (MaxPool2d(1,s), model_irse.py:53)
@@ -332,7 +278,6 @@ typedef struct FrApplyArgs {
   int32_t B, H, W, C;
   int32_t res_kind, res_stride; /* identity: res has geometry [B, H*res_stride, W*res_stride, C] */
   int32_t nblocks;     /* grid size == number of partial rows */
-  FrTail tail;         /* in-launch reduction of `part` (FR_TAIL_BN: the statistics of `out` for the next BatchNorm) */
 } FrApplyArgs;
 int fr_bn_apply(const FrApplyArgs* args, int dtype, void* stream);
 
@@ -367,7 +312,6 @@ typedef struct FrBnBwdArgs {
   int32_t add_kind;
   int32_t H, W, add_stride; /* geometry of gx for add_kind 2 */
   int32_t nblocks;
-  FrTail tail;         /* fr_bn_bwd_reduce: in-launch reduction of `part` (FR_TAIL_SUMS, K = 3) */
 } FrBnBwdArgs;
 int fr_bn_bwd_reduce(const FrBnBwdArgs* args, int dtype, void* stream);
 int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream);
@@ -375,13 +319,6 @@ int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream);
 /* add partial rows in double: o_k[c] = sum_blk part[blk][k][c], k < K <= 3; NULL outputs are skipped.
  * Used for d gamma (k=1), d beta (k=0), d PReLU slope (k=2) and for the conv-epilogue partials. */
 int fr_reduce_parts(const float* part, int nparts, int K, int C, float* o0, float* o1, float* o2, void* stream);
-
-/* fr_reduce_parts of fr_bn_bwd_reduce's rows part[nparts][3][C] (o0 = d beta, o1 = d gamma; NULL skipped) and, in the same
- * launch, the BatchNorm backward as an affine map of (g, x) -- gx = ca*g + cb*x + cc, see FR_TAIL_BNBWD -- which the
- * FR_PRO_BNBWD2 prologue of the following data gradient applies instead of a fr_bn_bwd_apply pass.  The stand-alone form of
- * the FR_TAIL_BNBWD tail (same arithmetic, same bits).  Replaces the autograd of BatchNorm2d (backbone/model_irse.py:60). */
-int fr_bn_bwd_coeffs(const float* part, int nparts, int C, double count, const float* gamma, const float* mean,
-                     const float* invstd, int bn_eval, float* o0, float* o1, float* ca, float* cb, float* cc, void* stream);
 
 /* eval-mode BatchNorm coefficients from the running statistics */
 int fr_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
@@ -606,7 +543,7 @@ int fr_abi_version(void);
 int fr_set_option(const char* name, int value);
 int fr_get_option(const char* name, int dflt);
 /* sizeof() of the argument structs as compiled, for binding self-checks: 0 FrConvArgs, 1 FrWgradArgs,
- * 2 FrApplyArgs, 3 FrBnBwdArgs, 4 FrSgdTensor, 5 FrPackTensor, 6 FrAdamTensor, 7 FrBnEvalEntry, 8 FrTail */
+ * 2 FrApplyArgs, 3 FrBnBwdArgs, 4 FrSgdTensor, 5 FrPackTensor, 6 FrAdamTensor, 7 FrBnEvalEntry, 8 FrBnFinArgs */
 int fr_struct_size(int which);
 const char* fr_last_error_string(void);
 

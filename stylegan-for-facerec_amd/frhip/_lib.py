@@ -35,7 +35,7 @@ def _ctype(decl, structs):
         if base in structs:
             return ctypes.POINTER(structs[base])
         return ctypes.c_void_p
-    if t in structs:  # a struct member held by value (FrTail inside the argument structs)
+    if t in structs:  # a struct member held by value
         return structs[t]
     return _SCALARS[t]
 
@@ -85,13 +85,12 @@ FrSgdTensor = structs["FrSgdTensor"]
 FrPackTensor = structs["FrPackTensor"]
 FrAdamTensor = structs["FrAdamTensor"]
 FrBnEvalEntry = structs["FrBnEvalEntry"]
-FrTail = structs["FrTail"]
+FrBnFinArgs = structs["FrBnFinArgs"]
 
 # enums of the header
 FR_F32, FR_BF16 = 0, 1
-PRO_NONE, PRO_BN, PRO_PRELU, PRO_BNBWD2, PRO_RESBN, PRO_RESBN_SE = 0, 1, 2, 3, 4, 5
+PRO_NONE, PRO_BN, PRO_PRELU, PRO_RESBN, PRO_RESBN_SE = 0, 1, 2, 4, 5
 EPI_STORE, EPI_STATS, EPI_PRELU_BWD, EPI_BNBWD, EPI_MARGIN, EPI_ATOMIC, EPI_SLAB, EPI_BIAS_RES, EPI_STATS_X = range(9)
-TAIL_NONE, TAIL_SUMS, TAIL_BN, TAIL_BNBWD = range(4)
 
 
 class FrhipError(RuntimeError):
@@ -115,9 +114,9 @@ lib = _load()
 
 
 def self_check():
-    assert lib.fr_abi_version() == 4
+    assert lib.fr_abi_version() == 5
     for i, s in enumerate((FrConvArgs, FrWgradArgs, FrApplyArgs, FrBnBwdArgs, FrSgdTensor, FrPackTensor, FrAdamTensor, FrBnEvalEntry,
-                           FrTail)):
+                           FrBnFinArgs)):
         got = lib.fr_struct_size(i)
         if got != ctypes.sizeof(s):
             raise FrhipError("frhip: struct %s is %d bytes in libfrhip.so but %d in the ctypes binding"

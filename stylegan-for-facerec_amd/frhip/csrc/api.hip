@@ -25,7 +25,7 @@ extern "C" int fr_struct_size(int which) {
     case 5: return (int)sizeof(FrPackTensor);
     case 6: return (int)sizeof(FrAdamTensor);
     case 7: return (int)sizeof(FrBnEvalEntry);
-    case 8: return (int)sizeof(FrTail);
+    case 8: return (int)sizeof(FrBnFinArgs);
   }
   return -1;
 }
@@ -72,20 +72,6 @@ extern "C" int fr_set_option(const char* name, int value) {
 }
 
 extern "C" int fr_get_option(const char* name, int dflt) { return *fr_option_slot(name, dflt); }
-
-// Workgroups that share the in-launch reduction of a launch's partial rows (tail.h) when the caller leaves FrTail.nred 0:
-// enough that every 256-thread reduction block takes one 8-column group, capped here.  FRHIP_TAIL_NRED overrides the cap
-// (1 = the last workgroup to arrive adds everything alone).
-int fr_tail_default_nred() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FRHIP_TAIL_NRED");
-    v = e ? atoi(e) : 16;
-    if (v < 1) v = 1;
-    if (v > 64) v = 64;
-  }
-  return v;
-}
 
 namespace {
 __global__ void fill_rows_kernel(float* __restrict__ out, const float* __restrict__ bias, long long n, int C) {

@@ -125,6 +125,9 @@ __device__ __forceinline__ U128 zero16() {
   return u;
 }
 
+// one partial sum of a workgroup's row of part[row][K][C] (added by a later launch: fr_bn_finalize / fr_reduce_parts)
+__device__ __forceinline__ void st_part(float* p, float v) { *p = v; }
+
 // ---------------------------------------------------------------------------------------------------------
 // wave / block reductions (64-wide)
 // ---------------------------------------------------------------------------------------------------------

@@ -13,7 +13,6 @@
 // The data gradient of the same layer is the same GEMM with the transposed weight and dense rows.
 #include "common.h"
 #include "frhip_internal.h"
-#include "tail.h"
 
 namespace {
 
@@ -175,8 +174,8 @@ extern "C" int fr_conv1x1_stream(const FrConvArgs* args, void* stream) {
   const FrConvArgs& a = *args;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a.KH != 1 || a.KW != 1 || a.pad != 0 || a.mode != 0 || a.pro != FR_PRO_NONE || a.out_f32 || a.splitk > 1 || a.bias ||
-      (a.epi != FR_EPI_STORE && a.epi != FR_EPI_STATS) || a.tail.ticket)
-    FR_UNSUPPORTED("fr_conv1x1_stream: 1x1, no padding / prologue / bias / tail, epilogue STORE or STATS");
+      (a.epi != FR_EPI_STORE && a.epi != FR_EPI_STATS))
+    FR_UNSUPPORTED("fr_conv1x1_stream: 1x1, no padding / prologue / bias, epilogue STORE or STATS");
   if (!c1_shape(a.SC, a.N)) FR_UNSUPPORTED("fr_conv1x1_stream: shape not served (64->128, 128->256, 256->512 and their transposes)");
   if ((a.stride != 1 && a.stride != 2) || a.SH != a.RH * a.stride || a.SW != a.RW * a.stride)
     FR_UNSUPPORTED("fr_conv1x1_stream: stride 1 or 2 with SH = RH * stride, SW = RW * stride");

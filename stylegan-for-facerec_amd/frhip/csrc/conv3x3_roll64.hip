@@ -27,7 +27,6 @@
 
 #include "common.h"
 #include "frhip_internal.h"
-#include "tail.h"
 
 #ifdef FRHIP_STAMPS
 // diagnostic build only (make stamps): per-workgroup phase times, accumulated over the walk (tools/stamps.py --roll)
@@ -242,8 +241,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_roll64_kernel(const FrConvArgs
       drain_tile(row_first + (nit - 1) * K::RI);
       __syncthreads();  // end of item: the tile is empty, the ring may be primed again (+ the statistics hand-over)
     }
-    if (p.epi != FR_EPI_STORE && p.epi != FR_EPI_BIAS_RES)  // in-launch reduction of the items' rows (tail.h)
-      fr_tail<K::NTH>(p.tail, p.part, nitems, gridDim.x, smem, tid);
     return;
   }
 
@@ -467,20 +464,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_roll64_kernel(const FrConvArgs
       st_part(p.part + ((size_t)item * 2 + k) * K::C + n, red[(0 * 2 + k) * K::C + n] + red[(1 * 2 + k) * K::C + n]);
     }
   }
-  if (p.epi != FR_EPI_STORE && p.epi != FR_EPI_BIAS_RES) fr_tail<K::NTH>(p.tail, p.part, nitems, gridDim.x, smem, tid);
 }
 
 int roll_nseg(int B, int W) {
   // row segments per (image, band): enough workgroups for one per CU on 256 CUs; H / 4 iterations must divide evenly
   const int bands = W / R64::BW;
   static const int cand[4] = {1, 2, 7, 14};
-  static int forced = -2;
-  if (forced == -2) {
-    const char* e = getenv("FRHIP_ROLL_NSEG");
-    forced = e ? atoi(e) : -1;
-  }
+  static const int* forced = fr_option_slot("FRHIP_ROLL_NSEG", -1);  // test hook: walks of whole images at small batches
   for (int k = 0; k < 4; ++k) {
-    if (forced == cand[k]) return cand[k];
+    if (*forced == cand[k]) return cand[k];
   }
   for (int k = 0; k < 4; ++k) {
     if ((long long)B * bands * cand[k] >= 256) return cand[k];
@@ -499,10 +491,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
   const int items = a.B * (W / R64::BW) * nseg;
   // one workgroup per CU (156 KB of LDS), persistent over its items: weights and coefficients are staged once
   const int grid = items < 256 ? items : 256;
-  FrConvArgs k = a;
-  const bool sums = a.part && a.epi != FR_EPI_STORE && a.epi != FR_EPI_BIAS_RES;
-  if (fr_tail_prepare(a.tail, 2, a.N, R64::NTH / FR_RT, &k.tail, sums)) return -1;
-  hipLaunchKernelGGL((conv3x3_roll64_kernel<W, PRO, AUX>), dim3(grid), dim3(R64::NTH), R64::LDS, st, k, nseg, items);
+  hipLaunchKernelGGL((conv3x3_roll64_kernel<W, PRO, AUX>), dim3(grid), dim3(R64::NTH), R64::LDS, st, a, nseg, items);
   FR_LAUNCH_CHECK();
 }
 
@@ -530,12 +519,8 @@ int by_pro(const FrConvArgs& a, hipStream_t st) {
 
 // FRHIP_ROLL64=0: the 64 -> 64 layers stay on the LDS-strip kernel (A/B switch)
 bool fr_roll64_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FRHIP_ROLL64");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v != 0;
+  static const int* v = fr_option_slot("FRHIP_ROLL64", 1);
+  return *v != 0;
 }
 
 int fr_roll64_parts(int B, int W) { return B * (W / R64::BW) * roll_nseg(B, W); }

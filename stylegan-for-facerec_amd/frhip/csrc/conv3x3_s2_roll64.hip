@@ -25,7 +25,6 @@
 
 #include "common.h"
 #include "frhip_internal.h"
-#include "tail.h"
 
 namespace {
 
@@ -350,8 +349,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_roll64_kernel(const FrConvA
       }
       __syncthreads();  // end of item: tiles drained, the ring may be primed again (+ the statistics hand-over)
     }
-    if (p.epi != FR_EPI_STORE && p.epi != FR_EPI_BIAS_RES)  // in-launch reduction of the items' rows (tail.h)
-      fr_tail<S2R::NTH>(p.tail, p.part, nitems, gridDim.x, smem, tid);
     return;
   }
 
@@ -515,14 +512,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_roll64_kernel(const FrConvA
       st_part(p.part + ((size_t)item * 2 + k) * K::C + n, red[(0 * 2 + k) * K::C + n] + red[(1 * 2 + k) * K::C + n]);
     }
   }
-  if (p.epi != FR_EPI_STORE && p.epi != FR_EPI_BIAS_RES) fr_tail<S2R::NTH>(p.tail, p.part, nitems, gridDim.x, smem, tid);
 }
 
 int s2roll_nseg(int B) {
   // row segments per image: enough workgroups for one per CU on 256 CUs; 56 rows must divide evenly
   static const int cand[6] = {1, 2, 4, 7, 14, 28};  // rows per walk 56 / nseg: even (the data-moving loop is unrolled by two)
-  const char* e = getenv("FRHIP_S2ROLL_NSEG");  // read per call: the tests walk whole images with small batches
-  const int forced = e ? atoi(e) : -1;
+  static const int* fslot = fr_option_slot("FRHIP_S2ROLL_NSEG", -1);  // test hook: the tests walk whole images with small batches
+  const int forced = *fslot;
   for (int k = 0; k < 6; ++k)
     if (forced == cand[k]) return cand[k];
   for (int k = 0; k < 6; ++k)
@@ -541,24 +537,14 @@ int launch(const FrConvArgs& a, hipStream_t st) {
   const int nseg = s2roll_nseg(a.B);
   const int items = a.B * nseg;
   const int grid = items < 256 ? items : 256;  // persistent: weights are loaded into registers once per workgroup
-  FrConvArgs k = a;
-  const bool sums = a.part && a.epi != FR_EPI_STORE && a.epi != FR_EPI_BIAS_RES;
-  if (fr_tail_prepare(a.tail, 2, a.N, S2R::NTH / FR_RT, &k.tail, sums)) return -1;
-  hipLaunchKernelGGL((conv3x3_s2_roll64_kernel<KIND, PRO>), dim3(grid), dim3(S2R::NTH), LY::LDS, st, k, nseg, items);
+  hipLaunchKernelGGL((conv3x3_s2_roll64_kernel<KIND, PRO>), dim3(grid), dim3(S2R::NTH), LY::LDS, st, a, nseg, items);
   FR_LAUNCH_CHECK();
 }
 
 }  // namespace
 
-// FRHIP_S2ROLL=0: the 64-channel stride-2 layer stays on the LDS-strip kernel (A/B switch)
-bool fr_s2roll_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FRHIP_S2ROLL");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v != 0;
-}
+// FRHIP_ROLL64=0: the 64-channel layers (this stride-2 one too) stay on the LDS-strip kernels (A/B switch)
+bool fr_s2roll_enabled() { return fr_roll64_enabled(); }
 
 // served: 64 -> 64, low-res side 56; forward (mode 0) with the STORE / STATS epilogues, gradient (mode 2) with PReLU backward
 bool fr_s2roll_serves(const FrConvArgs& a) {

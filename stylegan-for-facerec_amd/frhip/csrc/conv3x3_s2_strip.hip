@@ -22,7 +22,6 @@
 
 #include "common.h"
 #include "frhip_internal.h"
-#include "tail.h"
 
 namespace {
 
@@ -527,18 +526,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
     mma_taps<C, CIN, 1, 3>(smem, abase, acc, wrow);
     epilogue(3);
   }
-  // in-launch reduction of the partial rows (tail.h): forward one row per strip, gradient [class][strip]
-  if (p.epi == FR_EPI_STATS || p.epi == FR_EPI_PRELU_BWD || p.epi == FR_EPI_BNBWD)
-    fr_tail<NTH>(p.tail, p.part, (KIND == 1 ? 4 : 1) * nstrips, gridDim.x, smem, tid);
 }
 
 static int s2_xcd_order() {  // FRHIP_XCD_ORDER=0: strips in dispatch order (A/B switch)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FRHIP_XCD_ORDER");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
+  static const int* v = fr_option_slot("FRHIP_XCD_ORDER", 1);
+  return *v != 0;
 }
 
 template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND, int PRO, int NSPL, int NIMG>
@@ -550,11 +542,8 @@ int launch(const FrConvArgs& a, hipStream_t st) {
         reinterpret_cast<const void*>(&conv3x3_s2_kernel<CIN, COUT, WL, ROWS, WN, NW, KIND, PRO, NSPL, NIMG>),
         hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
   }
-  FrConvArgs k = a;
-  const bool sums = a.part && (a.epi == FR_EPI_STATS || a.epi == FR_EPI_PRELU_BWD || a.epi == FR_EPI_BNBWD);
-  if (fr_tail_prepare(a.tail, 2, a.N, C::NTH / FR_RT, &k.tail, sums)) return -1;
   hipLaunchKernelGGL((conv3x3_s2_kernel<CIN, COUT, WL, ROWS, WN, NW, KIND, PRO, NSPL, NIMG>),
-                     dim3(a.B * C::NS / NIMG * NSPL), dim3(C::NTH), C::LDS, st, k, s2_xcd_order());
+                     dim3(a.B * C::NS / NIMG * NSPL), dim3(C::NTH), C::LDS, st, a, s2_xcd_order());
   FR_LAUNCH_CHECK();
 }
 

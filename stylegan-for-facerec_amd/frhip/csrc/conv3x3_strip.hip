@@ -25,7 +25,6 @@
 
 #include "common.h"
 #include "frhip_internal.h"
-#include "tail.h"
 
 #ifdef FRHIP_STAMPS
 // Diagnostic build only (make stamps -> libfrhip_stamps.so; never the product library): wave 0 of every workgroup
@@ -102,7 +101,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: keeps the tile loops branch-free
   const int wn = wave % WN, wm = wave / WN;
-  constexpr bool TWO = PRO == FR_PRO_BNBWD2 || PRO == FR_PRO_RESBN || PRO == FR_PRO_RESBN_SE;  // two-source prologues
+  constexpr bool TWO = PRO == FR_PRO_RESBN || PRO == FR_PRO_RESBN_SE;  // two-source prologues
   const bf16_t* __restrict__ src = reinterpret_cast<const bf16_t*>(p.src);
   const bf16_t* __restrict__ wgt = reinterpret_cast<const bf16_t*>(p.w);
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
@@ -137,9 +136,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
       }
     }
   };
-  // FR_PRO_BNBWD2: the operand is ca*g + cb*x2 + cc of TWO tensors (the backward of the BatchNorm behind this convolution,
-  // applied while its data gradient loads the strip: the pass that used to materialise it -- 75 MB of traffic and a launch per
-  // 14x14 unit -- is gone); the rounded result also goes to p.pro_out, once per pixel, for the weight gradient to read.
+  // (Round 4 also carried FR_PRO_BNBWD2 here -- the backward of BN2 applied while conv2's data gradient loads its strip: -0.19 ms
+  // per step on one stream, nothing on two, profiles/r04_ab_fuse_bn2_schedule.txt; removed in round 5 with ABI v5.)
   // FR_PRO_RESBN (forward): the operand is BN1 of o = round(a*y + b + x2) -- the output of the unit in front, formed here from
   // its conv2 output y and its input x2 instead of by a BN-apply pass; o goes to p.pro_out, the residual stream.
   const bf16_t* __restrict__ src2 = reinterpret_cast<const bf16_t*>(p.src2);
@@ -173,12 +171,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
       if (PRO != FR_PRO_NONE && ok) {
         float f[8];
         unpack16<bf16_t>(x, f);
-        if (PRO == FR_PRO_BNBWD2) {
-          float f2[8];
-          unpack16<bf16_t>(x2, f2);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] = fmaf(pa[j], f[j], fmaf(pb[j], f2[j], pc[j]));
-        } else if (RES) {
+        if (RES) {
           float f2[8];
           unpack16<bf16_t>(x2, f2);
 #pragma unroll
@@ -199,7 +192,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
           }
         }
         x = pack16<bf16_t>(f);
-        if (PRO == FR_PRO_BNBWD2 && own && nh == 0 && pro_out) st16(pro_out + off, x);
       }
       st16(smem + ioff + gh * C::RSTR + gw * C::PSTR + ch * 16, x);
     }
@@ -503,81 +495,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
         for (int g = 0; g < C::WM; ++g) t += red[(g * NV + k) * COUT + n];
         st_part(p.part + ((size_t)sblk * NV + k) * (COUT * NSPL) + ncol0 + n, t);
       }
-      // in-launch reduction of the rows (tail.h); everything in LDS is dead by now
-      fr_tail<NTH>(p.tail, p.part, (int)(gridDim.x / NSPL), gridDim.x, smem, tid);
-#ifdef FRHIP_EXP_GRIDBAR
-      // EXPERIMENT (never in the product library): what the grid-wide synchronisation of a fused
-      // conv2 -> BatchNorm statistics -> apply epilogue would cost inside this launch.  Two counter barriers (release /
-      // relaxed sc1 poll / acquire, MI355X_MICROARCH.md "barrier-counter") around a distributed finalize: workgroup w adds
-      // column w of the partial rows and publishes (scale, shift) of channel w, then every thread reads its channels'
-      // coefficients back.  The counters live in p.cos_t (unused by this kernel): [0] arrivals, [1] exits.
-      if (p.cos_t && NSPL == 1 && (int)gridDim.x >= COUT) {
-        unsigned* cnt = reinterpret_cast<unsigned*>(p.cos_t);
-        float* coef = reinterpret_cast<float*>(cnt + 16);  // [2][COUT]
-        auto grid_barrier = [&](unsigned target) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
-          if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 22))
-              __builtin_amdgcn_s_sleep(2);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-          __syncthreads();
-        };
-        grid_barrier(gridDim.x);
-        if ((int)blockIdx.x < COUT) {  // channel blockIdx.x: sums over all rows (256 rows x 2 floats, one round trip)
-          float a = 0.f, c = 0.f;
-          for (int r = tid; r < (int)gridDim.x; r += NTH) {
-            a += p.part[((size_t)r * 2 + 0) * COUT + blockIdx.x];
-            c += p.part[((size_t)r * 2 + 1) * COUT + blockIdx.x];
-          }
-          float* red2 = reinterpret_cast<float*>(smem);
-          red2[tid] = a;
-          red2[NTH + tid] = c;
-          __syncthreads();
-          if (tid == 0) {
-            float sa = 0.f, sc = 0.f;
-            for (int t = 0; t < NTH; ++t) {
-              sa += red2[t];
-              sc += red2[NTH + t];
-            }
-            const float m = sa / (float)(gridDim.x * C::M), var = sc / (float)(gridDim.x * C::M) - m * m;
-            const float is = rsqrtf(fmaxf(var, 0.f) + 1e-5f);
-            __hip_atomic_store(coef + blockIdx.x, is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(coef + COUT + blockIdx.x, -m * is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        grid_barrier(2u * gridDim.x);
-        float acc2 = 0.f;
-        for (int c = tid; c < 2 * COUT; c += NTH) acc2 += coef[c];
-        if (acc2 == 123456.789f) p.part[0] = acc2;  // keep the reads
-        __syncthreads();
-        if (tid == 0) {
-          const unsigned done = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (done + 1 == gridDim.x) {
-            __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-      }
-#endif
     }
   }
 }
 
 // FRHIP_XCD_ORDER=0: workgroups take strips in dispatch order (A/B switch for tools/kbench.py)
 static int xcd_order() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FRHIP_XCD_ORDER");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
+  static const int* v = fr_option_slot("FRHIP_XCD_ORDER", 1);
+  return *v != 0;
 }
 
 template <int CIN, int COUT, int W, int ROWS, int WN, int NW, int NSPL, int PRO, int NIMG = 1, int KSPL = 1>
@@ -590,13 +515,10 @@ int launch(const FrConvArgs& a, hipStream_t st) {
         hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
   }
   const int strips = a.B * C::NS / NIMG;
-  FrConvArgs k = a;
-  const bool sums = a.part && (a.epi == FR_EPI_STATS || a.epi == FR_EPI_PRELU_BWD || a.epi == FR_EPI_BNBWD);
-  if (a.epi == FR_EPI_STATS_X && (!a.part || !a.aux || a.tail.ticket))
-    FR_UNSUPPORTED("fr_conv3x3_strip: FR_EPI_STATS_X needs part and aux and takes no tail (its rows go to fr_bn_finalize_res)");
-  if (fr_tail_prepare(a.tail, 2, a.N, C::NTH / FR_RT, &k.tail, sums)) return -1;
+  if (a.epi == FR_EPI_STATS_X && (!a.part || !a.aux))
+    FR_UNSUPPORTED("fr_conv3x3_strip: FR_EPI_STATS_X needs part and aux (its rows go to fr_bn_finalize_res)");
   hipLaunchKernelGGL((conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, NSPL, PRO, NIMG, KSPL>),
-                     dim3(strips * NSPL), dim3(C::NTH), C::LDS, st, k, xcd_order());
+                     dim3(strips * NSPL), dim3(C::NTH), C::LDS, st, a, xcd_order());
   FR_LAUNCH_CHECK();
 }
 
@@ -606,13 +528,6 @@ int by_pro(const FrConvArgs& a, hipStream_t st) {
     case FR_PRO_NONE: return launch<CIN, COUT, W, ROWS, WN, NW, NSPL, FR_PRO_NONE, NIMG, KSPL>(a, st);
     case FR_PRO_BN: return launch<CIN, COUT, W, ROWS, WN, NW, NSPL, FR_PRO_BN, NIMG, KSPL>(a, st);
     case FR_PRO_PRELU: return launch<CIN, COUT, W, ROWS, WN, NW, NSPL, FR_PRO_PRELU, NIMG, KSPL>(a, st);
-    case FR_PRO_BNBWD2:  // the data gradient of a unit's second convolution: square layers only
-      if constexpr (CIN == COUT * NSPL) {
-        if (!a.src2 || !a.pro_a || !a.pro_b || !a.pro_c) FR_UNSUPPORTED("fr_conv3x3_strip: FR_PRO_BNBWD2 needs src2, pro_a, pro_b, pro_c");
-        return launch<CIN, COUT, W, ROWS, WN, NW, NSPL, FR_PRO_BNBWD2, NIMG, KSPL>(a, st);
-      } else {
-        FR_UNSUPPORTED("fr_conv3x3_strip: FR_PRO_BNBWD2 is served for Cin == Cout only");
-      }
     case FR_PRO_RESBN:  // conv1 of a unit behind an identity unit (both sources have this layer's input channels)
       if (!a.src2 || !a.pro_a || !a.pro_b || !a.pro_c || !a.pro_d || !a.pro_out || a.mode != 0)
         FR_UNSUPPORTED("fr_conv3x3_strip: FR_PRO_RESBN needs src2, pro_a ... pro_d, pro_out and mode 0");
@@ -642,12 +557,8 @@ int by_pro(const FrConvArgs& a, hipStream_t st) {
 // ones, so that CUs taken by another resident kernel (RCCL's all-reduce under data parallelism) cost a proportional
 // share instead of a whole second round of workgroups (A/B switch for multi-GPU runs; slower stand-alone).
 static bool small_batch(int B) {
-  static int force = -1;
-  if (force < 0) {
-    const char* e = getenv("FRHIP_SPLIT_STRIPS");
-    force = (e && e[0] == '1') ? 1 : 0;
-  }
-  return B <= 160 || force;
+  static const int* force = fr_option_slot("FRHIP_SPLIT_STRIPS", 0);
+  return B <= 160 || *force == 1;
 }
 
 // rows per strip for a shape (0 = not served)
@@ -669,9 +580,9 @@ static int strip_rows(int Cin, int Cout, int W) {
   return 0;
 }
 
-// FR_PRO_BNBWD2 (two-source prologue) exists on the LDS-strip instances of the square layers; the 64-channel layers run on
-// the rolling-window kernel, which does not take it.
-extern "C" int fr_conv3x3_strip_serves_bnbwd2(int B, int C, int W) {
+// The two-source prologues (FR_PRO_RESBN[_SE]) and the cross-moment epilogue (FR_EPI_STATS_X) exist on the LDS-strip instances
+// of the square layers; the 64-channel layers run on the rolling-window kernel, which takes neither.
+extern "C" int fr_conv3x3_strip_serves_resbn(int B, int C, int W) {
   if (C == 64 && (W == 112 || W == 56) && fr_roll64_enabled()) return 0;
   return fr_conv3x3_strip_parts(B, C, C, W, FR_EPI_PRELU_BWD) > 0 ? 1 : 0;
 }

@@ -24,7 +24,6 @@
 
 #include "common.h"
 #include "frhip_internal.h"
-#include "tail.h"
 
 namespace {
 
@@ -454,8 +453,6 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(const FrConvArgs p) {
         st_part(p.part + (((size_t)blockIdx.y * mb_count + mb) * 2 + k) * (size_t)p.N + n0 + col, s);
       }
     }
-    // in-launch reduction of the [class][M tile] rows (tail.h)
-    fr_tail<NT>(p.tail, p.part, (int)gridDim.y * mb_count, gridDim.x * gridDim.y * gridDim.z, Red, tid);
   }
 }
 
@@ -470,10 +467,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BN, PRO>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
   }
-  FrConvArgs k = a;
-  const bool sums = a.part && (a.epi == FR_EPI_STATS || a.epi == FR_EPI_PRELU_BWD || a.epi == FR_EPI_BNBWD);
-  if (fr_tail_prepare(a.tail, 2, a.N, NT / FR_RT, &k.tail, sums)) return -1;
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, PRO>), grid, dim3(NT), C::LDS_BYTES, st, k);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, PRO>), grid, dim3(NT), C::LDS_BYTES, st, a);
   FR_LAUNCH_CHECK();
 }
 
@@ -485,11 +479,11 @@ int dispatch(const FrConvArgs& a, hipStream_t st) {
   // tiles: the two instances differ only in the ORDER in which a tile's rows enter the per-tile partial sums (and in
   // nothing else: tests/test_gpu_kernels.py::test_igemm_tile_width_changes_only_the_partial_sum_order), and at batch 4-16 the
   // fp32 fixture networks amplify that last-bit difference of a BatchNorm statistic past bars that were set from ONE
-  // selection's readings.  FRHIP_IGEMM_BN=64 / 128 forces an instance (read per call: test switch).
-  const char* force = getenv("FRHIP_IGEMM_BN");
+  // selection's readings.  FRHIP_IGEMM_BN=64 / 128 forces an instance (test switch: fr_set_option).
+  static const int* force = fr_option_slot("FRHIP_IGEMM_BN", 0);
   bool narrow = a.N <= 64 || a.epi == FR_EPI_MARGIN;
-  if (force && force[0] == '6') narrow = true;
-  if (force && force[0] == '1') narrow = a.N <= 64;
+  if (*force == 64) narrow = true;
+  if (*force == 128) narrow = a.N <= 64;
   switch (a.pro) {
     case FR_PRO_NONE:
       return narrow ? launch<T, 64, FR_PRO_NONE>(a, st) : launch<T, 128, FR_PRO_NONE>(a, st);

@@ -1256,31 +1256,11 @@ extern "C" int fr_debug_set_stamp_buffer_wgr(void* dev_ptr) {
 }
 #endif
 
-// FRHIP_WGRAD_ROLL=0: back to the strip kernel for every shape (A/B switch)
+// FRHIP_WGRAD_ROLL=0: back to the strip kernel for every shape (A/B switch; rounds 3-4 also had one switch per shape family:
+// profiles/r03_switch_matrix.txt, r04_switch_matrix.txt)
 bool fr_wgrad_roll_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("FRHIP_WGRAD_ROLL");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
-
-// FRHIP_WGRAD_VR=0: 56x56 / 112x112 back on the strip kernel (A/B switch)
-static bool fr_wgrad_vr_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("FRHIP_WGRAD_VR");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
-
-// FRHIP_WGRAD_ROLL7=0: 7x7 back on the strip kernel (A/B switch)
-static bool fr_wgrad_roll7_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("FRHIP_WGRAD_ROLL7");
-    return !(e && e[0] == '0');
-  }();
-  return on;
+  static const int* on = fr_option_slot("FRHIP_WGRAD_ROLL", 1);
+  return *on != 0;
 }
 
 // stride-1 3x3 at 7x7 / 14x14 / 28x28 / 56x56 / 112x112, channel counts multiples of 64, at least one image (14x14) / phase (28x28) per group
@@ -1290,31 +1270,17 @@ bool fr_wgrad_roll_serves(const FrWgradArgs& a) {
     return false;
   if (a.SW == 14) return a.nsplit <= a.B;
   if (a.SW == 28) return a.nsplit <= a.B * RC<28>::NPH;
-  if (a.SW == 7) return fr_wgrad_roll7_enabled() && a.nsplit <= a.B;
-  if (a.SW == 56 || a.SW == 112) return fr_wgrad_vr_enabled() && a.nsplit <= a.B * (a.SW + 2);
+  if (a.SW == 7) return a.nsplit <= a.B;
+  if (a.SW == 56 || a.SW == 112) return a.nsplit <= a.B * (a.SW + 2);
   return false;
 }
 
-// FRHIP_WGRAD_S2ROLL56=0: the 64-channel stride-2 weight gradient back on the strip kernel (A/B switch)
-static bool s2roll56_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("FRHIP_WGRAD_S2ROLL56");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
-
-// FRHIP_WGRAD_S2ROLL=0: stride-2 weight gradients back on the strip kernel (A/B switch)
 // stride-2 3x3 with a 28 / 14 / 7 wide gradient, channel counts multiples of 64, at least one phase per group
 bool fr_wgrad_s2roll_serves(const FrWgradArgs& a) {
-  static const bool on = [] {
-    const char* e = getenv("FRHIP_WGRAD_S2ROLL");
-    return !(e && e[0] == '0');
-  }();
-  if (!(on && fr_wgrad_roll_enabled() && a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad == 1 && a.GH == a.GW &&
+  if (!(fr_wgrad_roll_enabled() && a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad == 1 && a.GH == a.GW &&
         a.SH == 2 * a.GH && a.SW == 2 * a.GW && a.Cout % CT == 0 && a.SC % CT == 0 && a.nsplit >= 1))
     return false;
-  if (a.GW == 56) return s2roll56_enabled() && a.nsplit <= a.B * SC2<56>::NPH;
+  if (a.GW == 56) return a.nsplit <= a.B * SC2<56>::NPH;
   if (a.GW == 28) return a.nsplit <= a.B * SC2<28>::NPH;
   if (a.GW == 14) return a.nsplit <= a.B * SC2<14>::NPH;
   if (a.GW == 7) return a.nsplit <= a.B * SC2<7>::NPH;

@@ -416,14 +416,8 @@ int by_pro(const FrWgradArgs& a, hipStream_t st) {
   FR_UNSUPPORTED("fr_conv_wgrad_strip: unknown prologue");
 }
 
-// FRHIP_WGRAD_ROWK=0: the 28x28 / 14x14 instances without the row-aligned K layout (A/B switch)
-bool row_k() {
-  static const bool on = [] {
-    const char* e = getenv("FRHIP_WGRAD_ROWK");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+// the 28x28 / 14x14 instances use the row-aligned K layout (round 2; its A/B switch left in round 5)
+bool row_k() { return true; }
 
 }  // namespace
 
@@ -435,12 +429,9 @@ extern "C" int fr_conv_wgrad_strip_supported(int Cout, int Cin, int W) {
 
 // every shape fr_conv_wgrad_strip serves honours defer / prev_* (FRHIP_WGRAD_DEFER=0 turns the answer off: A/B switch)
 extern "C" int fr_conv_wgrad_strip_defers(const FrWgradArgs* args) {
-  static const bool on = [] {
-    const char* e = getenv("FRHIP_WGRAD_DEFER");
-    return !(e && e[0] == '0');
-  }();
+  static const int* on = fr_option_slot("FRHIP_WGRAD_DEFER", 1);
   const FrWgradArgs& a = *args;
-  if (!on || a.ldg % 8 || a.lda % 8 || !a.slab || a.nsplit < 1 || a.nsplit > 256 || a.KH != 3 || a.KW != 3 || a.pad != 1 ||
+  if (!*on || a.ldg % 8 || a.lda % 8 || !a.slab || a.nsplit < 1 || a.nsplit > 256 || a.KH != 3 || a.KW != 3 || a.pad != 1 ||
       a.Cout % CT || a.SC % CT)
     return 0;
   if (a.stride == 2) return a.GH == a.GW && a.SH == 2 * a.GH && a.SW == 2 * a.GW && (a.GW == 56 || a.GW == 28 || a.GW == 14 || a.GW == 7);

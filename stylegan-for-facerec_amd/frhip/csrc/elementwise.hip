@@ -16,7 +16,7 @@
 
 #include "common.h"
 #include "frhip_internal.h"
-#include "tail.h"
+#include "reduce_rows.h"
 
 namespace {
 
@@ -39,7 +39,7 @@ __device__ __forceinline__ void block_col_reduce(float (&acc)[K][VEC], float* re
     float s = 0.f;
     for (int r = 0; r < rt_count; ++r) s += red[(r * cpr + cc) * (K * VEC) + kj];
     const int k = kj / VEC, j = kj - k * VEC;
-    st_part(part_blk + (size_t)k * C + cc * VEC + j, s);  // write-through: a tail of the same launch may read it
+    st_part(part_blk + (size_t)k * C + cc * VEC + j, s);
   }
 }
 
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void stem_im2col_rows_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------ partial-row reduction
-// fr_reduce_rows8 (tail.h) is shared with the in-launch tails of the producing kernels: one summation order everywhere.
+// fr_reduce_rows8 (reduce_rows.h): one summation order everywhere.
 constexpr int RT = FR_RT;  // threads of the partial-sum reduction kernels: small workgroups, so that they still find
                            // a slot on CUs that hold a resident strip workgroup of the side stream (512: +0.1 ms / step)
 
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(RT) void bn_finalize_kernel(const float* __restrict
 // So BN2's coefficients and the next unit's BN1 coefficients come out of the same launch, and the BN-apply pass that
 // materialised o' only to measure it is gone (its consumer forms o' itself: FR_PRO_RESBN).  Centred form in double: the
 // variances add, no difference of large sums beyond the ones fr_bn_finalize already takes.
-static FrBnFin fin_of(const FrTail& t) {
+static FrBnFin fin_of(const FrBnFinArgs& t) {
   FrBnFin f;
   f.count = t.count;
   f.gamma = t.gamma;
@@ -173,17 +173,6 @@ __global__ __launch_bounds__(RT) void bn_finalize_res_kernel(const float* __rest
   }
 }
 
-// fr_reduce_parts of fr_bn_bwd_reduce's rows (vectors 0 and 1) + the coefficients FR_PRO_BNBWD2 applies, in one launch
-__global__ __launch_bounds__(RT) void bn_bwd_coeffs_kernel(const float* __restrict__ part, int nparts, int C, FrBnBwdCo f) {
-  __shared__ double lds[2 * (RT / 64) * 8];
-  const int c0 = blockIdx.x * 8;
-  const int cols[2] = {c0, C + c0};
-  double sq[2];
-  fr_reduce_rows8<2>(part, nparts, 3 * C, cols, sq, lds, threadIdx.x);
-  const int c = c0 + threadIdx.x;
-  if (threadIdx.x < 8 && c < C) fr_bnbwd_channel(f, c, sq[0], sq[1]);
-}
-
 // eval-mode coefficients from running statistics
 __global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, const float* gamma, const float* beta,
                                       float eps, int C, float* mean, float* invstd, float* scale, float* shift) {
@@ -215,7 +204,7 @@ __global__ __launch_bounds__(RT) void reduce_parts_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------ channel stats
 template <typename T>
 __global__ __launch_bounds__(NT) void channel_stats_kernel(const T* __restrict__ x, long long rows, int C,
-                                                           float* __restrict__ part, const FrTail tail) {
+                                                           float* __restrict__ part) {
   constexpr int VEC = Elt<T>::VEC;
   __shared__ float red[NT * 2 * VEC];
   const int cpr = C / VEC, tid = threadIdx.x;
@@ -234,7 +223,6 @@ __global__ __launch_bounds__(NT) void channel_stats_kernel(const T* __restrict__
     }
   }
   block_col_reduce<2, VEC>(acc, red, part + (size_t)blockIdx.x * 2 * C, C, cpr, tid);
-  fr_tail<NT>(tail, part, gridDim.x, gridDim.x, red, tid);
 }
 
 // ------------------------------------------------------------------------------------------ BN apply (+SE, +PReLU, +residual)
@@ -303,10 +291,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const FrApplyArgs p) {
       }
     }
   }
-  if (p.part) {
-    block_col_reduce<2, VEC>(acc, red, p.part + (size_t)blockIdx.x * 2 * C, C, cpr, tid);
-    fr_tail<NT>(p.tail, p.part, gridDim.x, gridDim.x, red, tid);
-  }
+  if (p.part) block_col_reduce<2, VEC>(acc, red, p.part + (size_t)blockIdx.x * 2 * C, C, cpr, tid);
 }
 
 // ------------------------------------------------------------------------------------------ BN backward
@@ -369,7 +354,6 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const FrBnBwdArgs p) 
     }
   }
   block_col_reduce<3, VEC>(acc, red, p.part + (size_t)blockIdx.x * 3 * C, C, cpr, tid);
-  fr_tail<NT>(p.tail, p.part, gridDim.x, gridDim.x, red, tid);
 }
 
 template <typename T>
@@ -526,10 +510,7 @@ __global__ __launch_bounds__(NT, 6) void bn_apply_lean_kernel(const FrApplyArgs 
       }
     }
   }
-  if (STATS) {
-    block_col_reduce<2, LV>(acc, red, p.part + (size_t)blockIdx.x * 2 * C, C, cpr, tid);
-    fr_tail<NT>(p.tail, p.part, gridDim.x, gridDim.x, red, tid);
-  }
+  if (STATS) block_col_reduce<2, LV>(acc, red, p.part + (size_t)blockIdx.x * 2 * C, C, cpr, tid);
 }
 
 // SLOPE: BN followed by PReLU (the stem, model_irse.py:141-142): g' = g * prelu'(u), u = x*scale + shift, and the third
@@ -599,7 +580,6 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_reduce_lean_kernel(const FrBnBwd
     }
   }
   block_col_reduce<3, LV>(acc, red, p.part + (size_t)blockIdx.x * 3 * C, C, cpr, tid);
-  fr_tail<NT>(p.tail, p.part, gridDim.x, gridDim.x, red, tid);
 }
 
 // ADD: 0 none, 1 a tensor of the same geometry, 2 (round 4) the strided scatter of a stride-2 shortcut gradient -- add[b, h/2,
@@ -1386,8 +1366,8 @@ extern "C" int fr_bn_finalize(const float* part, int nparts, int C, double count
   FR_LAUNCH_CHECK();
 }
 
-extern "C" int fr_bn_finalize_res(const float* part, int nparts, int C, const FrTail* bn, const float* in_mean,
-                                  const float* in_invstd, float in_eps, const FrTail* next, void* stream) {
+extern "C" int fr_bn_finalize_res(const float* part, int nparts, int C, const FrBnFinArgs* bn, const float* in_mean,
+                                  const float* in_invstd, float in_eps, const FrBnFinArgs* next, void* stream) {
   if (!part || nparts < 1 || C < 1 || !bn || (next && (!in_mean || !in_invstd)))
     FR_UNSUPPORTED("fr_bn_finalize_res: part and bn are required, in_mean / in_invstd with next");
   if (!(bn->count > 0.0) || !bn->mean || !bn->invstd || !bn->scale || !bn->shift ||
@@ -1397,26 +1377,6 @@ extern "C" int fr_bn_finalize_res(const float* part, int nparts, int C, const Fr
   fn.count = bn->count;  // same pixels
   hipLaunchKernelGGL(bn_finalize_res_kernel, dim3((C + 7) / 8), dim3(RT), 0, (hipStream_t)stream, part, nparts, C, f,
                      in_mean, in_invstd, in_eps, fn, next != nullptr);
-  FR_LAUNCH_CHECK();
-}
-
-extern "C" int fr_bn_bwd_coeffs(const float* part, int nparts, int C, double count, const float* gamma, const float* mean,
-                                const float* invstd, int bn_eval, float* o0, float* o1, float* ca, float* cb, float* cc,
-                                void* stream) {
-  if (!part || nparts < 1 || C < 1 || !(count > 0.0) || !mean || !invstd || !ca || !cb || !cc)
-    FR_UNSUPPORTED("fr_bn_bwd_coeffs: part, count, mean, invstd, ca, cb, cc are required");
-  FrBnBwdCo f;
-  f.count = count;
-  f.gamma = gamma;
-  f.mean = mean;
-  f.invstd = invstd;
-  f.bn_eval = bn_eval;
-  f.o0 = o0;
-  f.o1 = o1;
-  f.ca = ca;
-  f.cb = cb;
-  f.cc = cc;
-  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + 7) / 8), dim3(RT), 0, (hipStream_t)stream, part, nparts, C, f);
   FR_LAUNCH_CHECK();
 }
 
@@ -1455,27 +1415,22 @@ extern "C" int fr_reduce_parts(const float* part, int nparts, int K, int C, floa
 }
 
 extern "C" int fr_channel_stats(const void* x, long long rows, int C, float* part, int nblocks, int dtype,
-                                const FrTail* tail, void* stream) {
+                                void* stream) {
   if (!chan_ok(C, dtype)) FR_UNSUPPORTED("fr_channel_stats: unsupported channel count");
   hipStream_t st = (hipStream_t)stream;
-  FrTail t;
-  if (fr_tail_prepare(tail ? *tail : FrTail{}, 2, C, NT / FR_RT, &t, part != nullptr)) return -1;
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(channel_stats_kernel<float>, dim3(nblocks), dim3(NT), 0, st, (const float*)x, rows,
-                                C, part, t),
+                                C, part),
              hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, dim3(nblocks), dim3(NT), 0, st, (const bf16_t*)x,
-                                rows, C, part, t),
+                                rows, C, part),
              "fr_channel_stats");
   FR_LAUNCH_CHECK();
 }
 
-extern "C" int fr_bn_apply(const FrApplyArgs* args_in, int dtype, void* stream) {
-  if (!chan_ok(args_in->C, dtype)) FR_UNSUPPORTED("fr_bn_apply: unsupported channel count");
-  if (args_in->nblocks < 1) FR_UNSUPPORTED("fr_bn_apply: nblocks < 1");
+extern "C" int fr_bn_apply(const FrApplyArgs* args, int dtype, void* stream) {
+  if (!chan_ok(args->C, dtype)) FR_UNSUPPORTED("fr_bn_apply: unsupported channel count");
+  if (args->nblocks < 1) FR_UNSUPPORTED("fr_bn_apply: nblocks < 1");
   hipStream_t st = (hipStream_t)stream;
-  FrApplyArgs prepared = *args_in;
-  if (fr_tail_prepare(args_in->tail, 2, args_in->C, NT / FR_RT, &prepared.tail, args_in->part != nullptr)) return -1;
-  const FrApplyArgs* args = &prepared;
   if (dtype == FR_BF16 && lean_ok(args->C) && !args->slope &&
       !(args->res_kind == 1 && args->res_stride > 1) && (long long)args->B * args->H * args->W < (1ll << 31)) {
     const dim3 grid(args->nblocks), blk(NT);
@@ -1502,12 +1457,9 @@ extern "C" int fr_bn_apply(const FrApplyArgs* args_in, int dtype, void* stream) 
   FR_LAUNCH_CHECK();
 }
 
-extern "C" int fr_bn_bwd_reduce(const FrBnBwdArgs* args_in, int dtype, void* stream) {
-  if (!chan_ok(args_in->C, dtype)) FR_UNSUPPORTED("fr_bn_bwd_reduce: unsupported channel count");
+extern "C" int fr_bn_bwd_reduce(const FrBnBwdArgs* args, int dtype, void* stream) {
+  if (!chan_ok(args->C, dtype)) FR_UNSUPPORTED("fr_bn_bwd_reduce: unsupported channel count");
   hipStream_t st = (hipStream_t)stream;
-  FrBnBwdArgs prepared = *args_in;
-  if (fr_tail_prepare(args_in->tail, 3, args_in->C, NT / FR_RT, &prepared.tail, args_in->part != nullptr)) return -1;
-  const FrBnBwdArgs* args = &prepared;
   if (dtype == FR_BF16 && lean_ok(args->C) && args->rows < (1ll << 31) && !(args->se && args->slope) &&
       (!args->slope || (args->scale && args->shift))) {
     const dim3 grid(args->nblocks), blk(NT);

@@ -8,103 +8,14 @@
 // wave streams 16-row tiles, and both are HBM-bound by construction (forward: 64 B in, 128 B out per row).
 #include "common.h"
 #include "frhip_internal.h"
-#include "tail.h"
 
 namespace {
 
 constexpr int SN = 64;  // output channels of the stem
 
-// Round 4: the im2col rows need not exist.  X0 [B*112*112][K] is 205 MB written by fr_stem_im2col and read back by both
-// GEMMs (410 MB + a launch per step in the forward pass, 205 MB more in the backward pass) to carry 38.5 MB of image.  With a
-// StemSrc the two kernels build their 16-byte row chunks from the fp32 NCHW batch (and pSp's constant average image) in
-// registers -- the same values, rounded to bf16 the same way, so the results are bit-identical to the X0 path.
-struct StemSrc {
-  const float* x;    // [B][C][H][W] fp32, or NULL: read the materialised rows
-  const float* avg;  // [Cavg][H][W] or NULL
-  int H, W, C, Cavg;
-  float inv_w, inv_hw;
-};
-
-// im2col row `row` = pixel (b, h, w), elements k0 .. k0 + 7 (k = tap*CT + c, zero beyond 9*CT and outside the image)
-template <int CT>
-__device__ __forceinline__ U128 stem_row_chunk(const StemSrc& s, int row, int k0) {
-  uint32_t b, rem, h, w;
-  fast_divmod((uint32_t)row, (uint32_t)(s.H * s.W), s.inv_hw, b, rem);
-  fast_divmod(rem, (uint32_t)s.W, s.inv_w, h, w);
-  float f[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int k = k0 + j;
-    const int tap = k / CT, c = k - tap * CT;
-    const int th = tap / 3;
-    const int sh = (int)h + th - 1, sw = (int)w + (tap - th * 3) - 1;
-    const bool ok = k < 9 * CT && (unsigned)sh < (unsigned)s.H && (unsigned)sw < (unsigned)s.W;
-    const int shc = ok ? sh : (int)h, swc = ok ? sw : (int)w;  // always a valid address; the value is dropped
-    const int cc = k < 9 * CT ? c : 0;
-    const float* p = (CT > 3 && cc >= s.C) ? s.avg + ((size_t)(cc - s.C) * s.H + shc) * s.W + swc
-                                           : s.x + (((size_t)b * s.C + cc) * s.H + shc) * s.W + swc;
-    const float v = *p;
-    f[j] = ok ? v : 0.f;
-  }
-  return pack16<bf16_t>(f);
-}
-
-// Round 4, second version of the implicit rows: the 27 / 54 scalar gathers per row above cost more than the rows they save
-// (forward 171 us against 93 + 122, weight gradient 299 against 180).  The workgroup instead STAGES the image rows it needs in
-// LDS as bf16 -- an item = IMG_RB image rows of one image: (IMG_RB + 2) x (W + 2) pixels x CTP channels (3 -> 4, 6 -> 8: the
-// pad channels and the halo columns stay zero) -- and a lane builds its 16-byte chunk of an im2col row with eight ds_read_u16
-// at (pixel base + per-lane constant offsets).  Same values, same rounding: bit-identical to the materialised rows.
-constexpr int IMG_RB = 4;      // image rows per item
-constexpr int IMG_WMAX = 224;  // widest image served
-template <int CT>
-struct StemImg {
-  static constexpr int CTP = CT == 3 ? 4 : 8;
-  static constexpr int ELEMS = (IMG_RB + 2) * (IMG_WMAX + 2) * CTP;
-  // zero everything once: pad channels and halo columns are never written again
-  static __device__ __forceinline__ void clear(unsigned short* img, int tid, int nth) {
-    for (int i = tid; i < ELEMS / 8; i += nth) st16(img + i * 8, zero16());
-  }
-  // rows h0 - 1 .. h0 + IMG_RB of image b (zeros outside the image).  All loads of a batch are requested before the first
-  // conversion (as a load -> convert -> store loop an item cost eight dependent round trips: 74 us for the statistics pass)
-  static __device__ __forceinline__ void stage(unsigned short* img, const StemSrc& s, int b, int h0, int tid, int nth) {
-    const int n = (IMG_RB + 2) * CT * s.W;
-    constexpr int UB = 8;
-    for (int base = 0; base < n; base += UB * nth) {
-      float v[UB];
-      int dst[UB];
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int idx = base + u * nth + tid;
-        uint32_t rc, w;
-        fast_divmod((uint32_t)(idx < n ? idx : 0), (uint32_t)s.W, s.inv_w, rc, w);
-        const int r = (int)rc / CT, c = (int)rc - r * CT;
-        const int h = h0 - 1 + r;
-        v[u] = 0.f;
-        dst[u] = idx < n ? (r * (s.W + 2) + (int)w + 1) * CTP + c : -1;
-        if (idx < n && (unsigned)h < (unsigned)s.H)
-          v[u] = (CT > 3 && c >= s.C) ? s.avg[((size_t)(c - s.C) * s.H + h) * s.W + w]
-                                      : s.x[(((size_t)b * s.C + c) * s.H + h) * s.W + w];
-      }
-#pragma unroll
-      for (int u = 0; u < UB; ++u)
-        if (dst[u] >= 0) img[dst[u]] = f2bf(v[u]);
-    }
-  }
-  // element offsets of the chunk k0 .. k0 + 7 relative to the pixel base (lh * (W + 2) + w) * CTP
-  static __device__ __forceinline__ void offsets(int W, int k0, int (&off)[8]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = k0 + j, tap = k / CT, c = k - tap * CT, th = tap / 3;
-      off[j] = k < 9 * CT ? (th * (W + 2) + (tap - th * 3)) * CTP + c : CT;  // CT = a pad channel: zero
-    }
-  }
-  static __device__ __forceinline__ s16x8 chunk(const unsigned short* img, int pbase, const int (&off)[8]) {
-    s16x8 v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (short)img[pbase + off[j]];
-    return v;
-  }
-};
+// (Round 4 also carried these GEMMs on IMPLICIT rows -- built in registers / from LDS-staged image rows out of the fp32 batch,
+// bit-identical, 205 MB less memory and +0.05-0.09 ms per step: profiles/r04_ab_stem_implicit.txt.  Removed in round 5 with
+// ABI v5; git tag r05-before-prune.)
 
 // ------------------------------------------------------------------------------------------ forward + BN statistics
 // out[m][n] = sum_k X[m][k] W[n][k];  part[blk][0][n] = sum_m out, part[blk][1][n] = sum_m out^2 (of the rounded bf16)
@@ -117,11 +28,10 @@ struct StemAct {
   const float *scale, *shift, *slope;
   bf16_t* zout;
 };
-template <int K, bool IMPL, int MODE = 0>
+template <int K, int MODE = 0>
 __global__ __launch_bounds__(256) void stem_gemm_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wp,
                                                         bf16_t* __restrict__ out, float* __restrict__ part, int M,
-                                                        const FrTail tail, const StemSrc src, const StemAct act) {
-  constexpr int CT = K == 32 ? 3 : 6;
+                                                        const StemAct act) {
   constexpr int KS = K / 32;
   constexpr int OSTR = SN * 2 + 16;                    // per-wave transpose tile [16 rows][64 ch], padded rows
   __shared__ __attribute__((aligned(16))) char tiles[(MODE == 2 ? 8 : 4) * 16 * OSTR];
@@ -157,39 +67,13 @@ __global__ __launch_bounds__(256) void stem_gemm_kernel(const bf16_t* __restrict
       }
   }
   const int ntiles = (M + 15) / 16;
-  // IMPL: a workgroup walks ITEMS (IMG_RB image rows of one image, staged in LDS), its four waves the item's 16-row tiles;
-  // otherwise the waves of the whole grid stride over the materialised rows (one pseudo-item)
-  using IM = StemImg<CT>;
-  __shared__ __attribute__((aligned(16))) unsigned short img[IMPL ? IM::ELEMS : 8];
-  int koff[IMPL ? KS : 1][8];
-  if (IMPL) {
-    IM::clear(img, tid, 256);
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) IM::offsets(src.W, kk * 32 + fq * 8, koff[kk]);
-  }
-  const int nrg = IMPL ? (src.H + IMG_RB - 1) / IMG_RB : 1;
-  const int nitems = IMPL ? (M / (src.H * src.W)) * nrg : 1;
+  // the waves of the whole grid stride over the rows
   // the statistics-only mode has no barrier in the loop: several tiles per trip, all their loads requested before the first MFMA
   constexpr int NT = MODE == 1 ? 4 : 1;
-  for (int item = IMPL ? blockIdx.x : 0; item < nitems; item += IMPL ? gridDim.x : 1) {
-  int tbase, tmul, tlim, trips, pix0 = 0;
-  if (IMPL) {
-    const int b = item / nrg, h0 = (item - b * nrg) * IMG_RB;
-    __syncthreads();  // the previous item's fragments have been read (first item: the image is cleared)
-    IM::stage(img, src, b, h0, tid, 256);
-    __syncthreads();
-    const int rows_valid = src.H - h0 < IMG_RB ? src.H - h0 : IMG_RB;
-    pix0 = (b * src.H + h0) * src.W;  // a multiple of 16 (W % 16 == 0)
-    tbase = pix0 / 16 + wave;
-    tmul = 4;
-    tlim = pix0 / 16 + rows_valid * src.W / 16;
-    trips = (IMG_RB * src.W / 16 + 3) / 4;  // same for every wave and item: the loop body has barriers
-  } else {
-    tbase = blockIdx.x * 4 + wave;
-    tmul = gridDim.x * 4;
-    tlim = ntiles;
-    trips = (ntiles + tmul - 1) / tmul;  // same trip count for every wave: the loop body has barriers
-  }
+  const int tbase = blockIdx.x * 4 + wave;
+  const int tmul = gridDim.x * 4;
+  const int tlim = ntiles;
+  const int trips = (ntiles + tmul - 1) / tmul;  // same trip count for every wave: the loop body has barriers
   for (int it = 0; it < trips; it += NT) {
     s16x8 afs[NT][KS];
     bool oks[NT];
@@ -198,19 +82,10 @@ __global__ __launch_bounds__(256) void stem_gemm_kernel(const bf16_t* __restrict
       const int t = tbase + (it + u) * tmul;
       const int row = t * 16 + fr;
       oks[u] = it + u < trips && t < tlim && row < M;
-      int pbase = 0;
-      if (IMPL) {  // pixel (lh, w) of the staged rows
-        uint32_t lh, w;
-        fast_divmod((uint32_t)(oks[u] ? row - pix0 : 0), (uint32_t)src.W, src.inv_w, lh, w);
-        pbase = ((int)lh * (src.W + 2) + (int)w) * IM::CTP;
-      }
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
         afs[u][kk] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (oks[u]) {
-          if (IMPL) afs[u][kk] = IM::chunk(img, pbase, koff[kk]);
-          else afs[u][kk] = *reinterpret_cast<const s16x8*>(X + (size_t)row * K + kk * 32 + fq * 8);
-        }
+        if (oks[u]) afs[u][kk] = *reinterpret_cast<const s16x8*>(X + (size_t)row * K + kk * 32 + fq * 8);
       }
     }
 #pragma unroll
@@ -271,7 +146,6 @@ __global__ __launch_bounds__(256) void stem_gemm_kernel(const bf16_t* __restrict
     __syncthreads();
     }
   }
-  }  // items
   // column sums: fold the 16 row lanes, then the 4 waves
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -294,7 +168,6 @@ __global__ __launch_bounds__(256) void stem_gemm_kernel(const bf16_t* __restrict
     st_part(part + ((size_t)blockIdx.x * NV + k) * SN + n, red[(0 * NV + k) * SN + n] + red[(1 * NV + k) * SN + n] +
                                                               red[(2 * NV + k) * SN + n] + red[(3 * NV + k) * SN + n]);
   }
-  fr_tail<256>(tail, part, gridDim.x, gridDim.x, tiles, tid);  // in-launch BatchNorm statistics (tail.h)
 }
 
 // ------------------------------------------------------------------------------------------ BN / PReLU backward sums
@@ -446,11 +319,9 @@ struct StemBn {
   const bf16_t* wp;  // RECOMP: the packed stem weight [64][K]
 };
 
-template <int K, bool BN, bool IMPL = false, bool RECOMP = false>
+template <int K, bool BN, bool RECOMP = false>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
-                                                         float* __restrict__ slab, int M, const StemBn bn,
-                                                         const StemSrc src) {
-  constexpr int CT = K == 32 ? 3 : 6;
+                                                         float* __restrict__ slab, int M, const StemBn bn) {
   constexpr int RB = 64;                     // rows staged per trip (two 32-deep MFMA steps)
   constexpr int GSTR = SN * 2 + 32;          // conflict-free row strides for the transposing reads
   constexpr int XSTR = K * 2 + 32;
@@ -531,7 +402,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16_t* __restric
         }
       } else if (idx < NCH) {
         const int a = idx - GCH, r = a / (K / 8), c = a - r * (K / 8);
-        if (row0 + r < M) v[u] = IMPL ? stem_row_chunk<CT>(src, row0 + r, c * 8) : ld16(X + (size_t)(row0 + r) * K + c * 8);
+        if (row0 + r < M) v[u] = ld16(X + (size_t)(row0 + r) * K + c * 8);
       }
     }
     __syncthreads();  // the previous trip's fragments have been read
@@ -603,39 +474,16 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16_t* __restric
 
 }  // namespace
 
-namespace {
-int stem_src(const float* x, const float* avg, int B, int H, int W, int C, int Cavg, int K, StemSrc* s, long long* M) {
-  if (!x || B < 1 || H < 1 || W < 1) FR_UNSUPPORTED("stem (implicit im2col): x and a positive geometry are required");
-  if (!((K == 32 && C == 3 && Cavg == 0) || (K == 64 && C + Cavg == 6 && C >= 1 && (Cavg == 0 || avg))))
-    FR_UNSUPPORTED("stem (implicit im2col): 3 image channels (K = 32) or 6 channels in all, image + average image (K = 64)");
-  *M = (long long)B * H * W;
-  if (*M >= (1ll << 24)) FR_UNSUPPORTED("stem (implicit im2col): fewer than 2^24 pixels per launch");
-  if (W % 16 || W > IMG_WMAX) FR_UNSUPPORTED("stem (implicit im2col): the image width must be a multiple of 16, at most 224");
-  s->x = x;
-  s->avg = avg;
-  s->H = H;
-  s->W = W;
-  s->C = C;
-  s->Cavg = Cavg;
-  s->inv_w = 1.0f / (float)W;
-  s->inv_hw = 1.0f / (float)(H * W);
-  return 0;
-}
-}  // namespace
-
 extern "C" int fr_stem_gemm(const void* X, const void* Wp, void* out, float* part, long long M, int K, int nblocks,
-                            const FrTail* tail, void* stream) {
+                            void* stream) {
   if ((K != 32 && K != 64) || M < 1 || M >= (1ll << 31) - 64 || nblocks < 1)
     FR_UNSUPPORTED("fr_stem_gemm: K must be 32 or 64, 0 < M < 2^31, nblocks >= 1");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  FrTail t;
-  if (fr_tail_prepare(tail ? *tail : FrTail{}, 2, SN, 1, &t, part != nullptr)) return -1;
-  const StemSrc none = {};
   const StemAct noact = {};
-  if (!out && !part) FR_UNSUPPORTED("fr_stem_gemm: out == NULL asks for the statistics only, which need part");
-#define STEM_FWD(KK, MD)                                                                                                  \
-  hipLaunchKernelGGL((stem_gemm_kernel<KK, false, MD>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)X, (const bf16_t*)Wp, \
-                     (bf16_t*)out, part, (int)M, t, none, noact)
+  if (!part) FR_UNSUPPORTED("fr_stem_gemm: part is required (the statistics rows)");
+#define STEM_FWD(KK, MD)                                                                                           \
+  hipLaunchKernelGGL((stem_gemm_kernel<KK, MD>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)X, (const bf16_t*)Wp, \
+                     (bf16_t*)out, part, (int)M, noact)
   if (K == 32) {
     if (out) STEM_FWD(32, 0);
     else STEM_FWD(32, 1);
@@ -648,22 +496,18 @@ extern "C" int fr_stem_gemm(const void* X, const void* Wp, void* out, float* par
 }
 
 extern "C" int fr_stem_gemm_bn_prelu(const void* X, const void* Wp, const float* scale, const float* shift, const float* slope,
-                                     void* y, void* z, float* part, long long M, int K, int nblocks, const FrTail* tail,
-                                     void* stream) {
+                                     void* y, void* z, float* part, long long M, int K, int nblocks, void* stream) {
   if ((K != 32 && K != 64) || M < 1 || M >= (1ll << 31) - 64 || nblocks < 1)
     FR_UNSUPPORTED("fr_stem_gemm_bn_prelu: K must be 32 or 64, 0 < M < 2^31, nblocks >= 1");
   if (!X || !Wp || !scale || !shift || !slope || !z) FR_UNSUPPORTED("fr_stem_gemm_bn_prelu: X, Wp, scale, shift, slope, z are required");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  FrTail t;
-  if (fr_tail_prepare(tail ? *tail : FrTail{}, 2, SN, 1, &t, part != nullptr)) return -1;
-  const StemSrc none = {};
   const StemAct act = {scale, shift, slope, (bf16_t*)z};
   if (K == 32)
-    hipLaunchKernelGGL((stem_gemm_kernel<32, false, 2>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)X, (const bf16_t*)Wp,
-                       (bf16_t*)y, part, (int)M, t, none, act);
+    hipLaunchKernelGGL((stem_gemm_kernel<32, 2>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)X, (const bf16_t*)Wp,
+                       (bf16_t*)y, part, (int)M, act);
   else
-    hipLaunchKernelGGL((stem_gemm_kernel<64, false, 2>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)X, (const bf16_t*)Wp,
-                       (bf16_t*)y, part, (int)M, t, none, act);
+    hipLaunchKernelGGL((stem_gemm_kernel<64, 2>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)X, (const bf16_t*)Wp,
+                       (bf16_t*)y, part, (int)M, act);
   FR_LAUNCH_CHECK();
 }
 
@@ -694,59 +538,12 @@ extern "C" int fr_stem_wgrad_bn_r(const void* G, const void* X, const void* Wp, 
     FR_UNSUPPORTED("fr_stem_wgrad_bn_r: the packed weight and every BatchNorm / PReLU coefficient vector are required");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const StemBn bn = {nullptr, mean, invstd, scale, shift, slope, gamma, s0, s1, inv_count, (const bf16_t*)Wp};
-  const StemSrc nosrc = {};
   if (K == 32)
-    hipLaunchKernelGGL((stem_wgrad_kernel<32, true, false, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G,
-                       (const bf16_t*)X, slab, (int)M, bn, nosrc);
+    hipLaunchKernelGGL((stem_wgrad_kernel<32, true, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G,
+                       (const bf16_t*)X, slab, (int)M, bn);
   else
-    hipLaunchKernelGGL((stem_wgrad_kernel<64, true, false, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G,
-                       (const bf16_t*)X, slab, (int)M, bn, nosrc);
-  FR_LAUNCH_CHECK();
-}
-
-extern "C" int fr_stem_gemm_x(const float* x, const float* avg, const void* Wp, void* out, float* part, int B, int H, int W,
-                              int C, int Cavg, int K, int nblocks, const FrTail* tail, void* stream) {
-  StemSrc src;
-  long long M;
-  if (stem_src(x, avg, B, H, W, C, Cavg, K, &src, &M)) return -1;
-  if (nblocks < 1) FR_UNSUPPORTED("fr_stem_gemm_x: nblocks >= 1");
-  if (!out && !part) FR_UNSUPPORTED("fr_stem_gemm_x: out == NULL asks for the statistics only, which need part");
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  FrTail t;
-  if (fr_tail_prepare(tail ? *tail : FrTail{}, 2, SN, 1, &t, part != nullptr)) return -1;
-  const StemAct noact = {};
-#define STEM_FWD_X(KK, MD)                                                                                           \
-  hipLaunchKernelGGL((stem_gemm_kernel<KK, true, MD>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)nullptr,      \
-                     (const bf16_t*)Wp, (bf16_t*)out, part, (int)M, t, src, noact)
-  if (K == 32) {
-    if (out) STEM_FWD_X(32, 0);
-    else STEM_FWD_X(32, 1);
-  } else {
-    if (out) STEM_FWD_X(64, 0);
-    else STEM_FWD_X(64, 1);
-  }
-#undef STEM_FWD_X
-  FR_LAUNCH_CHECK();
-}
-
-extern "C" int fr_stem_gemm_bn_prelu_x(const float* x, const float* avg, const void* Wp, const float* scale,
-                                       const float* shift, const float* slope, void* y, void* z, float* part, int B, int H,
-                                       int W, int C, int Cavg, int K, int nblocks, const FrTail* tail, void* stream) {
-  StemSrc src;
-  long long M;
-  if (stem_src(x, avg, B, H, W, C, Cavg, K, &src, &M)) return -1;
-  if (nblocks < 1 || !Wp || !scale || !shift || !slope || !z)
-    FR_UNSUPPORTED("fr_stem_gemm_bn_prelu_x: Wp, scale, shift, slope, z and nblocks >= 1 are required");
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  FrTail t;
-  if (fr_tail_prepare(tail ? *tail : FrTail{}, 2, SN, 1, &t, part != nullptr)) return -1;
-  const StemAct act = {scale, shift, slope, (bf16_t*)z};
-  if (K == 32)
-    hipLaunchKernelGGL((stem_gemm_kernel<32, true, 2>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)nullptr,
-                       (const bf16_t*)Wp, (bf16_t*)y, part, (int)M, t, src, act);
-  else
-    hipLaunchKernelGGL((stem_gemm_kernel<64, true, 2>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)nullptr,
-                       (const bf16_t*)Wp, (bf16_t*)y, part, (int)M, t, src, act);
+    hipLaunchKernelGGL((stem_wgrad_kernel<64, true, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G,
+                       (const bf16_t*)X, slab, (int)M, bn);
   FR_LAUNCH_CHECK();
 }
 
@@ -755,13 +552,12 @@ extern "C" int fr_stem_wgrad(const void* G, const void* X, float* slab, long lon
     FR_UNSUPPORTED("fr_stem_wgrad: K must be 32 or 64, 0 < M < 2^31, nblocks >= 1");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const StemBn none = {};
-  const StemSrc nosrc = {};
   if (K == 32)
     hipLaunchKernelGGL((stem_wgrad_kernel<32, false>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X,
-                       slab, (int)M, none, nosrc);
+                       slab, (int)M, none);
   else
     hipLaunchKernelGGL((stem_wgrad_kernel<64, false>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X,
-                       slab, (int)M, none, nosrc);
+                       slab, (int)M, none);
   FR_LAUNCH_CHECK();
 }
 
@@ -775,33 +571,11 @@ extern "C" int fr_stem_wgrad_bn(const void* G, const void* Y, const void* X, con
     FR_UNSUPPORTED("fr_stem_wgrad_bn: every BatchNorm / PReLU coefficient vector is required");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const StemBn bn = {(const bf16_t*)Y, mean, invstd, scale, shift, slope, gamma, s0, s1, inv_count, nullptr};
-  const StemSrc nosrc = {};
   if (K == 32)
     hipLaunchKernelGGL((stem_wgrad_kernel<32, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X,
-                       slab, (int)M, bn, nosrc);
+                       slab, (int)M, bn);
   else
     hipLaunchKernelGGL((stem_wgrad_kernel<64, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X,
-                       slab, (int)M, bn, nosrc);
-  FR_LAUNCH_CHECK();
-}
-
-extern "C" int fr_stem_wgrad_bn_x(const void* G, const void* Y, const float* x, const float* avg, const float* mean,
-                                  const float* invstd, const float* scale, const float* shift, const float* slope,
-                                  const float* gamma, const float* s0, const float* s1, float inv_count, float* slab, int B,
-                                  int H, int W, int C, int Cavg, int K, int nblocks, void* stream) {
-  StemSrc src;
-  long long M;
-  if (stem_src(x, avg, B, H, W, C, Cavg, K, &src, &M)) return -1;
-  if (nblocks < 1) FR_UNSUPPORTED("fr_stem_wgrad_bn_x: nblocks >= 1");
-  if (!Y || !mean || !invstd || !scale || !shift || !slope || !gamma || !s0 || !s1)
-    FR_UNSUPPORTED("fr_stem_wgrad_bn_x: every BatchNorm / PReLU coefficient vector is required");
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const StemBn bn = {(const bf16_t*)Y, mean, invstd, scale, shift, slope, gamma, s0, s1, inv_count, nullptr};
-  if (K == 32)
-    hipLaunchKernelGGL((stem_wgrad_kernel<32, true, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G,
-                       (const bf16_t*)nullptr, slab, (int)M, bn, src);
-  else
-    hipLaunchKernelGGL((stem_wgrad_kernel<64, true, true>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)G,
-                       (const bf16_t*)nullptr, slab, (int)M, bn, src);
+                       slab, (int)M, bn);
   FR_LAUNCH_CHECK();
 }

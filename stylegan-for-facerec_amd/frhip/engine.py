@@ -32,6 +32,11 @@ from ._lib import FR_BF16, FR_F32
 _EPS, _MOM = 1e-5, 0.1
 
 
+def _switch(name, default):
+    """An engine-level switch (README "Switches"): an integer environment variable, read when a plan is built."""
+    return int(os.environ.get(name, default))
+
+
 def compute_dtype_default():
     v = os.environ.get("FRHIP_COMPUTE_DTYPE", "fp32").lower()
     return torch.bfloat16 if v in ("bf16", "bfloat16") else torch.float32
@@ -119,11 +124,10 @@ def ready_order_params(module):
 
 class _BN(object):
     """Device-side coefficients of one BatchNorm: mean, invstd, scale (= gamma*invstd), shift."""
-    __slots__ = ("mod", "C", "mean", "invstd", "scale", "shift", "tailed")
+    __slots__ = ("mod", "C", "mean", "invstd", "scale", "shift")
 
     def __init__(self, mod, pool):
         self.mod, self.C = mod, mod.num_features
-        self.tailed = False  # its statistics are finalised by the tail of the launch that produces them (ops.tail_bn)
         self.mean, self.invstd, self.scale, self.shift = (pool.take(self.C) for _ in range(4))
 
 
@@ -219,13 +223,14 @@ def _side_stream(device, priority):
 class BackbonePlan(object):
     def __init__(self, module, B, dtype, device, in_channels, avg_channels, single_stream=False, infer=False):
         self.module, self.B, self.device = module, B, device
+        ops.sync_switches()  # the library's own switches follow the environment as of now
         # infer: forward only (no gradient arena, no backward scratch, no backward list).  fold: additionally every
         # BatchNorm runs on its running statistics, so BN2 / the shortcut BN are folded into the packed conv weights and
         # the residual add moves into conv2's epilogue (reference: util/utils.py:254-307 evaluates in eval mode).
         self.infer = infer
         self.fold = infer and all(not m.training for m in module.modules()
                                   if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d))) and \
-            os.environ.get("FRHIP_NO_FOLD", "0") != "1"
+            not _switch("FRHIP_NO_FOLD", 0)
         self.tdtype = dtype
         self.fr = FR_F32 if dtype == torch.float32 else FR_BF16
         self.esz = 4 if dtype == torch.float32 else 2
@@ -238,46 +243,25 @@ class BackbonePlan(object):
         # Weight gradients feed nothing downstream in backward, so they run on a side stream: an MFMA-bound wgrad
         # kernel and the HBM-bound BN-backward / residual passes of the next unit then share the CUs (measured with
         # tools/overlap_probe.py: ~2/3 of an elementwise pass hides under a wgrad strip kernel).
-        self.dual = os.environ.get("FRHIP_SINGLE_STREAM", "0") != "1" and not single_stream
+        self.dual = not _switch("FRHIP_SINGLE_STREAM", 0) and not single_stream
         # the side stream is low priority: weight gradients fill the CUs the main chain (dgrads, BN/PReLU backward)
-        # leaves idle instead of splitting the machine with it (FRHIP_SIDE_PRIORITY overrides, HIP: 1 low .. -1 high)
-        prio = int(os.environ.get("FRHIP_SIDE_PRIORITY", "1"))
-        self.stream2_t = _side_stream(device, prio) if self.dual else self.stream1_t
+        # leaves idle instead of splitting the machine with it (HIP: 1 low .. -1 high; either way measured the same)
+        self.stream2_t = _side_stream(device, 1) if self.dual else self.stream1_t
         # Workgroups of a weight-gradient launch (dW tiles x image groups).  224 of 256: the launches take the same time (a
         # 224-workgroup 256x256@14 launch 0.069 ms against 0.068 with 256: 12 % fewer slabs to write and sum), and the 32 CUs
         # without a persistent weight-gradient workgroup take the channel-wise kernels of the main stream at full speed:
         # 15.06-15.10 against 15.13-15.16 ms per step (192: 15.09, 240: 15.25, 160: 15.15; FRHIP_WGRAD_WGS, one box).
-        self.wgrad_wgs = min(256, max(64, int(os.environ.get("FRHIP_WGRAD_WGS", "224"))))  # the slab sum takes <= 256 groups
+        self.wgrad_wgs = min(256, max(64, _switch("FRHIP_WGRAD_WGS", 224)))  # the slab sum takes <= 256 groups
         self.stream2 = ctypes.c_void_p(self.stream2_t.cuda_stream)
         self.S = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
         self.generation = 0
         # (FRHIP_GRAPH, rounds 2-3: the two launch lists captured into HIP graphs.  Replay was SLOWER than eager launches at
         # every batch size on this stack -- ms per step eager / graph: B = 8: 6.05 / 6.86, 64: 7.67 / 8.11, 256: 16.0 / 16.4 --
         # and a packed native list executor left both the enqueue time and the step time unchanged; removed in round 4.)
-        # In-launch reductions (csrc/tail.h): the launches that write partial rows also add them (last workgroups to arrive),
-        # instead of a fr_bn_finalize / fr_reduce_parts launch behind each of them.  FRHIP_TAIL=0: the separate launches (A/B
-        # switch; bit-identical results either way).
-        # MEASURED SLOWER, so opt-in (FRHIP_TAIL=1; profiles/r04_ab_tail*.txt): 15.97 against 15.22 ms per step with every
-        # reduction in its producer and 16 reducers, 15.68 with 32, 17.8 with 4, 22.9 with the last workgroup alone.  What a tail
-        # adds behind the last workgroup -- drain + ticket (~1.5 us), acquire (1.7), one load round trip per 8 rows and thread
-        # of 256-1024 rows x 512-1536 columns (2.5-8), the double-precision finalize -- is MORE than the 1.5-us launch boundary +
-        # 3-5 us of the stand-alone kernel it removes: a few hundred KB of partial rows is past what a last-arriver reduction
-        # pays for (cdna_hip_programming.md, split-K seam: "a few tens of KB").  FRHIP_TAIL_MASK picks the producers: 1 forward
-        # convolutions, 2 forward channel-wise, 4 backward BatchNorm sums, 8 backward convolution epilogues.
-        self.use_tail = os.environ.get("FRHIP_TAIL", "0") == "1"
-        self.tail_mask = int(os.environ.get("FRHIP_TAIL_MASK", "15"))
-        self.tickets = ops.Tickets(8 * len(self.units) + 32, device)
-        # FR_PRO_BNBWD2 (round 4): the backward of BN2 applied by the data gradient of conv2 while it loads its strip (two
-        # sources), which also writes the result once for the weight gradient: no fr_bn_bwd_apply pass for BN2 (28 launches,
-        # 0.57 ms of kernel time alone).  MEASURED: -0.19 ms per step on ONE stream (15.95 against 16.14) and nothing on two
-        # (15.20-15.29 against 15.21-15.22; 14.70 against 14.66-14.67 on a faster box: profiles/r04_ab_fuse_bn2_schedule.txt,
-        # r04_ab_edges.txt).  The pass it deletes ran beside the weight gradients of the side stream, i.e. it was already
-        # hidden; its work moved into the CU-exclusive strip load of the data gradient (0.0627 -> 0.0716 ms warm, 0.0723 ->
-        # 0.0841 ms behind a cache flush: profiles/r04_kbench_warm_cold.txt).  The backward pass is the SUM of its four MFMA
-        # kernels per unit (72 + 72 + 66 + 66 us from cold caches = the 270-280 us a 14x14 unit takes in the timeline);
-        # channel-wise work only matters where nothing runs beside it.  So: opt-in (FRHIP_FUSE_BN2=1), default off.
-        self.fuse_bn2 = os.environ.get("FRHIP_FUSE_BN2", "0") == "1"
-        self.use_strip = os.environ.get("FRHIP_NO_STRIP", "0") != "1"
+        # (Round 4, built, bit-identical, measured and removed in round 5 -- DESIGN.md section 8, git tag r05-before-prune:
+        # in-launch reductions of the partial rows by arrival ticket, FRHIP_TAIL, +0.35-0.75 ms per step; the backward of BN2
+        # inside conv2's data gradient, FRHIP_FUSE_BN2, -0.19 ms on one stream and nothing on two.)
+        self.use_strip = not _switch("FRHIP_NO_STRIP", 0)  # 1: every LDS-strip family back on the generic GEMM
         # Residual-sum statistics from moments (round 4).  In the FORWARD pass nothing runs beside the channel-wise passes, and
         # per identity unit the pass `out = BN2(y2) + x` (fr_bn_apply: 75 MB of traffic at 14x14) existed for two reasons: the
         # next unit's conv1 reads `out`, and its train-mode BN1 needs the batch statistics of `out` first.  The statistics do
@@ -288,19 +272,17 @@ class BackbonePlan(object):
         # applies BN1 to it (FR_PRO_RESBN).  Per fused edge: bn_apply + one finalize launch gone.  Identity units without SE
         # whose conv2 and whose successor's conv1 run on LDS-strip instances (IR-50: 17 of 24 units).  FRHIP_RES_MOMENTS=0:
         # A/B switch.
-        self.res_moments = (os.environ.get("FRHIP_RES_MOMENTS", "1") != "0" and self.fr == FR_BF16 and self.use_strip
-                            and not self.fold)
+        self.res_moments = bool(_switch("FRHIP_RES_MOMENTS", 1)) and self.fr == FR_BF16 and self.use_strip and not self.fold
         # ... and behind squeeze-excite units (out = gate[image][c] * BN2(y2) + x): the same moments PER IMAGE, combined with
         # the gates by the launch that computes them (fr_se_pool_parts_mlp_fwd_res); the moments of x are carried from unit to
-        # unit (one fr_image_moments pass at the head of a stage).  FRHIP_RES_MOMENTS_SE=0: A/B switch for this half.
-        self.res_moments_se = self.res_moments and os.environ.get("FRHIP_RES_MOMENTS_SE", "1") != "0"
-        self.use_stem_gemm = (self.fr == FR_BF16 and os.environ.get("FRHIP_NO_STEM_GEMM", "0") != "1" and
-                              not self.body_only)
-        self.use_s2 = os.environ.get("FRHIP_NO_S2_STRIP", "0") != "1"  # stride-2 strip kernels (A/B switch)
+        # unit (one fr_image_moments pass at the head of a stage).
+        self.res_moments_se = self.res_moments
+        self.use_stem_gemm = self.fr == FR_BF16 and not _switch("FRHIP_NO_STEM_GEMM", 0) and not self.body_only
+        self.use_s2 = self.use_strip  # the stride-2 strip kernels follow FRHIP_NO_STRIP
         self.slab, self._slab_users = None, []
         # deferred slab sums (FrWgradArgs.defer / prev_*): a weight-gradient launch that supports it leaves the sum of its
         # slabs to the NEXT such launch of the side stream (two slab buffers alternate); fr_reduce_slabs flushes the last
-        self.defer_slabs = os.environ.get("FRHIP_NO_DEFER_SLABS", "0") != "1"
+        self.defer_slabs = True  # (FRHIP_WGRAD_DEFER=0 turns the library's answer off)
         self.slab2, self._slab2_users, self._slab_flip = None, [], 0
         self._pending = None  # (launch that wrote the slabs, groups, n, dw tensor, parameter)
         self.part_slope = None  # per-buffer-set partial rows of the PReLU slope gradient (side-stream reduction)
@@ -326,36 +308,15 @@ class BackbonePlan(object):
         C0 = self.units[0].cin if self.body_only else 64  # channels of the first unit's input
         self.z0 = self._act(M0, C0)
         if not self.body_only:
-            # Round 4: the stem GEMMs can build their im2col rows from the fp32 batch in registers (fr_stem_gemm_x /
-            # fr_stem_wgrad_bn_x: bit-identical to the materialised rows).  Per launch at batch 256 (event table): forward 171
-            # us against 93 (fr_stem_im2col) + 122; weight gradient 299 against 180 -- 27 scalar gathers per row cost more in
-            # the weight gradient than the 205 MB of rows they save: +0.05-0.09 ms per step (profiles/r04_ab_stem_implicit.txt;
-            # also measured there: forward implicit + the weight gradient's rows built on the side stream during the forward
-            # pass, +0.1 ms against materialised rows -- removed).  Second version: the forward passes stage the image rows in
-            # LDS (stem_gemm.hip, StemImg): statistics 69 + GEMM/BN/PReLU 133 us against im2col 66 + 43 + 157 on materialised
-            # rows (stand-alone, warm) -- the forward is then the faster one, the weight gradient still gathers from global
-            # memory.  So: opt-in, FRHIP_STEM_IMPLICIT=1 (no X0: 205 MB less memory at batch 256); default = rows materialised.
-            mode = os.environ.get("FRHIP_STEM_IMPLICIT", "0")
-            self.stem_x = (self.use_stem_gemm and mode != "0" and S % 16 == 0 and S <= 224 and
-                           os.environ.get("FRHIP_NO_STEM_BNFUSE", "0") != "1" and M0 < (1 << 24) and
-                           ((self.K0 == 32 and self.in_channels == 3 and self.avg_channels == 0) or
-                            (self.K0 == 64 and self.in_channels + self.avg_channels == 6)))
-            self.X0 = None if self.stem_x else self._act(M0, self.K0)
+            # (Round 4 also carried the stem GEMMs on implicit im2col rows, FRHIP_STEM_IMPLICIT: 205 MB less memory, +0.05-0.09
+            # ms per step, profiles/r04_ab_stem_implicit.txt; removed in round 5.)
+            self.X0 = self._act(M0, self.K0)
             # Round 4: the stem forward as two passes over the rows (statistics, then GEMM + BN + PReLU in one kernel) and its
             # backward on a RECOMPUTED y0: the GEMM is 13 GFLOP at batch 256, its output 411 MB -- y0 is never written or
-            # read, the fr_bn_apply pass over it is gone.  FRHIP_STEM_TWO_PASS=0 / FRHIP_STEM_RECOMPUTE=0: A/B switches
-            # (the second one keeps y0 for the backward kernels of round 3).
-            self.stem_two_pass = (self.use_stem_gemm and not self.fold and
-                                  os.environ.get("FRHIP_STEM_TWO_PASS", "1") != "0")
-            # (on implicit rows -- FRHIP_STEM_IMPLICIT=1 -- the two forward passes stage image rows in LDS; the backward kernels
-            # of that mode read y0)
-            self.stem_recompute = (self.stem_two_pass and not self.stem_x and
-                                   os.environ.get("FRHIP_NO_STEM_BNFUSE", "0") != "1" and
-                                   os.environ.get("FRHIP_STEM_RECOMPUTE", "1") != "0")
+            # read, the fr_bn_apply pass over it is gone (-0.06 ... -0.09 ms per step, profiles/r04_ab_stem_two_pass.txt).
+            self.stem_two_pass = self.use_stem_gemm and not self.fold
+            self.stem_recompute = self.stem_two_pass
             self.y0 = None if (self.stem_recompute or (self.stem_two_pass and self.infer)) else self._act(M0, 64)
-            # (Measured and removed: the forward passes on LDS-staged image rows while the materialised rows -- which then only
-            # the two backward kernels read -- are built on the side stream at the start of the backward pass: 14.26-14.36
-            # against 14.28-14.34 ms per step, nothing; profiles/r04_ab_stem_implicit.txt.)
             self.W0p = torch.empty(64, self.K0, device=dev, dtype=self.tdtype)
             self.gW0p = torch.zeros(64, self.K0, device=dev)
             self.bn0 = _BN(self.stem[1], self.pool)
@@ -405,9 +366,9 @@ class BackbonePlan(object):
             self.f = torch.empty(B, 512, device=dev)
             self.feat = torch.empty(B, 512, device=dev)
             # Linear(25088, 512) on the master weight in its own (reference Flatten) layout: the activation `a` is written
-            # c-major instead (csrc/linear_gemm.hip; bf16 path; FRHIP_LINEAR_CM=0: the per-step permuted copies, A/B switch)
+            # c-major instead (csrc/linear_gemm.hip; bf16 path; fp32 and odd shapes: per-step permuted copies)
             ol = self.out[2]
-            self.lin_cm = (self.fr == FR_BF16 and os.environ.get("FRHIP_LINEAR_CM", "1") != "0" and last.depth % 64 == 0 and
+            self.lin_cm = (self.fr == FR_BF16 and last.depth % 64 == 0 and
                            self.feat_in % 128 == 0 and ol.weight.is_contiguous() and
                            _lib.lib.fr_linear_slices(512, self.feat_in) > 0)
             if self.lin_cm:
@@ -424,14 +385,14 @@ class BackbonePlan(object):
         self.g_pp = [self._act(max_in, 1).view(-1), self._act(max_in, 1).view(-1)]   # unit input/output gradients
         # gradients consumed by the side-stream wgrads are double-buffered by unit parity (the next unit must not
         # overwrite what a still-running weight gradient reads)
-        # FRHIP_WGRAD_SETS: how many units the main stream may run ahead of the side stream's weight gradients
+        # two sets: the main stream may run one unit ahead of the side stream's weight gradients (three: measured the same)
         # (Round 4, measured and removed: the two-stream timeline shows a ~6-us gap on the main stream at every event edge,
         # three per residual unit; ONE main -> side edge per unit behind the second data gradient and four buffer sets with
         # the main stream waiting every second unit ran 14.92-15.02 ms per step against 14.66-14.67 with the round-3 edges on
         # the same box -- profiles/r04_ab_edges.txt.  The early edge behind conv2's data gradient is worth more than its gap:
         # the side stream's kernels are queued while the first data gradient still holds the CUs and take them as its
         # workgroups retire.)
-        nset = max(2, int(os.environ.get("FRHIP_WGRAD_SETS", "2"))) if self.dual else 1
+        nset = 2 if self.dual else 1
         self.nset = nset
         self.g_y2s = [self._act(max_out, 1).view(-1) for _ in range(nset)]
         self.g_ySs = [self._act(max_out, 1).view(-1) if max_xs else None for _ in range(nset)]
@@ -447,7 +408,7 @@ class BackbonePlan(object):
         # _check_part() verifies every launch against the allocation when the plan is built.
         self.part = torch.zeros(max(4 * 1024 * 1024, ((M0 + 127) // 128) * 2 * 64 + 4096, B * 4 * 28 * 2 * 64 + 4096),
                                 device=dev)
-        self.side_slope = self.dual and os.environ.get("FRHIP_SLOPE_ON_MAIN", "0") != "1"  # A/B switch
+        self.side_slope = self.dual  # the PReLU-slope partial sums are added on the side stream (on the main one: +0.1 ms)
         if self.side_slope:
             self.part_slope = [torch.zeros_like(self.part) for _ in range(nset)]
         self.se_scratch = torch.zeros(2, 512 * 64, device=dev)  # dW1/dW2 sink while the SE weights are frozen
@@ -643,29 +604,13 @@ class BackbonePlan(object):
         return done
 
     # ---- forward -----------------------------------------------------------------------------------
-    def _bn_tail(self, bn, count, cls=1):
-        """The in-launch form of fr_bn_finalize for the launch that produces bn's (sum, sum of squares) rows: pass the result
-        as that launch's `tail`; _bn_train_launches then appends nothing.  None: the separate launch stays.  cls: the
-        producer class bit of FRHIP_TAIL_MASK."""
-        m = bn.mod
-        if not self.use_tail or not (self.tail_mask & cls) or self.fold or not m.training:
-            return None
-        bn.tailed = True
-        return ops.tail_bn(self.tickets.take(), bn.C, count, m.weight, m.bias, m.eps,
-                           m.momentum if m.momentum is not None else 0.1,
-                           m.running_mean if m.track_running_stats else None,
-                           m.running_var if m.track_running_stats else None,
-                           m.num_batches_tracked if m.track_running_stats else None, bn.mean, bn.invstd, bn.scale,
-                           bn.shift)
-
     def _bn_fields(self, bn, count):
         """The BatchNorm arguments of fr_bn_finalize as a struct (fr_bn_finalize_res takes two)."""
         m = bn.mod
-        return ops.tail_bn(None, bn.C, count, m.weight, m.bias, m.eps, m.momentum if m.momentum is not None else 0.1,
-                           m.running_mean if m.track_running_stats else None,
-                           m.running_var if m.track_running_stats else None,
-                           m.num_batches_tracked if m.track_running_stats else None, bn.mean, bn.invstd, bn.scale,
-                           bn.shift)
+        return ops.bn_fin(count, m.weight, m.bias, m.eps, m.momentum if m.momentum is not None else 0.1,
+                          m.running_mean if m.track_running_stats else None,
+                          m.running_var if m.track_running_stats else None,
+                          m.num_batches_tracked if m.track_running_stats else None, bn.mean, bn.invstd, bn.scale, bn.shift)
 
     def _res_edge(self, i):
         """Non-zero when unit i's output is formed by unit i+1's conv1 and its statistics come from moments: 1 = plain unit
@@ -682,7 +627,7 @@ class BackbonePlan(object):
         # conv2 of unit i and conv1 of unit i + 1 on LDS-strip instances (the 64 -> 64 rolling-window kernel takes neither.
         # Measured and removed: the two 56x56 64-channel edges on the strip instance instead -- 14.83-15.07 against 14.87-15.04
         # ms per step, nothing: what the apply pass costs there the slower convolution instance gives back)
-        if not _lib.lib.fr_conv3x3_strip_serves_bnbwd2(self.B, u.depth, u.Ho):
+        if not _lib.lib.fr_conv3x3_strip_serves_resbn(self.B, u.depth, u.Ho):
             return 0
         if n.cin != n.depth and ops.strip_parts(self.B, n.cin, n.depth, n.H, ops.EPI_STORE) <= 0:
             return 0
@@ -699,33 +644,20 @@ class BackbonePlan(object):
         return 2
 
     def _c1_parts(self, B, Ho, K, N, stride, H):
-        """Partial rows of fr_conv1x1_stream for a 1x1 convolution K -> N on a Ho x Ho output grid, 0 = use the generic GEMM
-        (FRHIP_C1_STREAM=0: A/B switch)."""
-        if self.fr != FR_BF16 or os.environ.get("FRHIP_C1_STREAM", "1") == "0" or H != Ho * stride:
+        """Partial rows of fr_conv1x1_stream for a 1x1 convolution K -> N on a Ho x Ho output grid, 0 = use the generic GEMM."""
+        if self.fr != FR_BF16 or not self.use_strip or H != Ho * stride:
             return 0
-        if B < 32 and os.environ.get("FRHIP_C1_STREAM", "1") != "force":
+        if B < 32:
             # small batches keep the tiled GEMM: nothing to gain there, and the batch-4 bf16 golden fixture sits within the
             # noise of the summation order of these statistics (profiles/r04_bf16_g6b_kernel_selection_noise.txt)
             return 0
         return ops.conv1x1_stream_parts(B, Ho, Ho, K, N)
-
-    def _sum_tail(self, K, C, o0, o1=None, o2=None, cls=4):
-        """The in-launch form of fr_reduce_parts(part, rows, K, C, o0, o1, o2), or None without FRHIP_TAIL=1."""
-        if not self.use_tail or not (self.tail_mask & cls):
-            return None
-        return ops.tail_sums(self.tickets.take(), K, C, o0, o1, o2)
-
-    @staticmethod
-    def _tail_kw(tail):
-        return {} if tail is None else {"tail": tail}
 
     def _bn_train_launches(self, L, bn, part, nparts, count):
         m = bn.mod
         st = self.stream
         if self.fold:  # one fr_bn_eval_coeffs_multi launch in front of the weight packing covers every BatchNorm
             self._fold_bns.append(bn)
-            return
-        if bn.tailed:  # the producing launch carries the reduction (ops.tail_bn)
             return
         if m.training:
             L.append(ops.call("fr_bn_finalize", part, nparts, bn.C, float(count), m.weight, m.bias, float(m.eps),
@@ -753,8 +685,7 @@ class BackbonePlan(object):
             C0 = self.units[0].cin
             nb = ops.grid_blocks(self.M0, C0, fr)
             if not fold:
-                L.append(ops.call("fr_channel_stats", self.z0, self.M0, C0, self.part, nb, fr,
-                                  self._bn_tail(first_bn, self.M0, 2), st))
+                L.append(ops.call("fr_channel_stats", self.z0, self.M0, C0, self.part, nb, fr, st))
             self._bn_train_launches(L, first_bn, self.part, nb, self.M0)
         else:
             sc, sb, sp = self.stem
@@ -769,48 +700,26 @@ class BackbonePlan(object):
                 # y0 and writes z0 = PReLU(BN0(y0)) (+ y0 for the backward pass) with the statistics of z0 in its epilogue:
                 # the fr_bn_apply pass over the stem output (822 MB of traffic, 161 us at batch 256) is gone.
                 mt0 = int(min(2048, (self.M0 + 63) // 64))
-                self.l_stem_fwd = self.l_stem_fwd2 = None
-                geo = (B, S, S, self.in_channels, self.avg_channels, self.K0, mt0)
                 if self.bn0.mod.training:
-                    if self.stem_x:  # x / avg pointers are bound per call (run_forward)
-                        self.l_stem_fwd = ops.call("fr_stem_gemm_x", None, None, self.W0p, None, self.part, *geo,
-                                                   self._bn_tail(self.bn0, self.M0), st)
-                        L.append(self.l_stem_fwd)
-                    else:
-                        L.append(ops.call("fr_stem_gemm", self.X0, self.W0p, None, self.part, self.M0, self.K0, mt0,
-                                          self._bn_tail(self.bn0, self.M0), st))
+                    L.append(ops.call("fr_stem_gemm", self.X0, self.W0p, None, self.part, self.M0, self.K0, mt0, st))
                 self._bn_train_launches(L, self.bn0, self.part, mt0, self.M0)
-                if self.stem_x:
-                    self.l_stem_fwd2 = ops.call("fr_stem_gemm_bn_prelu_x", None, None, self.W0p, self.bn0.scale,
-                                                self.bn0.shift, sp.weight, self.y0, self.z0, stats_part, *geo,
-                                                self._bn_tail(first_bn, self.M0, 2), st)
-                    L.append(self.l_stem_fwd2)
-                else:
-                    L.append(ops.call("fr_stem_gemm_bn_prelu", self.X0, self.W0p, self.bn0.scale, self.bn0.shift, sp.weight,
-                                      self.y0, self.z0, stats_part, self.M0, self.K0, mt0,
-                                      self._bn_tail(first_bn, self.M0, 2), st))
+                L.append(ops.call("fr_stem_gemm_bn_prelu", self.X0, self.W0p, self.bn0.scale, self.bn0.shift, sp.weight,
+                                  self.y0, self.z0, stats_part, self.M0, self.K0, mt0, st))
                 self._bn_train_launches(L, first_bn, self.part, mt0, self.M0)
             elif self.use_stem_gemm:  # 3.2 M rows x 64 columns x K0: the row-streaming kernels of stem_gemm.hip
                 mt0 = int(min(2048, (self.M0 + 63) // 64))
-                if self.stem_x:  # x / avg pointers are bound per call (run_forward)
-                    self.l_stem_fwd = ops.call("fr_stem_gemm_x", None, None, self.W0p, self.y0, self.part, B, S, S,
-                                               self.in_channels, self.avg_channels, self.K0, mt0,
-                                               self._bn_tail(self.bn0, self.M0), st)
-                    L.append(self.l_stem_fwd)
-                else:
-                    L.append(ops.call("fr_stem_gemm", self.X0, self.W0p, self.y0, self.part, self.M0, self.K0, mt0,
-                                      self._bn_tail(self.bn0, self.M0), st))
+                L.append(ops.call("fr_stem_gemm", self.X0, self.W0p, self.y0, self.part, self.M0, self.K0, mt0, st))
             else:
                 mt0 = (self.M0 + 127) // 128
                 L.append(ops.conv(st, fr, src=self.X0, w=self.W0p, out=self.y0, B=self.M0, RH=1, RW=1, SH=1, SW=1,
                                   SC=self.K0, N=64, KH=1, KW=1, stride=1, pad=0, mode=0, lda=self.K0, ldc=64, pro=0,
-                                  epi=ops.EPI_STATS, part=self.part, **self._tail_kw(self._bn_tail(self.bn0, self.M0))))
+                                  epi=ops.EPI_STATS, part=self.part))
             if not two_pass:
                 self._bn_train_launches(L, self.bn0, self.part, mt0, self.M0)
                 nb = ops.grid_blocks(self.M0, 64, fr)
                 L.append(ops.bn_apply(st, fr, x=self.y0, out=self.z0, scale=self.bn0.scale, shift=self.bn0.shift,
                                       slope=sp.weight, part=stats_part, B=B, H=S, W=S, C=64, res_kind=0, res_stride=1,
-                                      nblocks=nb, **self._tail_kw(self._bn_tail(first_bn, self.M0, 2))))
+                                      nblocks=nb))
                 self._bn_train_launches(L, first_bn, self.part, nb, self.M0)
         x = self.z0
         for i, u in enumerate(self.units):
@@ -893,8 +802,7 @@ class BackbonePlan(object):
                 continue
             np2 = self._conv(L, src=d["y1"], w=wp2, out=d["y2"], B=B, RH=u.Ho, RW=u.Ho, SH=u.H, SW=u.H,
                              SC=u.depth, N=u.depth, KH=3, KW=3, stride=u.stride, pad=1, mode=0, lda=u.depth,
-                             ldc=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight, epi=stats_epi,
-                             part=stats_part, **self._tail_kw(self._bn_tail(bn2, rout)))
+                             ldc=u.depth, pro=ops.PRO_PRELU, pro_a=u.prelu.weight, epi=stats_epi, part=stats_part)
             self._bn_train_launches(L, bn2, self.part, np2, rout)
             strips2 = self._last_conv_strips if not fold else 0  # conv2's partial rows, if they are whole strips of single images
             if u.sc_conv is not None:
@@ -913,7 +821,7 @@ class BackbonePlan(object):
                     L.append(ops.conv1x1_stream(st, **kws))
                     self._bn_train_launches(L, d["bnS"], self.part, nps, rout)
                 else:
-                    L.append(ops.conv(st, fr, **kws, **self._tail_kw(self._bn_tail(d["bnS"], rout))))
+                    L.append(ops.conv(st, fr, **kws))
                     self._bn_train_launches(L, d["bnS"], self.part, (rout + 127) // 128, rout)
             if u.se is not None:
                 R = u.se.fc1.out_channels
@@ -940,8 +848,6 @@ class BackbonePlan(object):
             nxt = self.ubuf[i + 1]["bn1"] if i + 1 < len(self.units) else (None if self.body_only else self.bn_out)
             if nxt is None:
                 kw["part"] = None  # nobody consumes the statistics of a bare stack's output
-            elif not fold:
-                kw.update(self._tail_kw(self._bn_tail(nxt, rout, 2)))
             L.append(ops.bn_apply(st, fr, **kw))
             if nxt is not None:
                 self._bn_train_launches(L, nxt, self.part, nb, rout)
@@ -983,7 +889,7 @@ class BackbonePlan(object):
         L.append(ops.call("fr_reduce_parts", self.lin_slab, self.lin_splitk, 1, B * 512, self.f, None, None, st))
         nbf = ops.grid_blocks(B, 512, FR_F32)
         if not fold:
-            L.append(ops.call("fr_channel_stats", self.f, B, 512, self.part, nbf, FR_F32, self._bn_tail(self.bn1d, B, 2), st))
+            L.append(ops.call("fr_channel_stats", self.f, B, 512, self.part, nbf, FR_F32, st))
         self._bn_train_launches(L, self.bn1d, self.part, nbf, B)
         L.append(ops.bn_apply(st, FR_F32, x=self.f, out=self.feat, scale=self.bn1d.scale, shift=self.bn1d.shift, B=B,
                               H=1, W=1, C=512, res_kind=0, res_stride=1, nblocks=nbf))
@@ -1004,7 +910,7 @@ class BackbonePlan(object):
             arr[i].wt = wt.data_ptr() if wt is not None else None
             arr[i].oscale = req[6].data_ptr() if len(req) > 6 else None
             arr[i].Cout, arr[i].taps, arr[i].Cin = cout, taps, cin
-            if self.fr == FR_BF16 and cout % 64 == 0 and cin % 64 == 0 and os.environ.get("FRHIP_PACK64", "1") != "0":
+            if self.fr == FR_BF16 and cout % 64 == 0 and cin % 64 == 0:
                 # 64 x 64 tiles with 16-byte accesses (chunk index -(tile + 1)): every 3x3 / shortcut convolution of the IR nets
                 chunks.extend((i, -(t + 1)) for t in range(taps * (cout // 64) * (cin // 64)))
                 continue
@@ -1036,10 +942,9 @@ class BackbonePlan(object):
         return ops.Launch("fr_bn_eval_coeffs_multi", [table, len(bns), self.stream], keep=(bns,))
 
     # ---- backward ----------------------------------------------------------------------------------
-    def _reduce(self, L, nparts, K, C, o0, o1, o2=None, tail=None):
-        """Add the partial rows the last launch wrote -- unless that launch carried the reduction itself (tail)."""
-        if tail is None:
-            L.append(ops.call("fr_reduce_parts", self.part, nparts, K, C, o0, o1, o2, self.stream))
+    def _reduce(self, L, nparts, K, C, o0, o1, o2=None):
+        """Add the partial rows the last launch wrote."""
+        L.append(ops.call("fr_reduce_parts", self.part, nparts, K, C, o0, o1, o2, self.stream))
 
     def _bn_grads(self, bn):
         """(dbeta target, dgamma target): the parameter gradients when they train, scratch otherwise."""
@@ -1070,18 +975,16 @@ class BackbonePlan(object):
         db, dg = self._bn_grads(self.bn1d)
         common = dict(g=self.g_feat_in, x=self.f, mean=self.bn1d.mean, invstd=self.bn1d.invstd, rows=B, C=512,
                       rows_per_image=1, nblocks=nbf)
-        t = self._sum_tail(3, 512, db, dg)
-        L.append(ops.bn_bwd_reduce(st, FR_F32, part=self.part, **self._tail_kw(t), **common))
-        self._reduce(L, nbf, 3, 512, db, dg, tail=t)
+        L.append(ops.bn_bwd_reduce(st, FR_F32, part=self.part, **common))
+        self._reduce(L, nbf, 3, 512, db, dg)
         s0, s1 = self._s01(self.bn1d, db, dg)
         L.append(ops.bn_bwd_apply(st, FR_F32, gx=self.g_f32, gamma=ob1.weight, s0=s0, s1=s1, inv_count=1.0 / B,
                                   **common))
         # Linear bias gradient = column sums of g_f
         gbias = self.grad_of(ol.bias)
         if gbias is not None:
-            t = self._sum_tail(1, 512, gbias)
-            L.append(ops.call("fr_channel_stats", self.g_f32, B, 512, self.part, nbf, FR_F32, t, st))
-            self._reduce(L, nbf, 2, 512, gbias, None, tail=t)
+            L.append(ops.call("fr_channel_stats", self.g_f32, B, 512, self.part, nbf, FR_F32, st))
+            self._reduce(L, nbf, 2, 512, gbias, None)
         if fr == FR_BF16:
             L.append(ops.call("fr_cast", self.g_f32, self.g_fT, B * 512, FR_F32, FR_BF16, st))
             gfT = self.g_fT
@@ -1118,9 +1021,8 @@ class BackbonePlan(object):
         db, dg = self._bn_grads(self.bn_out)
         common = dict(g=g_a, x=x_last, mean=self.bn_out.mean, invstd=self.bn_out.invstd, rows=rows_o, C=C,
                       rows_per_image=self.HWo, nblocks=nb)
-        t = self._sum_tail(3, C, db, dg)
-        L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **self._tail_kw(t), **common))
-        self._reduce(L, nb, 3, C, db, dg, tail=t)
+        L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
+        self._reduce(L, nb, 3, C, db, dg)
         s0, s1 = self._s01(self.bn_out, db, dg)
         cur = 0
         g_out = self.g_pp[cur][:rows_o * C]
@@ -1176,27 +1078,10 @@ class BackbonePlan(object):
             db, dg = self._bn_grads(bn2)
             common = dict(g=g_out, x=d["y2"], mean=bn2.mean, invstd=bn2.invstd, rows=rout, C=u.depth,
                           rows_per_image=HWo, nblocks=nb, **se_kw)
-            # BN2 backward inside the data gradient of conv2 (FR_PRO_BNBWD2): bf16 strip instances of the stride-1 units
-            fuse2 = (self.fuse_bn2 and fr == FR_BF16 and self.use_strip and u.stride == 1 and u.se is None and
-                     bool(_lib.lib.fr_conv3x3_strip_serves_bnbwd2(B, u.depth, u.H)))
-            if fuse2:
-                co = [self.pool.take(u.depth) for _ in range(3)]
-                ev = not bn2.mod.training
-                if self.use_tail and (self.tail_mask & 4):
-                    t = ops.tail_bnbwd(self.tickets.take(), 3, u.depth, db, dg, None, rout, u.bn2.weight, bn2.mean,
-                                       bn2.invstd, co[0], co[1], co[2], bn_eval=ev)
-                    L.append(ops.bn_bwd_reduce(st, fr, part=self.part, tail=t, **common))
-                else:
-                    L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
-                    L.append(ops.call("fr_bn_bwd_coeffs", self.part, nb, u.depth, float(rout), u.bn2.weight, bn2.mean,
-                                      bn2.invstd, 1 if ev else 0, db, dg, co[0], co[1], co[2], st))
-            else:
-                t = self._sum_tail(3, u.depth, db, dg)
-                L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **self._tail_kw(t), **common))
-                self._reduce(L, nb, 3, u.depth, db, dg, tail=t)
-                s0, s1 = self._s01(bn2, db, dg)
-                L.append(ops.bn_bwd_apply(st, fr, gx=g_y2, gamma=u.bn2.weight, s0=s0, s1=s1, inv_count=1.0 / rout,
-                                          **common))
+            L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
+            self._reduce(L, nb, 3, u.depth, db, dg)
+            s0, s1 = self._s01(bn2, db, dg)
+            L.append(ops.bn_bwd_apply(st, fr, gx=g_y2, gamma=u.bn2.weight, s0=s0, s1=s1, inv_count=1.0 / rout, **common))
             g_xS = None
             if u.sc_conv is not None:
                 bnS = d["bnS"]
@@ -1204,9 +1089,8 @@ class BackbonePlan(object):
                 db, dg = self._bn_grads(bnS)
                 common = dict(g=g_out, x=d["yS"], mean=bnS.mean, invstd=bnS.invstd, rows=rout, C=u.depth,
                               rows_per_image=HWo, nblocks=nb)
-                t = self._sum_tail(3, u.depth, db, dg)
-                L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **self._tail_kw(t), **common))
-                self._reduce(L, nb, 3, u.depth, db, dg, tail=t)
+                L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
+                self._reduce(L, nb, 3, u.depth, db, dg)
                 s0, s1 = self._s01(bnS, db, dg)
                 L.append(ops.bn_bwd_apply(st, fr, gx=g_yS, gamma=u.sc_bn.weight, s0=s0, s1=s1,
                                           inv_count=1.0 / rout, **common))
@@ -1234,27 +1118,19 @@ class BackbonePlan(object):
             c2 = dict(src=g_y2, w=d["wt2"], out=g_y1, B=B, RH=u.H, RW=u.H, SH=u.Ho, SW=u.Ho, SC=u.depth, N=u.depth,
                       KH=3, KW=3, stride=u.stride, pad=1, lda=u.depth, ldc=u.depth, ldaux=u.depth, pro=0,
                       epi=ops.EPI_PRELU_BWD, aux=d["y1"], epi_a=u.prelu.weight)
-            if fuse2:  # the operand is ca*g_out + cb*y2 + cc; g_y2 is written on the way for the weight gradient
-                c2.update(src=g_out, src2=d["y2"], pro=ops.PRO_BNBWD2, pro_a=co[0], pro_b=co[1], pro_c=co[2],
-                          pro_out=g_y2 if self.grad_of(u.conv2.weight) is not None else None)
             # The PReLU-slope partial sums of this data gradient feed nothing downstream (a parameter gradient): with the
             # side stream they go to a buffer of their own (one per buffer set) and are added there, off the main chain.
             gsl = self.grad_of(u.prelu.weight)
             gsl = gsl if gsl is not None else self.sums[2, :u.depth]
-            # with the in-launch reduction the data gradient adds its own slope partials: nothing for the side stream to do
-            tsl = self._sum_tail(1, u.depth, gsl, cls=8)
-            part2 = self.part_slope[par] if (self.side_slope and tsl is None) else self.part
+            part2 = self.part_slope[par] if self.side_slope else self.part
             if u.stride == 2 and u.H % 2 == 0:
                 # one launch per output-pixel parity class: 9/4 taps per pixel instead of 9 (3/4 of them misses)
                 # (all four classes in one launch: par = -1; partial rows come back as [class][M tile])
-                mt = self._conv(L, mode=2, par_h=-1, par_w=-1, part=part2, **self._tail_kw(tsl), **c2)
+                mt = self._conv(L, mode=2, par_h=-1, par_w=-1, part=part2, **c2)
             else:
-                mt = self._conv(L, mode=1, part=part2, **self._tail_kw(tsl), **c2)
+                mt = self._conv(L, mode=1, part=part2, **c2)
             gw2 = self.grad_of(u.conv2.weight)
-            if tsl is not None:
-                if gw2 is not None:
-                    edge()  # g_y1, g_y2 (BN2 backward) and y1 are final
-            elif self.side_slope:
+            if self.side_slope:
                 edge()  # g_y1 / the slope partials, g_y2 (BN2 backward) and y1 are final
                 r = ops.call("fr_reduce_parts", part2, mt, 2, u.depth, gsl, None, None, self.stream2)
                 r.tstream = self.stream2_t
@@ -1263,7 +1139,7 @@ class BackbonePlan(object):
                 self._reduce(L, mt, 2, u.depth, gsl, None)
             if gw2 is not None:
                 tiles = ((u.depth + 127) // 128) ** 2 * 9
-                if not self.side_slope and tsl is None:
+                if not self.side_slope:
                     edge()
                 kw2 = dict(param=u.conv2.weight, g=g_y2, src=d["y1"], dw=gw2, B=B, GH=u.Ho, GW=u.Ho,
                            Cout=u.depth, SH=u.H, SW=u.H, SC=u.depth, KH=3, KW=3, stride=u.stride, pad=1,
@@ -1275,12 +1151,11 @@ class BackbonePlan(object):
             # conv1: data gradient with the BN1-backward sums epilogue, then the weight gradient
             g_xh = self.g_xh[:rin * u.cin]
             db, dg = self._bn_grads(bn1)
-            t = self._sum_tail(2, u.cin, db, dg, cls=8)
             mt = self._conv(L, src=g_y1, w=d["wt1"], out=g_xh, B=B, RH=u.H, RW=u.H, SH=u.H, SW=u.H,
                             SC=u.depth, N=u.cin, KH=3, KW=3, stride=1, pad=1, mode=1, lda=u.depth, ldc=u.cin,
                             ldaux=u.cin, pro=0, epi=ops.EPI_BNBWD, aux=x, epi_a=bn1.mean, epi_b=bn1.invstd,
-                            part=self.part, **self._tail_kw(t))
-            self._reduce(L, mt, 2, u.cin, db, dg, tail=t)
+                            part=self.part)
+            self._reduce(L, mt, 2, u.cin, db, dg)
             gw1 = self.grad_of(u.conv1.weight)
             if gw1 is not None:
                 tiles = ((u.depth + 127) // 128) * ((u.cin + 127) // 128) * 9
@@ -1342,15 +1217,14 @@ class BackbonePlan(object):
                               self.bn0.shift, sp.weight, self.part, self.M0, self.K0, nb, st))
             self._reduce(L, nb, 3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64])
         else:
-            t = self._sum_tail(3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64])
-            L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **self._tail_kw(t), **common))
-            self._reduce(L, nb, 3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64], tail=t)
+            L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
+            self._reduce(L, nb, 3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64])
         s0, s1 = self._s01(self.bn0, db, dg)
         g_y0 = self.g_y1s[1 if self.dual else 0][:self.M0 * 64]  # unit 0's wgrads (side stream) still read set 0
         if self.dual and 1 in unit_done:
             L.append(_EvWait(self.stream1_t, unit_done[1]))  # set 1 was last read by unit 1's weight gradients
         gw0 = self.grad_of(sc.weight)
-        fuse = self.use_stem_gemm and os.environ.get("FRHIP_NO_STEM_BNFUSE", "0") != "1"
+        fuse = self.use_stem_gemm  # BN0 / PReLU backward applied while the weight gradient stages its rows
         if gw0 is not None and not fuse:
             L.append(ops.bn_bwd_apply(st, fr, gx=g_y0, gamma=sb.weight, s0=s0, s1=s1, inv_count=1.0 / self.M0,
                                       **common))
@@ -1362,13 +1236,7 @@ class BackbonePlan(object):
             elif fuse:
                 # BN0 backward is applied while the gradient rows are staged: g_y0 is never materialised
                 nsl = int(min(1024 if self.K0 == 32 else 512, (self.M0 + 63) // 64))  # partials live in self.part
-                if self.stem_x:
-                    self.l_stem_bwd = ops.call("fr_stem_wgrad_bn_x", g_out, self.y0, None, None, self.bn0.mean,
-                                               self.bn0.invstd, self.bn0.scale, self.bn0.shift, sp.weight, sb.weight, s0,
-                                               s1, 1.0 / self.M0, self.part, B, self.S, self.S, self.in_channels,
-                                               self.avg_channels, self.K0, nsl, st)
-                    L.append(self.l_stem_bwd)
-                elif self.stem_recompute:
+                if self.stem_recompute:
                     L.append(ops.call("fr_stem_wgrad_bn_r", g_out, self.X0, self.W0p, self.bn0.mean, self.bn0.invstd,
                                       self.bn0.scale, self.bn0.shift, sp.weight, sb.weight, s0, s1, 1.0 / self.M0,
                                       self.part, self.M0, self.K0, nsl, st))
@@ -1445,17 +1313,7 @@ class BackbonePlan(object):
         B, S = self.B, self.S
         st = self.stream
         avg = avg_image
-        if self.stem_x:
-            # the stem kernels read the batch itself: bind its address (and keep it alive until the backward pass has run)
-            self._x_ref = (x, avg)
-            for l in (self.l_stem_fwd, getattr(self, "l_stem_fwd2", None)):
-                if l is not None:
-                    l.args[0], l.args[1] = ops.ptr(x), ops.ptr(avg)
-            if getattr(self, "l_stem_bwd", None) is not None:
-                self.l_stem_bwd.args[2], self.l_stem_bwd.args[3] = ops.ptr(x), ops.ptr(avg)
-        else:
-            ops.call("fr_stem_im2col", x, avg, self.X0, B, S, S, self.in_channels, self.avg_channels, self.K0, self.fr,
-                     st)()
+        ops.call("fr_stem_im2col", x, avg, self.X0, B, S, S, self.in_channels, self.avg_channels, self.K0, self.fr, st)()
         od = self.out[1]
         p = float(od.p) if od.training else 0.0
         self.l_drop_fwd.args[7] = p

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import (EPI_ATOMIC, EPI_BIAS_RES, EPI_BNBWD, EPI_MARGIN, EPI_PRELU_BWD, EPI_SLAB, EPI_STATS, EPI_STATS_X, EPI_STORE,  # noqa: F401
                    FR_BF16,
                    FR_F32,
-                   PRO_BN, PRO_BNBWD2, PRO_NONE, PRO_PRELU, PRO_RESBN, PRO_RESBN_SE, lib)
+                   PRO_BN, PRO_NONE, PRO_PRELU, PRO_RESBN, PRO_RESBN_SE, lib)
 
 TORCH_DTYPE = {FR_F32: torch.float32, FR_BF16: torch.bfloat16}
 
@@ -138,62 +138,31 @@ def bn_bwd_apply(stream, dtype, **kw):
     return Launch("fr_bn_bwd_apply", [ctypes.byref(a), dtype, stream], keep=(a, kw))
 
 
-class Tickets(object):
-    """Arrival tickets of the in-launch reductions (FrTail.ticket): 4 words each on a cache line of its own, zero when
-    handed out and left zero by every launch that used them (the last reducer resets its ticket)."""
-
-    STRIDE = 32  # uint32 words: 128 bytes
-
-    def __init__(self, n, device):
-        self.buf = torch.zeros(n * self.STRIDE, dtype=torch.int32, device=device)
-        self.n, self.used = n, 0
-
-    def take(self):
-        if self.used >= self.n:
-            raise _lib.FrhipError("frhip: ticket pool exhausted")
-        t = self.buf[self.used * self.STRIDE:self.used * self.STRIDE + 4]
-        self.used += 1
-        return t
-
-    def check_idle(self):
-        """Host-side assertion for tests (synchronises): every ticket is back at zero and no reducer ever gave up."""
-        torch.cuda.synchronize(self.buf.device)
-        bad = self.buf.view(-1, self.STRIDE)[:, :4].ne(0).any(dim=1).nonzero().flatten().tolist()
-        if bad:
-            raise _lib.FrhipError("frhip: tickets %s are not idle: %s" % (
-                bad[:8], self.buf.view(-1, self.STRIDE)[bad[:8], :4].tolist()))
-
-
-def tail_sums(ticket, K, C, o0, o1=None, o2=None, nred=0):
-    """FrTail that adds a launch's partial rows part[row][K][C] into o_k[C] (what fr_reduce_parts would do)."""
-    t = _lib.FrTail()
-    _fill(t, ticket=ticket, o0=o0, o1=o1, o2=o2)
-    t.kind, t.K, t.C, t.nred = _lib.TAIL_SUMS, K, C, nred
-    t._keep = (ticket, o0, o1, o2)
-    return t
-
-
-def tail_bnbwd(ticket, K, C, o0, o1, o2, count, gamma, mean, invstd, ca, cb, cc, bn_eval=False, nred=0):
-    """tail_sums of fr_bn_bwd_reduce's rows + the coefficients of the BatchNorm backward as gx = ca*g + cb*x + cc (what the
-    FR_PRO_BNBWD2 prologue of the following data gradient applies)."""
-    t = _lib.FrTail()
-    _fill(t, ticket=ticket, o0=o0, o1=o1, o2=o2, gamma=gamma, in_mean=mean, in_invstd=invstd, ca=ca, cb=cb, cc=cc)
-    t.kind, t.K, t.C, t.nred = _lib.TAIL_BNBWD, K, C, nred
-    t.count, t.bn_eval = float(count), 1 if bn_eval else 0
-    t._keep = (ticket, o0, o1, o2, gamma, mean, invstd, ca, cb, cc)
-    return t
-
-
-def tail_bn(ticket, C, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, invstd, scale, shift,
-            nred=0):
-    """FrTail that turns a launch's (sum, sum of squares) rows into BatchNorm coefficients (what fr_bn_finalize would do)."""
-    t = _lib.FrTail()
-    _fill(t, ticket=ticket, gamma=gamma, beta=beta, running_mean=running_mean, running_var=running_var, nbt=nbt,
-          mean=mean, invstd=invstd, scale=scale, shift=shift)
-    t.kind, t.K, t.C, t.nred = _lib.TAIL_BN, 2, C, nred
+def bn_fin(count, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, invstd, scale, shift):
+    """FrBnFinArgs: the BatchNorm arguments of fr_bn_finalize as a struct (fr_bn_finalize_res takes two)."""
+    t = _lib.FrBnFinArgs()
+    _fill(t, gamma=gamma, beta=beta, running_mean=running_mean, running_var=running_var, nbt=nbt, mean=mean, invstd=invstd,
+          scale=scale, shift=shift)
     t.count, t.eps, t.momentum = float(count), float(eps), float(momentum)
-    t._keep = (ticket, gamma, beta, running_mean, running_var, nbt, mean, invstd, scale, shift)
+    t._keep = (gamma, beta, running_mean, running_var, nbt, mean, invstd, scale, shift)
     return t
+
+
+def set_option(name, value):
+    """Override a run-time switch of the library (fr_set_option); returns the previous value."""
+    return int(lib.fr_set_option(name.encode(), int(value)))
+
+
+# Switches the LIBRARY reads (kernel-family A/B switches and test hooks; README "Switches").  The library caches a switch at
+# its first use, so the environment is pushed again whenever a plan is built (and by tests that flip one in-process).
+LIB_SWITCHES = {"FRHIP_ROLL64": 1, "FRHIP_WGRAD_ROLL": 1, "FRHIP_WGRAD_DEFER": 1, "FRHIP_SPLIT_STRIPS": 0, "FRHIP_XCD_ORDER": 1,
+                "FRHIP_IGEMM_BN": 0, "FRHIP_ROLL_NSEG": -1, "FRHIP_S2ROLL_NSEG": -1}
+
+
+def sync_switches():
+    import os
+    for name, dflt in LIB_SWITCHES.items():
+        set_option(name, int(os.environ.get(name, dflt)))
 
 
 def call(name, *args):

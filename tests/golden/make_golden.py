@@ -11,7 +11,9 @@ repo's own counter-based generator (stylegan-for-facerec_amd/frhip/synth.py) and
 Fixtures: g1_head, g2_focal, g3_blocks, g4_se, g5_ir50, g6_psp, g7_sgd, g8_structure.json,
 g9_stage2, g10_verification (8f rank 2: the k-fold verification metrics of util/verification.py),
 g11_dataset.json (dataset.py FacesDataset on a tiny tree with `Race^id` directory names), g12_resnet_structure.json
-(state-dict keys / shapes of backbone/model_resnet.py, which train.py:6 imports).
+(state-dict keys / shapes of backbone/model_resnet.py, which train.py:6 imports), g13_* (round 5: one training step of every
+BASELINE config AT ITS OWN SIZE -- batch 100 / 128 / 256, 100 / 7000 / 28000 identities -- run by the reference itself in fp32
+on the host cores: `python tests/golden/make_golden.py g13` takes ~10 minutes and ~40 GB; one config per process).
 """
 import importlib.util
 import json
@@ -500,6 +502,73 @@ def g12_resnet_structure():
     print("g12_resnet_structure.json", {k: (len(v["keys"]), v["n_params"]) for k, v in info.items()})
 
 
+# ------------------------------------------------------------------------------------------------ G13
+# One training step of the BASELINE configs at their own sizes (BASELINE.json configs[0..4]; bench.py times exactly these), by
+# the reference modules in fp32.  What is stored is small: loss, features, a sample of the logits (label column + 63 fixed
+# columns per row), every per-parameter gradient norm, a fixed sample of <= 16384 elements of gradient tensors along the depth
+# (+ the head weight), and the running statistics of three BatchNorms.
+BENCH_SIZE = {
+    "g13_configs1_ir50_arc7000_b256": ("ir50", "ArcFace", 7000, 256),
+    "g13_configs2_ir50_arc28000_b256": ("ir50", "ArcFace", 28000, 256),
+    "g13_configs3_irse101_cos28000_b128": ("irse101", "CosFace", 28000, 128),
+    "g13_configs4_psp_arc28000_b256": ("psp", "ArcFace", 28000, 256),
+    "g13_configs0_psp_arc100_b100": ("psp", "ArcFace", 100, 100),
+}
+
+
+def bench_probe_names(prefix):
+    return ([prefix + "input_layer.0.weight"] +
+            [prefix + "body.%d.res_layer.%d.weight" % (u, k) for u, k in ((0, 1), (0, 3), (3, 3), (12, 1), (21, 3), (23, 1))] +
+            [prefix + "output_layer.3.weight", prefix + "output_layer.4.weight", prefix + "body.7.res_layer.4.weight"])
+
+
+def sample_index(name, numel, n=16384):
+    """A fixed sample of element indices of a tensor (all of it when it is small): a counter hash of the name, stored with the
+    fixture so that no random-number library is part of the contract."""
+    if numel <= n:
+        return np.arange(numel, dtype=np.int64)
+    seed = sum((i + 1) * ord(c) for i, c in enumerate(name)) % 1000003
+    k = np.arange(n, dtype=np.uint64)
+    h = (k * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed) * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    h ^= h >> np.uint64(31)
+    h = (h * np.uint64(0x94D049BB133111EB)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    h ^= h >> np.uint64(29)
+    return np.unique((h % np.uint64(numel)).astype(np.int64))
+
+
+def run_bench_size(tag):
+    kind, head_name, nclass, batch = BENCH_SIZE[tag]
+    model, prefix, avg = full_model(kind)
+    model.train()
+    x = synth.uniform(33, "big.x", (batch, 3, 112, 112))
+    label = synth.labels(33, "big.y", batch, nclass)
+    head = getattr(ref_heads, head_name)(512, nclass, None)
+    with torch.no_grad():
+        head.weight.copy_(synth.uniform(33, "big.head", (nclass, 512), -0.05, 0.05))
+    feats = model(x)
+    logits = head(feats, label, onehot_vec=onehot(label, nclass)) if head_name == "ArcFace" else head(feats, label)
+    loss, _ = RefFocal()(logits, label)
+    named = list(model.named_parameters())
+    gs = torch.autograd.grad(loss, [p for _, p in named] + [head.weight])
+    out = {"features": npy(feats), "loss": npy(loss), "labels": npy(label)}
+    cols = np.stack([np.concatenate(([int(label[r])], (np.arange(63) * 109 + 7 * r + 1) % nclass)) for r in range(batch)])
+    out["logit_cols"] = cols.astype(np.int32)
+    out["logit_vals"] = npy(logits)[np.arange(batch)[:, None], cols]
+    out["logit_absmax"] = np.array(float(logits.detach().abs().max()))
+    out["grad_names"] = np.array([n for n, _ in named] + ["head.weight"])
+    out["grad_norms"] = np.array([float(g.double().norm()) for g in gs])
+    gd = dict(zip([n for n, _ in named] + ["head.weight"], gs))
+    for n in bench_probe_names(prefix) + ["head.weight"]:
+        idx = sample_index(n, gd[n].numel())
+        out["gi." + n] = idx
+        out["g." + n] = npy(gd[n]).reshape(-1)[idx]
+    bufs = dict(model.named_buffers())
+    for n in (prefix + "input_layer.1", prefix + "body.7.res_layer.4", prefix + "output_layer.4"):
+        out["buf." + n + ".running_mean"] = npy(bufs[n + ".running_mean"])
+        out["buf." + n + ".running_var"] = npy(bufs[n + ".running_var"])
+    save(tag, **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g6c", "g7", "g8", "g9", "g10", "g11", "g12"]
     if "g1" in which:
@@ -531,3 +600,10 @@ if __name__ == "__main__":
         g11_dataset()
     if "g12" in which:
         g12_resnet_structure()
+    if "g13" in which:  # tens of GB each: one process per config
+        import subprocess
+        for tag in BENCH_SIZE:
+            subprocess.run([sys.executable, os.path.abspath(__file__), tag], check=True)
+    for tag in which:
+        if tag in BENCH_SIZE:
+            run_bench_size(tag)

@@ -426,7 +426,7 @@ def test_bn_apply_and_backward(K, name, dtype, tol):
     rows = B * H * H
     nb = K.grid_blocks(rows, C, fr)
     part = torch.zeros(nb, 2, C, device="cuda")
-    K.call("fr_channel_stats", xd, rows, C, part, nb, fr, None, st)()
+    K.call("fr_channel_stats", xd, rows, C, part, nb, fr, st)()
     mean, invstd, scale, shift = (torch.zeros(C, device="cuda") for _ in range(4))
     rmd, rvd, nbt = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.zeros((), dtype=torch.int64,
                                                                                               device="cuda")
@@ -867,11 +867,13 @@ S2_CASES = [s + (3, "") for s in S2_SHAPES] + [(64, 56, 20, ""), (64, 56, 40, ""
 
 
 @pytest.fixture
-def s2_walk(monkeypatch):
+def s2_walk(K):
+    """FRHIP_S2ROLL_NSEG = 1 (test hook of the library): walks of whole images at small batches."""
     def set_walk(walk):
         if walk == "whole":
-            monkeypatch.setenv("FRHIP_S2ROLL_NSEG", "1")
-    return set_walk
+            K.set_option("FRHIP_S2ROLL_NSEG", 1)
+    yield set_walk
+    K.set_option("FRHIP_S2ROLL_NSEG", -1)
 
 
 @pytest.mark.parametrize("C,WL,B,walk", S2_CASES, ids=["%d_%d_b%d%s" % s for s in S2_CASES])
@@ -977,7 +979,7 @@ def test_stem_gemm_and_wgrad(K, Kp, M):
     nb = 5
     out = torch.zeros(M, 64, device="cuda", dtype=dtype)
     part = torch.zeros(nb, 2, 64, device="cuda")
-    K.call("fr_stem_gemm", x.to("cuda", dtype), w.to("cuda", dtype), out, part, M, Kp, nb, None, st)()
+    K.call("fr_stem_gemm", x.to("cuda", dtype), w.to("cuda", dtype), out, part, M, Kp, nb, st)()
     torch.cuda.synchronize()
     got = out.float().cpu()
     assert relerr(got, y) < tol
@@ -1166,286 +1168,12 @@ def _bn_outputs(C):
     return [torch.zeros(C, device="cuda") for _ in range(4)]
 
 
-@pytest.mark.parametrize("nred", [0, 1, 3, 16])
-@pytest.mark.parametrize("dname,C,rows,nb", [("bf16", 64, 5000, 333), ("bf16", 256, 4099, 1024), ("f32", 512, 777, 97),
-                                             ("bf16", 128, 300, 2)])
-def test_tail_equals_the_stand_alone_reductions(K, dname, C, rows, nb, nred):
-    """FrTail on the channel-wise producers (fr_channel_stats, fr_bn_apply, fr_bn_bwd_reduce): the launch that writes the
-    partial rows also adds them -- BatchNorm coefficients + running statistics (FR_TAIL_BN) and gradient sums
-    (FR_TAIL_SUMS) must be BIT-identical to fr_bn_finalize / fr_reduce_parts on the same rows, for one reducer (the last
-    workgroup alone), several (they wait for the arrival count) and more reducers than workgroups; tickets end at zero."""
-    dtype = torch.float32 if dname == "f32" else torch.bfloat16
-    fr, st = K.fr_dtype(torch.empty(0, dtype=dtype)), K.current_stream_ptr()
-    x = synth.normal(31, "tx", (rows, C)).to("cuda", dtype)
-    g = synth.normal(31, "tg", (rows, C)).to("cuda", dtype)
-    gamma, beta = synth.uniform(31, "tga", (C,), 0.8, 1.2).cuda(), synth.uniform(31, "tbe", (C,), -0.1, 0.1).cuda()
-    tickets = K.Tickets(8, "cuda")
-    # ---- statistics: stand-alone
-    part = torch.zeros(nb, 2, C, device="cuda")
-    K.call("fr_channel_stats", x, rows, C, part, nb, fr, None, st)()
-    ref = _bn_outputs(C)
-    rm0, rv0, nbt0 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.zeros((), dtype=torch.int64, device="cuda")
-    K.call("fr_bn_finalize", part, nb, C, float(rows), gamma, beta, 1e-5, 0.1, rm0, rv0, nbt0, *ref, st)()
-    # ---- statistics: tail
-    part_t = torch.zeros(nb, 2, C, device="cuda")
-    got = _bn_outputs(C)
-    rm1, rv1, nbt1 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.zeros((), dtype=torch.int64, device="cuda")
-    t = K.tail_bn(tickets.take(), C, rows, gamma, beta, 1e-5, 0.1, rm1, rv1, nbt1, *got, nred=nred)
-    K.call("fr_channel_stats", x, rows, C, part_t, nb, fr, t, st)()
-    torch.cuda.synchronize()
-    assert torch.equal(part, part_t)
-    for a, b in zip(ref + [rm0, rv0], got + [rm1, rv1]):
-        assert torch.equal(a, b)
-    assert int(nbt1) == 1
-    # ---- bn_apply with the statistics of its output
-    out0, out1 = torch.zeros(rows, C, device="cuda", dtype=dtype), torch.zeros(rows, C, device="cuda", dtype=dtype)
-    p0, p1 = torch.zeros(nb, 2, C, device="cuda"), torch.zeros(nb, 2, C, device="cuda")
-    kw = dict(x=x, scale=ref[2], shift=ref[3], B=1, H=rows, W=1, C=C, res_kind=0, res_stride=1, nblocks=nb)
-    K.bn_apply(st, fr, out=out0, part=p0, **kw)()
-    ref2, got2 = _bn_outputs(C), _bn_outputs(C)
-    K.call("fr_bn_finalize", p0, nb, C, float(rows), gamma, beta, 1e-5, 0.1, None, None, None, *ref2, st)()
-    t2 = K.tail_bn(tickets.take(), C, rows, gamma, beta, 1e-5, 0.1, None, None, None, *got2, nred=nred)
-    K.bn_apply(st, fr, out=out1, part=p1, tail=t2, **kw)()
-    torch.cuda.synchronize()
-    assert torch.equal(out0, out1) and torch.equal(p0, p1)
-    for a, b in zip(ref2, got2):
-        assert torch.equal(a, b)
-    # ---- backward sums: K = 3 rows, two outputs wanted
-    common = dict(g=g, x=x, mean=ref[0], invstd=ref[1], rows=rows, C=C, rows_per_image=rows, nblocks=nb)
-    q0, q1 = torch.zeros(nb, 3, C, device="cuda"), torch.zeros(nb, 3, C, device="cuda")
-    K.bn_bwd_reduce(st, fr, part=q0, **common)()
-    s_ref = [torch.zeros(C, device="cuda") for _ in range(2)]
-    K.call("fr_reduce_parts", q0, nb, 3, C, s_ref[0], s_ref[1], None, st)()
-    s_got = [torch.zeros(C, device="cuda") for _ in range(2)]
-    t3 = K.tail_sums(tickets.take(), 3, C, s_got[0], s_got[1], None, nred=nred)
-    K.bn_bwd_reduce(st, fr, part=q1, tail=t3, **common)()
-    torch.cuda.synchronize()
-    assert torch.equal(q0, q1)
-    assert torch.equal(s_ref[0], s_got[0]) and torch.equal(s_ref[1], s_got[1])
-    tickets.check_idle()
-
-
-def test_tail_rejects_what_it_cannot_serve(K):
-    """A tail on a launch without partial rows, with the wrong channel count, or without its outputs is refused (rc < 0),
-    never silently dropped."""
-    from frhip import _lib
-    st = K.current_stream_ptr()
-    C, rows, nb = 64, 100, 4
-    x = torch.zeros(rows, C, device="cuda", dtype=torch.bfloat16)
-    out = torch.zeros_like(x)
-    sc = torch.ones(C, device="cuda")
-    tickets = K.Tickets(4, "cuda")
-    o = torch.zeros(C, device="cuda")
-    kw = dict(x=x, out=out, scale=sc, shift=sc, B=1, H=rows, W=1, C=C, res_kind=0, res_stride=1, nblocks=nb)
-    with pytest.raises(_lib.FrhipError, match="no partial rows"):
-        K.bn_apply(st, _lib.FR_BF16, tail=K.tail_sums(tickets.take(), 2, C, o, o), **kw)()
-    part = torch.zeros(nb, 2, C, device="cuda")
-    with pytest.raises(_lib.FrhipError, match="C must equal"):
-        K.bn_apply(st, _lib.FR_BF16, part=part, tail=K.tail_sums(tickets.take(), 2, 2 * C, o, o), **kw)()
-    bad = K.tail_bn(tickets.take(), C, rows, None, None, 1e-5, 0.1, None, None, None, None, o, o, o)
-    with pytest.raises(_lib.FrhipError, match="FR_TAIL_BN needs"):
-        K.bn_apply(st, _lib.FR_BF16, part=part, tail=bad, **kw)()
-    torch.cuda.synchronize()
-    tickets.check_idle()
-
-
-@pytest.mark.parametrize("shape", ["strip_256_14_b162", "strip_128_28_b40", "roll64_56_b130", "s2_128_28_b40",
-                                   "s2grad_128_28_b40", "igemm_f32_1x1", "strip_512_7_b12"])
-def test_conv_epilogue_tails_equal_the_stand_alone_reductions(K, shape):
-    """FrTail on the convolution epilogues that write partial rows (strip, rolling-window, stride-2 parity planes, generic
-    implicit GEMM; STATS / BNBWD / PRELU_BWD): output tensor and partial rows unchanged, reduced vectors bit-identical to
-    fr_bn_finalize / fr_reduce_parts run on those rows; the instances named are the ones the training step launches (B = 162 /
-    130: more strips than CUs; 512 @7: four images per workgroup, output channels over four workgroups)."""
-    from frhip import _lib
-    st = K.current_stream_ptr()
-    bf = torch.bfloat16
-    tickets = K.Tickets(8, "cuda")
-    spec = {"strip_256_14_b162": (162, 256, 256, 14, 1, "strip", ops_epi("BNBWD")),
-            "strip_128_28_b40": (40, 128, 128, 28, 1, "strip", ops_epi("STATS")),
-            "roll64_56_b130": (130, 64, 64, 56, 1, "strip", ops_epi("PRELU_BWD")),
-            "s2_128_28_b40": (40, 128, 128, 28, 2, "s2", ops_epi("STATS")),
-            "s2grad_128_28_b40": (40, 128, 128, 28, 2, "s2grad", ops_epi("PRELU_BWD")),
-            "igemm_f32_1x1": (6, 64, 128, 28, 2, "igemm", ops_epi("STATS")),
-            "strip_512_7_b12": (12, 512, 512, 7, 1, "strip", ops_epi("STATS"))}[shape]
-    B, Cin, Cout, Wd, stride, fam, epi = spec
-    dtype = torch.float32 if fam == "igemm" else bf
-    fr = _lib.FR_F32 if fam == "igemm" else _lib.FR_BF16
-    if fam == "igemm":  # 1x1 stride-2 shortcut convolution, forward with statistics
-        Hs = 2 * Wd
-        src = synth.normal(41, "cs", (B * Hs * Hs, Cin)).to("cuda", dtype)
-        w = (synth.normal(41, "cw", (Cout, 1, Cin)) * 0.1).to("cuda", dtype)
-        kw = dict(src=src, w=w, B=B, RH=Wd, RW=Wd, SH=Hs, SW=Hs, SC=Cin, N=Cout, KH=1, KW=1, stride=2, pad=0, mode=0,
-                  lda=Cin, ldc=Cout, pro=0, epi=epi)
-        rows_out = B * Wd * Wd
-        nparts = (rows_out + 127) // 128
-        mk = lambda **k: K.conv(st, fr, **k)  # noqa: E731
-    else:
-        Hs = Wd * (2 if fam == "s2" else 1)  # source side
-        Ro = Wd * (2 if fam == "s2grad" else 1)  # output side
-        src = synth.normal(41, "cs", (B * Hs * Hs, Cin)).to("cuda", dtype)
-        w = (synth.normal(41, "cw", (Cout, 9, Cin)) * 0.05).to("cuda", dtype)
-        mode = {"strip": 1 if epi != _lib.EPI_STATS else 0, "s2": 0, "s2grad": 2}[fam]
-        kw = dict(src=src, w=w, B=B, RH=Ro, RW=Ro, SH=Hs, SW=Hs, SC=Cin, N=Cout, KH=3, KW=3, stride=stride, pad=1,
-                  mode=mode, lda=Cin, ldc=Cout, ldaux=Cout, pro=0, epi=epi)
-        if fam == "s2grad":
-            kw.update(par_h=-1, par_w=-1)
-        rows_out = B * Ro * Ro
-        if fam == "strip":
-            nparts = K.strip_parts(B, Cin, Cout, Wd, epi)
-            mk = lambda **k: K.conv_strip(st, **k)  # noqa: E731
-        else:
-            nparts = K.s2_strip_parts(B, Cin, Cout, Wd, mode)
-            mk = lambda **k: K.conv_s2_strip(st, **k)  # noqa: E731
-        assert nparts > 0, "shape not served by the kernel family under test"
-    if epi != _lib.EPI_STATS:
-        kw.update(aux=synth.normal(41, "ca", (rows_out, Cout)).to("cuda", dtype),
-                  epi_a=synth.uniform(41, "ea", (Cout,), -0.2, 0.3).cuda(), epi_b=synth.uniform(41, "eb", (Cout,), 0.5, 1.5).cuda())
-    out0 = torch.zeros(rows_out, Cout, device="cuda", dtype=dtype)
-    out1 = torch.zeros(rows_out, Cout, device="cuda", dtype=dtype)
-    p0, p1 = torch.zeros(nparts, 2, Cout, device="cuda"), torch.zeros(nparts, 2, Cout, device="cuda")
-    mk(out=out0, part=p0, **kw)()
-    if epi == _lib.EPI_STATS:
-        ref, got = _bn_outputs(Cout), _bn_outputs(Cout)
-        K.call("fr_bn_finalize", p0, nparts, Cout, float(rows_out), None, None, 1e-5, 0.1, None, None, None, *ref, st)()
-        t = K.tail_bn(tickets.take(), Cout, rows_out, None, None, 1e-5, 0.1, None, None, None, *got)
-    else:
-        want2 = epi == _lib.EPI_BNBWD
-        ref, got = [torch.zeros(Cout, device="cuda") for _ in range(2)], [torch.zeros(Cout, device="cuda") for _ in range(2)]
-        K.call("fr_reduce_parts", p0, nparts, 2, Cout, ref[0], ref[1] if want2 else None, None, st)()
-        t = K.tail_sums(tickets.take(), 2 if want2 else 1, Cout, got[0], got[1] if want2 else None)
-    mk(out=out1, part=p1, tail=t, **kw)()
-    torch.cuda.synchronize()
-    assert torch.equal(out0, out1) and torch.equal(p0, p1)
-    assert float(p0.abs().sum()) > 0
-    for a, b in zip(ref, got):
-        assert torch.equal(a, b)
-    tickets.check_idle()
-
-
 def ops_epi(name):
     from frhip import _lib
     return getattr(_lib, "EPI_" + name)
 
 
-def test_tail_under_uneven_load_and_warm_caches(K):
-    """The hand-off inside a launch (write-through rows -> arrival count -> acquire -> plain loads) checked the way the
-    CDNA4 guide asks: many back-to-back launches that REUSE the same partial-row buffer with new values every time (so a
-    reducer that trusted a stale L1 / L2 line would return the previous launch's sums), while a second stream keeps a share
-    of the CUs busy with an unrelated streaming kernel (uneven arrival order).  Every launch's sums must equal the
-    stand-alone reduction of a private copy of its rows, bit for bit."""
-    from frhip import _lib
-    st = K.current_stream_ptr()
-    C, rows, nb, iters = 256, 40000, 1024, 60
-    fr = _lib.FR_BF16
-    xs = [(synth.normal(51, "lx%d" % (i % 6), (rows, C)) * (1.0 + i)).to("cuda", torch.bfloat16) for i in range(6)]
-    part = torch.zeros(nb, 2, C, device="cuda")            # shared by every tail launch
-    got = torch.zeros(iters, 4, C, device="cuda")
-    ref = torch.zeros(iters, 4, C, device="cuda")
-    tickets = K.Tickets(2, "cuda")
-    tk = tickets.take()
-    side = torch.cuda.Stream()
-    big = torch.zeros(64 * 1024 * 1024, device="cuda")
-    launches, refs = [], []
-    for i in range(iters):
-        x = xs[i % 6][: rows - 37 * (i % 5)]
-        t = K.tail_bn(tk, C, x.shape[0], None, None, 1e-5, 0.1, None, None, None, *[got[i, k] for k in range(4)],
-                      nred=(1, 4, 16)[i % 3])
-        launches.append(K.call("fr_channel_stats", x, x.shape[0], C, part, nb, fr, t, st))
-        pi = torch.zeros(nb, 2, C, device="cuda")
-        refs.append((K.call("fr_channel_stats", x, x.shape[0], C, pi, nb, fr, None, st),
-                     K.call("fr_bn_finalize", pi, nb, C, float(x.shape[0]), None, None, 1e-5, 0.1, None, None, None,
-                            *[ref[i, k] for k in range(4)], st)))
-    torch.cuda.synchronize()
-    with torch.cuda.stream(side):
-        for _ in range(40):
-            big.mul_(1.0001)
-    for l in launches:
-        l()
-    torch.cuda.synchronize()
-    for a, b in refs:
-        a()
-        b()
-    torch.cuda.synchronize()
-    bad = [i for i in range(iters) if not torch.equal(got[i], ref[i])]
-    assert not bad, "launches %s returned other sums than the stand-alone reduction" % bad[:10]
-    tickets.check_idle()
-
-
 # ------------------------------------------------------------------------------------------------ BN2 backward in the data gradient
-
-
-@pytest.mark.parametrize("B,C,W", [(162, 256, 14), (6, 256, 14), (40, 128, 28), (12, 512, 7), (16, 512, 7), (3, 512, 7)])
-def test_bnbwd2_prologue_equals_apply_then_data_gradient(K, B, C, W):
-    """FR_PRO_BNBWD2 (round 4): the data gradient of a unit's second convolution applies the backward of BN2 to its operand
-    while it loads the strip -- operand = ca*g + cb*y2 + cc with the coefficients of fr_bn_bwd_coeffs -- and stores the
-    rounded operand once per pixel (pro_out) for the weight gradient.  Against the two-pass path it replaces
-    (fr_bn_bwd_apply -> fr_conv3x3_strip): pro_out equals the materialised gradient to one bf16 rounding of an algebraically
-    re-associated fp32 expression, every pixel written exactly once (NaN sentinel), the data gradient + fused PReLU-backward
-    epilogue and its slope partial sums agree to bf16 tolerance; and against torch autograd of BatchNorm2d in float64.
-    Instances: whole images (14x14, large and small batch = channel-split workgroups), 7-row strips with shared halo rows
-    (28x28), 2 / 4 / 1 images per workgroup with channel stages and the output channels over 4 workgroups (7x7).
-    Reference: backbone/model_irse.py:58-60 (PReLU -> Conv2d -> BatchNorm2d) and its autograd."""
-    from frhip import _lib
-    if not _lib.lib.fr_conv3x3_strip_serves_bnbwd2(B, C, W):
-        pytest.skip("not served")
-    st, bf = K.current_stream_ptr(), torch.bfloat16
-    rows = B * W * W
-    g = synth.normal(61, "g", (rows, C)).to(bf)
-    y2 = (synth.normal(61, "y2", (rows, C)) * 1.7 + 0.3).to(bf)
-    y1 = synth.normal(61, "y1", (rows, C)).to(bf)
-    gamma = synth.uniform(61, "ga", (C,), 0.5, 1.5)
-    w = (synth.normal(61, "w", (C, 9, C)) * 0.03).to(bf)   # [Cin][tap][Cout] as the data gradient wants it
-    slope = synth.uniform(61, "sl", (C,), 0.1, 0.4)
-    gd, yd, y1d, wd = g.cuda(), y2.cuda(), y1.cuda(), w.cuda()
-    # statistics of the forward pass, in double on the host
-    y64 = y2.double()
-    mean64, var64 = y64.mean(0), y64.var(0, unbiased=False)
-    mean, invstd = mean64.float().cuda(), (1.0 / torch.sqrt(var64 + 1e-5)).float().cuda()
-    fr = _lib.FR_BF16
-    nb = K.grid_blocks(rows, C, fr)
-    part = torch.zeros(nb, 3, C, device="cuda")
-    common = dict(g=gd, x=yd, mean=mean, invstd=invstd, rows=rows, C=C, rows_per_image=W * W, nblocks=nb)
-    K.bn_bwd_reduce(st, fr, part=part, **common)()
-    s0, s1 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
-    K.call("fr_reduce_parts", part, nb, 3, C, s0, s1, None, st)()
-    o0, o1, ca, cb, cc = (torch.zeros(C, device="cuda") for _ in range(5))
-    K.call("fr_bn_bwd_coeffs", part, nb, C, float(rows), gamma.cuda(), mean, invstd, 0, o0, o1, ca, cb, cc, st)()
-    torch.cuda.synchronize()
-    assert torch.equal(o0, s0) and torch.equal(o1, s1)
-    # ---- two-pass path
-    gy2 = torch.zeros(rows, C, device="cuda", dtype=bf)
-    K.bn_bwd_apply(st, fr, gx=gy2, gamma=gamma.cuda(), s0=s0, s1=s1, inv_count=1.0 / rows, **common)()
-    conv = dict(w=wd, B=B, RH=W, RW=W, SH=W, SW=W, SC=C, N=C, KH=3, KW=3, stride=1, pad=1, mode=1, lda=C, ldc=C,
-                ldaux=C, epi=_lib.EPI_PRELU_BWD, aux=y1d, epi_a=slope.cuda())
-    nparts = K.strip_parts(B, C, C, W, _lib.EPI_PRELU_BWD)
-    out0, p0 = torch.zeros(rows, C, device="cuda", dtype=bf), torch.zeros(nparts, 2, C, device="cuda")
-    K.conv_strip(st, src=gy2, out=out0, part=p0, pro=0, **conv)()
-    # ---- fused path
-    out1, p1 = torch.zeros(rows, C, device="cuda", dtype=bf), torch.zeros(nparts, 2, C, device="cuda")
-    po = torch.full((rows, C), float("nan"), device="cuda", dtype=bf)
-    K.conv_strip(st, src=gd, src2=yd, out=out1, part=p1, pro=_lib.PRO_BNBWD2, pro_a=ca, pro_b=cb, pro_c=cc, pro_out=po,
-                 **conv)()
-    torch.cuda.synchronize()
-    assert not torch.isnan(po.float()).any(), "pro_out has pixels nobody wrote"
-    # float64 autograd of BatchNorm2d (training mode) on the same bf16 inputs
-    yq = y64.clone().requires_grad_(True)
-    z = torch.nn.functional.batch_norm(yq.t().reshape(1, C, -1), None, None, gamma.double(), torch.zeros(C).double(), True,
-                                       0.1, 1e-5)
-    (gref,) = torch.autograd.grad(z, yq, g.double().t().reshape(1, C, -1))
-    scale = float(gref.abs().max())
-    assert float((po.double().cpu() - gref).abs().max()) < BF16_TOL * scale
-    assert float((gy2.double().cpu() - gref).abs().max()) < BF16_TOL * scale
-    d = (po.float() - gy2.float()).abs()
-    assert float(d.max()) <= 2.0 ** -7 * scale and float((d > 0).float().mean()) < 0.2, (float(d.max()), scale)
-    oscale = float(out0.float().abs().max())
-    assert float((out1.float() - out0.float()).abs().max()) < BF16_TOL * oscale
-    ps = float(p0.sum(0).abs().max())
-    assert float((p1.sum(0) - p0.sum(0)).abs().max()) < 2e-3 * ps + 1e-3
-    # the same launch without pro_out (frozen conv2 weight): identical result, nothing else touched
-    out2, p2 = torch.zeros(rows, C, device="cuda", dtype=bf), torch.zeros(nparts, 2, C, device="cuda")
-    K.conv_strip(st, src=gd, src2=yd, out=out2, part=p2, pro=_lib.PRO_BNBWD2, pro_a=ca, pro_b=cb, pro_c=cc, **conv)()
-    torch.cuda.synchronize()
-    assert torch.equal(out1, out2) and torch.equal(p1, p2)
 
 
 # ------------------------------------------------------------------------------------------------ residual sum formed by its consumer
@@ -1468,7 +1196,7 @@ def test_residual_sum_by_its_consumer_and_statistics_from_moments(K, B, C, W, Cn
     output channels, the second one reading the tensor the first one stored).
     Reference: bottleneck_IR.forward, backbone/model_irse.py:57-66 (BN -> conv -> PReLU -> conv -> BN, res + shortcut)."""
     from frhip import _lib
-    if not _lib.lib.fr_conv3x3_strip_serves_bnbwd2(B, C, W):
+    if not _lib.lib.fr_conv3x3_strip_serves_resbn(B, C, W):
         pytest.skip("not served")
     st, bf, fr = K.current_stream_ptr(), torch.bfloat16, _lib.FR_BF16
     rows = B * W * W
@@ -1483,7 +1211,7 @@ def test_residual_sum_by_its_consumer_and_statistics_from_moments(K, B, C, W, Cn
     # statistics of x as the unit's own BN1 holds them
     nb = K.grid_blocks(rows, C, fr)
     px = torch.zeros(nb, 2, C, device="cuda")
-    K.call("fr_channel_stats", x, rows, C, px, nb, fr, None, st)()
+    K.call("fr_channel_stats", x, rows, C, px, nb, fr, st)()
     bnx = [torch.zeros(C, device="cuda") for _ in range(4)]
     K.call("fr_bn_finalize", px, nb, C, float(rows), None, None, 1e-5, 0.1, None, None, None, *bnx, st)()
     conv2 = dict(src=y1, w=w2, B=B, RH=W, RW=W, SH=W, SW=W, SC=C, N=C, KH=3, KW=3, stride=1, pad=1, mode=0, lda=C, ldc=C,
@@ -1512,8 +1240,8 @@ def test_residual_sum_by_its_consumer_and_statistics_from_moments(K, B, C, W, Cn
     bn1b = [torch.zeros(C, device="cuda") for _ in range(4)]
     K.call("fr_bn_finalize", pa, nparts, C, float(rows), g2, b2, 1e-5, 0.1, rm[0], rv[0], nbt[0], *bn2a, st)()
     K.call("fr_bn_finalize_res", pb, nparts, C,
-           K.tail_bn(None, C, rows, g2, b2, 1e-5, 0.1, rm[1], rv[1], nbt[1], *bn2b), bnx[0], bnx[1], 1e-5,
-           K.tail_bn(None, C, rows, g1n, b1n, 1e-5, 0.1, rm[3], rv[3], nbt[3], *bn1b), st)()
+           K.bn_fin(rows, g2, b2, 1e-5, 0.1, rm[1], rv[1], nbt[1], *bn2b), bnx[0], bnx[1], 1e-5,
+           K.bn_fin(rows, g1n, b1n, 1e-5, 0.1, rm[3], rv[3], nbt[3], *bn1b), st)()
     # the two-pass path: out = BN2(y2) + x with the statistics of what was stored, then their finalize
     out_ref = torch.zeros(rows, C, device="cuda", dtype=bf)
     po = torch.zeros(nb, 2, C, device="cuda")
@@ -1587,7 +1315,7 @@ def test_residual_sum_behind_a_squeeze_excite_unit(K, B, C, W, Cn):
     bn2a = [torch.zeros(C, device="cuda") for _ in range(4)]
     bn2b = [torch.zeros(C, device="cuda") for _ in range(4)]
     K.call("fr_bn_finalize", pa, nparts, C, float(rows), g2, b2, 1e-5, 0.1, None, None, None, *bn2a, st)()
-    K.call("fr_bn_finalize_res", pb, nparts, C, K.tail_bn(None, C, rows, g2, b2, 1e-5, 0.1, None, None, None, *bn2b), None,
+    K.call("fr_bn_finalize_res", pb, nparts, C, K.bn_fin(rows, g2, b2, 1e-5, 0.1, None, None, None, *bn2b), None,
            None, 0.0, None, st)()
     xm = torch.zeros(B, 2, C, device="cuda")
     K.call("fr_image_moments", x, B, HW, C, xm, st)()
@@ -1748,7 +1476,7 @@ def test_igemm_tile_width_changes_only_the_partial_sum_order(K, dname, mode, N, 
     nparts = (4 if mode == 2 else 1) * (((rows // 4 if mode == 2 else rows) + 127) // 128)
     res = {}
     for width in ("128", "64"):
-        os.environ["FRHIP_IGEMM_BN"] = width
+        K.set_option("FRHIP_IGEMM_BN", int(width))
         try:
             out = torch.zeros(rows, N, device="cuda", dtype=dtype)
             part = torch.zeros(nparts, 2, N, device="cuda")
@@ -1757,7 +1485,7 @@ def test_igemm_tile_width_changes_only_the_partial_sum_order(K, dname, mode, N, 
             torch.cuda.synchronize()
             res[width] = (out, part)
         finally:
-            os.environ.pop("FRHIP_IGEMM_BN")
+            K.set_option("FRHIP_IGEMM_BN", 0)
     (o128, p128), (o64, p64) = res["128"], res["64"]
     assert torch.equal(o128, o64), "the two tile widths give different OUTPUTS"
     if epi != _lib.EPI_STORE:
@@ -1824,62 +1552,6 @@ def test_se_branch_against_autograd_with_every_gate_decided(K, B, C, H):
 # ------------------------------------------------------------------------------------------------ stem without im2col rows
 
 
-@pytest.mark.parametrize("Cavg,Kp", [(0, 32), (3, 64)])
-@pytest.mark.parametrize("B,S", [(3, 16), (2, 48), (5, 112), (1, 224)])
-def test_stem_gemms_without_materialised_rows(K, Cavg, Kp, B, S):
-    """fr_stem_gemm_x / fr_stem_wgrad_bn_x (round 4): the input-layer GEMM and its weight gradient build the im2col rows of
-    Conv2d(3|6, 64, 3, 1, 1) from the fp32 NCHW batch (+ pSp's average image) in registers.  Same values, same rounding:
-    output, BatchNorm partial rows and weight-gradient slabs must equal fr_stem_im2col + fr_stem_gemm / fr_stem_wgrad_bn
-    BIT FOR BIT (image borders, the zero tail of K, row counts that end inside a 16-row tile / a 64-row staging chunk).
-    Reference: input_layer of backbone/model_irse.py:140, restyle_psp.py:137,445-447."""
-    st, bf = K.current_stream_ptr(), torch.bfloat16
-    fr = K.fr_dtype(torch.empty(0, dtype=bf))
-    M = B * S * S
-    x = synth.normal(77, "sx", (B, 3, S, S)).cuda()
-    avg = synth.normal(77, "sa", (Cavg, S, S)).cuda() if Cavg else None
-    w = (synth.normal(77, "sw", (64, Kp)) * 0.2).to("cuda", bf)
-    rows = torch.zeros(M, Kp, device="cuda", dtype=bf)
-    K.call("fr_stem_im2col", x, avg, rows, B, S, S, 3, Cavg, Kp, fr, st)()
-    nb = 7
-    out0, out1 = torch.zeros(M, 64, device="cuda", dtype=bf), torch.zeros(M, 64, device="cuda", dtype=bf)
-    p0, p1 = torch.zeros(nb, 2, 64, device="cuda"), torch.zeros(nb, 2, 64, device="cuda")
-    K.call("fr_stem_gemm", rows, w, out0, p0, M, Kp, nb, None, st)()
-    K.call("fr_stem_gemm_x", x, avg, w, out1, p1, B, S, S, 3, Cavg, Kp, nb, None, st)()
-    torch.cuda.synchronize()
-    # (second version: the workgroup stages image rows in LDS and walks them item by item -- another assignment of rows to
-    # workgroups than the materialised-rows kernel, so the partial rows agree as sums, the output bit for bit)
-    assert torch.equal(out0, out1) and float(out0.float().abs().max()) > 0
-    assert float((p0.double().sum(0) - p1.double().sum(0)).abs().max()) < 1e-5 * float(p0.double().sum(0).abs().max())
-    # statistics only / GEMM + BN + PReLU on the implicit rows against the same passes on materialised rows
-    vec0 = lambda n, lo, hi: synth.uniform(78, n, (64,), lo, hi).cuda()  # noqa: E731
-    sc_, sh_, sl_ = vec0("sc", 0.5, 1.5), vec0("sh", -0.3, 0.3), vec0("sl", 0.1, 0.4)
-    p2 = torch.zeros(nb, 2, 64, device="cuda")
-    K.call("fr_stem_gemm_x", x, avg, w, None, p2, B, S, S, 3, Cavg, Kp, nb, None, st)()
-    y3, z3, p3 = (torch.full((M, 64), float("nan"), device="cuda", dtype=bf) for _ in range(2)), None, None
-    y3, z3 = y3
-    p3, p4 = torch.zeros(nb, 2, 64, device="cuda"), torch.zeros(nb, 2, 64, device="cuda")
-    z4 = torch.zeros(M, 64, device="cuda", dtype=bf)
-    K.call("fr_stem_gemm_bn_prelu", rows, w, sc_, sh_, sl_, None, z4, p4, M, Kp, nb, None, st)()
-    K.call("fr_stem_gemm_bn_prelu_x", x, avg, w, sc_, sh_, sl_, y3, z3, p3, B, S, S, 3, Cavg, Kp, nb, None, st)()
-    torch.cuda.synchronize()
-    assert torch.equal(p2, p1) and torch.equal(y3, out0) and torch.equal(z3, z4)
-    assert float((p3.double().sum(0) - p4.double().sum(0)).abs().max()) < 1e-5 * float(p4.double().sum(0).abs().max())
-    g = synth.normal(77, "sg", (M, 64)).to("cuda", bf)
-    vec = lambda n, lo, hi: synth.uniform(77, n, (64,), lo, hi).cuda()  # noqa: E731
-    mean, invstd, gamma, slope = vec("m", -0.3, 0.3), vec("i", 0.5, 2.0), vec("g", 0.8, 1.2), vec("s", 0.1, 0.4)
-    s0, s1 = vec("s0", -50.0, 50.0), vec("s1", -50.0, 50.0)
-    scale = gamma * invstd
-    shift = vec("b", -0.2, 0.2) - mean * scale
-    ns = 5
-    slab0, slab1 = torch.zeros(ns, 64, Kp, device="cuda"), torch.zeros(ns, 64, Kp, device="cuda")
-    K.call("fr_stem_wgrad_bn", g, out0, rows, mean, invstd, scale, shift, slope, gamma, s0, s1, 1.0 / M, slab0, M, Kp, ns,
-           st)()
-    K.call("fr_stem_wgrad_bn_x", g, out0, x, avg, mean, invstd, scale, shift, slope, gamma, s0, s1, 1.0 / M, slab1, B, S, S,
-           3, Cavg, Kp, ns, st)()
-    torch.cuda.synchronize()
-    assert torch.equal(slab0, slab1) and float(slab0.abs().max()) > 0
-
-
 @pytest.mark.parametrize("Kp", [32, 64])
 @pytest.mark.parametrize("M", [16 * 37 + 5, 64 * 2048 + 64 * 3 + 9])
 def test_stem_two_pass_forward_equals_gemm_then_bn_apply(K, Kp, M):
@@ -1895,9 +1567,9 @@ def test_stem_two_pass_forward_equals_gemm_then_bn_apply(K, Kp, M):
     scale, shift, slope = vec("sc", 0.5, 1.5), vec("sh", -0.3, 0.3), vec("sl", 0.1, 0.4)
     nb = 13
     y0, p0 = torch.zeros(M, 64, device="cuda", dtype=bf), torch.zeros(nb, 2, 64, device="cuda")
-    K.call("fr_stem_gemm", rows, w, y0, p0, M, Kp, nb, None, st)()
+    K.call("fr_stem_gemm", rows, w, y0, p0, M, Kp, nb, st)()
     p1 = torch.zeros(nb, 2, 64, device="cuda")
-    K.call("fr_stem_gemm", rows, w, None, p1, M, Kp, nb, None, st)()
+    K.call("fr_stem_gemm", rows, w, None, p1, M, Kp, nb, st)()
     nba = K.grid_blocks(M, 64, fr)
     z0, pz0 = torch.zeros(M, 64, device="cuda", dtype=bf), torch.zeros(nba, 2, 64, device="cuda")
     K.bn_apply(st, fr, x=y0, out=z0, scale=scale, shift=shift, slope=slope, part=pz0, B=1, H=1, W=M, C=64, res_kind=0,
@@ -1905,9 +1577,9 @@ def test_stem_two_pass_forward_equals_gemm_then_bn_apply(K, Kp, M):
     y1 = torch.full((M, 64), float("nan"), device="cuda", dtype=bf)
     z1 = torch.full((M, 64), float("nan"), device="cuda", dtype=bf)
     pz1 = torch.zeros(nb, 2, 64, device="cuda")
-    K.call("fr_stem_gemm_bn_prelu", rows, w, scale, shift, slope, y1, z1, pz1, M, Kp, nb, None, st)()
+    K.call("fr_stem_gemm_bn_prelu", rows, w, scale, shift, slope, y1, z1, pz1, M, Kp, nb, st)()
     z2, pz2 = torch.full((M, 64), float("nan"), device="cuda", dtype=bf), torch.zeros(nb, 2, 64, device="cuda")
-    K.call("fr_stem_gemm_bn_prelu", rows, w, scale, shift, slope, None, z2, pz2, M, Kp, nb, None, st)()
+    K.call("fr_stem_gemm_bn_prelu", rows, w, scale, shift, slope, None, z2, pz2, M, Kp, nb, st)()
     torch.cuda.synchronize()
     assert torch.equal(p0, p1) and float(p0.abs().max()) > 0
     assert torch.equal(y1, y0) and torch.equal(z1, z0) and torch.equal(z2, z0) and torch.equal(pz2, pz1)
@@ -1917,7 +1589,7 @@ def test_stem_two_pass_forward_equals_gemm_then_bn_apply(K, Kp, M):
     assert float((got[0] - ref[0]).abs().max()) < 1e-5 * float(z0.float().abs().sum(0).max())
     assert float((got[1] / ref[1] - 1).abs().max()) < 1e-5
     with pytest.raises(K._lib.FrhipError):
-        K.call("fr_stem_gemm", rows, w, None, None, M, Kp, nb, None, st)()
+        K.call("fr_stem_gemm", rows, w, None, None, M, Kp, nb, st)()
 
 
 @pytest.mark.parametrize("Kp", [32, 64])
@@ -1937,7 +1609,7 @@ def test_stem_backward_on_recomputed_rows(K, Kp, M):
     scale = gamma * invstd
     shift = vec("b", -0.2, 0.2) - mean * scale
     y, p = torch.zeros(M, 64, device="cuda", dtype=bf), torch.zeros(8, 2, 64, device="cuda")
-    K.call("fr_stem_gemm", rows, w, y, p, M, Kp, 8, None, st)()
+    K.call("fr_stem_gemm", rows, w, y, p, M, Kp, 8, st)()
     nb = K.grid_blocks(M, 64, fr)
     pa = torch.zeros(nb, 3, 64, device="cuda")
     K.bn_bwd_reduce(st, fr, part=pa, g=g, x=y, mean=mean, invstd=invstd, scale=scale, shift=shift, slope=slope, rows=M, C=64,

@@ -1343,114 +1343,6 @@ def test_freeze_then_unfreeze_from_a_stage2_checkpoint(tmp_path, ranks):
     assert list(h.keys()) == ["weight"] and tuple(h["weight"].shape) == (12, 512) and torch.isfinite(h["weight"]).all()
 
 
-@pytest.mark.parametrize("kind,B", [("IR_50", 6), ("IR_50", 162), ("pSp", 5), ("IR_50_fp32", 4)])
-def test_in_launch_reductions_are_bit_identical_to_separate_launches(kind, B):
-    """FrTail (round 4, csrc/tail.h): every launch that writes partial rows -- BatchNorm statistics, BatchNorm-backward sums,
-    PReLU slope sums -- adds them itself (the last workgroups to arrive, same summation tree as fr_bn_finalize /
-    fr_reduce_parts) instead of leaving them to a second launch.  A training step with FRHIP_TAIL=1 (default) must give bit
-    for bit the loss, features, gradients and BatchNorm running statistics of FRHIP_TAIL=0, have none of the stand-alone
-    reductions left behind its convolutions / channel-wise passes, and leave every ticket at zero.  B = 6 / 5 / 4 run the
-    small-batch kernel instances, B = 162 the ones the bs-256 benchmark runs; pSp adds the squeeze-excite units, the fp32
-    case the generic implicit-GEMM epilogues.  Reference arithmetic: backbone/model_irse.py:57-60,141-148."""
-    _need_gpu()
-    from head.metrics import ArcFace
-    from loss.focal import FocalLoss
-
-    def run(tail):
-        os.environ["FRHIP_TAIL"] = tail
-        try:
-            m, _prefix = build(kind.replace("_fp32", ""))
-            inner = m.encoder if hasattr(m, "encoder") else m
-            inner.compute_dtype = torch.float32 if kind.endswith("fp32") else torch.bfloat16
-            m = m.train()
-            head = ArcFace(512, 100, None).cuda()
-            with torch.no_grad():
-                head.weight.copy_(synth.uniform(16, "full.head", (100, 512), -0.1, 0.1))
-            x = synth.uniform(16, "tail.x", (B, 3, 112, 112)).cuda()
-            y = synth.labels(16, "tail.label", B, 100).cuda()
-            outs = []
-            for _ in range(2):  # twice: the tickets must have been left at zero by the first step
-                for p in list(m.parameters()) + list(head.parameters()):
-                    p.grad = None
-                f = m(x)
-                loss, _ = FocalLoss()(head(f, y), y)
-                loss.backward()
-                torch.cuda.synchronize()
-                outs.append((f.detach().clone(), float(loss.detach()),
-                             {n: p.grad.detach().clone() for n, p in m.named_parameters()},
-                             {n: t.detach().clone() for n, t in m.state_dict().items() if "running" in n or "num_batches" in n}))
-            plan = inner._runner[0].plan
-            plan.tickets.check_idle()
-            names = [getattr(l, "name", "") for l in plan.fwd_list + plan.bwd_list]
-            # (behind a squeeze-excite unit whose statistics come from per-image moments the finalize of those moments stays
-            # a launch: its rows are written by the gate launch, not by a kernel that carries a tail)
-            return (outs, names.count("fr_bn_finalize") - names.count("fr_se_pool_parts_mlp_fwd_res"),
-                    names.count("fr_reduce_parts"), plan.tickets.used)
-        finally:
-            os.environ.pop("FRHIP_TAIL")
-
-    on, fin1, red1, used1 = run("1")
-    off, fin0, red0, used0 = run("0")
-    # (the identity -> identity edges of IR-50 take their statistics from moments -- fr_bn_finalize_res -- with or without tails)
-    assert used0 == 0 and used1 > 60, (used0, used1)
-    # (the three streaming shortcut convolutions of a batch >= 32 plan take no tail: their statistics launches stay)
-    assert fin1 <= 3 and fin0 >= 18, (fin1, fin0)
-    # what stays a launch of its own: the split-K slabs of Linear(25088, 512), the stem weight-gradient slabs and the rows of
-    # the stem's backward sums (fr_stem_bwd_sums takes no tail)
-    assert red1 <= 3 and red0 >= 78, (red1, red0)
-    for step in range(2):
-        f1, l1, g1, r1 = on[step]
-        f0, l0, g0, r0 = off[step]
-        assert l1 == l0 and torch.equal(f1, f0), (step, l1, l0)
-        bad = [n for n in g0 if not torch.equal(g0[n], g1[n])]
-        assert not bad, (step, bad[:5])
-        bad = [n for n in r0 if not torch.equal(r0[n], r1[n])]
-        assert not bad, (step, bad[:5])
-
-
-def test_bn2_backward_inside_the_data_gradient_tracks_the_two_pass_path():
-    """FR_PRO_BNBWD2 in the engine (round 4, opt-in FRHIP_FUSE_BN2=1: measured no faster on two streams): the 18 stride-1 strip units of IR-50
-    form dy2 = BN2-backward(g_out, y2) inside conv2's data gradient instead of in a fr_bn_bwd_apply pass.  Same arithmetic up to
-    one re-associated fp32 expression before the bf16 rounding: the loss and features are identical (forward untouched), every
-    parameter gradient agrees in direction (cos >= 0.9995) and norm (5e-3; measured 2.1e-3 at worst), and the apply launches are gone."""
-    _need_gpu()
-    from head.metrics import ArcFace
-    from loss.focal import FocalLoss
-
-    def run(fuse):
-        os.environ["FRHIP_FUSE_BN2"] = fuse
-        try:
-            m, _ = build("IR_50")
-            m.compute_dtype = torch.bfloat16
-            m = m.train()
-            head = ArcFace(512, 100, None).cuda()
-            with torch.no_grad():
-                head.weight.copy_(synth.uniform(16, "full.head", (100, 512), -0.1, 0.1))
-            x = synth.uniform(16, "fuse.x", (12, 3, 112, 112)).cuda()
-            y = synth.labels(16, "fuse.label", 12, 100).cuda()
-            f = m(x)
-            loss, _ = FocalLoss()(head(f, y), y)
-            loss.backward()
-            torch.cuda.synchronize()
-            names = [getattr(l, "name", "") for l in m._runner[0].plan.bwd_list]
-            return (f.detach().clone(), float(loss.detach()), {n: p.grad.detach().clone() for n, p in m.named_parameters()},
-                    names.count("fr_bn_bwd_apply"), names.count("fr_bn_bwd_coeffs"))
-        finally:
-            os.environ.pop("FRHIP_FUSE_BN2")
-
-    f1, l1, g1, a1, c1 = run("1")
-    f0, l0, g0, a0, c0 = run("0")
-    assert l1 == l0 and torch.equal(f1, f0)
-    assert (c1, c0) == (18, 0) and a0 - a1 == 18, (a1, a0, c1, c0)
-    for n in g0:
-        if n.endswith(ZERO_GRAD_SUFFIXES):  # true gradient exactly zero: both runs hold rounding noise
-            continue
-        a, b = g1[n].float().flatten(), g0[n].float().flatten()
-        cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
-        # (measured: cos 0.99989 at the stem weight, the end of 24 units of re-rounded bf16 gradients; >= 0.99995 elsewhere)
-        assert cos >= 0.9995 and abs(float(a.norm() / b.norm()) - 1.0) < 5e-3, (n, cos, float(a.norm() / b.norm()))
-
-
 @pytest.mark.parametrize("kind,min_edges", [("IR_50", 12), ("pSp", 12)])
 def test_residual_sums_formed_by_their_consumer_track_the_two_pass_path(kind, min_edges):
     """Round 4 (FRHIP_RES_MOMENTS, default on): 17 of IR-50's 24 units hand their output to the next conv1 unmaterialised
@@ -1541,128 +1433,117 @@ def test_residual_sums_formed_by_their_consumer_track_the_two_pass_path(kind, mi
     assert abs(l1 - lr_) <= max(1e-3 * abs(lr_), 2.0 * abs(l0 - lr_)), (l1, l0, lr_)
 
 
-BENCH_SIZE = [("configs1_ir50_arc7000_b256", "IR_50", 50, False, "ArcFace", 7000, 256),
-              ("configs2_ir50_arc28000_b256", "IR_50", 50, False, "ArcFace", 28000, 256),
-              ("configs3_irse101_cos28000_b128", "IR_SE_101", 100, True, "CosFace", 28000, 128),
-              ("configs4_psp_arc28000_b256", "pSp", 50, True, "ArcFace", 28000, 256),
+BENCH_SIZE = [("configs1_ir50_arc7000_b256", "IR_50", "ArcFace", 7000, 256),
+              ("configs2_ir50_arc28000_b256", "IR_50", "ArcFace", 28000, 256),
+              ("configs3_irse101_cos28000_b128", "IR_SE_101", "CosFace", 28000, 128),
+              ("configs4_psp_arc28000_b256", "pSp", "ArcFace", 28000, 256),
               # BASELINE configs[0] at ITS size (configs/config_BUPT_IR_50_baseline.py:20,33: pSp, BATCH_SIZE = 100; the synthetic
               # set has 100 identities): 100 images select the small-batch strip instances, another table than 128 / 256
-              ("configs0_psp_arc100_b100", "pSp", 50, True, "ArcFace", 100, 100)]
+              ("configs0_psp_arc100_b100", "pSp", "ArcFace", 100, 100)]
 
 
-@pytest.mark.parametrize("tag,kind,layers,se,head_name,N,B", BENCH_SIZE, ids=[c[0] for c in BENCH_SIZE])
-def test_bench_size_step_tracks_the_oracle(tag, kind, layers, se, head_name, N, B):
-    """The BASELINE configs at THEIR sizes, as bench.py times them (headline + `other_configs`) -- IR-50 + ArcFace(7000 / 28000)
-    bs 256, IR-SE-101 + CosFace(28000) bs 128, pSp (IR-SE-50 trunk, 6-channel stem, average image) + ArcFace(28000) bs 256, Focal loss,
-    bf16 storage, the large-batch kernel instances -- against the CPU oracle (fp32, oracle/irse_ref.py train_step; 10-40 s and
-    tens of GB on the host cores): loss, features, every per-parameter gradient norm, and direction + norm of gradient tensors
-    along the whole depth.  At 128-256 images the bf16 noise averages down: the bars are tighter than the batch-4 / 8 / 16
-    golden fixtures' (the squeeze-excite fc1 weights keep their own bar, see SE_FC1_BARS)."""
-    _need_gpu()
+def _bench_size_step(golden_dir, tag, kind, head_name, N, B, dtype):
+    """One training step of a BASELINE config at its own size on the HIP path, and the reference's capture of the same step
+    (tests/golden/g13_*.npz: the REFERENCE modules run in fp32 on the host cores by tests/golden/make_golden.py g13 -- same
+    synthetic batch, labels and weights)."""
     import head.metrics as metrics
     from loss.focal import FocalLoss
-    from oracle import irse_ref as O
+    g = np.load(os.path.join(golden_dir, "g13_%s.npz" % tag))
     x = synth.uniform(33, "big.x", (B, 3, 112, 112))
     y = synth.labels(33, "big.y", B, N)
+    assert np.array_equal(y.numpy(), g["labels"])
     m, prefix = build(kind)
     inner = m.encoder if kind == "pSp" else m
-    inner.compute_dtype = torch.bfloat16
+    inner.compute_dtype = dtype
     m.train()
     head = getattr(metrics, head_name)(512, N, None).cuda()
     with torch.no_grad():
         head.weight.copy_(synth.uniform(33, "big.head", (N, 512), -0.05, 0.05))
-    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
-    for k, v in sd.items():
-        if v.is_floating_point() and "running_" not in k and "avg_image" not in k:
-            v.requires_grad_(True)
-    hw = head.weight.detach().cpu().clone().requires_grad_(True)
     feats = m(x.cuda())
     logits = head(feats, y.cuda())
     loss, _ = FocalLoss()(logits, y.cuda())
     loss.backward()
     torch.cuda.synchronize()
     plan = inner._runner[0].plan
-    assert plan.tdtype == torch.bfloat16 and plan.use_strip
-    avg = synth.uniform(15, "avg_image", (3, 112, 112)) if kind == "pSp" else None
-    rf, rl, rloss, rg = O.train_step(sd, x, y, hw, num_layers=layers, se=se, prefix=prefix, avg_image=avg, head=head_name,
-                                     s=64.0, m=0.5)
-    cosf = torch.nn.functional.cosine_similarity
-    loss_rel = abs(float(loss.detach()) - float(rloss.detach())) / abs(float(rloss.detach()))
-    feat_cos = float(cosf(feats.detach().cpu().float(), rf.detach(), dim=1).min())
+    assert plan.tdtype == dtype and plan.use_strip
     named = dict(m.named_parameters())
-    names = [n for n in named if n in rg and named[n].grad is not None and not n.endswith(ZERO_GRAD_SUFFIXES)]
+    named["head.weight"] = head.weight
+    ref_norm = dict(zip([str(n) for n in g["grad_names"]], g["grad_norms"]))
+    names = [n for n in named if n in ref_norm and named[n].grad is not None and not n.endswith(ZERO_GRAD_SUFFIXES)]
     got = np.array([float(named[n].grad.double().norm()) for n in names])
-    ref = np.array([float(rg[n].double().norm()) for n in names])
+    ref = np.array([ref_norm[n] for n in names])
     ratio = np.abs(got - ref) / np.maximum(ref, 1e-12)
+    cols = torch.from_numpy(g["logit_cols"].astype(np.int64)).cuda()
+    lsample = logits.detach().gather(1, cols).cpu().numpy()
+    rep = dict(loss_rel=abs(float(loss.detach()) - float(g["loss"])) / abs(float(g["loss"])),
+               max_dlogit=float(np.abs(lsample - g["logit_vals"]).max()),
+               max_dfeature=float((feats.detach().cpu() - torch.from_numpy(g["features"])).abs().max()),
+               feat_cos_min=float(torch.nn.functional.cosine_similarity(feats.detach().cpu().float(),
+                                                                         torch.from_numpy(g["features"]), dim=1).min()))
+    probes = {}
+    for key in g.files:
+        if key.startswith("gi."):
+            n = key[3:]
+            v = named[n].grad.detach().reshape(-1)[torch.from_numpy(g[key]).cuda()].cpu().double().numpy()
+            r = g["g." + n].astype(np.float64)
+            probes[n] = (float(v @ r / (np.linalg.norm(v) * np.linalg.norm(r) + 1e-300)),
+                         float(np.linalg.norm(v) / (np.linalg.norm(r) + 1e-300)))
+    return rep, names, ratio, probes, prefix, g, m
+
+
+@pytest.mark.parametrize("tag,kind,head_name,N,B", BENCH_SIZE, ids=[c[0] for c in BENCH_SIZE])
+def test_bench_size_step_tracks_the_reference(golden_dir, tag, kind, head_name, N, B):
+    """The BASELINE configs at THEIR sizes, as bench.py times them (headline + `other_configs`) -- IR-50 + ArcFace(7000 / 28000)
+    bs 256, IR-SE-101 + CosFace(28000) bs 128, pSp (IR-SE-50 trunk, 6-channel stem, average image) + ArcFace(28000) bs 256 and
+    ArcFace(100) bs 100, Focal loss, bf16 storage, the large-batch kernel instances -- against the REFERENCE's own fp32 step
+    at that size (g13 captures; rounds 3-4 compared with the CPU oracle run inside the test, 130 s of host time per suite run):
+    loss, features, every per-parameter gradient norm, and direction + norm of gradient tensors along the whole depth (on a
+    fixed sample of their elements).  At 100-256 images the bf16 noise averages down: the bars are tighter than the batch-4 / 8 /
+    16 golden fixtures' (the squeeze-excite fc1 weights keep their own bar, see SE_FC1_BARS)."""
+    _need_gpu()
+    rep, names, ratio, probes, prefix, g, m = _bench_size_step(golden_dir, tag, kind, head_name, N, B, torch.bfloat16)
     gate = np.array([n.endswith(SE_FC1) for n in names])
     plain = ratio[~gate]
     worst = int(np.argmax(np.where(gate, 0, ratio)))
-    rep = dict(loss_rel=loss_rel, feat_cos_min=feat_cos, norms_median=float(np.median(plain)),
-               norms_p95=float(np.percentile(plain, 95)), norms_worst=float(ratio[worst]), worst_name=names[worst],
-               se_fc1_worst=float(ratio[gate].max()) if gate.any() else 0.0, tensors=len(names))
-    print("\nbf16 %s step vs oracle: %s" % (tag, json.dumps(rep)))
+    rep.update(norms_median=float(np.median(plain)), norms_p95=float(np.percentile(plain, 95)), norms_worst=float(ratio[worst]),
+               worst_name=names[worst], se_fc1_worst=float(ratio[gate].max()) if gate.any() else 0.0, tensors=len(names))
+    print("\nbf16 %s step vs the reference: %s" % (tag, json.dumps(rep)))
     # measured (round 3, MI355X), IR-50 bs 256: loss 1e-4, features 0.99976, norms median 0.2 % / p95 2.1 % / worst 6.0 % (the BN1
     # weight of unit 0), captured tensors cos 0.987 (first units) ... 0.9998 (output layer), norm ratios within 0.12 %
-    assert loss_rel < 2e-3 and feat_cos > 0.9995, rep
+    assert rep["loss_rel"] < 2e-3 and rep["feat_cos_min"] > 0.9995, rep
     # (the other three configs: median 0.2-0.3 %, p95 1.9-3.3 % -- the 28 000-class IR-50 case is the 3.3 --, worst 3.5-5.1 %)
     assert rep["norms_median"] < 0.005 and rep["norms_p95"] < 0.05 and rep["norms_worst"] < 0.10, rep
     assert rep["se_fc1_worst"] < SE_FC1_BARS["grad_norm_ratio"], rep
-    stem = prefix + "input_layer.0.weight"
-    probe = [stem] + [prefix + "body.%d.res_layer.%d.weight" % (u, k) for u, k in ((0, 1), (0, 3), (3, 3), (12, 1), (21, 3), (23, 1))]
-    probe.append(prefix + "output_layer.3.weight")
-    for n in probe:
-        c = float(cosf(named[n].grad.detach().cpu().double().reshape(1, -1), rg[n].double().reshape(1, -1)))
-        r = float(named[n].grad.double().norm()) / float(rg[n].double().norm())
+    for n, (c, r) in sorted(probes.items()):
         print("   grad %-44s cos %.5f  norm ratio %.4f" % (n, c, r))
-        assert c > 0.975 and abs(r - 1) < 0.02, (n, c, r)
-    c = float(cosf(head.weight.grad.detach().cpu().double().reshape(1, -1), rg["head.weight"].double().reshape(1, -1)))
-    assert c > 0.999, c
+        if n.endswith(("output_layer.4.weight", "res_layer.4.weight")):  # BatchNorm weights: a few hundred elements
+            assert c > 0.95 and abs(r - 1) < 0.05, (n, c, r)
+        elif n == "head.weight":
+            assert c > 0.999, (n, c)
+        else:
+            assert c > 0.975 and abs(r - 1) < 0.02, (n, c, r)
 
 
-def test_configs0_fp32_step_at_its_own_size():
-    """BASELINE configs[0] on the fp32 parity path at its own size -- pSp (IR-SE-50 trunk, 6-channel stem, average image) +
-    ArcFace over 100 identities, batch 100 (reference configs/config_BUPT_IR_50_baseline.py:20,33), Focal loss -- against the
-    fp32 CPU oracle: logits within north_star's 1e-3 (max |dlogit|), loss, and every parameter gradient norm.  The fixture
-    tests run this network at batch 8 and the train driver at batch 20; 100 images is the size the reference's own config
-    names."""
+@pytest.mark.parametrize("tag,kind,head_name,N,B", BENCH_SIZE, ids=[c[0] for c in BENCH_SIZE])
+def test_bench_size_fp32_step_matches_the_reference(golden_dir, tag, kind, head_name, N, B):
+    """north_star's parity sentence at the sizes it names: the fp32 path of every BASELINE config AT ITS OWN SIZE -- headline:
+    IR-50 + ArcFace(7000), 256 images (head/metrics.py:97-140); IR-SE-101 + CosFace(28000), 128 images (:164-191) -- against
+    the reference's fp32 step (g13 captures): logits within 1e-3 (label column + 63 columns of every row), loss 1e-4, features
+    1e-3, every per-parameter gradient norm, gradient tensors along the depth.  Rounds 1-4 checked the fp32 path against
+    batch-4 ... 16 fixtures and, at batch 100, the oracle."""
     _need_gpu()
-    from head.metrics import ArcFace
-    from loss.focal import FocalLoss
-    from oracle import irse_ref as O
-    B, N = 100, 100
-    x = synth.uniform(35, "c0.x", (B, 3, 112, 112))
-    y = synth.labels(35, "c0.y", B, N)
-    m, prefix = build("pSp")
-    m.encoder.compute_dtype = torch.float32
-    m.train()
-    head = ArcFace(512, N, None).cuda()
-    with torch.no_grad():
-        head.weight.copy_(synth.uniform(35, "c0.head", (N, 512), -0.05, 0.05))
-    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
-    for k, v in sd.items():
-        if v.is_floating_point() and "running_" not in k and "avg_image" not in k:
-            v.requires_grad_(True)
-    hw = head.weight.detach().cpu().clone().requires_grad_(True)
-    feats = m(x.cuda())
-    logits = head(feats, y.cuda())
-    loss, _ = FocalLoss()(logits, y.cuda())
-    loss.backward()
-    torch.cuda.synchronize()
-    assert m.encoder._runner[0].plan.tdtype == torch.float32
-    avg = synth.uniform(15, "avg_image", (3, 112, 112))
-    rf, rl, rloss, rg = O.train_step(sd, x, y, hw, num_layers=50, se=True, prefix=prefix, avg_image=avg, head="ArcFace",
-                                     s=64.0, m=0.5)
-    dlogit = float((logits.detach().cpu() - rl.detach()).abs().max())
-    loss_rel = abs(float(loss.detach()) - float(rloss.detach())) / abs(float(rloss.detach()))
-    named = dict(m.named_parameters())
-    names = [n for n in named if n in rg and named[n].grad is not None and not n.endswith(ZERO_GRAD_SUFFIXES)]
-    got = np.array([float(named[n].grad.double().norm()) for n in names])
-    ref = np.array([float(rg[n].double().norm()) for n in names])
-    ratio = np.abs(got - ref) / np.maximum(ref, 1e-12)
+    rep, names, ratio, probes, prefix, g, m = _bench_size_step(golden_dir, tag, kind, head_name, N, B, torch.float32)
     worst = int(np.argmax(ratio))
-    rep = dict(max_dlogit=dlogit, loss_rel=loss_rel, norms_median=float(np.median(ratio)),
-               norms_p95=float(np.percentile(ratio, 95)), norms_worst=float(ratio[worst]), worst_name=names[worst],
-               tensors=len(names))
-    print("\nfp32 configs[0] step (pSp, ArcFace(100), bs 100) vs oracle: %s" % json.dumps(rep))
-    assert dlogit < 1e-3 and loss_rel < 1e-4, rep
+    rep.update(norms_median=float(np.median(ratio)), norms_p95=float(np.percentile(ratio, 95)), norms_worst=float(ratio[worst]),
+               worst_name=names[worst], tensors=len(names))
+    print("\nfp32 %s step vs the reference: %s" % (tag, json.dumps(rep)))
+    assert rep["max_dlogit"] < 1e-3 and rep["loss_rel"] < 1e-4 and rep["max_dfeature"] < 1e-3, rep
     assert rep["norms_median"] < 1e-3 and rep["norms_p95"] < 5e-3 and rep["norms_worst"] < 2.5e-2, rep
+    for n, (c, r) in sorted(probes.items()):
+        print("   grad %-44s cos %.6f  norm ratio %.5f" % (n, c, r))
+        assert c > 0.999 and abs(r - 1) < 5e-3, (n, c, r)
+    bufs = dict(m.named_buffers())
+    for key in g.files:
+        if key.startswith("buf."):
+            got = bufs[key[4:]].detach().cpu().numpy()
+            assert np.abs(got - g[key]).max() < 1e-4 * max(1.0, float(np.abs(g[key]).max())), key

@@ -175,6 +175,31 @@ def test_full_models(golden_dir, spec):
             _close(sd[k[4:]], g[k], 1e-5)
 
 
+def test_oracle_at_a_baseline_config_size(golden_dir):
+    """Round 5: the oracle against the reference's own step at a BASELINE size -- configs[0]: pSp (IR-SE-50 trunk, 6-channel
+    stem, average image) + ArcFace(100), batch 100 (g13 capture; the four larger configs take a minute and tens of GB each and
+    are replayed by the GPU suite against the HIP path instead)."""
+    g = _load(golden_dir, "g13_configs0_psp_arc100_b100")
+    sd, info = build_state(golden_dir, "pSp")
+    B, N = 100, 100
+    x = synth.uniform(33, "big.x", (B, 3, 112, 112))
+    label = synth.labels(33, "big.y", B, N)
+    hw = synth.uniform(33, "big.head", (N, 512), -0.05, 0.05).requires_grad_(True)
+    avg = synth.uniform(15, "avg_image", (3, 112, 112))
+    feats, logits, loss, grads = O.train_step(sd, x, label, hw, num_layers=50, se=True, prefix="encoder.", avg_image=avg,
+                                              head="ArcFace", s=64.0, m=0.5)
+    _close(feats, g["features"], 1e-5)
+    _close(loss, g["loss"], 1e-5)
+    cols = torch.from_numpy(g["logit_cols"].astype(np.int64))
+    _close(logits.detach().gather(1, cols), g["logit_vals"], 1e-5 * 64)
+    names = list(g["grad_names"])
+    norms = np.array([float(grads[n].double().norm()) for n in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-3, atol=1e-7)
+    for k in g.files:
+        if k.startswith("gi."):
+            _close(grads[k[3:]].detach().reshape(-1)[torch.from_numpy(g[k])], g["g." + k[3:]], 1e-4, 2e-3)
+
+
 def test_g7_two_sgd_steps(golden_dir):
     """A0/A15: two full steps with the param-group split (is_bn_key) and oracle sgd_step."""
     g = _load(golden_dir, "g7_sgd")

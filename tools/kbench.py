@@ -92,10 +92,6 @@ def conv_case(kind, cin, cout, W, B, stride=1, pro=1, epi=1, mode=0, iters=20):
               part=part)
     TOUCH[:] = [src, aux]
     flops = 2.0 * B * Ho * Ho * N * 9 * SC  # stride 2: both directions do 9 taps per LOW-res pixel
-    if os.environ.get("KBENCH_GRIDBAR", "0") == "1":  # libfrhip_gridbar.so: counters + coefficient scratch behind cos_t
-        kw["cos_t"] = torch.zeros(16 + 2 * 512, device="cuda")
-    if pro == 3:  # FR_PRO_BNBWD2: two sources, three coefficient vectors, the operand stored on the way
-        kw.update(src2=rnd(*src.shape), pro_c=vb, pro_out=torch.empty_like(src))
     if pro == 4:  # FR_PRO_RESBN: the residual sum formed by its consumer (two sources, two coefficient pairs, stored once)
         kw.update(src2=rnd(*src.shape), pro_c=va, pro_d=vb, pro_out=torch.empty_like(src))
     if kind == "s2":  # stride-2 parity-plane kernel: mode 0 forward (W = input side), mode 2 all-class data gradient
@@ -163,9 +159,7 @@ def suite_cases(B):
         # (FR_EPI_STATS_X -- `strip 256 256 14 --pro 2 --epi 8` -- shares its kernel name with the case above: not in the suite,
         # whose PMC rows are matched by name)
         ("strip_256_256_14_dgrad", lambda it: conv_case("strip", 256, 256, 14, B, pro=0, epi=2, mode=1, iters=it)),
-        ("strip_256_256_14_dgrad_bnbwd2", lambda it: conv_case("strip", 256, 256, 14, B, pro=3, epi=2, mode=1, iters=it)),
         ("strip_128_128_28_dgrad", lambda it: conv_case("strip", 128, 128, 28, B, pro=0, epi=2, mode=1, iters=it)),
-        ("strip_128_128_28_dgrad_bnbwd2", lambda it: conv_case("strip", 128, 128, 28, B, pro=3, epi=2, mode=1, iters=it)),
         ("wgs_256_256_14", lambda it: wgrad_case("wgs", 256, 256, 14, B, pro=2, iters=it)),
         ("wgs_256_256_14_bn", lambda it: wgrad_case("wgs", 256, 256, 14, B, pro=1, iters=it)),
         ("wgs_512_512_7", lambda it: wgrad_case("wgs", 512, 512, 7, B, pro=2, iters=it)),
