@@ -375,12 +375,16 @@ int fr_se_gscale(const void* g, const void* x, const float* scale, const float* 
 int fr_se_mlp_bwd(const float* gs, const float* s, const float* hidden, const float* pooled, const float* w1,
                   const float* w2, float* gpooled, float* dw1, float* dw2, float* gz, float* gh, int B, int C, int R,
                   int HW, void* stream);
-/* fr_se_gscale followed by fr_se_mlp_bwd with one launch less (gs stays in LDS; same arithmetic, same order): the backward
- * of the squeeze-excite branch of bottleneck_IR_SE (model_irse.py:23-46); g = gradient at the unit output branch, x = y2 */
+/* fr_se_gscale followed by fr_se_mlp_bwd: the backward of the squeeze-excite branch of bottleneck_IR_SE (model_irse.py:23-46);
+ * g = gradient at the unit output branch, x = y2.  gs_part == NULL: one 1024-thread workgroup per image, gs stays in LDS (same
+ * arithmetic and order as the two calls).  gs_part != NULL (round 5; scratch [B][fr_se_gscale_slices(B, HW)][C] floats): the
+ * squeeze runs over row slices of an image in 256-thread workgroups (B x slices of them: every CU has work at batch 128, and
+ * they fit beside resident weight-gradient workgroups), the slices are added in order in front of the MLP part. */
 int fr_se_gscale_mlp_bwd(const void* g, const void* x, const float* scale, const float* shift, const float* s,
                          const float* hidden, const float* pooled, const float* w1, const float* w2, float* gpooled,
-                         float* dw1, float* dw2, float* gz, float* gh, int B, int C, int R, int HW, int dtype,
+                         float* dw1, float* dw2, float* gz, float* gh, float* gs_part, int B, int C, int R, int HW, int dtype,
                          void* stream);
+int fr_se_gscale_slices(int B, int HW);
 
 /* ---- output layer pieces (model_irse.py:144-148) */
 /* a[b][(h*7+w)*C + c] = dropout(x*scale+shift): mask from a counter hash of (seed, element index in the

@@ -936,6 +936,77 @@ __global__ __launch_bounds__(SNT_GS) void se_gscale_mlp_bwd_kernel(const T* __re
   se_mlp_bwd_body(sm, s, hidden, w1, w2, gpooled, gz_out, gh_out, C, R, inv_hw, sm + C, sm + 2 * C);
 }
 
+// Round 5: the gradient squeeze over S row slices per image, 256-thread workgroups (B x S of them).  The fused kernel above is
+// one 1024-thread workgroup per image: at batch 128 (IR-SE-101) half the CUs have none, and with four waves per SIMD it finds
+// no room beside the resident weight-gradient workgroups of the side stream (18 us per unit in the step for 25 MB of reads).
+// part[(b*S + s)][c] = sum over the rows of slice s of g * (x*scale + shift); se_mlp_bwd_parts_kernel adds the S rows of an
+// image in slice order and runs the MLP part.
+template <typename T>
+__global__ __launch_bounds__(256) void se_gsq_part_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float* __restrict__ part, int HW, int C, int S) {
+  constexpr int VEC = Elt<T>::VEC;
+  __shared__ float red[256 * VEC];
+  const int cpr = C / VEC, tid = threadIdx.x, b = blockIdx.x, sl = blockIdx.y;
+  const int cc = tid % cpr, rtc = 256 / cpr, rt = tid / cpr, c0 = cc * VEC;
+  const int r_lo = (int)((long long)HW * sl / S), r_hi = (int)((long long)HW * (sl + 1) / S);
+  float acc[VEC], scv[VEC], shv[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    acc[j] = 0.f;
+    scv[j] = scale[c0 + j];
+    shv[j] = shift[c0 + j];
+  }
+  constexpr int UN = 8;
+  for (int r0 = r_lo + rt; r0 < r_hi; r0 += rtc * UN) {
+    U128 xv[UN], gq[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      int r = r0 + u * rtc;
+      r = r < r_hi ? r : r_hi - 1;  // clamp: the batch of loads stays branch-free (the duplicate is not added)
+      xv[u] = ld16(x + ((size_t)b * HW + r) * C + c0);
+      gq[u] = ld16(g + ((size_t)b * HW + r) * C + c0);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (r0 + u * rtc < r_hi) {
+        float f[VEC], gv[VEC];
+        unpack16<T>(xv[u], f);
+        unpack16<T>(gq[u], gv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = fmaf(gv[j], fmaf(f[j], scv[j], shv[j]), acc[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[tid * VEC + j] = acc[j];
+  __syncthreads();
+  if (rt == 0) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float t = 0.f;
+      for (int r = 0; r < rtc; ++r) t += red[(r * cpr + cc) * VEC + j];
+      part[((size_t)b * S + sl) * C + c0 + j] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void se_mlp_bwd_parts_kernel(const float* __restrict__ part, int S,
+                                                               const float* __restrict__ s, const float* __restrict__ hidden,
+                                                               const float* __restrict__ w1, const float* __restrict__ w2,
+                                                               float* __restrict__ gpooled, float* __restrict__ gz_out,
+                                                               float* __restrict__ gh_out, int C, int R, float inv_hw) {
+  extern __shared__ float sm[];  // [C] gs, [C] gz, [R] gh
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float t = 0.f;
+    for (int k = 0; k < S; ++k) t += part[((size_t)b * S + k) * C + c];
+    sm[c] = t;
+  }
+  __syncthreads();
+  se_mlp_bwd_body(sm, s, hidden, w1, w2, gpooled, gz_out, gh_out, C, R, inv_hw, sm + C, sm + 2 * C);
+}
+
 // weight part: dW1[r][c] = sum_b gh[b][r] * pooled[b][c],  dW2[c][r] = sum_b gz[b][c] * hidden[b][r].  Block = 64
 // channels x 4 batch quarters of one r; each thread walks its quarter with 8 independent loads in flight, the four
 // partial sums are added in quarter order through LDS (reproducible); overwrites.
@@ -1581,16 +1652,37 @@ extern "C" int fr_se_mlp_bwd(const float* gs, const float* s, const float* hidde
   FR_LAUNCH_CHECK();
 }
 
+extern "C" int fr_se_gscale_slices(int B, int HW) {
+  int S = (512 + B - 1) / B;  // >= 512 workgroups of one wave per SIMD: they fit beside a resident weight-gradient workgroup
+  if (S > 8) S = 8;
+  if (S > HW) S = HW;
+  return S < 1 ? 1 : S;
+}
+
 extern "C" int fr_se_gscale_mlp_bwd(const void* g, const void* x, const float* scale, const float* shift, const float* s,
                                     const float* hidden, const float* pooled, const float* w1, const float* w2,
-                                    float* gpooled, float* dw1, float* dw2, float* gz, float* gh, int B, int C, int R,
-                                    int HW, int dtype, void* stream) {
+                                    float* gpooled, float* dw1, float* dw2, float* gz, float* gh, float* gs_part, int B, int C,
+                                    int R, int HW, int dtype, void* stream) {
   if (!gz || !gh) FR_UNSUPPORTED("fr_se_gscale_mlp_bwd: gz [B][C] and gh [B][R] scratch are required");
   if (!chan_ok(C, dtype)) FR_UNSUPPORTED("fr_se_gscale_mlp_bwd: unsupported channel count");
   const int vec = dtype == FR_BF16 ? 8 : 4;
   if (C % vec || C / vec > SNT_GS || SNT_GS % (C / vec)) FR_UNSUPPORTED("fr_se_gscale_mlp_bwd: C / vector width must divide the block");
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)(2 * C + R) * sizeof(float);
+  if (gs_part && C / vec <= 256 && 256 % (C / vec) == 0) {  // round 5: the squeeze over row slices (scratch [B][slices][C])
+    const int S = fr_se_gscale_slices(B, HW);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(se_gsq_part_kernel<float>, dim3(B, S), dim3(256), 0, st, (const float*)x, (const float*)g,
+                                  scale, shift, gs_part, HW, C, S),
+               hipLaunchKernelGGL(se_gsq_part_kernel<bf16_t>, dim3(B, S), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g,
+                                  scale, shift, gs_part, HW, C, S),
+               "fr_se_gscale_mlp_bwd");
+    hipLaunchKernelGGL(se_mlp_bwd_parts_kernel, dim3(B), dim3(256), lds, st, gs_part, S, s, hidden, w1, w2, gpooled, gz, gh, C,
+                       R, 1.0f / (float)HW);
+    hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, gz, gh, hidden, pooled, dw1, dw2, B, C,
+                       R);
+    FR_LAUNCH_CHECK();
+  }
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(se_gscale_mlp_bwd_kernel<float>, dim3(B), dim3(SNT_GS), lds, st, (const float*)x,
                                 (const float*)g, scale, shift, s, hidden, w1, w2, gpooled, gz, gh, HW, C, R,

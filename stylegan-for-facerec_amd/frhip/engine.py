@@ -412,6 +412,7 @@ class BackbonePlan(object):
         if self.side_slope:
             self.part_slope = [torch.zeros_like(self.part) for _ in range(nset)]
         self.se_scratch = torch.zeros(2, 512 * 64, device=dev)  # dW1/dW2 sink while the SE weights are frozen
+        self.se_gs_part = torch.empty(B * 8 * 512, device=dev)  # row-slice partials of the squeeze-excite gradient squeeze
         self.sums = torch.zeros(3, 512, device=dev)      # scratch reduce target for frozen parameters
         self.nbt_dummy = None
 
@@ -1066,13 +1067,16 @@ class BackbonePlan(object):
                 if g2 is None:
                     g2 = self.se_scratch[1, :R * u.depth]
                 # gradient wrt the excite scale (a pass over g and y2) + the MLP backward of the same image in one launch.
+                # Round 5: with fewer images than CUs the squeeze runs over row slices of an image in 256-thread workgroups
+                # (IR-SE-101 + CosFace(28000), bs 128: 17.57 against 17.66-17.81 ms per step; at bs 256 -- pSp -- the one
+                # 1024-thread workgroup per image is the faster one: 16.05 against 16.17; profiles/r05_ab_se_slices.txt).
                 # (Round 4, measured and removed: the same pass also leaving the per-image sums BN2's backward needs, so that
                 # fr_bn_bwd_reduce disappears from the IR-SE units -- IR-SE-101 + CosFace(28000), bs 128: 19.50-19.52 against
                 # 19.22-19.30 ms per step; pSp bs 256: 17.31 against 17.22; profiles/r04_ab_se_sums.txt: the pass it deleted ran
                 # beside the weight gradients of the side stream, the extra work sat in a 128-workgroup launch.)
                 L.append(ops.call("fr_se_gscale_mlp_bwd", g_out, d["y2"], bn2.scale, bn2.shift, d["s"], d["hidden"],
                                   d["pooled"], u.se.fc1.weight, u.se.fc2.weight, d["gpooled"], g1, g2, d["gz"],
-                                  d["gh"], B, u.depth, R, HWo, fr, st))
+                                  d["gh"], self.se_gs_part if B <= 160 else None, B, u.depth, R, HWo, fr, st))
                 se_kw = dict(se=d["s"], gse=d["gpooled"])
                 ready += [u.se.fc1.weight, u.se.fc2.weight]
             db, dg = self._bn_grads(bn2)

@@ -24,7 +24,13 @@ from util.utils import accuracy  # noqa: E402
 
 
 def main():
-    args = argparse.Namespace(model="IR_50", head="ArcFace", classes=7000, batch=256, dtype="bf16", sharded_head=False,
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="IR_50")
+    ap.add_argument("--head", default="ArcFace")
+    ap.add_argument("--classes", type=int, default=7000)
+    ap.add_argument("--batch", type=int, default=256)
+    a = ap.parse_args()
+    args = argparse.Namespace(model=a.model, head=a.head, classes=a.classes, batch=a.batch, dtype="bf16", sharded_head=False,
                               resident_batches=4)
     dev = torch.device("cuda", 0)
     model, head, loss_fn, opt, xs, ys = bench.build_job(args, dev, 0)
