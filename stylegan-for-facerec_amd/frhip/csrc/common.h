@@ -36,14 +36,21 @@ extern "C" void fr_set_error(const char* msg);
     return 0;                                  \
   } while (0)
 
-// hipFuncSetAttribute (dynamic LDS above 64 KB) is per function AND per device: launchers keep one bit per device
+// hipFuncSetAttribute (dynamic LDS above 64 KB) is per function AND per device: launchers keep one bit per device.  The mask
+// is updated atomically (host threads driving different devices may launch the same instance for the first time together);
+// a thread that loses the race sets the attribute once more, which is harmless.  Devices 64 and above always set it.
 inline bool fr_attr_needed(unsigned long long& done_mask) {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const unsigned long long bit = 1ull << (dev & 63);
-  if (done_mask & bit) return false;
-  done_mask |= bit;
+  if (dev >= 64) return true;
+  const unsigned long long bit = 1ull << dev;
+  if (__atomic_load_n(&done_mask, __ATOMIC_ACQUIRE) & bit) return false;
   return true;
+}
+inline void fr_attr_done(unsigned long long& done_mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 64) __atomic_fetch_or(&done_mask, 1ull << dev, __ATOMIC_RELEASE);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -486,6 +486,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
   if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_roll64_kernel<W, PRO, AUX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, R64::LDS);
+    fr_attr_done(attr_done);
   }
   const int nseg = roll_nseg(a.B, W);
   const int items = a.B * (W / R64::BW) * nseg;

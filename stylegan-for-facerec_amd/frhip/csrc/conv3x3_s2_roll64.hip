@@ -533,6 +533,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
   if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_s2_roll64_kernel<KIND, PRO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LY::LDS);
+    fr_attr_done(attr_done);
   }
   const int nseg = s2roll_nseg(a.B);
   const int items = a.B * nseg;

@@ -541,6 +541,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute(
         reinterpret_cast<const void*>(&conv3x3_s2_kernel<CIN, COUT, WL, ROWS, WN, NW, KIND, PRO, NSPL, NIMG>),
         hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    fr_attr_done(attr_done);
   }
   hipLaunchKernelGGL((conv3x3_s2_kernel<CIN, COUT, WL, ROWS, WN, NW, KIND, PRO, NSPL, NIMG>),
                      dim3(a.B * C::NS / NIMG * NSPL), dim3(C::NTH), C::LDS, st, a, s2_xcd_order());

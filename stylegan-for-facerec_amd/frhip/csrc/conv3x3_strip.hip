@@ -513,6 +513,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute(
         reinterpret_cast<const void*>(&conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, NSPL, PRO, NIMG, KSPL>),
         hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    fr_attr_done(attr_done);
   }
   const int strips = a.B * C::NS / NIMG;
   if (a.epi == FR_EPI_STATS_X && (!a.part || !a.aux))

@@ -466,6 +466,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
   if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BN, PRO>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    fr_attr_done(attr_done);
   }
   hipLaunchKernelGGL((conv_igemm_kernel<T, BN, PRO>), grid, dim3(NT), C::LDS_BYTES, st, a);
   FR_LAUNCH_CHECK();

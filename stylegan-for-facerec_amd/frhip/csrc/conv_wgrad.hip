@@ -237,6 +237,7 @@ int launch(const FrWgradArgs& a, hipStream_t st) {
   if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<T, BCO, BCI, PRO>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    fr_attr_done(attr_done);
   }
   hipLaunchKernelGGL((conv_wgrad_kernel<T, BCO, BCI, PRO>), grid, dim3(NT), LDS, st, a);
   if (a.slab) {  // reproducible mode: every pixel slice wrote its own slab; add them in a fixed order into dw

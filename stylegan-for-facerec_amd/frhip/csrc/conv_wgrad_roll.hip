@@ -1168,6 +1168,7 @@ int launch_s2(const FrWgradArgs& a, hipStream_t st) {
   if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_s2roll_kernel<WL, PRO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS);
+    fr_attr_done(attr_done);
   }
   const int tiles = (a.Cout / CT) * (a.SC / CT);
   hipLaunchKernelGGL((conv_wgrad_s2roll_kernel<WL, PRO>), dim3(tiles * a.nsplit), dim3(512), L::LDS, st, a);
@@ -1197,6 +1198,7 @@ int launch_vr(const FrWgradArgs& a, hipStream_t st) {
   if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_vr_kernel<W, PRO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    fr_attr_done(attr_done);
   }
   const int tiles = (a.Cout / CT) * (a.SC / CT);
   hipLaunchKernelGGL((conv_wgrad_vr_kernel<W, PRO>), dim3(tiles * a.nsplit), dim3(512), C::LDS, st, a);
@@ -1226,6 +1228,7 @@ int launch(const FrWgradArgs& a, hipStream_t st) {
   if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_roll_kernel<W, PRO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS);
+    fr_attr_done(attr_done);
   }
   const int tiles = (a.Cout / CT) * (a.SC / CT);
   hipLaunchKernelGGL((conv_wgrad_roll_kernel<W, PRO>), dim3(tiles * a.nsplit), dim3(512), L::LDS, st, a);

@@ -393,6 +393,7 @@ int launch(const FrWgradArgs& a, hipStream_t st) {
   if (fr_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<W, ROWS, NIMG, NW, PRO, S2, RK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    fr_attr_done(attr_done);
   }
   const int tiles = (a.Cout / CT) * (a.SC / CT);
   hipLaunchKernelGGL((conv_wgrad_strip_kernel<W, ROWS, NIMG, NW, PRO, S2, RK>), dim3(tiles * a.nsplit), dim3(C::NTH), C::LDS,

@@ -262,41 +262,54 @@ def perform_val(multi_gpu, device, embedding_size, batch_size, backbone, carray,
     if world > 1:
         import torch.distributed as dist
         own_buffers = [b.detach().clone() for b in backbone.buffers()]
+        # rank 0's buffers in ONE broadcast per dtype (a flat copy; 150+ small collectives per validation set otherwise)
+        by_dtype = {}
         for b in backbone.buffers():
-            dist.broadcast(b.data, src=0, group=group)
-    n = len(carray)
-    is_dev = torch.device(device).type == "cuda"
-    sums = torch.zeros(n, embedding_size, device=device, dtype=torch.float32)  # f(img) [+ f(hflip(img))], on the device
-    # two pinned staging buffers: the host prepares batch i+1 while the GPU works on batch i, and nothing in the loop waits
-    # for the device (the reference copies every batch's embeddings back before it reads the next batch)
-    stage, free = [None, None], [None, None]
-    with torch.no_grad():
-        for k, idx in enumerate(range(rank * batch_size, n, batch_size * world)):
-            host = torch.from_numpy(np.ascontiguousarray(carray[idx:idx + batch_size], dtype=np.float32))
-            if host.shape[-1] == 3:
-                host = host.permute(0, 3, 1, 2)
-            if is_dev:
-                slot = k & 1
-                if stage[slot] is None or stage[slot].shape != host.shape:
-                    stage[slot] = torch.empty(host.shape, dtype=torch.float32).pin_memory()
-                if free[slot] is not None:
-                    free[slot].synchronize()  # the copy that last read this buffer is done
-                stage[slot].copy_(host)
-                batch = stage[slot].to(device, non_blocking=True)
-                free[slot] = torch.cuda.Event()
-                free[slot].record()
-            else:
-                batch = host.contiguous().to(device)
-            cropped = ccrop_batch(batch) if ccrop else batch  # crop and flip run on the device (one launch each)
-            emb = backbone(cropped)
-            if tta:
-                emb = emb + backbone(hflip_batch(cropped))  # fp32 add: same bits as on the host
-            sums[idx:idx + batch.shape[0]] = emb
-    if world > 1:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-        with torch.no_grad():  # training continues with this rank's own running statistics
-            for b, mine in zip(backbone.buffers(), own_buffers):
-                b.data.copy_(mine)
+            by_dtype.setdefault(b.dtype, []).append(b)
+        for bufs in by_dtype.values():
+            flat = torch.cat([b.detach().reshape(-1) for b in bufs])
+            dist.broadcast(flat, src=0, group=group)
+            off = 0
+            with torch.no_grad():
+                for b in bufs:
+                    b.data.copy_(flat[off:off + b.numel()].view_as(b))
+                    off += b.numel()
+    try:
+        n = len(carray)
+        is_dev = torch.device(device).type == "cuda"
+        sums = torch.zeros(n, embedding_size, device=device, dtype=torch.float32)  # f(img) [+ f(hflip(img))], on the device
+        # two pinned staging buffers: the host prepares batch i+1 while the GPU works on batch i, and nothing in the loop waits
+        # for the device (the reference copies every batch's embeddings back before it reads the next batch)
+        stage, free = [None, None], [None, None]
+        with torch.no_grad():
+            for k, idx in enumerate(range(rank * batch_size, n, batch_size * world)):
+                host = torch.from_numpy(np.ascontiguousarray(carray[idx:idx + batch_size], dtype=np.float32))
+                if host.shape[-1] == 3:
+                    host = host.permute(0, 3, 1, 2)
+                if is_dev:
+                    slot = k & 1
+                    if stage[slot] is None or stage[slot].shape != host.shape:
+                        stage[slot] = torch.empty(host.shape, dtype=torch.float32).pin_memory()
+                    if free[slot] is not None:
+                        free[slot].synchronize()  # the copy that last read this buffer is done
+                    stage[slot].copy_(host)
+                    batch = stage[slot].to(device, non_blocking=True)
+                    free[slot] = torch.cuda.Event()
+                    free[slot].record()
+                else:
+                    batch = host.contiguous().to(device)
+                cropped = ccrop_batch(batch) if ccrop else batch  # crop and flip run on the device (one launch each)
+                emb = backbone(cropped)
+                if tta:
+                    emb = emb + backbone(hflip_batch(cropped))  # fp32 add: same bits as on the host
+                sums[idx:idx + batch.shape[0]] = emb
+            if world > 1:
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    finally:
+        if own_buffers is not None:  # training continues with this rank's own running statistics, also after an exception
+            with torch.no_grad():
+                for b, mine in zip(backbone.buffers(), own_buffers):
+                    b.data.copy_(mine)
     embeddings = np.zeros([n, embedding_size])
     embeddings[:] = l2_norm(sums.cpu()).numpy()  # one copy back; normalisation on the host, as in the reference
     tpr, fpr, acc, best_thresholds = evaluate(embeddings, issame, nrof_folds)

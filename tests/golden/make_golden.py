@@ -563,7 +563,11 @@ def run_bench_size(tag):
         out["gi." + n] = idx
         out["g." + n] = npy(gd[n]).reshape(-1)[idx]
     bufs = dict(model.named_buffers())
-    for n in (prefix + "input_layer.1", prefix + "body.7.res_layer.4", prefix + "output_layer.4"):
+    # running statistics after the step: the stem, one BN2, the output BatchNorm1d -- and BN1 of EVERY unit: on the bf16 path
+    # those are derived from moments along chains of up to 30 identity units (FR_PRO_RESBN), never measured on the tensor
+    nunits = sum(1 for k in bufs if k.endswith(".res_layer.0.running_mean"))
+    for n in [prefix + "input_layer.1", prefix + "body.7.res_layer.4", prefix + "output_layer.4"] + \
+            [prefix + "body.%d.res_layer.0" % u for u in range(nunits)]:
         out["buf." + n + ".running_mean"] = npy(bufs[n + ".running_mean"])
         out["buf." + n + ".running_var"] = npy(bufs[n + ".running_var"])
     save(tag, **out)
