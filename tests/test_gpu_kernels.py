@@ -581,6 +581,43 @@ STRIP_CASES = [s + (3,) for s in STRIP_SHAPES] + [(512, 512, 7, 4), (512, 512, 7
                                                   (64, 64, 56, 162), (64, 64, 112, 130), (64, 64, 56, 40)]
 
 
+def _image_subset(B):
+    """Images whose results are compared with the CPU reference: all of them up to 32; beyond that three blocks (the first 8, 8
+    in the middle, the last 8-11, block starts multiples of 4 so that a block is whole partial rows of the multi-image 7x7
+    workgroups).  A convolution is independent per image and the large-batch cases exist for the workgroup / item geometry:
+    every image is still computed by the kernel, the host just stops convolving 130-164 of them at 112x112 (22 s per case)."""
+    if B <= 32:
+        return list(range(B))
+    mid = (B // 2) // 8 * 8
+    return list(range(8)) + list(range(mid, mid + 8)) + list(range((B - 8) // 4 * 4, B))
+
+
+def _operand(B, sel, seed, tag, shape, dtype):
+    """A quantised NCHW activation as (CPU fp32 tensor of the images `sel`, device NHWC tensor of all images).  Up to 32 images
+    it comes from the repo's counter-based generator; the large-batch cases draw it on the device (104 M elements per tensor at
+    112x112 x 130 images took the host generator 3 s each) and copy the subset back."""
+    if B <= 32:
+        t = q(synth.normal(seed, tag, shape), dtype)
+        return t[sel], nhwc(t, dtype)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed * 1000 + sum((i + 1) * ord(c) for i, c in enumerate(tag)))
+    t = torch.randn(shape, device="cuda", generator=gen).to(dtype)
+    return t[sel].float().cpu(), t.permute(0, 2, 3, 1).contiguous()
+
+
+def _part_rows(nparts, B, sel):
+    """Partial rows that belong to the images `sel` (rows are image-major: whole strips / items of one image, or -- 7x7 -- one
+    row per group of 2 / 4 consecutive images)."""
+    if nparts % B == 0:
+        rpi = nparts // B
+        return [r for b in sel for r in range(b * rpi, (b + 1) * rpi)]
+    assert B % nparts == 0
+    ipr = B // nparts
+    rows = sorted({b // ipr for b in sel})
+    assert all(b in sel for r in rows for b in range(r * ipr, (r + 1) * ipr))
+    return rows
+
+
 @pytest.mark.parametrize("cin,cout,W,B", STRIP_CASES, ids=["%d_%d_%d_b%d" % s for s in STRIP_CASES])
 def test_conv3x3_strip(K, cin, cout, W, B):
     """LDS-resident-strip 3x3 s1 conv (bf16): forward with BN prologue + statistics, and the mirrored-tap data
@@ -589,14 +626,14 @@ def test_conv3x3_strip(K, cin, cout, W, B):
     dtype, tol = torch.bfloat16, BF16_TOL
     assert K.strip_parts(B, cin, cout, W) > 0
     st = K.current_stream_ptr()
-    x = q(synth.normal(31, "sx", (B, cin, W, W)), dtype)
+    sel = _image_subset(B)
+    xs, xd = _operand(B, sel, 31, "sx", (B, cin, W, W), dtype)
     w = q(synth.normal(31, "sw", (cout, cin, 3, 3), std=0.05), dtype)
     pa = synth.uniform(31, "spa", (cin,), 0.5, 1.5)
     pb = synth.uniform(31, "spb", (cin,), -0.5, 0.5)
     # the kernel's prologue is one fmaf: form the reference product-sum in double so that it is rounded once, too
-    xin = q((x.double() * pa.double().view(1, -1, 1, 1) + pb.double().view(1, -1, 1, 1)).float(), dtype)
+    xin = q((xs.double() * pa.double().view(1, -1, 1, 1) + pb.double().view(1, -1, 1, 1)).float(), dtype)
     ref = F.conv2d(xin, w, padding=1)
-    xd = nhwc(x, dtype)
     out = torch.zeros(B, W, W, cout, device="cuda", dtype=dtype)
     nparts = K.strip_parts(B, cin, cout, W)
     part = torch.zeros(nparts, 2, cout, device="cuda")
@@ -606,21 +643,21 @@ def test_conv3x3_strip(K, cin, cout, W, B):
                  pro_a=pa.cuda(), pro_b=pb.cuda(), epi=K.EPI_STORE if store_only else K.EPI_STATS, part=part,
                  **common)()
     torch.cuda.synchronize()
-    assert relerr(from_nhwc(out), ref) < tol
+    assert torch.isfinite(out.float()).all()
+    assert relerr(from_nhwc(out[sel]), ref) < tol
     if not store_only:
-        s = part.sum(0).cpu()
+        s = part[_part_rows(nparts, B, sel)].sum(0).cpu()
         np.testing.assert_allclose(s[0], ref.sum((0, 2, 3)), rtol=1e-2, atol=1e-2 * float(ref.abs().sum() / cout))
         np.testing.assert_allclose(s[1], (ref * ref).sum((0, 2, 3)), rtol=1e-2)
     # data gradient: g [B, cout, W, W] -> gx [B, cin, W, W] with weights given as [cin][tap][cout]
-    g = q(synth.normal(31, "sg", (B, cout, W, W)), dtype)
-    xg = synth.normal(31, "sxx", (B, cin, W, W)).requires_grad_(True)
-    (gx,) = torch.autograd.grad(F.conv2d(xg, w, padding=1), [xg], g)
+    gs_, gd = _operand(B, sel, 31, "sg", (B, cout, W, W), dtype)
+    xg = synth.normal(31, "sxx", (len(sel), cin, W, W)).requires_grad_(True)
+    (gx,) = torch.autograd.grad(F.conv2d(xg, w, padding=1), [xg], gs_)
     wt = w.permute(1, 2, 3, 0).reshape(cin, 9, cout).contiguous().to("cuda", dtype)
-    aux = q(synth.normal(31, "sa", (B, cin, W, W)), dtype)
+    auxs, auxd = _operand(B, sel, 31, "sa", (B, cin, W, W), dtype)
     slope = synth.uniform(31, "ss", (cin,), 0.1, 0.4)
     mean = synth.uniform(31, "sm", (cin,), -0.3, 0.3)
     invstd = synth.uniform(31, "si", (cin,), 0.5, 2.0)
-    gd, auxd = nhwc(g, dtype), nhwc(aux, dtype)
     nparts = K.strip_parts(B, cout, cin, W, K.EPI_BNBWD)
     if nparts == 0:
         return
@@ -632,18 +669,20 @@ def test_conv3x3_strip(K, cin, cout, W, B):
         if epi == "prelu":
             K.conv_strip(st, epi=K.EPI_PRELU_BWD, epi_a=slope.cuda(), **kw)()
             torch.cuda.synchronize()
-            want = torch.where(aux > 0, gx, gx * slope.view(1, -1, 1, 1))
-            assert relerr(from_nhwc(o), want) < tol
-            np.testing.assert_allclose(part.sum(0)[0].cpu(), (gx * aux * (aux <= 0)).sum((0, 2, 3)), rtol=1e-2,
-                                       atol=1e-2 * float((gx * aux).abs().sum() / cin))
+            want = torch.where(auxs > 0, gx, gx * slope.view(1, -1, 1, 1))
+            assert torch.isfinite(o.float()).all() and relerr(from_nhwc(o[sel]), want) < tol
+            ps = part[_part_rows(nparts, B, sel)].sum(0)
+            np.testing.assert_allclose(ps[0].cpu(), (gx * auxs * (auxs <= 0)).sum((0, 2, 3)), rtol=1e-2,
+                                       atol=1e-2 * float((gx * auxs).abs().sum() / cin))
         else:
             K.conv_strip(st, epi=K.EPI_BNBWD, epi_a=mean.cuda(), epi_b=invstd.cuda(), **kw)()
             torch.cuda.synchronize()
-            xh = (aux - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
-            assert relerr(from_nhwc(o), gx) < tol
-            np.testing.assert_allclose(part.sum(0)[0].cpu(), gx.sum((0, 2, 3)), rtol=1e-2,
+            xh = (auxs - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+            assert torch.isfinite(o.float()).all() and relerr(from_nhwc(o[sel]), gx) < tol
+            ps = part[_part_rows(nparts, B, sel)].sum(0)
+            np.testing.assert_allclose(ps[0].cpu(), gx.sum((0, 2, 3)), rtol=1e-2,
                                        atol=1e-2 * float(gx.abs().sum() / cin))
-            np.testing.assert_allclose(part.sum(0)[1].cpu(), (gx * xh).sum((0, 2, 3)), rtol=1e-2,
+            np.testing.assert_allclose(ps[1].cpu(), (gx * xh).sum((0, 2, 3)), rtol=1e-2,
                                        atol=1e-2 * float((gx * xh).abs().sum() / cin))
 
 
@@ -890,7 +929,8 @@ def test_conv3x3_s2_strip_forward(K, s2_walk, C, WL, B, walk, pro):
     H = 2 * WL
     if B > 6 and pro != "prelu":
         pytest.skip("large batches: the prologue the step uses")
-    x = q(synth.normal(61, "sx", (B, C, H, H)), dtype)
+    sel = _image_subset(B)
+    x, xd = _operand(B, sel, 61, "sx", (B, C, H, H), dtype)  # x: the images `sel` (all of them up to 32)
     w = q(synth.normal(61, "sw", (C, C, 3, 3), std=0.05), dtype)
     pa = synth.uniform(61, "spa", (C,), 0.5, 1.5)
     pb = synth.uniform(61, "spb", (C,), -0.3, 0.3)
@@ -907,15 +947,16 @@ def test_conv3x3_s2_strip_forward(K, s2_walk, C, WL, B, walk, pro):
     out = torch.zeros(B, WL, WL, C, device="cuda", dtype=dtype)
     part = torch.zeros(n, 2, C, device="cuda")
     a_dev = (pa * 0.25 if pro == "prelu" else pa).cuda()
-    K.conv_s2_strip(K.current_stream_ptr(), src=nhwc(x, dtype), w=pack_w(w, dtype), out=out, B=B, RH=WL, RW=WL, SH=H,
+    K.conv_s2_strip(K.current_stream_ptr(), src=xd, w=pack_w(w, dtype), out=out, B=B, RH=WL, RW=WL, SH=H,
                     SW=H, SC=C, N=C, KH=3, KW=3, stride=2, pad=1, mode=0, lda=C, ldc=C,
                     pro={"none": 0, "bn": 1, "prelu": 2}[pro], pro_a=a_dev, pro_b=pb.cuda(), epi=K.EPI_STATS,
                     part=part)()
     torch.cuda.synchronize()
-    got = from_nhwc(out)
-    assert relerr(got, y) < tol
-    np.testing.assert_allclose(part.sum(0)[0].cpu(), y.sum((0, 2, 3)), rtol=tol, atol=tol * float(y.abs().sum() / C))
-    np.testing.assert_allclose(part.sum(0)[1].cpu(), (y * y).sum((0, 2, 3)), rtol=tol)
+    got = from_nhwc(out[sel])
+    assert torch.isfinite(out.float()).all() and relerr(got, y) < tol
+    ps = part[_part_rows(n, B, sel)].sum(0)  # forward rows are image-major, the same number per image
+    np.testing.assert_allclose(ps[0].cpu(), y.sum((0, 2, 3)), rtol=tol, atol=tol * float(y.abs().sum() / C))
+    np.testing.assert_allclose(ps[1].cpu(), (y * y).sum((0, 2, 3)), rtol=tol)
 
 
 @pytest.mark.parametrize("C,WL,B,walk", S2_CASES, ids=["%d_%d_b%d%s" % s for s in S2_CASES])
@@ -925,12 +966,13 @@ def test_conv3x3_s2_strip_dgrad(K, s2_walk, C, WL, B, walk):
     dtype, tol = torch.bfloat16, BF16_TOL
     s2_walk(walk)
     H = 2 * WL
-    x = synth.normal(63, "dx", (B, C, H, H)).requires_grad_(True)
+    sel = _image_subset(B)
+    x = synth.normal(63, "dx", (len(sel), C, H, H)).requires_grad_(True)
     w = q(synth.normal(63, "dw", (C, C, 3, 3), std=0.05), dtype)
     y = F.conv2d(x, w, stride=2, padding=1)
-    g = q(synth.normal(63, "dg", tuple(y.shape)), dtype)
+    g, gd = _operand(B, sel, 63, "dg", (B,) + tuple(y.shape[1:]), dtype)
     (gx,) = torch.autograd.grad(y, [x], g)
-    aux = q(synth.normal(63, "da", (B, C, H, H)), dtype)
+    aux, auxd = _operand(B, sel, 63, "da", (B, C, H, H), dtype)
     slope = synth.uniform(63, "ds", (C,), 0.1, 0.4)
     want = torch.where(aux > 0, gx, gx * slope.view(1, -1, 1, 1))
     wt = w.permute(1, 2, 3, 0).reshape(C, 9, C).contiguous().to("cuda", dtype)
@@ -938,13 +980,15 @@ def test_conv3x3_s2_strip_dgrad(K, s2_walk, C, WL, B, walk):
     n = K.s2_strip_parts(B, C, C, WL, 2)
     assert n > 0
     part = torch.zeros(n, 2, C, device="cuda")
-    K.conv_s2_strip(K.current_stream_ptr(), src=nhwc(g, dtype), w=wt, out=out, B=B, RH=H, RW=H, SH=WL, SW=WL, SC=C, N=C,
+    K.conv_s2_strip(K.current_stream_ptr(), src=gd, w=wt, out=out, B=B, RH=H, RW=H, SH=WL, SW=WL, SC=C, N=C,
                     KH=3, KW=3, stride=2, pad=1, mode=2, par_h=-1, par_w=-1, lda=C, ldc=C, ldaux=C, pro=0,
-                    epi=K.EPI_PRELU_BWD, aux=nhwc(aux, dtype), epi_a=slope.cuda(), part=part)()
+                    epi=K.EPI_PRELU_BWD, aux=auxd, epi_a=slope.cuda(), part=part)()
     torch.cuda.synchronize()
-    assert relerr(from_nhwc(out), want) < tol
-    np.testing.assert_allclose(part.sum(0)[0].cpu(), (gx * aux * (aux <= 0)).sum((0, 2, 3)), rtol=tol * 10,
-                               atol=tol * 10 * float((gx * aux).abs().sum() / C))
+    assert torch.isfinite(out.float()).all() and relerr(from_nhwc(out[sel]), want) < tol
+    if len(sel) == B:  # (beyond 32 images only a subset is convolved on the host; the slope sums of the large-batch geometry
+        #                are part of every bench-size training step compared with the reference: g13)
+        np.testing.assert_allclose(part.sum(0)[0].cpu(), (gx * aux * (aux <= 0)).sum((0, 2, 3)), rtol=tol * 10,
+                                   atol=tol * 10 * float((gx * aux).abs().sum() / C))
 
 
 @pytest.mark.parametrize("Cavg,ldk", [(0, 32), (3, 64)], ids=["ir", "psp"])

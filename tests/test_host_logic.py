@@ -40,6 +40,32 @@ def test_abi_rejects_bad_arguments_without_a_gpu():
         _lib.check(-1, "x")
 
 
+def test_run_time_switches_are_named_integers(monkeypatch):
+    """fr_set_option / fr_get_option (ABI v5): a switch is first read from the environment variable of its name, cached, and
+    overridable in-process; frhip.ops.sync_switches pushes the environment again (what a plan build does), so that no
+    launcher of the library calls getenv."""
+    from frhip import _lib, ops
+    lib = _lib.lib
+    assert _lib.lib.fr_abi_version() == 5
+    monkeypatch.setenv("FRHIP_TEST_SWITCH_A", "7")
+    assert lib.fr_get_option(b"FRHIP_TEST_SWITCH_A", 3) == 7          # from the environment
+    assert lib.fr_get_option(b"FRHIP_TEST_SWITCH_B", 3) == 3          # unset: the first reader's default
+    monkeypatch.setenv("FRHIP_TEST_SWITCH_B", "9")
+    assert lib.fr_get_option(b"FRHIP_TEST_SWITCH_B", 3) == 3          # cached for the life of the process ...
+    assert lib.fr_set_option(b"FRHIP_TEST_SWITCH_B", 11) == 3 and lib.fr_get_option(b"FRHIP_TEST_SWITCH_B", 0) == 11  # ... until set
+    monkeypatch.setenv("FRHIP_ROLL64", "0")
+    ops.sync_switches()
+    assert lib.fr_get_option(b"FRHIP_ROLL64", 1) == 0
+    monkeypatch.delenv("FRHIP_ROLL64")
+    ops.sync_switches()
+    assert lib.fr_get_option(b"FRHIP_ROLL64", 1) == 1
+    # no launcher reads the environment: the only getenv of the library is the registry's
+    csrc = os.path.join(os.path.dirname(_lib.__file__), "csrc")
+    hits = [(f, l.strip()) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h"))
+            for l in open(os.path.join(csrc, f)) if "getenv(" in l and not l.lstrip().startswith("//")]
+    assert [f for f, _ in hits] == ["api.hip"], hits
+
+
 @pytest.mark.parametrize("name", ["IR_50", "IR_SE_50", "IR_SE_101", "IR_101", "pSp", "pSp34"])
 def test_state_dict_layout_and_param_split(structure, name):
     from backbone import model_irse as M
