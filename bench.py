@@ -17,7 +17,7 @@ Besides the contract fields the line carries
                 duration, against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md); ``all_mfma`` = the same
                 quotient over EVERY MFMA launch of the step (convolutions, weight gradients, GEMMs); ``step_frac`` =
                 the whole step incl. the HBM-bound channel-wise passes; ``traffic`` = HBM bytes per launch of the
-                dominant family from the committed rocprofv3 --pmc passes (profiles/r02_pmc_kernels.json)
+                dominant family from the committed rocprofv3 --pmc passes (the newest profiles/rNN_pmc_kernels.json)
   cpu_baseline  the CPU oracle (oracle/irse_ref.py, a port of the reference's PyTorch path) timed on the host
                 cores of this box on a bounded sample of the same workload (N = 1, rank 0 only)
 """
@@ -607,12 +607,9 @@ def main():
                 # HBM bytes per launch cannot be counted from inside this process; they come from the committed
                 # rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections) over the same
                 # kernel instances (tools/pmc_round.sh + tools/pmc_summary.py), averaged over this family's launches
-                pmc = None
-                for tag in ("r04", "r03", "r02"):
-                    cand = os.path.join(REPO, "profiles", "%s_pmc_kernels.json" % tag)
-                    if os.path.exists(cand):
-                        pmc = cand
-                        break
+                import glob
+                cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_pmc_kernels.json")))
+                pmc = cands[-1] if cands else None  # the newest round's table
                 m = re.match(r"conv3x3_strip<(\d+),(\d+),(\d+)>", name)
                 if pmc and m:
                     with open(pmc) as f:
