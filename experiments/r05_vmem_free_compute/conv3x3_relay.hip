@@ -510,9 +510,8 @@ int launch(const FrConvArgs& a, hipStream_t st) {
 
 // FRHIP_RELAY=0: the 8-wave strip instance again (A/B switch)
 bool fr_relay_serves(const FrConvArgs& a) {
-  static const int* on = fr_option_slot("FRHIP_RELAY", 1);
+  static const int* on = fr_option_slot("FRHIP_RELAY", 0);
   if (!*on) return false;
-  if (a.pro == FR_PRO_BNBWD2) return false;
   return a.SC == 256 && a.N == 256 && a.SW == 14 && a.B > 160;
 }
 

@@ -4,7 +4,7 @@ and the stored residual stream for every prologue / epilogue pair the engine lau
 import os
 import sys
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(REPO, "tools"))
 sys.path.insert(0, os.path.join(REPO, "stylegan-for-facerec_amd"))
 import torch  # noqa: E402
