@@ -262,6 +262,10 @@ class BackbonePlan(object):
         # in-launch reductions of the partial rows by arrival ticket, FRHIP_TAIL, +0.35-0.75 ms per step; the backward of BN2
         # inside conv2's data gradient, FRHIP_FUSE_BN2, -0.19 ms on one stream and nothing on two.)
         self.use_strip = not _switch("FRHIP_NO_STRIP", 0)  # 1: every LDS-strip family back on the generic GEMM
+        # T > 0: a one-workgroup-per-image strip launch (256 -> 256 @14x14, more images than 160) becomes two launches, B - T
+        # whole images and then the last T images on the two-workgroups-per-image instance (what a
+        # compute unit held by a resident collective kernel costs such a launch; tools/hog_matrix.sh)
+        self.strip_tail = max(0, _switch("FRHIP_STRIP_TAIL", 0))
         # Residual-sum statistics from moments (round 4).  In the FORWARD pass nothing runs beside the channel-wise passes, and
         # per identity unit the pass `out = BN2(y2) + x` (fr_bn_apply: 75 MB of traffic at 14x14) existed for two reasons: the
         # next unit's conv1 reads `out`, and its train-mode BN1 needs the batch statistics of `out` first.  The statistics do
@@ -491,6 +495,20 @@ class BackbonePlan(object):
     def _conv_launch(self, L, **kw):
         if (self.fr == FR_BF16 and self.use_strip and kw["KH"] == 3 and kw["stride"] == 1 and kw["RH"] == kw["SH"]):
             n = ops.strip_parts(kw["B"], kw["SC"], kw["N"], kw["SW"], kw.get("epi", 0))
+            T = self.strip_tail
+            if n and T and n == kw["B"] and kw["B"] - T > 160 and kw["SC"] == 256 and kw["N"] == 256 and kw["SW"] == 14:
+                b0, px = kw["B"] - T, kw["SH"] * kw["SW"]
+                nv = 3 if kw.get("epi") == ops.EPI_STATS_X else 2
+                per_image = dict(src=px * kw["lda"], src2=px * kw["lda"], pro_out=px * kw["lda"], out=px * kw["ldc"],
+                                 aux=px * kw.get("ldaux", 0), pro_g=kw["SC"], part=nv * kw["N"])
+                tail = dict(kw, B=T)
+                for k, stride in per_image.items():
+                    if kw.get(k) is not None:
+                        tail[k] = kw[k].reshape(-1)[b0 * stride:]
+                L.append(ops.conv_strip(self.stream, **dict(kw, B=b0)))
+                L.append(ops.conv_strip(self.stream, **tail))
+                self._last_conv_strips = n
+                return n
             if n:
                 L.append(ops.conv_strip(self.stream, **kw))
                 self._last_conv_strips = n  # partial rows = strips, image-major
@@ -1190,6 +1208,8 @@ class BackbonePlan(object):
                 L.append(_EvRecord(done, self.stream2_t))
                 unit_done[i] = done
             self.ready_marks.append((len(L), ready, done))
+            if u.Ho < _switch("FRHIP_DP_GATE_HO", 28):  # 14x14 / 7x7 layers: one workgroup per compute unit and launch (see comm_gate below)
+                self._gate_end = len(L)
             g_out, cur = g_x, nxt
         # the slabs of the last deferring weight-gradient launch are summed by a launch of their own
         flushed = self._flush_pending(L)
@@ -1281,6 +1301,12 @@ class BackbonePlan(object):
         if pool or nxt != total:
             raise _lib.FrhipError("frhip: %d gradients were never announced (readiness bookkeeping)" % (total - nxt))
         self.ready_marks = out
+        # Data parallelism (frhip.parallel): the number of gradients announced by the time the backward pass has left the
+        # layers that launch ONE workgroup per compute unit (output grids below 28x28).  A collective kernel resident
+        # beside those launches doubles each of them (tools/cu_hog.py); behind this point every launch has thousands of
+        # workgroups and pays for held CUs in proportion.
+        gate_end = getattr(self, "_gate_end", 0)
+        self.comm_gate = sum(len([p for p in emit if p.requires_grad]) for end, emit, _d in out if end <= gate_end)
 
     # ---- execution ---------------------------------------------------------------------------------
     def check_current(self):
@@ -1344,27 +1370,37 @@ class BackbonePlan(object):
         if on_ready is None:
             ops.run(self.bwd_list)
             return
-        # Readiness callbacks (gradient all-reduce) run on their own stream, ordered behind the main stream up to this
-        # point and behind the unit's side-stream weight gradients -- the main stream itself never waits for the side
-        # stream here, so the two-stream overlap survives data-parallel runs.  The callee enqueues collectives on the
-        # current stream (ProcessGroupNCCL orders its own stream behind it).
+        # Readiness callbacks (gradient all-reduce): host bookkeeping only.  A callee that enqueues a collective first calls
+        # comm_fence(), which orders the communication stream behind the main stream up to this point and behind the side
+        # stream's weight gradients of the units announced so far -- the main stream itself never waits for the side stream
+        # here, so the two-stream overlap survives data-parallel runs.  (Round 5: the fence used to be set at every mark --
+        # 26 event records between the backward kernels of the main stream cost 0.2-0.3 ms per step with nothing to
+        # exchange; tools/cu_hog.py --comm, profiles/r05_comm_policy.txt.)
         if self.comm_stream_t is None:
             self.comm_stream_t = _side_stream(self.device, -1)  # one communication stream per device, too
             self.comm_events = [torch.cuda.Event() for _ in self.ready_marks]
-        comm = self.comm_stream_t
-        pos = 0
+        pos, last_done = 0, None
         for k, (end, params, done) in enumerate(self.ready_marks):
             ops.run(self.bwd_list[pos:end])
             pos = end
-            ev = self.comm_events[k]
-            ev.record(self.stream1_t)
-            comm.wait_event(ev)
             if done is not None:
-                comm.wait_event(done)
-            with torch.cuda.stream(comm):
-                on_ready([p for p in params if p.requires_grad])
+                last_done = done  # the side stream is FIFO: the latest event is behind every earlier unit's weight gradients
+            self._fence_at = (k, last_done)
+            on_ready([p for p in params if p.requires_grad])
         ops.run(self.bwd_list[pos:])
-        self.stream1_t.wait_stream(comm)  # whatever the callbacks enqueued themselves (not the async collectives)
+        self.stream1_t.wait_stream(self.comm_stream_t)  # whatever the callbacks enqueued themselves (not the async collectives)
+
+    def comm_fence(self):
+        """Called from inside a readiness callback: orders the communication stream behind every gradient announced so far
+        and returns it (collectives are enqueued under ``torch.cuda.stream(plan.comm_fence())``)."""
+        k, done = self._fence_at
+        comm = self.comm_stream_t
+        ev = self.comm_events[k]
+        ev.record(self.stream1_t)
+        comm.wait_event(ev)
+        if done is not None:
+            comm.wait_event(done)
+        return comm
 
 
 # ------------------------------------------------------------------------------------------------ autograd glue

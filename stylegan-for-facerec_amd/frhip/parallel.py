@@ -7,9 +7,16 @@ DataParallel), and the only exchange is the gradient average:
 
   * the engine writes gradients into one flat fp32 arena ordered by *readiness* (output layer first, stem last),
     so a bucket is a contiguous arena slice -- no gather/scatter copies around the collective;
-  * as soon as backward has produced every gradient of a bucket the bucket's all-reduce is enqueued
-    (``async_op=True``: RCCL runs it on its own stream while the remaining backward kernels keep the CUs busy);
-  * the head weight (N x 512, the largest single gradient, ready first) is reduced from its own autograd hook;
+  * a bucket's all-reduce is enqueued (``async_op=True``: RCCL runs it on its own stream beside the remaining backward
+    kernels) once backward has produced every gradient of the bucket AND the gate is open: the 7x7 / 14x14 layers launch
+    exactly one workgroup per compute unit, and a collective kernel holding even four CUs makes every such launch take two
+    rounds (+3.3 ms per step if it stays for the whole backward pass: tools/cu_hog.py, profiles/r05_hog_matrix.txt).  The
+    plan names the point of the backward pass behind which every launch has thousands of workgroups (the 28x28 layers
+    onward, ``plan.comm_gate``); complete buckets wait until then and are enqueued together -- 3 ms of backward are left at
+    that point for ~1 ms of exchange.  FRHIP_DP_OVERLAP=1 enqueues every bucket as soon as it is complete, =0 only in
+    ``synchronize()``;
+  * the head weight (N x 512, the largest single gradient, ready first) is announced from its own autograd hook and
+    waits for the same gate;
   * ``synchronize()`` before the optimizer step makes the compute stream wait for the outstanding collectives.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): IR-50's 174 MB of fp32 gradients need ~2 ms even on a single
@@ -25,8 +32,9 @@ import torch.distributed as dist
 
 
 class BucketedAllReduce(object):
-    def __init__(self, arena, slices, group=None, bucket_bytes=32 << 20):
-        """arena: flat tensor; slices: [(param, offset, numel)] in readiness order, offsets increasing."""
+    def __init__(self, arena, slices, group=None, bucket_bytes=32 << 20, gate=0):
+        """arena: flat tensor; slices: [(param, offset, numel)] in readiness order, offsets increasing.  gate: number of
+        announced parameters (arena order) from which on collectives may be enqueued (0: from the start)."""
         self.arena, self.group = arena, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = dist.is_initialized() and os.environ.get("FRHIP_FORCE_DP", "0") == "1"  # 1-rank self test
@@ -34,7 +42,10 @@ class BucketedAllReduce(object):
         # FRHIP_DP_OVERLAP=0 (A/B switch for multi-GPU runs): no collective during the backward pass -- everything is enqueued
         # by synchronize().  RCCL's kernels need CUs of their own; while one is resident a 256-workgroup strip launch takes two
         # rounds, so on some fabrics the un-overlapped exchange may be the faster one.  Unmeasured (no multi-GPU box so far).
-        self.overlap = os.environ.get("FRHIP_DP_OVERLAP", "1") != "0"
+        # Default 2: overlapped, but only behind the plan's gate (see the module docstring); 1: from the first complete bucket.
+        self.policy = int(os.environ.get("FRHIP_DP_OVERLAP", "2") or 2)
+        self.overlap = self.policy != 0
+        self.gate = gate if self.policy == 2 else 0
         self.buckets = []  # (start, end, [param ids])
         start, ids, nbytes = 0, [], 0
         esz = arena.element_size()
@@ -56,6 +67,9 @@ class BucketedAllReduce(object):
         self.pending = [len(ids) for (_s, _e, ids) in self.buckets]
         self.next_bucket = 0
         self.works = []
+        self.announced = 0
+        self.gate_open = self.overlap and self.gate <= 0
+        self.held = []  # stand-alone tensors announced before the gate opened
 
     def _launch(self, t):
         if self.world == 1 and not self.force:
@@ -65,26 +79,57 @@ class BucketedAllReduce(object):
         else:
             self.works.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), t))
 
-    def on_ready(self, params):
+    def on_ready(self, params, fence=None):
         """Called by the backward pass with parameters whose gradients are final.  Frozen parameters never show
-        up; their arena slots stay zero and are reduced along with their bucket."""
+        up; their arena slots stay zero and are reduced along with their bucket.  fence: called once before anything is
+        enqueued; returns the stream to enqueue on (ordered behind the announced gradients) or None for the current one."""
         for p in params:
             b = self.owner.get(id(p))
             if b is not None:
                 self.pending[b] -= 1
+                self.announced += 1
+        if self.overlap and not self.gate_open and self.announced >= self.gate:
+            self.gate_open = True
+        if not self.gate_open:
+            return
         # buckets complete in order because the arena is in readiness order; a bucket whose remaining members
-        # are all frozen is flushed by flush_frozen()
-        while self.overlap and self.next_bucket < len(self.buckets) and self.pending[self.next_bucket] <= 0:
+        # are all frozen is flushed by synchronize()
+        out, self.held = self.held, []
+        while self.next_bucket < len(self.buckets) and self.pending[self.next_bucket] <= 0:
             s, e, _ = self.buckets[self.next_bucket]
-            self._launch(self.arena[s:e])
+            out.append(self.arena[s:e])
             self.next_bucket += 1
+        self._enqueue(out, fence)
+
+    def _enqueue(self, tensors, fence):
+        if not tensors:
+            return
+        stream = fence() if fence is not None else None
+        if stream is None:
+            for t in tensors:
+                self._launch(t)
+        else:
+            with torch.cuda.stream(stream):
+                for t in tensors:
+                    self._launch(t)
+
+    def open_gate(self, fence=None):
+        self.gate_open = True
+        out, self.held = self.held, []
+        self._enqueue(out, fence)
 
     def add_tensor(self, t):
-        """Reduce a stand-alone gradient (the margin head's weight) right now."""
-        self._launch(t)
+        """Reduce a stand-alone gradient (the margin head's weight): now if the gate is open, else when it opens."""
+        if self.gate_open:
+            self._launch(t)
+        else:
+            self.held.append(t)
 
     def synchronize(self):
         """Enqueue whatever is left (buckets holding frozen parameters), then wait for every collective."""
+        for t in self.held:
+            self._launch(t)
+        self.held = []
         while self.next_bucket < len(self.buckets):
             s, e, _ = self.buckets[self.next_bucket]
             self._launch(self.arena[s:e])
@@ -128,7 +173,8 @@ class DataParallel(object):
         self.runner = inner._runner[0]
         self.runner.on_grads_ready = self._on_ready
         self.reducer, self.plan = None, None
-        self.extra = BucketedAllReduce(torch.zeros(0), [], group) if dist.is_initialized() else None
+        # the head's gradients: no arena, opened together with the backbone reducer's gate (_on_ready)
+        self.extra = BucketedAllReduce(torch.zeros(0), [], group, gate=1) if dist.is_initialized() else None
         if head is not None:
             for p in head.parameters():
                 p.register_post_accumulate_grad_hook(self._head_hook)
@@ -146,8 +192,11 @@ class DataParallel(object):
         plan = self.runner.plan
         if plan is not self.plan:
             self.plan = plan
-            self.reducer = BucketedAllReduce(plan.arena, plan.arena_slices, self.group, self.bucket_bytes)
-        self.reducer.on_ready(params)
+            self.reducer = BucketedAllReduce(plan.arena, plan.arena_slices, self.group, self.bucket_bytes,
+                                             gate=getattr(plan, "comm_gate", 0))
+        self.reducer.on_ready(params, plan.comm_fence)
+        if self.extra is not None and self.reducer.gate_open and not self.extra.gate_open and self.extra.overlap:
+            self.extra.open_gate(plan.comm_fence)
 
     def _head_hook(self, p):
         if self.extra is not None:

@@ -9,6 +9,9 @@ backward pass is still producing gradients, not after it:
   * E_done[k]   recorded on a probe stream that waits for the collective's work handle: the all-reduce has finished;
   * E_end       recorded on the main stream behind the last launch of the backward pass.
 
+FRHIP_DP_OVERLAP=1 enqueues a bucket the moment it is complete; the default (2) holds complete buckets until the backward pass
+has left the 7x7 / 14x14 layers (plan.comm_gate) and enqueues them together there.
+
 Asserted: every bucket but the last was ENQUEUED before the host finished enqueuing the backward pass (host order), the
 early buckets' inputs were final and their collectives complete on the GPU before E_end, and the gradients equal those of a
 run without data parallelism (one rank: AVG over one rank is the identity).
@@ -112,7 +115,16 @@ def main():
     done_lead = [r[3].elapsed_time(e_end) for r in buckets]
     print("backward %.2f ms; buckets: %s" % (bwd_ms, ", ".join(
         "%.1fMB ready %.2f / done %.2f ms before the end" % (r[1] * 4 / 1e6, a, b) for r, a, b in zip(buckets, ready_lead, done_lead))))
-    assert ready_lead[0] > 0.5 * bwd_ms, "the first bucket (output layer) must be ready in the first half of backward"
+    policy = int(os.environ.get("FRHIP_DP_OVERLAP", "2"))
+    gate = dp.runner.plan.comm_gate
+    assert 0 < gate < len(dp.runner.plan.arena_slices), gate
+    if policy == 1:
+        assert ready_lead[0] > 0.5 * bwd_ms, "the first bucket (output layer) must be ready in the first half of backward"
+    else:
+        # gated: nothing is enqueued beside the one-workgroup-per-CU layers; the buckets complete by then start together
+        assert 0.1 * bwd_ms < ready_lead[0] < 0.6 * bwd_ms, "first bucket enqueued %.2f of %.2f ms before the end" % (ready_lead[0], bwd_ms)
+        held = [r for r in log if r[4] == log[0][4]]
+        assert len(held) >= 3 and any(r[0] == "head" for r in held), "the gate released %d collectives at once" % len(held)
     overlapped = sum(1 for d in done_lead[:-1] if d > 0)
     assert overlapped >= len(buckets) - 2, "collectives did not complete under the backward pass: %s" % done_lead
     assert all(a > b for a, b in zip(ready_lead, done_lead))

@@ -777,10 +777,12 @@ def test_perform_val_matches_oracle_protocol():
 
 
 def test_readiness_callbacks_see_final_gradients():
-    """Data-parallel hook contract: ``on_grads_ready(params)`` runs on a communication stream that is ordered behind
-    the main stream and the unit's side-stream weight gradients.  A callback that copies the announced gradients on
-    its current stream must capture exactly the final values (a collective launched there would read the same bytes),
-    every trainable backbone parameter must be announced exactly once, and announcements follow the arena order."""
+    """Data-parallel hook contract: ``on_grads_ready(params)`` is host bookkeeping; ``plan.comm_fence()`` called from
+    inside it returns the communication stream, ordered behind the main stream and the side-stream weight gradients of
+    everything announced so far.  A callback that copies the announced gradients on that stream must capture exactly
+    the final values (a collective launched there would read the same bytes) -- whether it sets the fence at every
+    announcement or once for several --, every trainable backbone parameter must be announced exactly once, and
+    announcements follow the arena order."""
     _need_gpu()
     from backbone.model_irse import IR_50
     from head.metrics import ArcFace
@@ -793,19 +795,30 @@ def test_readiness_callbacks_see_final_gradients():
     head = ArcFace(512, 100, None).cuda()
     x = synth.uniform(16, "full.x", (8, 3, 112, 112)).cuda()
     y = synth.labels(16, "full.label", 8, 100).cuda()
-    seen, order = {}, []
+    seen, order, waiting, calls = {}, [], [], [0]
+    every = [1]
 
     def on_ready(params):
-        assert torch.cuda.current_stream() != torch.cuda.default_stream()
+        calls[0] += 1
         for p in params:
-            assert id(p) not in seen
-            seen[id(p)] = p.grad.clone()  # enqueued on the communication stream
+            assert id(p) not in seen and id(p) not in [id(q) for q in waiting]
             order.append(p.grad.data_ptr())
+        waiting.extend(params)
+        if calls[0] % every[0] == 0 or len(seen) + len(waiting) == ntrain:
+            comm = m._runner[0].plan.comm_fence()
+            assert comm != torch.cuda.default_stream() and comm != torch.cuda.current_stream()
+            with torch.cuda.stream(comm):
+                for p in waiting:
+                    seen[id(p)] = p.grad.clone()  # enqueued on the communication stream
+            del waiting[:]
 
+    ntrain = len([p for p in m.parameters() if p.requires_grad])
     m._runner[0].on_grads_ready = on_ready
-    for _ in range(2):  # second step: the plan (and its events) are reused
+    for it in range(3):  # later steps: the plan (and its events) are reused; the last one sets a fence every 5th announcement
+        every[0] = 5 if it == 2 else 1
         seen.clear()
         order.clear()
+        calls[0] = 0
         loss, _ = FocalLoss()(head(m(x), y), y)
         loss.backward()
         torch.cuda.synchronize()
@@ -855,15 +868,17 @@ def test_two_rank_gradients_are_the_rank_average():
     assert out.returncode == 0 and "DP_WORKER_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
-def test_gradient_allreduce_overlaps_backward():
+@pytest.mark.parametrize("policy", ["2", "1"])
+def test_gradient_allreduce_overlaps_backward(policy):
     """The overlap claim of frhip.parallel on the GPU timeline (tests/overlap_worker.py, one rank through RCCL): the
     gradient buckets are enqueued while the backward pass is still being enqueued, their inputs are final and their
-    all-reduces complete (HIP events) before the last backward kernel -- the collectives run under the backward pass."""
+    all-reduces complete (HIP events) before the last backward kernel -- the collectives run under the backward pass.
+    Policy 2 (default): held until the backward pass has left the 7x7 / 14x14 layers; 1: as soon as complete."""
     _need_gpu()
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FRHIP_DP_OVERLAP=policy)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29571", os.path.join(here, "overlap_worker.py")]
     out = subprocess.run(cmd, cwd=os.path.dirname(here), env=env, capture_output=True, text=True, timeout=900)

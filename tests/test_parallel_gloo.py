@@ -65,6 +65,35 @@ def _worker(rank, world, port, q):
                 want = sum(gathered) / world
                 assert torch.allclose(p.grad, want, atol=1e-6), "rank %d step %d mismatch" % (rank, step)
             assert torch.allclose(extra, torch.full((10,), sum(range(1, world + 1)) / world))
+        # the gate (default policy): complete buckets and stand-alone tensors wait until `gate` parameters have been
+        # announced, then go out together; the sums are the same
+        gated = BucketedAllReduce(arena, slices, bucket_bytes=4096, gate=4)
+        assert gated.policy == 2 and not gated.gate_open
+        arena.zero_()
+        g = torch.Generator().manual_seed(7 + rank)
+        local = {}
+        extra = torch.full((10,), float(rank + 1))
+        gated.add_tensor(extra)
+        for i in range(0, len(params), 2):
+            group = []
+            for p in params[i:i + 2]:
+                if p.requires_grad:
+                    p.grad.copy_(torch.randn(p.shape, generator=g))
+                    local[id(p)] = p.grad.clone()
+                    group.append(p)
+            gated.on_ready(group)
+            if i == 0:
+                assert not gated.works and gated.held, "a collective went out before the gate opened"
+            if i == 2:  # params 0..3 announced = gate
+                assert gated.gate_open and not gated.held and len(gated.works) >= 2, len(gated.works)
+        gated.synchronize()
+        assert not gated.gate_open and not gated.works  # closed again for the next step
+        for p in params:
+            if p.requires_grad:
+                gathered = [torch.zeros_like(p) for _ in range(world)]
+                dist.all_gather(gathered, local[id(p)])
+                assert torch.allclose(p.grad, sum(gathered) / world, atol=1e-6)
+        assert torch.allclose(extra, torch.full((10,), sum(range(1, world + 1)) / world))
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback

@@ -10,6 +10,10 @@ workgroups (96 KB of LDS each: nothing LDS-heavy fits beside them) on a third st
     FRHIP_SPLIT_STRIPS=1 python tools/cu_hog.py --hog 8            # the half-channel strip instances (proportional cost)
     bash tools/hog_matrix.sh                                       # K x variant table -> profiles/
 
+    python tools/cu_hog.py --comm 16 --comm-gbps 150               # every gradient collective of frhip.parallel replaced by a
+                                                                   # 16-CU hold of bytes / 150 GB/s on the communication
+                                                                   # stream, under FRHIP_DP_OVERLAP = 2 (gate, default) / 1 / 0
+
 Kernel-selection switches are read when the library / plan is first used, so every variant is its own process.
 """
 import argparse
@@ -41,12 +45,41 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--comm", type=int, default=0, help="CUs held per emulated collective (frhip.parallel's launch points)")
+    ap.add_argument("--comm-gbps", type=float, default=150.0, help="emulated all-reduce rate: a collective holds bytes / rate")
     a = ap.parse_args()
     device = torch.device("cuda:0")
     args = argparse.Namespace(dtype="bf16", sharded_head=False, resident_batches=8, model="IR_50", head="ArcFace",
                               classes=7000, batch=a.batch)
     model, head, loss_fn, opt, xs, ys = bench.build_job(args, device, 0)
-    step = bench.make_step(model, head, loss_fn, opt, None)
+    dp, held_ms = None, [0.0, 0]
+    if a.comm > 0:
+        # the data-parallel wrapper of a multi-GPU run on ONE GPU: same buckets, same launch points and streams; the
+        # collective itself is a hold of a.comm CUs for bytes / rate
+        from frhip import parallel
+        lib = hog_lib()
+
+        class Held(object):
+            def __init__(self, ev):
+                self.ev = ev
+
+            def wait(self):
+                torch.cuda.current_stream().wait_event(self.ev)
+
+        def launch(self, t):
+            sec = t.numel() * t.element_size() / (a.comm_gbps * 1e9)
+            held_ms[0] += sec * 1e3
+            held_ms[1] += 1
+            st = torch.cuda.current_stream()
+            assert lib.cu_hog_launch(a.comm, sec, ctypes.c_void_p(st.cuda_stream)) == 0
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self.works.append((Held(ev), None))
+
+        parallel.BucketedAllReduce._launch = launch
+        dp = parallel.DataParallel(model, head)
+        dp.extra = parallel.BucketedAllReduce(torch.zeros(0), [], None, gate=1)
+    step = bench.make_step(model, head, loss_fn, opt, dp)
     for i in range(a.warmup):
         step(xs[i % len(xs)], ys[i % len(ys)])
     torch.cuda.synchronize()
@@ -70,9 +103,14 @@ def main():
     t1.synchronize()
     ms = t0.elapsed_time(t1) / a.steps
     torch.cuda.synchronize()
-    print("hog %3d CUs  %-40s %.3f ms per step" % (
-        a.hog, " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items())
-                        if k.startswith("FRHIP_") and k not in ("FRHIP_COMPUTE_DTYPE",)) or "default", ms))
+    sw = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items())
+                  if k.startswith("FRHIP_") and k not in ("FRHIP_COMPUTE_DTYPE",)) or "default"
+    if a.comm > 0:
+        n = a.steps + a.warmup + 1
+        print("collectives = %d CUs held for bytes / %.0f GB/s (%d per step, %.2f ms per step)  %-24s %.3f ms per step" % (
+            a.comm, a.comm_gbps, held_ms[1] // n, held_ms[0] / n, sw, ms))
+    else:
+        print("hog %3d CUs  %-40s %.3f ms per step" % (a.hog, sw, ms))
 
 
 if __name__ == "__main__":
