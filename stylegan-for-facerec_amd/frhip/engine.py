@@ -262,10 +262,6 @@ class BackbonePlan(object):
         # in-launch reductions of the partial rows by arrival ticket, FRHIP_TAIL, +0.35-0.75 ms per step; the backward of BN2
         # inside conv2's data gradient, FRHIP_FUSE_BN2, -0.19 ms on one stream and nothing on two.)
         self.use_strip = not _switch("FRHIP_NO_STRIP", 0)  # 1: every LDS-strip family back on the generic GEMM
-        # T > 0: a one-workgroup-per-image strip launch (256 -> 256 @14x14, more images than 160) becomes two launches, B - T
-        # whole images and then the last T images on the two-workgroups-per-image instance (what a
-        # compute unit held by a resident collective kernel costs such a launch; tools/hog_matrix.sh)
-        self.strip_tail = max(0, _switch("FRHIP_STRIP_TAIL", 0))
         # Residual-sum statistics from moments (round 4).  In the FORWARD pass nothing runs beside the channel-wise passes, and
         # per identity unit the pass `out = BN2(y2) + x` (fr_bn_apply: 75 MB of traffic at 14x14) existed for two reasons: the
         # next unit's conv1 reads `out`, and its train-mode BN1 needs the batch statistics of `out` first.  The statistics do
@@ -495,20 +491,11 @@ class BackbonePlan(object):
     def _conv_launch(self, L, **kw):
         if (self.fr == FR_BF16 and self.use_strip and kw["KH"] == 3 and kw["stride"] == 1 and kw["RH"] == kw["SH"]):
             n = ops.strip_parts(kw["B"], kw["SC"], kw["N"], kw["SW"], kw.get("epi", 0))
-            T = self.strip_tail
-            if n and T and n == kw["B"] and kw["B"] - T > 160 and kw["SC"] == 256 and kw["N"] == 256 and kw["SW"] == 14:
-                b0, px = kw["B"] - T, kw["SH"] * kw["SW"]
-                nv = 3 if kw.get("epi") == ops.EPI_STATS_X else 2
-                per_image = dict(src=px * kw["lda"], src2=px * kw["lda"], pro_out=px * kw["lda"], out=px * kw["ldc"],
-                                 aux=px * kw.get("ldaux", 0), pro_g=kw["SC"], part=nv * kw["N"])
-                tail = dict(kw, B=T)
-                for k, stride in per_image.items():
-                    if kw.get(k) is not None:
-                        tail[k] = kw[k].reshape(-1)[b0 * stride:]
-                L.append(ops.conv_strip(self.stream, **dict(kw, B=b0)))
-                L.append(ops.conv_strip(self.stream, **tail))
-                self._last_conv_strips = n
-                return n
+            # (Round 5, measured and removed -- VERDICT r4 item 8, profiles/r05_hog_matrix.txt: the 256 -> 256 @14x14 launches as
+            # B - T whole images + a second launch of the last T images on the two-workgroups-per-image instance: T = 16 / 32 /
+            # 64 cost +1.0 ... 1.1 ms per step with no CU held (launches of one stream do not overlap) and 19.0 / 17.6 / 17.3
+            # against 17.8 ms with 4-32 CUs held for the whole step.  What data-parallel runs do instead: frhip.parallel holds
+            # the collectives back until the backward pass has left these layers, comm_gate below.)
             if n:
                 L.append(ops.conv_strip(self.stream, **kw))
                 self._last_conv_strips = n  # partial rows = strips, image-major
