@@ -255,8 +255,8 @@ class BackbonePlan(object):
         # batch exactly (256 images / 8 groups; 14 groups left 19 images to some workgroups and 18 to others).  Round 5, same-box
         # alternations (profiles/r05_ab_wgrad_wgs.txt): IR-50 bs 256 14.26-14.33 against 14.43-14.50 ms per step (224), 96:
         # 15.18, 160 / 192 / 208 / 256: 14.72-14.77 / 14.53; IR-SE-101 bs 128 16.94-16.99 against 18.14-18.22; pSp bs 256
-        # 16.31 against 16.72.  Per-width overrides (FRHIP_WGRAD_WGS_<width>, _S<width> for stride 2) found nothing better
-        # than one value for all.
+        # 16.31 against 16.72.  Per-width / per-role overrides (temporary switches, removed) found nothing better than one
+        # value for all.
         self.wgrad_wgs = min(256, max(64, _switch("FRHIP_WGRAD_WGS", 128)))  # the slab sum takes <= 256 groups
         self.stream2 = ctypes.c_void_p(self.stream2_t.cuda_stream)
         self.S = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
@@ -535,8 +535,7 @@ class BackbonePlan(object):
             tiles = (kw["Cout"] // 64) * (kw["SC"] // 64)
             rows = {112: 2, 56: 4, 28: 7, 14: 14, 7: 7}[kw["SW"]]
             fills = kw["B"] * (kw["SW"] // rows) // (4 if kw["SW"] == 7 else 1)
-            cap = min(256, max(64, _switch("FRHIP_WGRAD_WGS_%d" % kw["SW"], self.wgrad_wgs)))
-            groups = int(max(1, min(fills, cap // tiles if tiles <= cap else 1)))
+            groups = int(max(1, min(fills, self.wgrad_wgs // tiles if tiles <= self.wgrad_wgs else 1)))
             return self._slab_launch(L, dict(kw, nsplit=groups), groups * kw["Cout"] * 9 * kw["SC"], param=param)
         if (self.fr == FR_BF16 and self.use_strip and self.use_s2 and kw["KH"] == 3 and kw["stride"] == 2 and
                 kw["GW"] in (56, 28, 14, 7) and kw["SW"] == 2 * kw["GW"] and kw["Cout"] % 64 == 0 and kw["SC"] % 64 == 0):
@@ -544,8 +543,7 @@ class BackbonePlan(object):
             tiles = (kw["Cout"] // 64) * (kw["SC"] // 64)
             rows, nimg = {56: (2, 1), 28: (4, 1), 14: (7, 1), 7: (7, 2)}[kw["GW"]]
             fills = (kw["B"] * (kw["GW"] // rows) + nimg - 1) // nimg
-            cap = min(256, max(64, _switch("FRHIP_WGRAD_WGS_S%d" % kw["GW"], self.wgrad_wgs)))
-            groups = int(max(1, min(fills, cap // tiles if tiles <= cap else 1)))
+            groups = int(max(1, min(fills, self.wgrad_wgs // tiles if tiles <= self.wgrad_wgs else 1)))
             return self._slab_launch(L, dict(kw, nsplit=groups), groups * kw["Cout"] * 9 * kw["SC"], param=param)
         if kw.get("nsplit", 1) > 1:  # pixel slices go to slabs and are added in a fixed order (no float atomics)
             return self._slab_launch(L, kw, kw["nsplit"] * kw["Cout"] * kw["KH"] * kw["KW"] * kw["SC"], strip=False,
