@@ -605,7 +605,9 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdA
   }
   // (Round 2-3 carried a NEXT variant here that also formed the backward sums of the BatchNorm in front from the rounded
   // gx -- bit-identical, one pass less, and 0.04-0.6 ms SLOWER per step beside the weight gradients of the side stream: 80
-  // registers, one wave per SIMD where the two separate kernels run two.  Removed in round 4, ABI v4.)
+  // registers, one wave per SIMD where the two separate kernels run two.  Removed in round 4, ABI v4.  Round 5 rebuilt it once
+  // more for the 128-workgroup weight-gradient schedule, where half of the CUs carry no side-stream workgroup: bit-identical
+  // again, 14.98-15.03 against 14.51-14.59 ms per step, three same-box alternations; not kept.)
   const int nrows = (int)p.rows, rstep = gridDim.x * rtc * LUNRB;
   const unsigned W = (unsigned)p.W, HW = (unsigned)p.rows_per_image, Wh = W >> 1, HWq = HW >> 2;  // ADD == 2
   const float invW = 1.0f / (float)p.W, invHW = 1.0f / (float)p.rows_per_image;
