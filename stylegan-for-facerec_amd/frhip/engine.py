@@ -1062,7 +1062,8 @@ class BackbonePlan(object):
             # ONE main -> side edge per unit with both weight gradients behind it: +0.26 ms (the first weight gradient then
             # starts a data gradient later); the main stream waiting for the side stream every second unit with four buffer
             # sets: +0.05; no second edge in front of conv1's weight gradient: nothing; conv1's weight gradient before
-            # conv2's: +0.39 ms.)
+            # conv2's: +0.39 ms.  Round 5, 128-workgroup weight gradients: conv2's weight gradient launched BEFORE its data
+            # gradient -- it needs g_y2 and y1 only --: +0.3 ms at bs 256, +0.9 ms IR-SE-101 bs 128, bit-identical.)
             S = S2 = L
 
             def edge():
