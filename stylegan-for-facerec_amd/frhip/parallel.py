@@ -39,10 +39,10 @@ class BucketedAllReduce(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = dist.is_initialized() and os.environ.get("FRHIP_FORCE_DP", "0") == "1"  # 1-rank self test
         self.avg_native = dist.is_initialized() and dist.get_backend(group) == "nccl"
-        # FRHIP_DP_OVERLAP=0 (A/B switch for multi-GPU runs): no collective during the backward pass -- everything is enqueued
-        # by synchronize().  RCCL's kernels need CUs of their own; while one is resident a 256-workgroup strip launch takes two
-        # rounds, so on some fabrics the un-overlapped exchange may be the faster one.  Unmeasured (no multi-GPU box so far).
-        # Default 2: overlapped, but only behind the plan's gate (see the module docstring); 1: from the first complete bucket.
+        # FRHIP_DP_OVERLAP (A/B switch for multi-GPU runs): 2 (default) overlapped with the backward pass, but only behind the
+        # plan's gate (module docstring); 1 from the first complete bucket; 0 no collective during the backward pass --
+        # everything is enqueued by synchronize().  Emulated on one GPU (tools/cu_hog.py --comm, profiles/r05_comm_policy.txt):
+        # 14.45 / 14.73 / 15.43 ms per step for 2 / 1 / 0 with 1.26 ms of collectives per step; no multi-GPU box so far.
         self.policy = int(os.environ.get("FRHIP_DP_OVERLAP", "2") or 2)
         self.overlap = self.policy != 0
         self.gate = gate if self.policy == 2 else 0
