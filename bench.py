@@ -15,7 +15,8 @@ Besides the contract fields the line carries
   roofline      dominant kernel FAMILY (by time; prologue variants of one template counted together) of one
                 event-instrumented step after the timed region: algorithmic FLOPs of its launches / their summed
                 duration, against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md); ``all_mfma`` = the same
-                quotient over EVERY MFMA launch of the step (convolutions, weight gradients, GEMMs); ``step_frac`` =
+                quotient over EVERY MFMA launch of the step (convolutions, weight gradients, GEMMs), each timed ALONE on
+                one stream (the weight-gradient launches cover half of the CUs by design: half rate alone); ``step_frac`` =
                 the whole step incl. the HBM-bound channel-wise passes; ``traffic`` = HBM bytes per launch of the
                 dominant family from the committed rocprofv3 --pmc passes (the newest profiles/rNN_pmc_kernels.json)
   cpu_baseline  the CPU oracle (oracle/irse_ref.py, a port of the reference's PyTorch path) timed on the host
@@ -591,7 +592,10 @@ def main():
                                    "share_of_step": round(kms / total_ms, 3),
                                    "all_mfma": {"achieved": round(all_ach, 2), "frac": round(all_ach / peak, 4),
                                                 "ms": round(mf_ms, 3), "share_of_step": round(mf_ms / total_ms, 3),
-                                                "launches": sum(g[0] for g in groups.values())},
+                                                "launches": sum(g[0] for g in groups.values()),
+                                                "note": "every launch timed alone on one stream; the weight-gradient "
+                                                        "launches cover half of the CUs by design (they run beside the "
+                                                        "data gradients in the step), so their stand-alone rate is half"},
                                    "channelwise_ms": round(sum(v[1] for k, v in fams.items() if k.startswith(
                                        ("fr_bn_", "fr_reduce_parts", "fr_channel_stats", "fr_se_"))), 3),
                                    "launches_per_step": sum(v[0] for v in fams.values()),
