@@ -238,3 +238,38 @@ def test_perform_val_sharded_over_ranks_world2():
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+@pytest.mark.parametrize("policy", ["2", "1", "0"])
+def test_exchange_policies_launch_at_the_right_announcement(monkeypatch, policy):
+    """FRHIP_DP_OVERLAP: 2 = complete buckets and stand-alone tensors wait for the gate, 1 = enqueued the moment they are
+    complete, 0 = everything in synchronize().  One process, the collective replaced by a recorder; the fence is called exactly
+    once per announcement that enqueues something."""
+    from frhip import parallel
+    monkeypatch.setenv("FRHIP_DP_OVERLAP", policy)
+    log, fences = [], []
+    monkeypatch.setattr(parallel.BucketedAllReduce, "_launch", lambda self, t: log.append((t.data_ptr(), t.numel())))
+    params = [torch.nn.Parameter(torch.zeros(256)) for _ in range(8)]
+    arena = torch.zeros(8 * 256)
+    slices = [(p, i * 256, 256) for i, p in enumerate(params)]
+    red = parallel.BucketedAllReduce(arena, slices, bucket_bytes=2 * 256 * 4, gate=5)  # 4 buckets of two parameters
+    assert len(red.buckets) == 4
+    extra = torch.zeros(10)
+    for step in range(2):  # the second step: reset() has closed the gate again
+        del log[:], fences[:]
+        red.add_tensor(extra)
+        seen = []
+        for i, p in enumerate(params):
+            red.on_ready([p], fence=lambda: fences.append(1))
+            seen.append(len(log))
+        if policy == "1":
+            assert seen == [1, 2, 2, 3, 3, 4, 4, 5], seen          # the stand-alone tensor at once, a bucket per second parameter
+            assert len(fences) == 4
+        elif policy == "2":
+            assert seen == [0, 0, 0, 0, 3, 4, 4, 5], seen          # gate = 5 announcements: tensor + two complete buckets together
+            assert len(fences) == 3
+        else:
+            assert seen == [0] * 8 and not fences
+        red.synchronize()
+        assert len(log) == 5 and sorted(n for _p, n in log) == [10, 512, 512, 512, 512]
+        assert log[-4:] == [(arena.data_ptr() + k * 2048, 512) for k in range(4)] or policy != "0"
