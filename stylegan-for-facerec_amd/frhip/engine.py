@@ -20,7 +20,6 @@ materialised.  Parameter gradients are written straight into one flat fp32 arena
 which they become ready (output layer first, stem last) so that data-parallel buckets are contiguous slices.
 """
 import ctypes
-import math
 import os
 
 import torch

@@ -1,4 +1,4 @@
-import argparse, os, sys, ctypes
+import argparse, os, sys
 REPO = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tools"))
 import bench, torch
