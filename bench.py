@@ -430,7 +430,95 @@ class ClockSampler(threading.Thread):
         return out
 
 
-def timed_loop(step, xs, ys, warmup, steps, world, device, sampler=None):
+class SyncTimer(object):
+    """``dp.synchronize()`` of the timed steps bracketed by a HIP event pair on the compute stream: the time the main stream
+    spends waiting for collectives that the backward pass did not hide (RCCL: a stream wait; gloo: the host blocks).  Host
+    tensors (the CPU ``gloo`` test of this record): the host clock."""
+
+    def __init__(self, dp, use_events):
+        self.dp, self.use_events, self.on, self.marks = dp, use_events, False, []
+
+    def synchronize(self):
+        if not self.on:
+            return self.dp.synchronize()
+        if self.use_events:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.dp.synchronize()
+            e1.record()
+            self.marks.append((e0, e1))
+        else:
+            t0 = time.perf_counter()
+            self.dp.synchronize()
+            self.marks.append(time.perf_counter() - t0)
+
+    def mean_ms(self):
+        """Call after a device synchronize."""
+        if not self.marks:
+            return None
+        if self.use_events:
+            return sum(e0.elapsed_time(e1) for e0, e1 in self.marks) / len(self.marks)
+        return sum(self.marks) / len(self.marks) * 1e3
+
+
+def device_identity(device):
+    """What tells two ranks' devices apart: the PCI address of a GPU (domain:bus:device), host + pid for host tensors."""
+    device = torch.device(device)
+    if device.type == "cuda":
+        pr = torch.cuda.get_device_properties(device)
+        try:
+            return "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except AttributeError:
+            return "cuda:%d uuid %s" % (device.index, getattr(pr, "uuid", "?"))
+    return "cpu %s pid %d" % (socket.gethostname(), os.getpid())
+
+
+def collective_library():
+    """Backend of the default process group and the version of the library behind it ("nccl" IS RCCL on ROCm)."""
+    backend = dist.get_backend()
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            ver = "unknown"
+    return backend, ver
+
+
+def dp_record(rank, world, device, dp, timer, dt_local, steps):
+    """The part of the JSON line that lets a reader verify an N > 1 record against itself (collective: every rank calls
+    it): which process ran on which device (all-gathered, must be N distinct PCI addresses), the library and version the
+    gradients went through, the exchange policy and its buckets, the time the compute stream waited for collectives, and
+    every rank's own step time (the headline is the maximum)."""
+    mine = {"rank": rank, "device": device_identity(device), "host": socket.gethostname(), "pid": os.getpid(),
+            "ms_per_step": round(dt_local / steps * 1e3, 3),
+            "comm_exposed_ms": None if timer is None or timer.mean_ms() is None else round(timer.mean_ms(), 4)}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    if rank != 0:
+        return None
+    backend, ver = collective_library()
+    red = getattr(dp, "reducer", None)
+    policy = {"FRHIP_DP_OVERLAP": getattr(red, "policy", None), "gate_gradients": getattr(red, "gate", None),
+              "bucket_mb": getattr(dp, "bucket_bytes", 0) / 2.0 ** 20,
+              "buckets": len(red.buckets) if red is not None else None,
+              "arena_mb": round(red.arena.numel() * red.arena.element_size() / 2.0 ** 20, 1) if red is not None else None,
+              "meaning": {0: "after backward", 1: "as soon as a bucket is complete",
+                          2: "complete buckets, once backward has left the one-workgroup-per-CU layers"}.get(
+                              getattr(red, "policy", None))}
+    ms = [r["ms_per_step"] for r in everyone]
+    exposed = [r["comm_exposed_ms"] for r in everyone if r["comm_exposed_ms"] is not None]
+    return {"ranks": [[r["rank"], r["device"]] for r in everyone],
+            "ranks_distinct_devices": len(set(r["device"] for r in everyone)) == world and
+            sorted(r["rank"] for r in everyone) == list(range(world)),
+            "rank_pids": [r["pid"] for r in everyone],
+            "collective_backend": backend, "rccl_version": ver, "dp_policy": policy,
+            "comm_exposed_ms": round(sum(exposed) / len(exposed), 4) if exposed else None,
+            "comm_exposed_ms_max": round(max(exposed), 4) if exposed else None,
+            "ms_per_step_min": min(ms), "ms_per_step_max": max(ms), "ms_per_step_by_rank": ms}
+
+
+def timed_loop(step, xs, ys, warmup, steps, world, device, sampler=None, sync_timer=None):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
     nb = len(xs)
     for i in range(warmup):
@@ -440,13 +528,18 @@ def timed_loop(step, xs, ys, warmup, steps, world, device, sampler=None):
     torch.cuda.synchronize()
     if sampler is not None:
         sampler.start()
+    if sync_timer is not None:
+        sync_timer.on = True
     t0 = time.perf_counter()
     for i in range(steps):
         loss, _prec = step(xs[(warmup + i) % nb], ys[(warmup + i) % nb])
     torch.cuda.synchronize()
+    timed_loop.dt_local = time.perf_counter() - t0  # this rank's own time, before it waits for the slowest one
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if sync_timer is not None:
+        sync_timer.on = False
     clocks = sampler.stop() if sampler is not None else None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -462,12 +555,22 @@ OTHER_CONFIGS = (
     ("configs[3] IR-SE-101 + CosFace(28000), bs=128/GPU", dict(model="IR_SE_101", head="CosFace", classes=28000, batch=128)),
     ("configs[4] pSp IR-SE-50 6-ch stem + ArcFace(28000), bs=256/GPU", dict(model="pSp", head="ArcFace", classes=28000,
                                                                            batch=256)),
+    # "for the fp32 parity mode report against the fp32 matrix peak separately" -- the headline workload on the
+    # fp32 path (exact-fma f32 MFMA, the mode the parity tests run and COMPUTE_DTYPE='fp32' selects); step_frac is against
+    # PEAK_F32_TFLOPS
+    ("configs[1] on the fp32 parity path: IR-50 + ArcFace(7000), bs=256/GPU", dict(model="IR_50", head="ArcFace",
+                                                                                  classes=7000, batch=256, dtype="fp32",
+                                                                                  steps=6, warmup=2)),
 )
 
 
-def run_other_config(label, spec, args, device, rank, world, peak, steps=10, warmup=4):
+def run_other_config(label, spec, args, device, rank, world, steps=10, warmup=4):
     import gc
-    a = argparse.Namespace(dtype=args.dtype, sharded_head=False, resident_batches=warmup + steps, **spec)  # a new batch every step
+    spec = dict(spec)
+    steps, warmup = spec.pop("steps", steps), spec.pop("warmup", warmup)
+    spec.setdefault("dtype", args.dtype)
+    peak = PEAK_BF16_TFLOPS if spec["dtype"] == "bf16" else PEAK_F32_TFLOPS
+    a = argparse.Namespace(sharded_head=False, resident_batches=warmup + steps, **spec)  # a new batch every step
     model, head, loss_fn, opt, xs, ys = build_job(a, device, rank)
     dp = None
     if world > 1:
@@ -478,7 +581,8 @@ def run_other_config(label, spec, args, device, rank, world, peak, steps=10, war
     ips = a.batch * world * steps / dt
     flops_img = FLOPS_PER_IMG[a.model] + 6.0 * 512 * a.classes
     rec = {"config": label, "value": round(ips, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
-           "steps": steps, "warmup": warmup, "n_gpus": world, "final_loss": float("%.3e" % loss_val),
+           "steps": steps, "warmup": warmup, "n_gpus": world, "dtype": a.dtype, "final_loss": float("%.3e" % loss_val),
+           "step_achieved": round(flops_img * ips / world / 1e12, 2), "peak": peak,
            "step_frac": round(flops_img * ips / world / 1e12 / peak, 4)}
     inner = model.encoder if hasattr(model, "encoder") else model
     inner._runner[0].plans.clear()
@@ -516,11 +620,13 @@ def main():
     if world > 1 or force_dp:
         from frhip.parallel import DataParallel
         dp = DataParallel(model, None if args.sharded_head else head)  # a weight shard is complete on its owner
-    step = make_step(model, head, loss_fn, opt, dp)
+    sync_timer = SyncTimer(dp, True) if dp is not None else None
+    step = make_step(model, head, loss_fn, opt, sync_timer if dp is not None else None)
     x, y = xs[0], ys[0]
 
     sampler = ClockSampler(local) if rank == 0 else None
-    dt, loss_val, clocks = timed_loop(step, xs, ys, args.warmup, args.steps, world, device, sampler)
+    dt, loss_val, clocks = timed_loop(step, xs, ys, args.warmup, args.steps, world, device, sampler, sync_timer)
+    dp_rec = dp_record(rank, world, device, dp, sync_timer, timed_loop.dt_local, args.steps) if dp is not None else None
     assert loss_val == loss_val, "loss is NaN"
     if sampler is not None and args.clock_log:
         with open(args.clock_log, "w") as f:
@@ -543,6 +649,12 @@ def main():
                    "images_per_sec_per_gpu": round(ips / world, 1), "final_loss": float("%.3e" % loss_val),
                    "resident_batches": len(xs)},
     }
+    if dp_rec is not None:
+        # N > 1 (or FRHIP_FORCE_DP): the record verifies itself -- N ranks on N distinct devices through this library
+        for k in ("ranks", "ranks_distinct_devices", "rank_pids", "collective_backend", "rccl_version", "dp_policy"):
+            out["config"][k] = dp_rec[k]
+        for k in ("comm_exposed_ms", "comm_exposed_ms_max", "ms_per_step_min", "ms_per_step_max", "ms_per_step_by_rank"):
+            out[k] = dp_rec[k]
     fams = None
     inner = model.encoder if hasattr(model, "encoder") else model
     if not args.no_roofline:
@@ -645,7 +757,7 @@ def main():
         torch.cuda.empty_cache()
         others = []
         for label, spec in OTHER_CONFIGS:
-            others.append(run_other_config(label, spec, args, device, rank, world, peak))
+            others.append(run_other_config(label, spec, args, device, rank, world))
         if rank == 0:
             out["other_configs"] = others
     if rank == 0:

@@ -8,4 +8,5 @@ configurations = {1: stage3(
     EXP_NAME,
     ENCODER_CHECKPOINT="<path to the Stage-2 encoder checkpoint (.pt) trained with the AfrAsian prior>",
     ENCODER_AVG_IMAGE="<path to the avg_image.jpg written by Stage-2 training>",
+    COMPUTE_DTYPE="bf16",  # not a reference key (cfg.get): the throughput path bench.py measures; 'fp32' = parity path
 )}

@@ -8,4 +8,5 @@ EXP_NAME = "synthetic_smoke"
 
 configurations = {1: stage3(EXP_NAME, ENCODER_AVG_IMAGE=synth.uniform(900, 'avg_image', (3, 112, 112)), NUM_EPOCH=1,
                             BATCH_SIZE=100, NUM_WORKERS=0,
-                            FREEZE_BACKBONE_EPOCHS=None, DATA_ROOT="", STAGES=[])}
+                            FREEZE_BACKBONE_EPOCHS=None, DATA_ROOT="", STAGES=[],
+                            COMPUTE_DTYPE="fp32")}  # the parity path: the smoke run is compared with the CPU reference

@@ -30,3 +30,28 @@ def _warn_if_too_late():
 _requested_before_import = os.environ.get("GPU_MAX_HW_QUEUES")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 _warn_if_too_late()
+
+
+_DTYPE_NAMES = {"bf16": "bfloat16", "bfloat16": "bfloat16", "fp32": "float32", "float32": "float32", "f32": "float32"}
+
+
+def set_compute_dtype(model, dtype):
+    """Select the numerics of a backbone from a config value (``COMPUTE_DTYPE`` in ``configurations[1]``; the reference's
+    train.py:41-90 has no such key, so drivers read it with ``cfg.get``): 'bf16' = bf16 storage / fp32 accumulate on the
+    MFMA bf16 kernels (the path bench.py times), 'fp32' = the parity path.  ``None`` leaves the process default
+    (``FRHIP_COMPUTE_DTYPE``, fp32).  pSp keeps its trunk in ``.encoder``; the plan is keyed on the dtype, so switching
+    between steps rebuilds it.  Returns the torch dtype selected (or None)."""
+    if dtype is None:
+        return None
+    import torch
+    if isinstance(dtype, str):
+        name = _DTYPE_NAMES.get(dtype.lower())
+        if name is None:
+            raise ValueError("COMPUTE_DTYPE %r: expected 'bf16' or 'fp32'" % (dtype,))
+        dtype = getattr(torch, name)
+    if dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("COMPUTE_DTYPE %r: expected torch.bfloat16 or torch.float32" % (dtype,))
+    inner = model.module if hasattr(model, "module") and not hasattr(model, "_runner") else model
+    inner = inner.encoder if hasattr(inner, "encoder") else inner
+    inner.compute_dtype = dtype
+    return dtype

@@ -34,6 +34,7 @@ from backbone.model_resnet import ResNet_50, ResNet_101, ResNet_152  # noqa: F40
 from backbone.restyle_psp import pSp
 from dataset import FacesDataset, StageTransform, SyntheticFaces, TrainTransform
 from frhip import functional as FRF
+from frhip import set_compute_dtype
 from frhip.optim import SGD, Adam
 from frhip.parallel import DataParallel
 from head.metrics import Am_softmax, ArcFace, CosFace, SphereFace
@@ -179,6 +180,11 @@ def main():
     val = get_val_data(cfg["DATA_ROOT"]) if not args.synthetic else None
 
     backbone = build_backbone(cfg)
+    # COMPUTE_DTYPE ('bf16' | 'fp32', optional -- the reference's configs have no such key): the numerics of the backbone.
+    # The shipped BUPT configs select 'bf16', the path bench.py times; absent -> FRHIP_COMPUTE_DTYPE (default fp32).
+    cdt = set_compute_dtype(backbone, cfg.get("COMPUTE_DTYPE"))
+    if rank == 0:
+        print("Backbone compute dtype: {}".format(cdt if cdt is not None else "process default (FRHIP_COMPUTE_DTYPE)"))
     emb, s = cfg["EMBEDDING_SIZE"], cfg.get("ARCFACE_S", 64.0)
     heads = {"ArcFace": ArcFace(emb, num_class, None, s=s), "CosFace": CosFace(emb, num_class, None),
              "SphereFace": SphereFace(emb, num_class, None), "Am_softmax": Am_softmax(emb, num_class, None)}

@@ -439,3 +439,40 @@ def test_dispatch_geometry_of_the_strip_tables():
     ws = L.fr_conv_wgrad_strip_supported
     assert all(ws(c, c, w) == 1 for c, w in ((64, 112), (64, 56), (128, 28), (256, 14), (512, 7)))
     assert ws(96, 64, 56) == 0 and ws(64, 64, 20) == 0
+
+
+def test_configs_select_the_compute_dtype():
+    """COMPUTE_DTYPE is the config key that selects the numerics of the backbone (reference configs: train.py:41-90 have
+    none, so train.py reads it with cfg.get): the two BUPT configs run the bf16 path bench.py times, the synthetic smoke
+    config the fp32 parity path; frhip.set_compute_dtype puts it where the runner looks (pSp: on ``.encoder``)."""
+    import importlib
+    from frhip import set_compute_dtype
+    for name, want in (("config_BUPT_IR_50_baseline", "bf16"), ("config_BUPT_IR_50_AfrAsian", "bf16"),
+                       ("config_synthetic_smoke", "fp32")):
+        cfg = importlib.import_module("configs." + name).configurations[1]
+        assert cfg.get("COMPUTE_DTYPE") == want, name
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stylegan-for-facerec_amd",
+                            "train.py")).read()
+    assert 'cfg.get("COMPUTE_DTYPE")' in src  # optional key: a reference config without it still loads
+
+    class Trunk(object):
+        pass
+
+    class Psp(object):
+        def __init__(self):
+            self.encoder = Trunk()
+
+    class Wrapped(object):  # nn.DataParallel-style wrapper
+        def __init__(self, m):
+            self.module = m
+
+    t, p = Trunk(), Psp()
+    assert set_compute_dtype(t, "bf16") is torch.bfloat16 and t.compute_dtype is torch.bfloat16
+    assert set_compute_dtype(p, "FP32") is torch.float32 and p.encoder.compute_dtype is torch.float32
+    assert not hasattr(p, "compute_dtype")
+    assert set_compute_dtype(Wrapped(p), torch.bfloat16) is torch.bfloat16 and p.encoder.compute_dtype is torch.bfloat16
+    assert set_compute_dtype(t, None) is None and t.compute_dtype is torch.bfloat16  # absent key: nothing changes
+    with pytest.raises(ValueError):
+        set_compute_dtype(t, "fp16")
+    with pytest.raises(ValueError):
+        set_compute_dtype(t, torch.float16)
