@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 5
+#define FR_ABI_VERSION 6
 
 enum { FR_F32 = 0, FR_BF16 = 1 };
 
@@ -546,6 +546,17 @@ int fr_abi_version(void);
  * (returns the previous one); fr_get_option reads it (dflt when neither set nor in the environment). */
 int fr_set_option(const char* name, int value);
 int fr_get_option(const char* name, int dflt);
+/* Completion event of a kernel (ABI v6).  The backward pass hands its weight gradients to a second stream behind dependency
+ * edges (the reference runs them inside autograd's single stream: loss.backward(), train.py:314); an edge set with
+ * hipEventRecord costs the producing stream a marker packet the next kernel waits for (+3.0 ... 5.1 us per edge, three edges
+ * per residual unit; tools/edge_probe.hip).  fr_arm_stop_event(event) makes the NEXT kernel this thread launches through one
+ * of fr_conv3x3_strip / fr_conv3x3_s2_strip / fr_conv_igemm / fr_conv1x1_stream / fr_reduce_parts carry `event` (a
+ * hipEvent_t) as its own completion signal instead (+0.0 ... 1.6 us).  fr_finish_stop_event(stream) ends the bracket: it
+ * returns the number of kernels launched since the event was armed and, unless that is exactly one, records the event on
+ * `stream` the ordinary way (entry points that launch no such kernel, or several), so the event is ALWAYS behind the whole
+ * call.  Per-thread state, like the error string.  < 0: no event armed / hipEventRecord failed. */
+int fr_arm_stop_event(void* event);
+int fr_finish_stop_event(void* stream);
 /* sizeof() of the argument structs as compiled, for binding self-checks: 0 FrConvArgs, 1 FrWgradArgs,
  * 2 FrApplyArgs, 3 FrBnBwdArgs, 4 FrSgdTensor, 5 FrPackTensor, 6 FrAdamTensor, 7 FrBnEvalEntry, 8 FrBnFinArgs */
 int fr_struct_size(int which);

@@ -73,6 +73,34 @@ extern "C" int fr_set_option(const char* name, int value) {
 
 extern "C" int fr_get_option(const char* name, int dflt) { return *fr_option_slot(name, dflt); }
 
+// ---------------------------------------------------------------------------------------------------------
+// Completion event of the next kernel (common.h, FR_LAUNCH_KERNEL)
+// ---------------------------------------------------------------------------------------------------------
+thread_local hipEvent_t fr_tls_stop_event = nullptr;
+thread_local int fr_tls_stop_launches = 0;
+
+extern "C" int fr_arm_stop_event(void* event) {
+  fr_tls_stop_event = reinterpret_cast<hipEvent_t>(event);
+  fr_tls_stop_launches = 0;
+  return 0;
+}
+
+extern "C" int fr_finish_stop_event(void* stream) {
+  hipEvent_t ev = fr_tls_stop_event;
+  const int n = fr_tls_stop_launches;
+  fr_tls_stop_event = nullptr;
+  fr_tls_stop_launches = 0;
+  if (!ev) FR_UNSUPPORTED("fr_finish_stop_event: no event armed on this thread");
+  if (n != 1) {  // no launcher took it, or more kernels followed the one that did: a marker behind all of them
+    hipError_t e = hipEventRecord(ev, reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+      fr_set_error(hipGetErrorString(e));
+      return -(1000 + (int)e);
+    }
+  }
+  return n;
+}
+
 namespace {
 __global__ void fill_rows_kernel(float* __restrict__ out, const float* __restrict__ bias, long long n, int C) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)

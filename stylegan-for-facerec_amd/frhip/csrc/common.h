@@ -1,8 +1,12 @@
 // frhip -- shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
 // Wavefront = 64 lanes; MFMA 16x16x32 (bf16) / 16x16x4 (f32) fragments; all math accumulates in fp32.
 #pragma once
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <tuple>
+#include <utility>
 
 typedef uint16_t bf16_t;  // raw bfloat16 storage
 
@@ -34,6 +38,36 @@ extern "C" void fr_set_error(const char* msg);
       return (int)e__;                         \
     }                                          \
     return 0;                                  \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// Completion event of a kernel (fr_arm_stop_event, include/frhip.h).  A dependency edge main stream -> weight-gradient
+// stream set with hipEventRecord puts a marker packet behind the producer, and the NEXT kernel of the main stream waits for
+// that marker: +3.0 us per edge with nobody waiting, +5.1 us with a waiter (tools/edge_probe.hip, profiles/r06_edge_probe.txt).
+// The producer's own completion signal does the same job for +0.0 / +1.6 us: hipExtLaunchKernel(..., stopEvent).  The
+// launchers of the kernels that precede such edges go through FR_LAUNCH_KERNEL, which hands an armed event to the first
+// launch after fr_arm_stop_event (per host thread) and is hipLaunchKernelGGL otherwise.
+// ---------------------------------------------------------------------------------------------------------
+extern thread_local hipEvent_t fr_tls_stop_event;   // armed event (nullptr: none)
+extern thread_local int fr_tls_stop_launches;       // FR_LAUNCH_KERNEL launches since it was armed
+template <typename... P, typename... A, size_t... I>
+inline void fr_launch_ext_(void (*kern)(P...), dim3 g, dim3 b, unsigned lds, hipStream_t st, hipEvent_t stop,
+                           std::index_sequence<I...>, A&&... a) {
+  std::tuple<P...> params{static_cast<P>(std::forward<A>(a))...};  // the kernel's own parameter types, by value
+  void* ptrs[] = {static_cast<void*>(&std::get<I>(params))...};
+  (void)hipExtLaunchKernel(reinterpret_cast<const void*>(kern), g, b, ptrs, lds, st, nullptr, stop, 0);
+}
+template <typename... P, typename... A>
+inline void fr_launch_ext(void (*kern)(P...), dim3 g, dim3 b, unsigned lds, hipStream_t st, hipEvent_t stop, A&&... a) {
+  static_assert(sizeof...(P) == sizeof...(A), "kernel argument count");
+  fr_launch_ext_(kern, g, b, lds, st, stop, std::index_sequence_for<P...>{}, std::forward<A>(a)...);
+}
+#define FR_LAUNCH_KERNEL(kern, grid, block, lds, st, ...)                                    \
+  do {                                                                                        \
+    if (fr_tls_stop_event && fr_tls_stop_launches++ == 0)                                     \
+      fr_launch_ext(kern, grid, block, lds, st, fr_tls_stop_event, __VA_ARGS__);              \
+    else                                                                                      \
+      hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                            \
   } while (0)
 
 // hipFuncSetAttribute (dynamic LDS above 64 KB) is per function AND per device: launchers keep one bit per device.  The mask

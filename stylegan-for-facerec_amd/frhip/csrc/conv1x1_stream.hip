@@ -147,10 +147,10 @@ template <int K, int N, int NW>
 int c1_launch(const FrConvArgs& a, const C1Geo& g, hipStream_t st) {
   const int grid = c1_grid(g.M, K);
   if (a.epi == FR_EPI_STATS)
-    hipLaunchKernelGGL((conv1x1_stream_kernel<K, N, NW, true>), dim3(grid), dim3(NW * 64), 0, st, (const bf16_t*)a.src,
+    FR_LAUNCH_KERNEL((conv1x1_stream_kernel<K, N, NW, true>), dim3(grid), dim3(NW * 64), 0, st, (const bf16_t*)a.src,
                        (const bf16_t*)a.w, (bf16_t*)a.out, a.part, g);
   else
-    hipLaunchKernelGGL((conv1x1_stream_kernel<K, N, NW, false>), dim3(grid), dim3(NW * 64), 0, st, (const bf16_t*)a.src,
+    FR_LAUNCH_KERNEL((conv1x1_stream_kernel<K, N, NW, false>), dim3(grid), dim3(NW * 64), 0, st, (const bf16_t*)a.src,
                        (const bf16_t*)a.w, (bf16_t*)a.out, a.part, g);
   FR_LAUNCH_CHECK();
 }

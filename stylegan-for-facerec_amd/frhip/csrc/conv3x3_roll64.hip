@@ -492,7 +492,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
   const int items = a.B * (W / R64::BW) * nseg;
   // one workgroup per CU (156 KB of LDS), persistent over its items: weights and coefficients are staged once
   const int grid = items < 256 ? items : 256;
-  hipLaunchKernelGGL((conv3x3_roll64_kernel<W, PRO, AUX>), dim3(grid), dim3(R64::NTH), R64::LDS, st, a, nseg, items);
+  FR_LAUNCH_KERNEL((conv3x3_roll64_kernel<W, PRO, AUX>), dim3(grid), dim3(R64::NTH), R64::LDS, st, a, nseg, items);
   FR_LAUNCH_CHECK();
 }
 

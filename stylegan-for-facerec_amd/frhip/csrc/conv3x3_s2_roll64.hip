@@ -538,7 +538,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
   const int nseg = s2roll_nseg(a.B);
   const int items = a.B * nseg;
   const int grid = items < 256 ? items : 256;  // persistent: weights are loaded into registers once per workgroup
-  hipLaunchKernelGGL((conv3x3_s2_roll64_kernel<KIND, PRO>), dim3(grid), dim3(S2R::NTH), LY::LDS, st, a, nseg, items);
+  FR_LAUNCH_KERNEL((conv3x3_s2_roll64_kernel<KIND, PRO>), dim3(grid), dim3(S2R::NTH), LY::LDS, st, a, nseg, items);
   FR_LAUNCH_CHECK();
 }
 

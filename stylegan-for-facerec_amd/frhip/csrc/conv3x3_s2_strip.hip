@@ -23,6 +23,21 @@
 #include "common.h"
 #include "frhip_internal.h"
 
+#ifdef FRHIP_STAMPS
+// Diagnostic build only (make stamps -> libfrhip_stamps.so; never the product library): wave 0 of every workgroup writes
+// s_memrealtime (100 MHz) at its phase boundaries to a buffer of its own (16 slots per workgroup), read by tools/stamps_s2.py.
+__device__ unsigned long long* fr_stamp_buf_s2 = nullptr;
+extern "C" int fr_debug_set_stamp_buffer_s2(unsigned long long* dev_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(fr_stamp_buf_s2), &dev_ptr, sizeof(dev_ptr));
+}
+#define S2_STAMP(k)                                                                                          \
+  do {                                                                                                       \
+    if (threadIdx.x == 0 && fr_stamp_buf_s2) fr_stamp_buf_s2[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define S2_STAMP(k)
+#endif
+
 namespace {
 
 // COUT is the width ONE workgroup computes (NSPL workgroups share a strip, conv3x3_strip.hip); NIMG > 1: a workgroup owns
@@ -464,24 +479,38 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
 
   if (KIND == 0 && !PFP) {
     zero_acc();
+    S2_STAMP(0);
     load_image(0, 0);
+    S2_STAMP(1);
     __syncthreads();
+    S2_STAMP(2);
     mma_taps<C, CIN, 0, 0>(smem, abase, acc, wrow);
+    S2_STAMP(3);
     __syncthreads();  // every wave is done reading the plane
+    S2_STAMP(4);
     load_image(0, 1);
     __syncthreads();
+    S2_STAMP(5);
     mma_taps<C, CIN, 0, 1>(smem, abase, acc, wrow);
     __syncthreads();
+    S2_STAMP(6);
     load_image(1, 0);
     __syncthreads();
+    S2_STAMP(7);
     mma_taps<C, CIN, 0, 2>(smem, abase, acc, wrow);
     __syncthreads();
+    S2_STAMP(8);
     load_image(1, 1);
+    S2_STAMP(9);
     __syncthreads();
+    S2_STAMP(10);
     issue_aux(-1);
     mma_taps<C, CIN, 0, 3>(smem, abase, acc, wrow);
+    S2_STAMP(11);
     __syncthreads();  // LDS is now the output tile
+    S2_STAMP(12);
     epilogue(-1);
+    S2_STAMP(13);
   } else if (KIND == 0) {
     zero_acc();
     issue_plane(0, 0);
@@ -507,24 +536,35 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
     __syncthreads();  // LDS is now the output tile
     epilogue(-1);
   } else {
+    S2_STAMP(0);
     load_image(0, 0);
+    S2_STAMP(1);
     __syncthreads();
+    S2_STAMP(2);
     zero_acc();
     issue_aux(0);
     mma_taps<C, CIN, 1, 0>(smem, abase, acc, wrow);
+    S2_STAMP(3);
     epilogue(0);
+    S2_STAMP(4);
     zero_acc();
     issue_aux(1);
     mma_taps<C, CIN, 1, 1>(smem, abase, acc, wrow);
+    S2_STAMP(5);
     epilogue(1);
+    S2_STAMP(6);
     zero_acc();
     issue_aux(2);
     mma_taps<C, CIN, 1, 2>(smem, abase, acc, wrow);
+    S2_STAMP(7);
     epilogue(2);
+    S2_STAMP(8);
     zero_acc();
     issue_aux(3);
     mma_taps<C, CIN, 1, 3>(smem, abase, acc, wrow);
+    S2_STAMP(9);
     epilogue(3);
+    S2_STAMP(10);
   }
 }
 
@@ -543,7 +583,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
         hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     fr_attr_done(attr_done);
   }
-  hipLaunchKernelGGL((conv3x3_s2_kernel<CIN, COUT, WL, ROWS, WN, NW, KIND, PRO, NSPL, NIMG>),
+  FR_LAUNCH_KERNEL((conv3x3_s2_kernel<CIN, COUT, WL, ROWS, WN, NW, KIND, PRO, NSPL, NIMG>),
                      dim3(a.B * C::NS / NIMG * NSPL), dim3(C::NTH), C::LDS, st, a, s2_xcd_order());
   FR_LAUNCH_CHECK();
 }

@@ -518,7 +518,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
   const int strips = a.B * C::NS / NIMG;
   if (a.epi == FR_EPI_STATS_X && (!a.part || !a.aux))
     FR_UNSUPPORTED("fr_conv3x3_strip: FR_EPI_STATS_X needs part and aux (its rows go to fr_bn_finalize_res)");
-  hipLaunchKernelGGL((conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, NSPL, PRO, NIMG, KSPL>),
+  FR_LAUNCH_KERNEL((conv3x3_strip_kernel<CIN, COUT, W, ROWS, WN, NW, NSPL, PRO, NIMG, KSPL>),
                      dim3(strips * NSPL), dim3(C::NTH), C::LDS, st, a, xcd_order());
   FR_LAUNCH_CHECK();
 }

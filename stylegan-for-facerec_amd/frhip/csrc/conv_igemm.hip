@@ -468,7 +468,7 @@ int launch(const FrConvArgs& a, hipStream_t st) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     fr_attr_done(attr_done);
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, PRO>), grid, dim3(NT), C::LDS_BYTES, st, a);
+  FR_LAUNCH_KERNEL((conv_igemm_kernel<T, BN, PRO>), grid, dim3(NT), C::LDS_BYTES, st, a);
   FR_LAUNCH_CHECK();
 }
 

@@ -1482,7 +1482,7 @@ extern "C" int fr_bn_eval_coeffs(const float* rm, const float* rv, const float* 
 extern "C" int fr_reduce_parts(const float* part, int nparts, int K, int C, float* o0, float* o1, float* o2,
                                void* stream) {
   if (K < 1 || K > 3) FR_UNSUPPORTED("fr_reduce_parts: K must be 1..3");
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((K * C + 7) / 8), dim3(RT), 0, (hipStream_t)stream, part, nparts, K,
+  FR_LAUNCH_KERNEL(reduce_parts_kernel, dim3((K * C + 7) / 8), dim3(RT), 0, (hipStream_t)stream, part, nparts, K,
                      C, o0, o1, o2);
   FR_LAUNCH_CHECK();
 }

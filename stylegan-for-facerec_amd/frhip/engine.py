@@ -258,6 +258,7 @@ class BackbonePlan(object):
         # value for all.
         self.wgrad_wgs = min(256, max(64, _switch("FRHIP_WGRAD_WGS", 128)))  # the slab sum takes <= 256 groups
         self.stream2 = ctypes.c_void_p(self.stream2_t.cuda_stream)
+        self.edge_signal = bool(_switch("FRHIP_EDGE_SIGNAL", 1))  # dependency edges as completion signals (_side_after_main)
         self.S = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
         self.generation = 0
         # (FRHIP_GRAPH, rounds 2-3: the two launch lists captured into HIP graphs.  Replay was SLOWER than eager launches at
@@ -289,6 +290,7 @@ class BackbonePlan(object):
         # slabs to the NEXT such launch of the side stream (two slab buffers alternate); fr_reduce_slabs flushes the last
         self.defer_slabs = True  # (FRHIP_WGRAD_DEFER=0 turns the library's answer off)
         self.slab2, self._slab2_users, self._slab_flip = None, [], 0
+        self.slab3, self._slab3_users = None, []  # slabs of the launches that sum their own (the deferring chain skips them)
         self._pending = None  # (launch that wrote the slabs, groups, n, dw tensor, parameter)
         self.part_slope = None  # per-buffer-set partial rows of the PReLU slope gradient (side-stream reduction)
         self.comm_stream_t, self.comm_events = None, None  # readiness callbacks (run_backward)
@@ -397,11 +399,26 @@ class BackbonePlan(object):
         # the same box -- profiles/r04_ab_edges.txt.  The early edge behind conv2's data gradient is worth more than its gap:
         # the side stream's kernels are queued while the first data gradient still holds the CUs and take them as its
         # workgroups retire.)
-        nset = 2 if self.dual else 1
+        # Round 6: ONE buffer set per unit, each of its unit's own size (FRHIP_BWD_SETS=0, default; IR-50 at batch 256: 2.5 GB
+        # instead of 1.2 GB for two sets of the largest unit's size).  With two alternating sets the main stream waits at the
+        # head of every unit for the side stream's event of the unit two back -- a wait that (almost) never blocks, but costs
+        # the main stream a barrier packet its next kernel waits for: +3.7 us per unit (tools/edge_probe.hip); with a set per
+        # unit nothing is ever reused inside a step and the main stream waits for the side stream once, at the end.
+        sets = _switch("FRHIP_BWD_SETS", 0)
+        self.per_unit_sets = self.dual and sets <= 0
+        nset = (len(self.units) if self.per_unit_sets else max(2, sets)) if self.dual else 1
         self.nset = nset
-        self.g_y2s = [self._act(max_out, 1).view(-1) for _ in range(nset)]
-        self.g_ySs = [self._act(max_out, 1).view(-1) if max_xs else None for _ in range(nset)]
-        self.g_y1s = [self._act(max(max_mid, M0 * C0), 1).view(-1) for _ in range(nset)]
+        if self.per_unit_sets:
+            self.g_y2s, self.g_ySs, self.g_y1s = [], [], []
+            for u in self.units:
+                rin, rout = B * u.H * u.H, B * u.Ho * u.Ho
+                self.g_y2s.append(self._act(rout * u.depth, 1).view(-1))
+                self.g_ySs.append(self._act(rout * u.depth, 1).view(-1) if u.sc_conv is not None else None)
+                self.g_y1s.append(self._act(rin * u.depth, 1).view(-1))
+        else:
+            self.g_y2s = [self._act(max_out, 1).view(-1) for _ in range(nset)]
+            self.g_ySs = [self._act(max_out, 1).view(-1) if max_xs else None for _ in range(nset)]
+            self.g_y1s = [self._act(max(max_mid, M0 * C0), 1).view(-1) for _ in range(nset)]
         self.g_y1 = self.g_y1s[0]
         self.g_xh = self._act(max_in, 1).view(-1)
         self.g_xS = self._act(max_xs, 1).view(-1) if max_xs else None
@@ -415,7 +432,8 @@ class BackbonePlan(object):
                                 device=dev)
         self.side_slope = self.dual  # the PReLU-slope partial sums are added on the side stream (on the main one: +0.1 ms)
         if self.side_slope:
-            self.part_slope = [torch.zeros_like(self.part) for _ in range(nset)]
+            # (per-unit sets: sized when the backward list is built, from the rows the unit's data gradient writes)
+            self.part_slope = [None if self.per_unit_sets else torch.zeros_like(self.part) for _ in range(nset)]
         self.se_scratch = torch.zeros(2, 512 * 64, device=dev)  # dW1/dW2 sink while the SE weights are frozen
         self.se_gs_part = torch.empty(B * 8 * 512, device=dev)  # row-slice partials of the squeeze-excite gradient squeeze
         self.sums = torch.zeros(3, 512, device=dev)      # scratch reduce target for frozen parameters
@@ -520,10 +538,18 @@ class BackbonePlan(object):
         return (kw["B"] * kw["RH"] * kw["RW"] + 127) // 128
 
     def _side_after_main(self, L):
-        """Order the side stream behind everything enqueued on the main stream so far."""
+        """Order the side stream behind everything enqueued on the main stream so far.  Round 6: the edge is the completion
+        signal of the launch in front of it (ops.Launch.arm) where that is a launch of the main stream -- an event recorded
+        behind it costs the main stream a marker packet its next kernel waits for: +5.1 us per edge against +1.6 (three edges
+        per residual unit; tools/edge_probe.hip, profiles/r06_edge_probe.txt).  FRHIP_EDGE_SIGNAL=0: A/B switch."""
         if self.dual:
             ev = torch.cuda.Event()
-            L.append(_EvRecord(ev, self.stream1_t))
+            last = L[-1] if L else None
+            if (self.edge_signal and isinstance(last, ops.Launch) and last.tstream is None and last.stop_event is None):
+                ev.record(self.stream1_t)  # creates the hipEvent_t (torch allocates it at the first record)
+                last.arm(ev, self.stream)
+            else:
+                L.append(_EvRecord(ev, self.stream1_t))
             L.append(_EvWait(self.stream2_t, ev))
 
     def _wgrad(self, L, param=None, **kw):
@@ -554,7 +580,7 @@ class BackbonePlan(object):
 
     def _slab_buffer(self, which, need):
         """One of the two slab buffers, grown on demand (earlier launches are re-pointed at the new allocation)."""
-        name, users = ("slab", self._slab_users) if which == 0 else ("slab2", self._slab2_users)
+        name, users = (("slab", self._slab_users), ("slab2", self._slab2_users), ("slab3", self._slab3_users))[which]
         buf = getattr(self, name)
         if buf is None or buf.numel() < need:
             buf = torch.empty(need, device=self.device)
@@ -602,10 +628,17 @@ class BackbonePlan(object):
                 self._pending = (l, kw["nsplit"], kw["Cout"] * kw["KH"] * kw["KW"] * kw["SC"], kw["dw"], param, which)
                 L.append(l)
                 return done
-        flushed = self._flush_pending(L)  # keep the side stream's sums in order
-        if flushed is not None:
-            done.append(flushed)
-        buf, users = self._slab_buffer(0, need)
+        # A launch that sums its own slabs (1x1 shortcut weight gradients, shapes off the strip tables).  Rounds 3-5 first
+        # flushed the slabs a deferring launch had left behind (fr_reduce_slabs: 34-53 us on the weight-gradient stream, three
+        # times per IR-50 step) so that both could share buffer 0; with a buffer of its own the launch goes out at once and
+        # the deferred sum stays with the next deferring launch (FRHIP_WGRAD_SKIP_FLUSH=0: the old order).
+        if _switch("FRHIP_WGRAD_SKIP_FLUSH", 1) and self.defer_slabs:
+            buf, users = self._slab_buffer(2, need)
+        else:
+            flushed = self._flush_pending(L)  # keep the side stream's sums in order
+            if flushed is not None:
+                done.append(flushed)
+            buf, users = self._slab_buffer(0, need)
         kw = dict(kw, slab=buf)
         l = ops.wgrad_strip(self.stream2, **kw) if strip else ops.wgrad(self.stream2, self.fr, **kw)
         l.tstream = self.stream2_t
@@ -1137,6 +1170,11 @@ class BackbonePlan(object):
             # side stream they go to a buffer of their own (one per buffer set) and are added there, off the main chain.
             gsl = self.grad_of(u.prelu.weight)
             gsl = gsl if gsl is not None else self.sums[2, :u.depth]
+            if self.side_slope and self.part_slope[par] is None:  # this unit's own rows: [<= 4 classes x strips][2][depth] floats
+                probe = []
+                rows = self._conv_launch(probe, mode=2 if (u.stride == 2 and u.H % 2 == 0) else 1, par_h=-1, par_w=-1,
+                                         part=self.part, **c2)
+                self.part_slope[par] = torch.zeros(rows * 2 * u.depth + 4096, device=self.device)
             part2 = self.part_slope[par] if self.side_slope else self.part
             if u.stride == 2 and u.H % 2 == 0:
                 # one launch per output-pixel parity class: 9/4 taps per pixel instead of 9 (3/4 of them misses)
@@ -1237,11 +1275,16 @@ class BackbonePlan(object):
             L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
             self._reduce(L, nb, 3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64])
         s0, s1 = self._s01(self.bn0, db, dg)
-        g_y0 = self.g_y1s[1 if self.dual else 0][:self.M0 * 64]  # unit 0's wgrads (side stream) still read set 0
-        if self.dual and 1 in unit_done:
-            L.append(_EvWait(self.stream1_t, unit_done[1]))  # set 1 was last read by unit 1's weight gradients
         gw0 = self.grad_of(sc.weight)
         fuse = self.use_stem_gemm  # BN0 / PReLU backward applied while the weight gradient stages its rows
+        g_y0 = None
+        if gw0 is not None and not fuse:  # the materialised stem-output gradient (fp32 path)
+            if self.per_unit_sets:
+                g_y0 = self._act(self.M0 * 64, 1).view(-1)
+            else:
+                g_y0 = self.g_y1s[1 if self.dual else 0][:self.M0 * 64]  # unit 0's wgrads (side stream) still read set 0
+                if self.dual and 1 in unit_done:
+                    L.append(_EvWait(self.stream1_t, unit_done[1]))  # set 1 was last read by unit 1's weight gradients
         if gw0 is not None and not fuse:
             L.append(ops.bn_bwd_apply(st, fr, gx=g_y0, gamma=sb.weight, s0=s0, s1=s1, inv_count=1.0 / self.M0,
                                       **common))

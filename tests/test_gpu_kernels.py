@@ -1756,3 +1756,60 @@ def test_conv1x1_stream_equals_the_generic_gemm(K, Kc, N, B, Ho, stride):
         K.conv1x1_stream(st, out=o2, epi=_lib.EPI_STORE, **dict(kw, N=N // 2))()
     assert K.conv1x1_stream_parts(B, Ho, Ho, Kc, 96) == 0
 
+
+
+def test_completion_event_of_a_launch_orders_another_stream(K):
+    """fr_arm_stop_event / fr_finish_stop_event (ABI v6): the event rides on the kernel's own completion signal when the
+    entry point launches exactly one kernel through FR_LAUNCH_KERNEL (fr_reduce_parts here: returns 1) and is recorded the
+    ordinary way otherwise (fr_bn_finalize: returns 0) -- either way a second stream that waits for it sees the launch's
+    results.  This is the edge between the main stream's data gradients and the weight-gradient stream (engine.py
+    _side_after_main; reference: autograd runs both inside loss.backward(), train.py:314)."""
+    from frhip import _lib
+    nparts, C = 4096, 512
+    part = (torch.rand(nparts, 2, C, device="cuda") + 0.5)
+    ref = part.double().sum(0).float()
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    st = K.current_stream_ptr()
+    big = torch.rand(64 * 1024 * 1024, device="cuda")
+    for name, want_n in (("fr_reduce_parts", 1), ("fr_bn_finalize", 0)):
+        o0, o1 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        copy0 = torch.empty(C, device="cuda")
+        ev = torch.cuda.Event()
+        ev.record(main)  # torch allocates the hipEvent_t at the first record
+        if name == "fr_reduce_parts":
+            l = K.call(name, part, nparts, 2, C, o0, o1, None, st)
+        else:
+            l = K.call(name, part, nparts, C, float(nparts), None, None, 1e-5, 0.1, None, None, None, o0, o1,
+                       torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), st)
+        l.arm(ev, st)
+        torch.cuda.synchronize()
+        for _ in range(4):
+            big.mul_(1.0001)  # the main stream is busy: the launch below starts late
+        _lib.lib.fr_arm_stop_event(l.stop_handle)
+        assert l.fn(*l.args) == 0
+        n = _lib.lib.fr_finish_stop_event(l.stop_stream)
+        assert n == want_n, (name, n)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            copy0.copy_(o0)
+        torch.cuda.synchronize()
+        if name == "fr_reduce_parts":
+            np.testing.assert_allclose(copy0.cpu(), ref[0].cpu(), rtol=1e-6)
+        else:
+            np.testing.assert_allclose(copy0.cpu(), (ref[0] / nparts).cpu(), rtol=1e-5)
+    assert _lib.lib.fr_finish_stop_event(st) < 0 and b"no event armed" in _lib.lib.fr_last_error_string()
+    # Launch.__call__ does the same bracket
+    o0 = torch.zeros(C, device="cuda")
+    ev = torch.cuda.Event()
+    ev.record(main)
+    l = K.call("fr_reduce_parts", part, nparts, 2, C, o0, torch.zeros(C, device="cuda"), None, st)
+    l.arm(ev, st)
+    l()
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        got = o0.clone()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.cpu(), ref[0].cpu(), rtol=1e-6)
+    with pytest.raises(_lib.FrhipError):
+        K.call("fr_reduce_parts", part, nparts, 2, C, o0, o0, None, st).arm(torch.cuda.Event(), st)  # never recorded: no handle
