@@ -316,6 +316,17 @@ typedef struct FrBnBwdArgs {
 int fr_bn_bwd_reduce(const FrBnBwdArgs* args, int dtype, void* stream);
 int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream);
 
+/* Round 6 (ABI v6): the sums of fr_stem_bwd_sums when G is the LAST tensor the first residual unit would write -- gx of its BN1 backward
+ * (bottleneck_IR: BatchNorm2d(in_channel) at the head of res_layer, backbone/model_irse.py:57, + the shortcut gradient of
+ * MaxPool2d(1, stride) / the residual stream, :52-54, :64-66).  `unit` holds exactly the arguments of the fr_bn_bwd_apply
+ * call this replaces (g, x, gx, mean, invstd, gamma, s0, s1, inv_count, add, add_kind 0 | 1 | 2, H, W, add_stride = 2,
+ * rows_per_image; C = 64, rows = M; no slope, no gate): the kernel forms gx element for element as that call does, stores it
+ * (the weight-gradient kernel reads it next) and feeds the rounded values to the sums -- gx and part are bit-identical to
+ * fr_bn_bwd_apply followed by fr_stem_bwd_sums, and the 411-MB tensor (batch 256) is read once less. */
+int fr_stem_bwd_sums_from(const FrBnBwdArgs* unit, const void* X, const void* Wp, const float* mean, const float* invstd,
+                          const float* scale, const float* shift, const float* slope, float* part, long long M, int K,
+                          int nblocks, void* stream);
+
 /* add partial rows in double: o_k[c] = sum_blk part[blk][k][c], k < K <= 3; NULL outputs are skipped.
  * Used for d gamma (k=1), d beta (k=0), d PReLU slope (k=2) and for the conv-epilogue partials. */
 int fr_reduce_parts(const float* part, int nparts, int K, int C, float* o0, float* o1, float* o2, void* stream);

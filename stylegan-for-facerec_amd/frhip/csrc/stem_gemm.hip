@@ -294,6 +294,174 @@ __global__ __launch_bounds__(256) void stem_bwd_sums_kernel(const bf16_t* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------ ... fed by the first unit
+// Round 6.  The gradient the sums above read is the LAST thing the first residual unit writes: gx = BN1-backward(g) [+ the
+// shortcut gradient], fr_bn_bwd_apply over 3.2 M rows x 64 channels at batch 256 -- 411 MB written, and read straight back
+// by the kernel above (both HBM-bound; the 256-MB memory-side cache holds none of it).  Here the kernel above forms gx
+// itself: it loads the unit's (g, x [, add]) chunks where it used to load G, applies the expressions of
+// bn_bwd_apply_lean_kernel<ADD> element for element, stores the rounded gx (the weight-gradient kernel reads it next) and
+// feeds the ROUNDED values to its sums -- bit-identical gx and partial rows, one pass of 411 MB less.
+struct StemFromUnit {
+  const bf16_t* g;      // BN1-backward input of the unit [M][64]
+  const bf16_t* x;      // the unit's input (= the stem output z) [M][64]
+  const bf16_t* add;    // ADD 1: [M][64]; ADD 2: [B][H/2][W/2][64], lands on the pixels with even h and w
+  bf16_t* gx;           // out [M][64]
+  const float* mean;    // BN1 of the unit
+  const float* invstd;
+  const float* gamma;   // may be NULL (1)
+  const float* s0;
+  const float* s1;
+  float inv_count;
+  int W, HW;            // ADD 2: image width, pixels per image
+  float invW, invHW;
+};
+
+template <int K, int ADD>
+__global__ __launch_bounds__(256) void stem_bwd_sums_from_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wp,
+                                                                 const StemFromUnit un, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 const float* __restrict__ slope, float* __restrict__ part,
+                                                                 int M) {
+  constexpr int KS = K / 32, NT = 2;
+  constexpr int OSTR = SN * 2 + 16;
+  __shared__ __attribute__((aligned(16))) char tiles[4 * 16 * OSTR];
+  __shared__ float red[4 * 3 * SN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int c8 = lane & 7, r8 = lane >> 3;  // rows r8 and r8 + 8 of a tile, channels 8*c8 .. +7
+  char* tile = tiles + wave * 16 * OSTR;
+  s16x8 wf[4][KS];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+      wf[j][kk] = *reinterpret_cast<const s16x8*>(Wp + (size_t)(j * 16 + fr) * K + kk * 32 + fq * 8);
+  float sc[8], sh[8], sl[8], mu[8], is[8], a0[8], a1[8], a2[8];
+  float umu[8], uis[8], ucoef[8], ua[8], ub[8];  // the unit's BN1: names of bn_bwd_apply_lean_kernel
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    sc[q] = scale[c8 * 8 + q];
+    sh[q] = shift[c8 * 8 + q];
+    sl[q] = slope[c8 * 8 + q];
+    mu[q] = mean[c8 * 8 + q];
+    is[q] = invstd[c8 * 8 + q];
+    a0[q] = a1[q] = a2[q] = 0.f;
+    umu[q] = un.mean[c8 * 8 + q];
+    uis[q] = un.invstd[c8 * 8 + q];
+    ucoef[q] = (un.gamma ? un.gamma[c8 * 8 + q] : 1.f) * uis[q];
+    ua[q] = un.s0[c8 * 8 + q] * un.inv_count;
+    ub[q] = un.s1[c8 * 8 + q] * un.inv_count;
+  }
+  const unsigned Wd = (unsigned)un.W, HW = (unsigned)un.HW, Wh = Wd >> 1, HWq = HW >> 2;
+  const int ntiles = (M + 15) / 16;
+  const int tstep = gridDim.x * 4;
+  for (int t0 = blockIdx.x * 4 + wave; t0 < ntiles; t0 += tstep * NT) {  // the tile order of stem_bwd_sums_kernel
+    s16x8 af[NT][KS];
+    U128 gv[NT][2], xv[NT][2], ev[NT][2];
+    bool hit[NT][2];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int t = t0 + u * tstep, row = t * 16 + fr;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        af[u][kk] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (t < ntiles && row < M) af[u][kk] = *reinterpret_cast<const s16x8*>(X + (size_t)row * K + kk * 32 + fq * 8);
+      }
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const int grow = t * 16 + r8 + 8 * v;
+        gv[u][v] = xv[u][v] = ev[u][v] = zero16();
+        hit[u][v] = false;
+        if (t < ntiles && grow < M) {
+          gv[u][v] = ld16(un.g + (size_t)grow * SN + c8 * 8);
+          xv[u][v] = ld16(un.x + (size_t)grow * SN + c8 * 8);
+          if (ADD == 1) ev[u][v] = ld16(un.add + (size_t)grow * SN + c8 * 8);
+          if (ADD == 2) {
+            unsigned b, rem, h, w;
+            fast_divmod((unsigned)grow, HW, un.invHW, b, rem);
+            fast_divmod(rem, Wd, un.invW, h, w);
+            hit[u][v] = ((h | w) & 1u) == 0u;
+            if (hit[u][v]) ev[u][v] = ld16(un.add + ((size_t)b * HWq + (h >> 1) * Wh + (w >> 1)) * SN + c8 * 8);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int t = t0 + u * tstep;
+      f32x4 acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], af[u][kk], acc[j], 0, 0, 0);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint2 o;
+        o.x = pack2bf(acc[j][0], acc[j][1]);
+        o.y = pack2bf(acc[j][2], acc[j][3]);
+        *reinterpret_cast<uint2*>(tile + fr * OSTR + (j * 16 + fq * 4) * 2) = o;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const int rr = r8 + 8 * v;
+        if (t < ntiles && t * 16 + rr < M) {
+          float yv[8], gg[8], xx[8], ee[8];
+          unpack16<bf16_t>(ld16(tile + rr * OSTR + c8 * 16), yv);
+          unpack16<bf16_t>(gv[u][v], gg);
+          unpack16<bf16_t>(xv[u][v], xx);
+          unpack16<bf16_t>(ev[u][v], ee);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {  // bn_bwd_apply_lean_kernel<ADD>, element for element
+            float o = ucoef[q] * (gg[q] - ua[q] - (xx[q] - umu[q]) * uis[q] * ub[q]);
+            if (ADD == 1 || (ADD == 2 && hit[u][v])) o += ee[q];
+            gg[q] = o;
+          }
+          const U128 packed = pack16<bf16_t>(gg);
+          st16(un.gx + (size_t)(t * 16 + rr) * SN + c8 * 8, packed);
+          unpack16<bf16_t>(packed, gg);  // the sums see what the stored tensor holds
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {  // operation order of bn_bwd_reduce_lean_kernel<true>
+            float gq = gg[q];
+            const float uu = fmaf(yv[q], sc[q], sh[q]);
+            const bool pos = uu > 0.f;
+            a2[q] += pos ? 0.f : gq * uu;
+            gq = pos ? gq : gq * sl[q];
+            a0[q] += gq;
+            a1[q] = fmaf(gq, (yv[q] - mu[q]) * is[q], a1[q]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    float a = a0[q], c = a1[q], e = a2[q];
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      a += __shfl_xor(a, o, 64);
+      c += __shfl_xor(c, o, 64);
+      e += __shfl_xor(e, o, 64);
+    }
+    if (r8 == 0) {
+      red[(wave * 3 + 0) * SN + c8 * 8 + q] = a;
+      red[(wave * 3 + 1) * SN + c8 * 8 + q] = c;
+      red[(wave * 3 + 2) * SN + c8 * 8 + q] = e;
+    }
+  }
+  __syncthreads();
+  if (tid < 3 * SN) {
+    const int k = tid / SN, n = tid - k * SN;
+    part[((size_t)blockIdx.x * 3 + k) * SN + n] =
+        red[(0 * 3 + k) * SN + n] + red[(1 * 3 + k) * SN + n] + red[(2 * 3 + k) * SN + n] + red[(3 * 3 + k) * SN + n];
+  }
+}
+
 // ------------------------------------------------------------------------------------------ weight gradient
 // slab[blk][co][k] = sum over the workgroup's rows of g[m][co] * X[m][k]; fr_reduce_parts adds the slabs.
 typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
@@ -525,6 +693,41 @@ extern "C" int fr_stem_bwd_sums(const void* X, const void* Wp, const void* G, co
   else
     hipLaunchKernelGGL((stem_bwd_sums_kernel<64>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)X, (const bf16_t*)Wp,
                        (const bf16_t*)G, mean, invstd, scale, shift, slope, part, (int)M);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_stem_bwd_sums_from(const FrBnBwdArgs* unit, const void* X, const void* Wp, const float* mean,
+                                     const float* invstd, const float* scale, const float* shift, const float* slope,
+                                     float* part, long long M, int K, int nblocks, void* stream) {
+  if ((K != 32 && K != 64) || M < 1 || M >= (1ll << 24) || nblocks < 1)
+    FR_UNSUPPORTED("fr_stem_bwd_sums_from: K must be 32 or 64, 0 < M < 2^24, nblocks >= 1");
+  if (!unit || !X || !Wp || !mean || !invstd || !scale || !shift || !slope || !part)
+    FR_UNSUPPORTED("fr_stem_bwd_sums_from: unit, X, Wp, the five coefficient vectors and part are required");
+  const FrBnBwdArgs& u = *unit;
+  if (u.C != 64 || u.rows != M || !u.g || !u.x || !u.gx || !u.mean || !u.invstd || !u.s0 || !u.s1 || u.se || u.slope)
+    FR_UNSUPPORTED("fr_stem_bwd_sums_from: unit = the arguments of a plain fr_bn_bwd_apply over [M][64] (no slope, no gate)");
+  if (u.add_kind < 0 || u.add_kind > 2 || (u.add_kind && !u.add))
+    FR_UNSUPPORTED("fr_stem_bwd_sums_from: add_kind 0, 1 or 2 (with add)");
+  if (u.add_kind == 2 && (u.add_stride != 2 || u.H < 2 || u.W < 2 || (u.H & 1) || (u.W & 1) || u.rows_per_image != u.H * u.W ||
+                          M % u.rows_per_image))
+    FR_UNSUPPORTED("fr_stem_bwd_sums_from: add_kind 2 needs add_stride 2 and even H, W with rows_per_image = H * W");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  StemFromUnit un = {(const bf16_t*)u.g, (const bf16_t*)u.x, (const bf16_t*)u.add, (bf16_t*)u.gx, u.mean, u.invstd, u.gamma,
+                     u.s0, u.s1, u.inv_count, u.add_kind == 2 ? u.W : 1, u.add_kind == 2 ? u.rows_per_image : 1,
+                     u.add_kind == 2 ? 1.0f / (float)u.W : 1.f, u.add_kind == 2 ? 1.0f / (float)u.rows_per_image : 1.f};
+#define FROM(KK, AA)                                                                                                   \
+  hipLaunchKernelGGL((stem_bwd_sums_from_kernel<KK, AA>), dim3(nblocks), dim3(256), 0, st, (const bf16_t*)X,          \
+                     (const bf16_t*)Wp, un, mean, invstd, scale, shift, slope, part, (int)M)
+  if (K == 32) {
+    if (u.add_kind == 0) FROM(32, 0);
+    else if (u.add_kind == 1) FROM(32, 1);
+    else FROM(32, 2);
+  } else {
+    if (u.add_kind == 0) FROM(64, 0);
+    else if (u.add_kind == 1) FROM(64, 1);
+    else FROM(64, 2);
+  }
+#undef FROM
   FR_LAUNCH_CHECK();
 }
 

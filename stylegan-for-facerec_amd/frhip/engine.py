@@ -257,6 +257,8 @@ class BackbonePlan(object):
         # 16.31 against 16.72.  Per-width / per-role overrides (temporary switches, removed) found nothing better than one
         # value for all.
         self.wgrad_wgs = min(256, max(64, _switch("FRHIP_WGRAD_WGS", 128)))  # the slab sum takes <= 256 groups
+        # (Round 6, measured again with the lighter tail of the main stream: 256 / 192 workgroups for the two HBM-bound weight
+        # gradients of the first unit, 112x112 -- 14.055-14.078 / 14.085-14.094 against 14.021-14.064 ms per step: nothing.)
         self.stream2 = ctypes.c_void_p(self.stream2_t.cuda_stream)
         self.edge_signal = bool(_switch("FRHIP_EDGE_SIGNAL", 1))  # dependency edges as completion signals (_side_after_main)
         self.S = int(module.input_size if isinstance(module.input_size, int) else module.input_size[0])
@@ -1232,7 +1234,16 @@ class BackbonePlan(object):
                 kw.update(add=g_out, add_kind=1)
             else:
                 kw.update(add=g_out, add_kind=2, H=u.H, W=u.H, add_stride=u.stride)
-            L.append(ops.bn_bwd_apply(st, fr, **kw))
+            # Round 6: the first unit's input gradient is read by exactly one kernel, the stem's backward sums, and both are
+            # HBM-bound passes over 3.2 M rows x 64 channels: fr_stem_bwd_sums_from forms it on the way (bit-identical gx and
+            # sums, 411 MB less traffic at batch 256; FRHIP_STEM_FROM_UNIT=0: the two launches)
+            self._unit0_apply = None
+            if (i == 0 and not self.body_only and self.stem_recompute and fr == FR_BF16 and u.cin == 64 and
+                    self.M0 < (1 << 24) and self.bn0.mod.training and _switch("FRHIP_STEM_FROM_UNIT", 1)):
+                self._unit0_apply = ops._fill(_lib.FrBnBwdArgs(), **kw)
+                self._unit0_apply_keep = kw
+            else:
+                L.append(ops.bn_bwd_apply(st, fr, **kw))
             done = None
             if self.dual:
                 done = torch.cuda.Event()
@@ -1268,8 +1279,13 @@ class BackbonePlan(object):
                       nblocks=nb)
         if self.stem_recompute:  # the sums of fr_bn_bwd_reduce over (g, y0) with y0 recomputed from the rows
             nb = int(min(2048, (self.M0 + 63) // 64))
-            L.append(ops.call("fr_stem_bwd_sums", self.X0, self.W0p, g_out, self.bn0.mean, self.bn0.invstd, self.bn0.scale,
-                              self.bn0.shift, sp.weight, self.part, self.M0, self.K0, nb, st))
+            if getattr(self, "_unit0_apply", None) is not None:
+                L.append(ops.call("fr_stem_bwd_sums_from", self._unit0_apply, self.X0, self.W0p, self.bn0.mean,
+                                  self.bn0.invstd, self.bn0.scale, self.bn0.shift, sp.weight, self.part, self.M0, self.K0,
+                                  nb, st))
+            else:
+                L.append(ops.call("fr_stem_bwd_sums", self.X0, self.W0p, g_out, self.bn0.mean, self.bn0.invstd,
+                                  self.bn0.scale, self.bn0.shift, sp.weight, self.part, self.M0, self.K0, nb, st))
             self._reduce(L, nb, 3, 64, db, dg, gsl if gsl is not None else self.sums[2, :64])
         else:
             L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))

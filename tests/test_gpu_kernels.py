@@ -1680,6 +1680,55 @@ def test_stem_backward_on_recomputed_rows(K, Kp, M):
     assert torch.equal(slab0, slab1) and float(slab0.abs().max()) > 0
 
 
+@pytest.mark.parametrize("Kp", [32, 64])
+@pytest.mark.parametrize("add_kind,B,H", [(2, 3, 12), (2, 37, 16), (1, 2, 10), (0, 5, 6)])
+def test_stem_backward_sums_fed_by_the_first_unit(K, Kp, add_kind, B, H):
+    """Round 6: fr_stem_bwd_sums_from forms the first residual unit's input gradient itself -- gx = BN1-backward(g) [+ the
+    shortcut gradient: MaxPool2d(1, 2) scatter (add_kind 2) or the residual stream (add_kind 1)], backbone/model_irse.py:52-57,
+    64-66 -- instead of reading it back from fr_bn_bwd_apply: gx and the partial rows are BIT-IDENTICAL to the two launches
+    (ragged last tile, more tiles than waves, several images)."""
+    st, bf = K.current_stream_ptr(), torch.bfloat16
+    fr = K.fr_dtype(torch.empty(0, dtype=bf))
+    M = B * H * H
+    rows = (synth.normal(86, "r", (M, Kp)) * 0.7).to("cuda", bf)
+    w = (synth.normal(86, "w", (64, Kp)) * 0.2).to("cuda", bf)
+    g = synth.normal(86, "g", (M, 64)).to("cuda", bf)
+    x = synth.normal(86, "x", (M, 64)).to("cuda", bf)
+    add = None
+    if add_kind == 1:
+        add = synth.normal(86, "a1", (M, 64)).to("cuda", bf)
+    elif add_kind == 2:
+        add = synth.normal(86, "a2", (B * (H // 2) * (H // 2), 64)).to("cuda", bf)
+    vec = lambda n, lo, hi: synth.uniform(86, n, (64,), lo, hi).cuda()  # noqa: E731
+    mean, invstd, gamma, slope = vec("m", -0.3, 0.3), vec("i", 0.5, 2.0), vec("ga", 0.8, 1.2), vec("sl", 0.1, 0.4)
+    scale = gamma * invstd
+    shift = vec("b", -0.2, 0.2) - mean * scale
+    umean, uinvstd, ugamma = vec("um", -0.3, 0.3), vec("ui", 0.5, 2.0), vec("ug", 0.8, 1.2)
+    s0, s1 = vec("s0", -3.0, 3.0) * M / 50, vec("s1", -3.0, 3.0) * M / 50
+    gx0 = torch.zeros(M, 64, device="cuda", dtype=bf)
+    gx1 = torch.zeros_like(gx0)
+    kw = dict(g=g, x=x, mean=umean, invstd=uinvstd, gamma=ugamma, s0=s0, s1=s1, rows=M, inv_count=1.0 / M, C=64,
+              rows_per_image=H * H, nblocks=K.grid_blocks(M, 64, fr))
+    if add_kind == 1:
+        kw.update(add=add, add_kind=1)
+    elif add_kind == 2:
+        kw.update(add=add, add_kind=2, H=H, W=H, add_stride=2)
+    K.bn_bwd_apply(st, fr, gx=gx0, **kw)()
+    nbs = 7
+    p0, p1 = torch.zeros(nbs, 3, 64, device="cuda"), torch.zeros(nbs, 3, 64, device="cuda")
+    K.call("fr_stem_bwd_sums", rows, w, gx0, mean, invstd, scale, shift, slope, p0, M, Kp, nbs, st)()
+    from frhip import _lib
+    unit = K._fill(_lib.FrBnBwdArgs(), gx=gx1, **kw)
+    K.call("fr_stem_bwd_sums_from", unit, rows, w, mean, invstd, scale, shift, slope, p1, M, Kp, nbs, st)()
+    torch.cuda.synchronize()
+    assert torch.equal(gx0, gx1) and float(gx0.float().abs().max()) > 0
+    assert torch.equal(p0, p1) and float(p0.abs().max()) > 0
+    # a gated / sloped BatchNorm backward is not what this entry point fuses: refused, not silently mis-computed
+    bad = K._fill(_lib.FrBnBwdArgs(), gx=gx1, slope=slope, scale=scale, shift=shift, **kw)
+    with pytest.raises(_lib.FrhipError):
+        K.call("fr_stem_bwd_sums_from", bad, rows, w, mean, invstd, scale, shift, slope, p1, M, Kp, nbs, st)()
+
+
 @pytest.mark.parametrize("fold", [False, True])
 def test_pack_weights_64_tiles_equal_32_tiles(K, fold):
     """fr_pack_weights_multi (round 4): the 64 x 64-tile chunks (16-byte loads and stores; chunk index < 0) write the same bf16
