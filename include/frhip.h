@@ -395,6 +395,13 @@ int fr_se_gscale_mlp_bwd(const void* g, const void* x, const float* scale, const
                          const float* hidden, const float* pooled, const float* w1, const float* w2, float* gpooled,
                          float* dw1, float* dw2, float* gz, float* gh, float* gs_part, int B, int C, int R, int HW, int dtype,
                          void* stream);
+/* Round 6 (ABI v6): dw1 = dw2 = NULL in fr_se_gscale_mlp_bwd leaves out its last launch, the weight gradients of the two
+ * 1x1 convolutions of SEModule (fc1 / fc2, backbone/model_irse.py:28-35) -- sums over the batch in image order that feed
+ * nothing downstream in the backward pass -- and fr_se_mlp_wgrad is that launch on its own, so that the caller can put it on
+ * the weight-gradient stream (6-13 us per squeeze-excite unit off the main stream's chain).  gz [B][C], gh [B][R]: what
+ * fr_se_gscale_mlp_bwd left; dw1 [R][C], dw2 [C][R] OVERWRITTEN. */
+int fr_se_mlp_wgrad(const float* gz, const float* gh, const float* hidden, const float* pooled, float* dw1, float* dw2, int B,
+                    int C, int R, void* stream);
 int fr_se_gscale_slices(int B, int HW);
 
 /* ---- output layer pieces (model_irse.py:144-148) */

@@ -764,14 +764,26 @@ __global__ void se_mlp_fwd_kernel(const float* __restrict__ pooled_in, const flo
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
-  for (int r = wave; r < R; r += nw) {
-    float acc = 0.f;
-    for (int c = lane; c < C; c += 64) acc = fmaf(w1[(size_t)r * C + c], pv[c], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      const float h = acc > 0.f ? acc : 0.f;
-      hv[r] = h;
-      hidden[(size_t)b * R + r] = h;
+  for (int r0 = wave; r0 < R; r0 += 4 * nw) {  // four hidden units of a wave in flight (se_mlp_bwd_body); bit-identical sums
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int c = lane; c < C; c += 64) {
+      const float pc = pv[c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * nw;
+        acc[u] = fmaf(w1[(size_t)(r < R ? r : r0) * C + c], pc, acc[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * nw;
+      const float t = wave_sum(acc[u]);
+      if (lane == 0 && r < R) {
+        const float h = t > 0.f ? t : 0.f;
+        hv[r] = h;
+        hidden[(size_t)b * R + r] = h;
+      }
     }
   }
   __syncthreads();
@@ -849,15 +861,30 @@ __device__ __forceinline__ void se_mlp_bwd_body(const float* gs_row, const float
     gz_out[(size_t)b * C + c] = v;
   }
   __syncthreads();
+  // Round 6: a wave's hidden units four at a time -- the loads of four units in flight together, then their reductions (one
+  // unit per trip was load -> 6 shuffles -> store, R / waves dependent trips: 15 us per launch for a 256 x 16 product).
+  // Same partial sums, same order: bit-identical.
   const int wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
-  for (int r = wave; r < R; r += nw) {
-    float acc = 0.f;
-    for (int c = lane; c < C; c += 64) acc = fmaf(w2[(size_t)c * R + r], gz[c], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      const float v = hidden[(size_t)b * R + r] > 0.f ? acc : 0.f;
-      gh[r] = v;
-      gh_out[(size_t)b * R + r] = v;
+  for (int r0 = wave; r0 < R; r0 += 4 * nw) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int c = lane; c < C; c += 64) {
+      const float zc = gz[c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * nw;
+        acc[u] = fmaf(w2[(size_t)c * R + (r < R ? r : r0)], zc, acc[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * nw;
+      const float t = wave_sum(acc[u]);
+      if (lane == 0 && r < R) {
+        const float v = hidden[(size_t)b * R + r] > 0.f ? t : 0.f;
+        gh[r] = v;
+        gh_out[(size_t)b * R + r] = v;
+      }
     }
   }
   __syncthreads();
@@ -1681,8 +1708,9 @@ extern "C" int fr_se_gscale_mlp_bwd(const void* g, const void* x, const float* s
                "fr_se_gscale_mlp_bwd");
     hipLaunchKernelGGL(se_mlp_bwd_parts_kernel, dim3(B), dim3(256), lds, st, gs_part, S, s, hidden, w1, w2, gpooled, gz, gh, C,
                        R, 1.0f / (float)HW);
-    hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, gz, gh, hidden, pooled, dw1, dw2, B, C,
-                       R);
+    if (dw1 || dw2)
+      hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, gz, gh, hidden, pooled, dw1, dw2, B, C,
+                         R);
     FR_LAUNCH_CHECK();
   }
   DISPATCH_T(dtype,
@@ -1693,8 +1721,17 @@ extern "C" int fr_se_gscale_mlp_bwd(const void* g, const void* x, const float* s
                                 (const bf16_t*)g, scale, shift, s, hidden, w1, w2, gpooled, gz, gh, HW, C, R,
                                 1.0f / (float)HW),
              "fr_se_gscale_mlp_bwd");
-  hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, gz, gh, hidden, pooled, dw1, dw2, B,
-                     C, R);
+  if (dw1 || dw2)
+    hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 63) / 64, R), dim3(256), 0, st, gz, gh, hidden, pooled, dw1, dw2, B,
+                       C, R);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_se_mlp_wgrad(const float* gz, const float* gh, const float* hidden, const float* pooled, float* dw1,
+                               float* dw2, int B, int C, int R, void* stream) {
+  if (!gz || !gh || !hidden || !pooled || !dw1 || !dw2) FR_UNSUPPORTED("fr_se_mlp_wgrad: every pointer is required");
+  hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 63) / 64, R), dim3(256), 0, (hipStream_t)stream, gz, gh, hidden, pooled,
+                     dw1, dw2, B, C, R);
   FR_LAUNCH_CHECK();
 }
 

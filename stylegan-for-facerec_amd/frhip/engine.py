@@ -1120,9 +1120,19 @@ class BackbonePlan(object):
                 # fr_bn_bwd_reduce disappears from the IR-SE units -- IR-SE-101 + CosFace(28000), bs 128: 19.50-19.52 against
                 # 19.22-19.30 ms per step; pSp bs 256: 17.31 against 17.22; profiles/r04_ab_se_sums.txt: the pass it deleted ran
                 # beside the weight gradients of the side stream, the extra work sat in a 128-workgroup launch.)
+                # Round 6: the weight gradients of the two 1x1 convolutions of the MLP (one launch, 6-13 us, 4 workgroups) feed
+                # nothing downstream: with two streams they run on the weight-gradient stream behind conv2's data gradient
+                # (IR-SE-101 bs 128: 49 launches off a main stream whose channel-wise chain is longer than its convolutions)
+                se_side = self.dual and bool(_switch("FRHIP_SE_WGRAD_SIDE", 1))
                 L.append(ops.call("fr_se_gscale_mlp_bwd", g_out, d["y2"], bn2.scale, bn2.shift, d["s"], d["hidden"],
-                                  d["pooled"], u.se.fc1.weight, u.se.fc2.weight, d["gpooled"], g1, g2, d["gz"],
-                                  d["gh"], self.se_gs_part if B <= 160 else None, B, u.depth, R, HWo, fr, st))
+                                  d["pooled"], u.se.fc1.weight, u.se.fc2.weight, d["gpooled"], None if se_side else g1,
+                                  None if se_side else g2, d["gz"], d["gh"], self.se_gs_part if B <= 160 else None, B,
+                                  u.depth, R, HWo, fr, st))
+                se_wgrad = None
+                if se_side:
+                    se_wgrad = ops.call("fr_se_mlp_wgrad", d["gz"], d["gh"], d["hidden"], d["pooled"], g1, g2, B, u.depth, R,
+                                        self.stream2)
+                    se_wgrad.tstream = self.stream2_t
                 se_kw = dict(se=d["s"], gse=d["gpooled"])
                 ready += [u.se.fc1.weight, u.se.fc2.weight]
             db, dg = self._bn_grads(bn2)
@@ -1190,6 +1200,8 @@ class BackbonePlan(object):
                 r = ops.call("fr_reduce_parts", part2, mt, 2, u.depth, gsl, None, None, self.stream2)
                 r.tstream = self.stream2_t
                 S2.append(r)
+                if u.se is not None and se_wgrad is not None:
+                    S2.append(se_wgrad)
             else:
                 self._reduce(L, mt, 2, u.depth, gsl, None)
             if gw2 is not None:
