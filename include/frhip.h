@@ -402,6 +402,16 @@ int fr_se_gscale_mlp_bwd(const void* g, const void* x, const float* scale, const
  * fr_se_gscale_mlp_bwd left; dw1 [R][C], dw2 [C][R] OVERWRITTEN. */
 int fr_se_mlp_wgrad(const float* gz, const float* gh, const float* hidden, const float* pooled, float* dw1, float* dw2, int B,
                     int C, int R, void* stream);
+/* Round 6 (ABI v6): fr_se_gscale_mlp_bwd (sliced squeeze, no weight-gradient launch) that ALSO leaves the rows of BN2's
+ * backward sums, so that the fr_bn_bwd_reduce(se, gse) pass behind it -- a third read of (g, x) -- is not needed: behind the
+ * excite gate BatchNorm2d(depth) of res_layer (backbone/model_irse.py:76-80, 86-87) sees g' = g * s[b][c] + gse[b][c], constant
+ * over an image, so sum g' and sum g' * xhat follow from per-image sums of g, g * xhat and xhat taken in the squeeze pass:
+ *   bn_part[b][0][c] = s * sum g + HW * gse,   bn_part[b][1][c] = s * sum g * xhat + gse * sum xhat   (xhat = (x - mean) * invstd)
+ * fr_reduce_parts(bn_part, B, 2, C, dbeta, dgamma) adds the images.  gs_part: scratch [B][fr_se_gscale_slices(B, HW)][4][C]. */
+int fr_se_gscale_mlp_bwd_sums(const void* g, const void* x, const float* scale, const float* shift, const float* mean,
+                              const float* invstd, const float* s, const float* hidden, const float* w1, const float* w2,
+                              float* gpooled, float* gz, float* gh, float* gs_part, float* bn_part, int B, int C, int R, int HW,
+                              int dtype, void* stream);
 int fr_se_gscale_slices(int B, int HW);
 
 /* ---- output layer pieces (model_irse.py:144-148) */

@@ -970,23 +970,37 @@ __global__ __launch_bounds__(SNT_GS) void se_gscale_mlp_bwd_kernel(const T* __re
 // no room beside the resident weight-gradient workgroups of the side stream (18 us per unit in the step for 25 MB of reads).
 // part[(b*S + s)][c] = sum over the rows of slice s of g * (x*scale + shift); se_mlp_bwd_parts_kernel adds the S rows of an
 // image in slice order and runs the MLP part.
-template <typename T>
+// Round 6, SUMS: the same pass also leaves, per slice, what the backward of BN2 needs of (g, x): with the excite gate the
+// BatchNorm sees g' = g * s[b][c] + gse[b][c] (se_gprime), both constant over an image, so
+//   sum g'        = sum_b ( s_b * G_b  + HW * gse_b ),          G_b  = sum over the image of g
+//   sum g' * xhat = sum_b ( s_b * GX_b + gse_b * XH_b ),        GX_b = sum g * xhat,  XH_b = sum xhat,  xhat = (x - mean) * invstd
+// and fr_bn_bwd_reduce -- a third pass over (g, x) behind the MLP, 14-19 us per squeeze-excite unit on the main stream's
+// chain -- disappears: part[(b*S + s)][4][C] = gs, G, GX, XH.
+template <typename T, bool SUMS = false>
 __global__ __launch_bounds__(256) void se_gsq_part_kernel(const T* __restrict__ x, const T* __restrict__ g,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                                          float* __restrict__ part, int HW, int C, int S) {
+                                                          float* __restrict__ part, int HW, int C, int S,
+                                                          const float* __restrict__ mean = nullptr,
+                                                          const float* __restrict__ invstd = nullptr) {
   constexpr int VEC = Elt<T>::VEC;
+  constexpr int NV = SUMS ? 4 : 1;
   __shared__ float red[256 * VEC];
   const int cpr = C / VEC, tid = threadIdx.x, b = blockIdx.x, sl = blockIdx.y;
   const int cc = tid % cpr, rtc = 256 / cpr, rt = tid / cpr, c0 = cc * VEC;
   const int r_lo = (int)((long long)HW * sl / S), r_hi = (int)((long long)HW * (sl + 1) / S);
-  float acc[VEC], scv[VEC], shv[VEC];
+  float acc[NV][VEC], scv[VEC], shv[VEC], muv[SUMS ? VEC : 1], isv[SUMS ? VEC : 1];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
-    acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k][j] = 0.f;
     scv[j] = scale[c0 + j];
     shv[j] = shift[c0 + j];
+    if (SUMS) {
+      muv[j] = mean[c0 + j];
+      isv[j] = invstd[c0 + j];
+    }
   }
-  constexpr int UN = 8;
+  constexpr int UN = SUMS ? 4 : 8;
   for (int r0 = r_lo + rt; r0 < r_hi; r0 += rtc * UN) {
     U128 xv[UN], gq[UN];
 #pragma unroll
@@ -1003,19 +1017,31 @@ __global__ __launch_bounds__(256) void se_gsq_part_kernel(const T* __restrict__ 
         unpack16<T>(xv[u], f);
         unpack16<T>(gq[u], gv);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] = fmaf(gv[j], fmaf(f[j], scv[j], shv[j]), acc[j]);
+        for (int j = 0; j < VEC; ++j) {
+          acc[0][j] = fmaf(gv[j], fmaf(f[j], scv[j], shv[j]), acc[0][j]);
+          if (SUMS) {
+            const float xh = (f[j] - muv[j]) * isv[j];
+            acc[1][j] += gv[j];
+            acc[2][j] = fmaf(gv[j], xh, acc[2][j]);
+            acc[3][j] += xh;
+          }
+        }
       }
     }
   }
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) red[tid * VEC + j] = acc[j];
-  __syncthreads();
-  if (rt == 0) {
+  for (int k = 0; k < NV; ++k) {
+    if (k) __syncthreads();
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      float t = 0.f;
-      for (int r = 0; r < rtc; ++r) t += red[(r * cpr + cc) * VEC + j];
-      part[((size_t)b * S + sl) * C + c0 + j] = t;
+    for (int j = 0; j < VEC; ++j) red[tid * VEC + j] = acc[k][j];
+    __syncthreads();
+    if (rt == 0) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float t = 0.f;
+        for (int r = 0; r < rtc; ++r) t += red[(r * cpr + cc) * VEC + j];
+        part[(((size_t)b * S + sl) * NV + k) * C + c0 + j] = t;
+      }
     }
   }
 }
@@ -1024,16 +1050,33 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_parts_kernel(const float* __re
                                                                const float* __restrict__ s, const float* __restrict__ hidden,
                                                                const float* __restrict__ w1, const float* __restrict__ w2,
                                                                float* __restrict__ gpooled, float* __restrict__ gz_out,
-                                                               float* __restrict__ gh_out, int C, int R, float inv_hw) {
+                                                               float* __restrict__ gh_out, int C, int R, float inv_hw,
+                                                               float* __restrict__ bn_part = nullptr) {
   extern __shared__ float sm[];  // [C] gs, [C] gz, [R] gh
   const int b = blockIdx.x;
+  const int NV = bn_part ? 4 : 1;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float t = 0.f;
-    for (int k = 0; k < S; ++k) t += part[((size_t)b * S + k) * C + c];
+    for (int k = 0; k < S; ++k) t += part[(((size_t)b * S + k) * NV) * C + c];
     sm[c] = t;
   }
   __syncthreads();
   se_mlp_bwd_body(sm, s, hidden, w1, w2, gpooled, gz_out, gh_out, C, R, inv_hw, sm + C, sm + 2 * C);
+  if (bn_part) {  // this image's rows of the BN2-backward sums (se_gsq_part_kernel<SUMS>): [B][2][C], added by fr_reduce_parts
+    const float hw = 1.0f / inv_hw;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {  // the thread that wrote gpooled[b][c] above reads it back
+      float G = 0.f, GX = 0.f, XH = 0.f;
+      for (int k = 0; k < S; ++k) {
+        const float* row = part + (((size_t)b * S + k) * 4) * C + c;
+        G += row[C];
+        GX += row[2 * (size_t)C];
+        XH += row[3 * (size_t)C];
+      }
+      const float sv = s[(size_t)b * C + c], gse = gpooled[(size_t)b * C + c];
+      bn_part[((size_t)b * 2 + 0) * C + c] = fmaf(sv, G, hw * gse);
+      bn_part[((size_t)b * 2 + 1) * C + c] = fmaf(sv, GX, gse * XH);
+    }
+  }
 }
 
 // weight part: dW1[r][c] = sum_b gh[b][r] * pooled[b][c],  dW2[c][r] = sum_b gz[b][c] * hidden[b][r].  Block = 64
@@ -1732,6 +1775,30 @@ extern "C" int fr_se_mlp_wgrad(const float* gz, const float* gh, const float* hi
   if (!gz || !gh || !hidden || !pooled || !dw1 || !dw2) FR_UNSUPPORTED("fr_se_mlp_wgrad: every pointer is required");
   hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 63) / 64, R), dim3(256), 0, (hipStream_t)stream, gz, gh, hidden, pooled,
                      dw1, dw2, B, C, R);
+  FR_LAUNCH_CHECK();
+}
+
+extern "C" int fr_se_gscale_mlp_bwd_sums(const void* g, const void* x, const float* scale, const float* shift,
+                                         const float* mean, const float* invstd, const float* s, const float* hidden,
+                                         const float* w1, const float* w2, float* gpooled, float* gz, float* gh, float* gs_part,
+                                         float* bn_part, int B, int C, int R, int HW, int dtype, void* stream) {
+  if (!g || !x || !scale || !shift || !mean || !invstd || !s || !hidden || !w1 || !w2 || !gpooled || !gz || !gh || !gs_part ||
+      !bn_part)
+    FR_UNSUPPORTED("fr_se_gscale_mlp_bwd_sums: every pointer is required");
+  if (!chan_ok(C, dtype)) FR_UNSUPPORTED("fr_se_gscale_mlp_bwd_sums: unsupported channel count");
+  const int vec = dtype == FR_BF16 ? 8 : 4;
+  if (C % vec || C / vec > 256 || 256 % (C / vec)) FR_UNSUPPORTED("fr_se_gscale_mlp_bwd_sums: C / vector width must divide 256");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)(2 * C + R) * sizeof(float);
+  const int S = fr_se_gscale_slices(B, HW);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((se_gsq_part_kernel<float, true>), dim3(B, S), dim3(256), 0, st, (const float*)x,
+                                (const float*)g, scale, shift, gs_part, HW, C, S, mean, invstd),
+             hipLaunchKernelGGL((se_gsq_part_kernel<bf16_t, true>), dim3(B, S), dim3(256), 0, st, (const bf16_t*)x,
+                                (const bf16_t*)g, scale, shift, gs_part, HW, C, S, mean, invstd),
+             "fr_se_gscale_mlp_bwd_sums");
+  hipLaunchKernelGGL(se_mlp_bwd_parts_kernel, dim3(B), dim3(256), lds, st, gs_part, S, s, hidden, w1, w2, gpooled, gz, gh, C, R,
+                     1.0f / (float)HW, bn_part);
   FR_LAUNCH_CHECK();
 }
 

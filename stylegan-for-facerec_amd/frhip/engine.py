@@ -437,7 +437,7 @@ class BackbonePlan(object):
             # (per-unit sets: sized when the backward list is built, from the rows the unit's data gradient writes)
             self.part_slope = [None if self.per_unit_sets else torch.zeros_like(self.part) for _ in range(nset)]
         self.se_scratch = torch.zeros(2, 512 * 64, device=dev)  # dW1/dW2 sink while the SE weights are frozen
-        self.se_gs_part = torch.empty(B * 8 * 512, device=dev)  # row-slice partials of the squeeze-excite gradient squeeze
+        self.se_gs_part = torch.empty(B * 8 * 4 * 512, device=dev)  # row-slice partials of the squeeze-excite gradient squeeze (x 4 sums)
         self.sums = torch.zeros(3, 512, device=dev)      # scratch reduce target for frozen parameters
         self.nbt_dummy = None
 
@@ -1124,10 +1124,23 @@ class BackbonePlan(object):
                 # nothing downstream: with two streams they run on the weight-gradient stream behind conv2's data gradient
                 # (IR-SE-101 bs 128: 49 launches off a main stream whose channel-wise chain is longer than its convolutions)
                 se_side = self.dual and bool(_switch("FRHIP_SE_WGRAD_SIDE", 1))
-                L.append(ops.call("fr_se_gscale_mlp_bwd", g_out, d["y2"], bn2.scale, bn2.shift, d["s"], d["hidden"],
-                                  d["pooled"], u.se.fc1.weight, u.se.fc2.weight, d["gpooled"], None if se_side else g1,
-                                  None if se_side else g2, d["gz"], d["gh"], self.se_gs_part if B <= 160 else None, B,
-                                  u.depth, R, HWo, fr, st))
+                # Round 6: the squeeze pass also takes the per-image sums from which BN2's backward sums follow (the gate and
+                # its gradient are constant over an image): fr_bn_bwd_reduce -- a third pass over (g, y2) behind the MLP,
+                # 14-19 us per unit on the main stream's chain -- is gone (bf16 path; FRHIP_SE_BN_SUMS=0: A/B switch)
+                se_sums = (fr == FR_BF16 and bool(_switch("FRHIP_SE_BN_SUMS", 1)) and u.depth % 8 == 0 and
+                           (u.depth // 8) <= 256 and 256 % (u.depth // 8) == 0)
+                if se_sums:
+                    L.append(ops.call("fr_se_gscale_mlp_bwd_sums", g_out, d["y2"], bn2.scale, bn2.shift, bn2.mean, bn2.invstd,
+                                      d["s"], d["hidden"], u.se.fc1.weight, u.se.fc2.weight, d["gpooled"], d["gz"], d["gh"],
+                                      self.se_gs_part, self.part, B, u.depth, R, HWo, fr, st))
+                    if not se_side:
+                        L.append(ops.call("fr_se_mlp_wgrad", d["gz"], d["gh"], d["hidden"], d["pooled"], g1, g2, B, u.depth,
+                                          R, st))
+                else:
+                    L.append(ops.call("fr_se_gscale_mlp_bwd", g_out, d["y2"], bn2.scale, bn2.shift, d["s"], d["hidden"],
+                                      d["pooled"], u.se.fc1.weight, u.se.fc2.weight, d["gpooled"], None if se_side else g1,
+                                      None if se_side else g2, d["gz"], d["gh"], self.se_gs_part if B <= 160 else None, B,
+                                      u.depth, R, HWo, fr, st))
                 se_wgrad = None
                 if se_side:
                     se_wgrad = ops.call("fr_se_mlp_wgrad", d["gz"], d["gh"], d["hidden"], d["pooled"], g1, g2, B, u.depth, R,
@@ -1138,8 +1151,11 @@ class BackbonePlan(object):
             db, dg = self._bn_grads(bn2)
             common = dict(g=g_out, x=d["y2"], mean=bn2.mean, invstd=bn2.invstd, rows=rout, C=u.depth,
                           rows_per_image=HWo, nblocks=nb, **se_kw)
-            L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
-            self._reduce(L, nb, 3, u.depth, db, dg)
+            if u.se is not None and se_sums:
+                self._reduce(L, B, 2, u.depth, db, dg)  # one row pair per image, left by fr_se_gscale_mlp_bwd_sums
+            else:
+                L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
+                self._reduce(L, nb, 3, u.depth, db, dg)
             s0, s1 = self._s01(bn2, db, dg)
             L.append(ops.bn_bwd_apply(st, fr, gx=g_y2, gamma=u.bn2.weight, s0=s0, s1=s1, inv_count=1.0 / rout, **common))
             g_xS = None

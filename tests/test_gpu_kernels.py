@@ -1171,6 +1171,63 @@ def test_bn_backward_with_se_gate(K, name, dtype, tol, with_add):
     assert relerr(from_nhwc(gx), want) < tol * 2
 
 
+@pytest.mark.parametrize("name,dtype,tol", DT)
+@pytest.mark.parametrize("B,H,C", [(5, 7, 128), (3, 14, 256), (130, 4, 64)])
+def test_se_backward_leaves_the_sums_of_bn2(K, name, dtype, tol, B, H, C):
+    """Round 6: fr_se_gscale_mlp_bwd_sums == fr_se_gscale_mlp_bwd (gz, gh, gpooled bit for bit: same squeeze, same MLP) AND its
+    per-image rows add up to what fr_bn_bwd_reduce(se, gse) finds with a pass of its own over (g, x): behind the excite gate
+    BatchNorm2d(depth) of bottleneck_IR_SE (backbone/model_irse.py:76-80, 86-87) sees g' = g * s + gse, constant over an
+    image.  Also against the same algebra in float64 on the host."""
+    HW, rows, R = H * H, B * H * H, max(C // 16, 1)
+    x = q(synth.normal(87, "x", (B, C, H, H)), dtype)
+    g = q(synth.normal(87, "g", (B, C, H, H)), dtype)
+    gamma, beta = synth.uniform(87, "w", (C,), 0.8, 1.2), synth.uniform(87, "b", (C,), -0.2, 0.2)
+    mean = x.mean((0, 2, 3))
+    invstd = 1.0 / torch.sqrt(x.var((0, 2, 3), unbiased=False) + 1e-5)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    w1, w2 = synth.normal(87, "w1", (R, C)) * 0.2, synth.normal(87, "w2", (C, R)) * 0.2
+    s_gate = synth.uniform(87, "s", (B, C), 0.1, 0.9)
+    hidden = synth.uniform(87, "h", (B, R), -0.5, 1.0).clamp_min(0.0)
+    pooled = synth.normal(87, "p", (B, C))
+    fr, st = K.fr_dtype(torch.empty(0, dtype=dtype)), K.current_stream_ptr()
+    dev = lambda t: t.cuda().contiguous()  # noqa: E731
+    gd, xd = nhwc(g, dtype), nhwc(x, dtype)
+    S = int(K.lib.fr_se_gscale_slices(B, HW))
+    outs = []
+    for sums in (False, True):
+        gpooled, gz, gh = torch.zeros(B, C, device="cuda"), torch.zeros(B, C, device="cuda"), torch.zeros(B, R, device="cuda")
+        gs_part = torch.zeros(B * S * 4 * C, device="cuda")
+        bn_part = torch.zeros(B, 2, C, device="cuda")
+        if sums:
+            K.call("fr_se_gscale_mlp_bwd_sums", gd, xd, dev(scale), dev(shift), dev(mean), dev(invstd), dev(s_gate), dev(hidden),
+                   dev(w1), dev(w2), gpooled, gz, gh, gs_part, bn_part, B, C, R, HW, fr, st)()
+        else:
+            K.call("fr_se_gscale_mlp_bwd", gd, xd, dev(scale), dev(shift), dev(s_gate), dev(hidden), dev(pooled), dev(w1), dev(w2),
+                   gpooled, None, None, gz, gh, gs_part, B, C, R, HW, fr, st)()
+        torch.cuda.synchronize()
+        outs.append((gpooled, gz, gh, bn_part))
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b) and float(a.abs().max()) > 0
+    gpooled, bn_part = outs[1][0], outs[1][3]
+    s0, s1 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    K.call("fr_reduce_parts", bn_part, B, 2, C, s0, s1, None, st)()
+    nb = 6
+    part = torch.zeros(nb, 3, C, device="cuda")
+    K.bn_bwd_reduce(st, fr, part=part, g=gd, x=xd, mean=dev(mean), invstd=dev(invstd), se=dev(s_gate), gse=gpooled, rows=rows,
+                    C=C, rows_per_image=HW, nblocks=nb)()
+    r0, r1 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    K.call("fr_reduce_parts", part, nb, 3, C, r0, r1, None, st)()
+    torch.cuda.synchronize()
+    gp = g.double() * s_gate.double().view(B, C, 1, 1) + gpooled.cpu().double().view(B, C, 1, 1)
+    xhat = (x.double() - mean.double().view(1, C, 1, 1)) * invstd.double().view(1, C, 1, 1)
+    t0, t1 = gp.sum((0, 2, 3)), (gp * xhat).sum((0, 2, 3))
+    mag = (gp.abs().sum((0, 2, 3)) + 1.0)
+    for got, ref_pass, truth in ((s0, r0, t0), (s1, r1, t1)):
+        assert float(((got.cpu().double() - truth).abs() / mag).max()) < 2e-6, "sums from the squeeze pass vs float64"
+        assert float(((ref_pass.cpu().double() - truth).abs() / mag).max()) < 2e-6, "fr_bn_bwd_reduce vs float64"
+
+
 BIAS_RES_CASES = [("igemm_f32", torch.float32, 64, 10, 1), ("igemm_bf16", torch.bfloat16, 64, 10, 1),
                   ("igemm_f32_s2", torch.float32, 128, 12, 2), ("strip_256_14", torch.bfloat16, 256, 14, 1),
                   ("strip_128_28", torch.bfloat16, 128, 28, 1), ("roll64_56", torch.bfloat16, 64, 56, 1),
