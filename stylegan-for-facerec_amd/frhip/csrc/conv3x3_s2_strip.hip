@@ -625,6 +625,10 @@ extern "C" int fr_conv3x3_s2_strip_parts(int B, int Cin, int Cout, int WL, int m
   // 64 channels: one row per work item of the rolling-window kernel.  NOTE: the caller's epilogue decides whether that kernel
   // serves the launch (forward STORE / STATS, gradient PReLU backward); the combinations it does not serve write no sums.
   if (Cin == 64 && WL == 56 && fr_s2roll_enabled()) return fr_s2roll_parts(B);
+  if (mode == 0) {  // the warp-specialised forward kernel has its own strip count at 7x7 (four images per workgroup)
+    const int ws = fr_s2ws_strips(B, Cin, WL);
+    if (ws) return ws;
+  }
   const int strips = s2_strips(B, Cin, WL, mode);
   return mode == 2 ? 4 * strips : strips;
 }
@@ -644,6 +648,7 @@ extern "C" int fr_conv3x3_s2_strip(const FrConvArgs* args, void* stream) {
   if (WLo != HLo || WHi != 2 * WLo || HHi != 2 * HLo || a.SC != a.N)
     FR_UNSUPPORTED("fr_conv3x3_s2_strip: square images, high-res side = 2 x low-res side, Cin == Cout");
   if (fr_s2roll_serves(a)) return fr_s2roll_launch(a, st);
+  if (fr_s2ws_serves(a)) return fr_s2ws_launch(a, st);  // forward, 128 / 256 / 512 channels (round 6)
   // fr_conv3x3_s2_strip_parts() has no epilogue argument: for the 64-channel layer it answers with the row count of the
   // rolling-window kernel.  A summing epilogue that kernel does not serve would make the strip kernel below write a
   // DIFFERENT number of partial rows into a buffer sized from that answer -- refuse instead of overrunning it.

@@ -30,3 +30,9 @@ int fr_wgrad_roll_launch(const FrWgradArgs& a, hipStream_t st);
 // ... and the stride-2 ones with a 28 / 14 / 7 wide gradient (conv_wgrad_s2roll_kernel, same file)
 bool fr_wgrad_s2roll_serves(const FrWgradArgs& a);
 int fr_wgrad_s2roll_launch(const FrWgradArgs& a, hipStream_t st);
+
+// stride-2 3x3 forward at 128 / 256 / 512 channels on the warp-specialised kernel (conv3x3_s2_ws.hip); dispatched from
+// fr_conv3x3_s2_strip.  fr_s2ws_strips: partial-sum rows of a served (B, C, low-res width), 0 = not served.
+bool fr_s2ws_serves(const FrConvArgs& a);
+int fr_s2ws_strips(int B, int C, int WL);
+int fr_s2ws_launch(const FrConvArgs& a, hipStream_t st);

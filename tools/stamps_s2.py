@@ -21,9 +21,42 @@ import kbench  # noqa: E402
 from frhip import _lib  # noqa: E402
 
 
+def main_ws(label, B):
+    """conv3x3_s2_ws.hip: computing wave 0 and data-moving wave 4 of every workgroup (48 slots)."""
+    fn = dict(kbench.suite_cases(B))[label]
+    nblk = 1 << 14
+    buf = torch.zeros(nblk * 48, dtype=torch.int64, device="cuda")
+    dbg = ctypes.CDLL(_lib.LIB_PATH)
+    dbg.fr_debug_set_stamp_buffer_ws.argtypes = [ctypes.c_void_p]
+    fn(3)
+    assert dbg.fr_debug_set_stamp_buffer_ws(ctypes.c_void_p(buf.data_ptr())) == 0
+    torch.cuda.synchronize()
+    buf.zero_()
+    fn(1)
+    torch.cuda.synchronize()
+    s = buf.cpu().numpy().reshape(nblk, 48)
+    s = s[s[:, 0] != 0]
+    t = s.astype(np.float64) * 0.01
+    nc = int(np.max(np.nonzero(s[0, :24])[0]))
+    nl = int(np.max(np.nonzero(s[0, 24:])[0]))
+    print("%s (warp-specialised): %d workgroups, span %.1f us, lifetime median %.2f us" % (
+        label, len(s), t[:, nc].max() - t[:, 0].min(), np.median(t[:, nc] - t[:, 0])))
+    names = ["wait phase 0"] + ["taps %d" % k for k in range(nc - 4)] + ["cells", "barrier", "stores"]
+    for k in range(nc):
+        d = t[:, k + 1] - t[:, k]
+        print("  computing   %-14s median %6.2f  p90 %6.2f us   (cumulative %6.2f)" % (names[k] if k < len(names) else k, np.median(d),
+              np.percentile(d, 90), np.median(t[:, k + 1] - t[:, 0])))
+    for k in range(nl):
+        d = t[:, 24 + k + 1] - t[:, 24 + k]
+        print("  data-moving stage %2d        median %6.2f  p90 %6.2f us   (done at %6.2f)" % (k, np.median(d), np.percentile(d, 90),
+              np.median(t[:, 24 + k + 1] - t[:, 0])))
+
+
 def main():
     label = sys.argv[1]
-    B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    B = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 256
+    if "--ws" in sys.argv:
+        return main_ws(label, B)
     fn = dict(kbench.suite_cases(B))[label]
     nblk = 1 << 15
     buf = torch.zeros(nblk * 16, dtype=torch.int64, device="cuda")
