@@ -68,8 +68,9 @@ struct S2 {
   static constexpr int RED_BYTES = WM * 2 * COUT * 4;
   // forward: the output tile reuses the (dead) plane image; gradient: the g strip stays live across the four classes
   static constexpr int OUT_OFF = KIND == 0 ? 0 : (IMG_BYTES + 15) / 16 * 16;
+  static constexpr int SYNC_OFF = OUT_OFF + OUT_BYTES + RED_BYTES;  // gradient: counters of the half-workgroup barriers
   static constexpr int LDS = KIND == 0 ? (IMG_BYTES > OUT_BYTES + RED_BYTES ? IMG_BYTES : OUT_BYTES + RED_BYTES)
-                                       : OUT_OFF + OUT_BYTES + RED_BYTES;
+                                       : SYNC_OFF + 64;
   static constexpr int NS = HL / ROWS;
   static_assert(HL % ROWS == 0, "strip rows must divide the low-res image");
   static_assert(NIMG == 1 || ROWS == WL, "multi-image workgroups own whole images");
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
   const bf16_t* __restrict__ wgt = reinterpret_cast<const bf16_t*>(p.w);
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
 
-  const int lb = xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;  // halo-sharing strips (and the NSPL parts of one
+  const int lb = (xcd & 1) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;  // halo-sharing strips (and the NSPL parts of one
                                                                          // strip) meet in one XCD's L2
   const int nh = NSPL > 1 ? lb % NSPL : 0;
   const int ncol0 = nh * COUT;                                           // first output channel of this workgroup
@@ -323,6 +324,33 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
   const int epi = p.epi;
   const bool stats = epi == FR_EPI_STATS || epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD;
   constexpr int OCH = COUT / 8;
+  // Round 6, data gradient: the two HALVES of the workgroup run half a class out of step.  A wave owns 16 (or 32) output
+  // channels of every pixel, waves w and w + 4 share a SIMD; with all eight in lock-step the SIMD's matrix pipe idles through
+  // every epilogue (aux tile -> LDS, PReLU-backward cells, tile -> global: 5.2 of the 9.5 us a class takes, tools/stamps_s2.py)
+  // and its vector pipe through every tap list.  The halves touch disjoint columns of the output tile and of the reduction
+  // scratch, so each gets barriers of its own (an LDS counter, 4 waves) and waves 4-7 start their first tap list when waves
+  // 0-3 have finished theirs: from then on one wave of a SIMD issues MFMAs while the other runs its epilogue.  Same
+  // arithmetic, same order: bit-identical.  (xcd bit 1: FRHIP_S2_STAGGER, default on.)
+  constexpr bool STG = KIND == 1 && NW == 8 && WN == 8;
+  const bool stg = STG && (xcd & 2);
+  const int half = stg ? wave >> 2 : 0;
+  const int htid = stg ? (tid & 255) : tid;
+  const int hnth = stg ? 256 : NTH;
+  const int hoch = stg ? OCH / 2 : OCH;       // 16-byte chunks of a tile row this half moves
+  const int hc0 = half * hoch;
+  volatile unsigned* hctr = reinterpret_cast<volatile unsigned*>(smem + C::SYNC_OFF) + half;  // [0], [1]: barrier counters; [2]: start flag
+  unsigned hgen = 0;
+  auto hsync = [&]() {
+    if (!stg) {
+      __syncthreads();
+      return;
+    }
+    hgen += 4;  // four waves arrive per barrier; the counter only grows
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(const_cast<unsigned*>(hctr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (*hctr < hgen) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
   f32x4 acc[C::TM][C::TN];
   auto zero_acc = [&]() {
 #pragma unroll
@@ -351,9 +379,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
       const bf16_t* __restrict__ aux = reinterpret_cast<const bf16_t*>(p.aux);
 #pragma unroll
       for (int u = 0; u < NAX; ++u) {
-        int idx = u * NTH + tid;
-        idx = idx < C::M * OCH ? idx : C::M * OCH - 1;
-        const int r = idx / OCH, c8 = idx - r * OCH;
+        int idx = u * hnth + htid;
+        idx = idx < C::M * hoch ? idx : C::M * hoch - 1;
+        const int r = idx / hoch, c8 = hc0 + idx - r * hoch;
         axr[KIND == 1 ? u : 0] = ld16(aux + out_pix(cls, r) * (size_t)p.ldaux + ncol0 + c8 * 8);
       }
     }
@@ -364,9 +392,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
       if (KIND == 1) {
 #pragma unroll
         for (int u = 0; u < NAX; ++u) {
-          const int idx = u * NTH + tid;
-          if (idx < C::M * OCH) {
-            const int r = idx / OCH, c8 = idx - r * OCH;
+          const int idx = u * hnth + htid;
+          if (idx < C::M * hoch) {
+            const int r = idx / hoch, c8 = hc0 + idx - r * hoch;
             st16(otile + r * C::OSTR + c8 * 16, axr[KIND == 1 ? u : 0]);
           }
         }
@@ -377,7 +405,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
           st16(otile + r * C::OSTR + c8 * 16, ld16(aux + dst_pix(r) * (size_t)p.ldaux + ncol0 + c8 * 8));
         }
       }
-      __syncthreads();
+      hsync();
     }
     // weights were the MFMA A operand: a lane holds four consecutive channels (fq*4 + r) of one pixel (fr) per tile
     float* red = reinterpret_cast<float*>(otile + C::OUT_BYTES);  // [WM][2][COUT] column sums, behind the output tile
@@ -459,22 +487,23 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
       case FR_EPI_BIAS_RES: cells(std::integral_constant<int, FR_EPI_BIAS_RES>{}); break;
       default: cells(std::integral_constant<int, FR_EPI_STORE>{}); break;
     }
-    __syncthreads();
-    for (int idx = tid; idx < C::M * OCH; idx += NTH) {
-      const int r = idx / OCH, c8 = idx - r * OCH;
+    hsync();
+    for (int idx = htid; idx < C::M * hoch; idx += hnth) {
+      const int r = idx / hoch, c8 = hc0 + idx - r * hoch;
       st16(out + dst_pix(r) * (size_t)p.ldc + ncol0 + c8 * 8, ld16(otile + r * C::OSTR + c8 * 16));
     }
     if (stats) {
       const size_t prow = (size_t)(cls < 0 ? 0 : cls) * nstrips + sblk;  // gradient: rows ordered [class][strip]
-      for (int c = tid; c < 2 * COUT; c += NTH) {
-        const int k = c / COUT, n = c - k * COUT;
+      const int hcout = stg ? COUT / 2 : COUT;
+      for (int c = htid; c < 2 * hcout; c += hnth) {
+        const int k = c / hcout, n = half * hcout + c - k * hcout;
         float t = 0.f;
 #pragma unroll
         for (int g = 0; g < C::WM; ++g) t += red[(g * 2 + k) * COUT + n];
         st_part(p.part + (prow * 2 + k) * (COUT * NSPL) + ncol0 + n, t);
       }
     }
-    __syncthreads();  // the tile and the reduction scratch are free again
+    hsync();  // the tile and the reduction scratch (this half's columns) are free again
   };
 
   if (KIND == 0 && !PFP) {
@@ -537,13 +566,24 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
     epilogue(-1);
   } else {
     S2_STAMP(0);
+    if (STG && tid < 4) reinterpret_cast<unsigned*>(smem + C::SYNC_OFF)[tid] = 0u;
     load_image(0, 0);
     S2_STAMP(1);
     __syncthreads();
     S2_STAMP(2);
     zero_acc();
     issue_aux(0);
-    mma_taps<C, CIN, 1, 0>(smem, abase, acc, wrow);
+    if (stg) {
+      volatile unsigned* start = reinterpret_cast<volatile unsigned*>(smem + C::SYNC_OFF) + 2;
+      if (half == 1) {  // half a class behind: wait for waves 0-3 to finish their first tap list
+        while (*start < 4u) __builtin_amdgcn_s_sleep(2);
+      }
+      mma_taps<C, CIN, 1, 0>(smem, abase, acc, wrow);
+      if (half == 0 && lane == 0)
+        __hip_atomic_fetch_add(const_cast<unsigned*>(start), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      mma_taps<C, CIN, 1, 0>(smem, abase, acc, wrow);
+    }
     S2_STAMP(3);
     epilogue(0);
     S2_STAMP(4);
@@ -568,9 +608,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
   }
 }
 
-static int s2_xcd_order() {  // FRHIP_XCD_ORDER=0: strips in dispatch order (A/B switch)
+static int s2_xcd_order() {  // bit 0: FRHIP_XCD_ORDER=0: strips in dispatch order; bit 1: FRHIP_S2_STAGGER=0: halves in lock-step
   static const int* v = fr_option_slot("FRHIP_XCD_ORDER", 1);
-  return *v != 0;
+  static const int* g = fr_option_slot("FRHIP_S2_STAGGER", 1);
+  return (*v != 0 ? 1 : 0) | (*g != 0 ? 2 : 0);
 }
 
 template <int CIN, int COUT, int WL, int ROWS, int WN, int NW, int KIND, int PRO, int NSPL, int NIMG>
