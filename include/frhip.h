@@ -322,7 +322,9 @@ int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream);
  * call this replaces (g, x, gx, mean, invstd, gamma, s0, s1, inv_count, add, add_kind 0 | 1 | 2, H, W, add_stride = 2,
  * rows_per_image; C = 64, rows = M; no slope, no gate): the kernel forms gx element for element as that call does, stores it
  * (the weight-gradient kernel reads it next) and feeds the rounded values to the sums -- gx and part are bit-identical to
- * fr_bn_bwd_apply followed by fr_stem_bwd_sums, and the 411-MB tensor (batch 256) is read once less. */
+ * fr_bn_bwd_apply followed by fr_stem_bwd_sums, and the 411-MB tensor (batch 256) is read once less.  unit->x == NULL: the
+ * unit's input IS the stem's output z = PReLU(BN(X Wp^T)) of this step (fr_stem_gemm_bn_prelu with the same X, Wp, scale, shift,
+ * slope): it is recomputed from the y tile the sums need anyway, bit for bit, instead of read (another 411 MB less). */
 int fr_stem_bwd_sums_from(const FrBnBwdArgs* unit, const void* X, const void* Wp, const float* mean, const float* invstd,
                           const float* scale, const float* shift, const float* slope, float* part, long long M, int K,
                           int nblocks, void* stream);

@@ -1268,8 +1268,10 @@ class BackbonePlan(object):
             self._unit0_apply = None
             if (i == 0 and not self.body_only and self.stem_recompute and fr == FR_BF16 and u.cin == 64 and
                     self.M0 < (1 << 24) and self.bn0.mod.training and _switch("FRHIP_STEM_FROM_UNIT", 1)):
-                self._unit0_apply = ops._fill(_lib.FrBnBwdArgs(), **kw)
-                self._unit0_apply_keep = kw
+                # ... and x, the unit's input, is the stem's own output: recomputed from the rows instead of read (x = NULL)
+                kw0 = dict(kw, x=None) if (x is self.z0 and _switch("FRHIP_STEM_RECOMPUTE_X", 1)) else kw
+                self._unit0_apply = ops._fill(_lib.FrBnBwdArgs(), **kw0)
+                self._unit0_apply_keep = kw0
             else:
                 L.append(ops.bn_bwd_apply(st, fr, **kw))
             done = None

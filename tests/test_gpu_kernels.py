@@ -1780,6 +1780,19 @@ def test_stem_backward_sums_fed_by_the_first_unit(K, Kp, add_kind, B, H):
     torch.cuda.synchronize()
     assert torch.equal(gx0, gx1) and float(gx0.float().abs().max()) > 0
     assert torch.equal(p0, p1) and float(p0.abs().max()) > 0
+    # unit.x = NULL: the unit's input is the stem's own output z = PReLU(BN0(rows w^T)) -- recomputed from the rows, bit for bit
+    z = torch.zeros(M, 64, device="cuda", dtype=bf)
+    pz = torch.zeros(8, 2, 64, device="cuda")
+    K.call("fr_stem_gemm_bn_prelu", rows, w, scale, shift, slope, None, z, pz, M, Kp, 8, st)()
+    gx2, gx3 = torch.zeros_like(gx0), torch.zeros_like(gx0)
+    p2, p3 = torch.zeros_like(p0), torch.zeros_like(p0)
+    kwz = dict(kw, x=z)
+    K.call("fr_stem_bwd_sums_from", K._fill(_lib.FrBnBwdArgs(), gx=gx2, **kwz), rows, w, mean, invstd, scale, shift, slope, p2,
+           M, Kp, nbs, st)()
+    K.call("fr_stem_bwd_sums_from", K._fill(_lib.FrBnBwdArgs(), gx=gx3, **dict(kwz, x=None)), rows, w, mean, invstd, scale, shift,
+           slope, p3, M, Kp, nbs, st)()
+    torch.cuda.synchronize()
+    assert torch.equal(gx2, gx3) and torch.equal(p2, p3) and float(gx2.float().abs().max()) > 0
     # a gated / sloped BatchNorm backward is not what this entry point fuses: refused, not silently mis-computed
     bad = K._fill(_lib.FrBnBwdArgs(), gx=gx1, slope=slope, scale=scale, shift=shift, **kw)
     with pytest.raises(_lib.FrhipError):
