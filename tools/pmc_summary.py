@@ -35,11 +35,11 @@ def table():
         "strip_64_64_112_dgrad": (r"conv3x3_roll64_kernel<112, 0, true>|conv3x3_strip_kernel<64, 64, 112, \d+, \d+, \d+, 1, 0,", 3 * act(112, 64) + w3(64, 64), f3(112, 64, 64)),
         "s2_64_56_fwd": (r"conv3x3_s2_roll64_kernel<0, 2>|conv3x3_s2_kernel<64, 64, 56, \d+, \d+, \d+, 0, 2[,>]", act(112, 64) + act(56, 64) + w3(64, 64), f3(56, 64, 64)),
         "s2_64_56_dgrad": (r"conv3x3_s2_roll64_kernel<1, 0>|conv3x3_s2_kernel<64, 64, 56, \d+, \d+, \d+, 1, 0[,>]", act(56, 64) + 2 * act(112, 64) + w3(64, 64), f3(56, 64, 64)),
-        "s2_128_28_fwd": (r"conv3x3_s2_kernel<128, \d+, 28, \d+, \d+, \d+, 0, 2[,>]", act(56, 128) + act(28, 128) + w3(128, 128), f3(28, 128, 128)),
+        "s2_128_28_fwd": (r"conv3x3_s2_ws_kernel<128, 28, \d+, \d+, 2>|conv3x3_s2_kernel<128, \d+, 28, \d+, \d+, \d+, 0, 2[,>]", act(56, 128) + act(28, 128) + w3(128, 128), f3(28, 128, 128)),
         "s2_128_28_dgrad": (r"conv3x3_s2_kernel<128, \d+, 28, \d+, \d+, \d+, 1, 0[,>]", act(28, 128) + 2 * act(56, 128) + w3(128, 128), f3(28, 128, 128)),
-        "s2_256_14_fwd": (r"conv3x3_s2_kernel<256, \d+, 14, \d+, \d+, \d+, 0, 2[,>]", act(28, 256) + act(14, 256) + w3(256, 256), f3(14, 256, 256)),
+        "s2_256_14_fwd": (r"conv3x3_s2_ws_kernel<256, 14, \d+, \d+, 2>|conv3x3_s2_kernel<256, \d+, 14, \d+, \d+, \d+, 0, 2[,>]", act(28, 256) + act(14, 256) + w3(256, 256), f3(14, 256, 256)),
         "s2_256_14_dgrad": (r"conv3x3_s2_kernel<256, \d+, 14, \d+, \d+, \d+, 1, 0[,>]", act(14, 256) + 2 * act(28, 256) + w3(256, 256), f3(14, 256, 256)),
-        "s2_512_7_fwd": (r"conv3x3_s2_kernel<512, \d+, 7, \d+, \d+, \d+, 0, 2[,>]", act(14, 512) + act(7, 512) + w3(512, 512), f3(7, 512, 512)),
+        "s2_512_7_fwd": (r"conv3x3_s2_ws_kernel<512, 7, \d+, \d+, 2>|conv3x3_s2_kernel<512, \d+, 7, \d+, \d+, \d+, 0, 2[,>]", act(14, 512) + act(7, 512) + w3(512, 512), f3(7, 512, 512)),
         "s2_512_7_dgrad": (r"conv3x3_s2_kernel<512, \d+, 7, \d+, \d+, \d+, 1, 0[,>]", act(7, 512) + 2 * act(14, 512) + w3(512, 512), f3(7, 512, 512)),
         "strip_64_64_56_fwd_bn": (r"conv3x3_roll64_kernel<56, 1, false>|conv3x3_strip_kernel<64, 64, 56, \d+, \d+, \d+, 1, 1,", 2 * act(56, 64) + w3(64, 64), f3(56, 64, 64)),
         "strip_64_64_56_fwd_prelu": (r"conv3x3_roll64_kernel<56, 2, false>|conv3x3_strip_kernel<64, 64, 56, \d+, \d+, \d+, 1, 2,", 2 * act(56, 64) + w3(64, 64), f3(56, 64, 64)),
