@@ -433,7 +433,8 @@ def test_dispatch_geometry_of_the_strip_tables():
     s2 = L.fr_conv3x3_s2_strip_parts
     assert s2(256, 128, 128, 28, 0) == 1024 and s2(256, 128, 128, 28, 2) == 4096    # mode 2: four parity classes
     assert s2(256, 256, 256, 14, 0) == 256 and s2(256, 256, 256, 14, 2) == 4 * 512  # forward whole images, gradient 7-row strips
-    assert s2(256, 512, 512, 7, 0) == 128 and s2(256, 512, 512, 7, 2) == 4 * 128    # image pairs
+    assert s2(256, 512, 512, 7, 0) == 64 and s2(256, 512, 512, 7, 2) == 4 * 128     # forward (round 6, warp-specialised): four
+    assert s2(6, 512, 512, 7, 0) == 3                                               # images per workgroup; else image pairs
     assert s2(3, 512, 512, 7, 0) == 3                                               # odd batch: one image
     assert s2(256, 128, 256, 28, 0) == 0                                            # Cin != Cout: generic kernel
     ws = L.fr_conv_wgrad_strip_supported
