@@ -174,15 +174,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_roll64_kernel(const FrConvArgs
           if (rrow[u] < nrows) {
             const bool ok = (okmask >> u) & 1u;
             U128 x = ok ? st[u] : zero16();
-            if (PRO != FR_PRO_NONE && ok) {
-              float f[8];
-              unpack16<bf16_t>(x, f);
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                if (PRO == FR_PRO_BN) f[j] = fmaf(f[j], pa[j], pb[j]);
-                else f[j] = f[j] > 0.f ? f[j] : f[j] * pa[j];
-              }
-              x = pack16<bf16_t>(f);
+            if (PRO != FR_PRO_NONE && ok) {  // pro2 (frhip_internal.h): 5 / 7 vector instructions per dword instead of 11-12
+              x.x = pro2<PRO>(x.x, pa[0], pb[0], pa[1], pb[1]);
+              x.y = pro2<PRO>(x.y, pa[2], pb[2], pa[3], pb[3]);
+              x.z = pro2<PRO>(x.z, pa[4], pb[4], pa[5], pb[5]);
+              x.w = pro2<PRO>(x.w, pa[6], pb[6], pa[7], pb[7]);
             }
             int slot = s0 + rrow[u];
             slot = slot >= K::NR ? slot - K::NR : slot;

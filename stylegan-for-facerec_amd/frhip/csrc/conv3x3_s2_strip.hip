@@ -231,15 +231,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
           pc -= img * PLANE;
           const int gh = pc / C::GW, gw = pc - gh * C::GW;
           U128 x = v[u];
-          if (PRO != FR_PRO_NONE && ok[u]) {
-            float f[8];
-            unpack16<bf16_t>(x, f);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              if (PRO == FR_PRO_BN) f[j] = fmaf(f[j], pa[j], pb[j]);
-              else f[j] = f[j] > 0.f ? f[j] : f[j] * pa[j];
-            }
-            x = pack16<bf16_t>(f);
+          if (PRO != FR_PRO_NONE && ok[u]) {  // pro2 (frhip_internal.h): the prologue on packed pairs
+            x.x = pro2<PRO>(x.x, pa[0], pb[0], pa[1], pb[1]);
+            x.y = pro2<PRO>(x.y, pa[2], pb[2], pa[3], pb[3]);
+            x.z = pro2<PRO>(x.z, pa[4], pb[4], pa[5], pb[5]);
+            x.w = pro2<PRO>(x.w, pa[6], pb[6], pa[7], pb[7]);
           }
           st16(smem + img * C::ISTR + gh * C::RSTR + gw * C::PSTR + ch * 16, x);
         }
@@ -292,14 +288,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
         const int gh = pc / C::GW, gw = pc - gh * C::GW;
         U128 x = pf[PFP ? u : 0];
         if (PRO != FR_PRO_NONE && ((pfok >> u) & 1u)) {
-          float f[8];
-          unpack16<bf16_t>(x, f);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (PRO == FR_PRO_BN) f[j] = fmaf(f[j], pa[j], pb[j]);
-            else f[j] = f[j] > 0.f ? f[j] : f[j] * pa[j];
-          }
-          x = pack16<bf16_t>(f);
+          x.x = pro2<PRO>(x.x, pa[0], pb[0], pa[1], pb[1]);
+          x.y = pro2<PRO>(x.y, pa[2], pb[2], pa[3], pb[3]);
+          x.z = pro2<PRO>(x.z, pa[4], pb[4], pa[5], pb[5]);
+          x.w = pro2<PRO>(x.w, pa[6], pb[6], pa[7], pb[7]);
         }
         st16(smem + img * C::ISTR + gh * C::RSTR + gw * C::PSTR + ch * 16, x);
       }

@@ -241,14 +241,13 @@ __global__ __launch_bounds__(512) void conv3x3_s2_ws_kernel(const FrConvArgs p, 
       for (int u = 0; u < C::PER; ++u) {
         U128 x = v[u];
         if (PRO != FR_PRO_NONE) {
-          float f[8];
-          unpack16<bf16_t>(x, f);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (PRO == FR_PRO_BN) f[j] = fmaf(f[j], pa[j], pb[j]);
-            else f[j] = f[j] > 0.f ? f[j] : f[j] * pa[j];
-          }
-          x = pack16<bf16_t>(f);
+          // pro2 (frhip_internal.h): the prologue on packed pairs, written as instructions -- 5 (BN) / 7 (PReLU) vector
+          // instructions per dword where the C form compiles to 11-12 (16-bit compares + selects + permutes).  The loader's
+          // vector instructions are what a stage costs beside the computing wave of its SIMD (file header).
+          x.x = pro2<PRO>(x.x, pa[0], pb[0], pa[1], pb[1]);
+          x.y = pro2<PRO>(x.y, pa[2], pb[2], pa[3], pb[3]);
+          x.z = pro2<PRO>(x.z, pa[4], pb[4], pa[5], pb[5]);
+          x.w = pro2<PRO>(x.w, pa[6], pb[6], pa[7], pb[7]);
         }
         const unsigned keep = ((okm >> u) & 1u) ? 0xFFFFFFFFu : 0u;  // zero padding stays zero (BN would turn it into the shift)
         x.x &= keep;

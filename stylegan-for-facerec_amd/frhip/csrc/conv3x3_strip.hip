@@ -168,7 +168,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
         ioff = img * C::ISTR;
       }
       const int gh = pc_ / WP, gw = pc_ - gh * WP;
-      if (PRO != FR_PRO_NONE && ok) {
+      if ((PRO == FR_PRO_BN || PRO == FR_PRO_PRELU) && ok) {
+        // pro2 (frhip_internal.h): the prologue on packed pairs, 5 / 7 vector instructions per dword where the C form below
+        // compiles to 11-12 (round 6: the strip's vector work is what its load phase costs beside the other waves)
+        constexpr int P2 = PRO == FR_PRO_BN ? FR_PRO_BN : FR_PRO_PRELU;
+        x.x = pro2<P2>(x.x, pa[0], pb[0], pa[1], pb[1]);
+        x.y = pro2<P2>(x.y, pa[2], pb[2], pa[3], pb[3]);
+        x.z = pro2<P2>(x.z, pa[4], pb[4], pa[5], pb[5]);
+        x.w = pro2<P2>(x.w, pa[6], pb[6], pa[7], pb[7]);
+      } else if (PRO != FR_PRO_NONE && ok) {
         float f[8];
         unpack16<bf16_t>(x, f);
         if (RES) {

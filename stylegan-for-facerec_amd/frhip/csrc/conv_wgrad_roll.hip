@@ -85,37 +85,7 @@ struct RL {  // LDS layout: buffer 0 holds the even phases of the schedule, buff
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-// prologue on one dword (two bf16): BN apply or PReLU, fp32 arithmetic, one rounding back to bf16
-// Written as instructions: from the equivalent C the compiler rebuilds 16-bit compares + v_cndmask + v_perm (49 vector
-// instructions per 16-byte chunk instead of 28) -- and these run on the SIMDs whose issue slots the MFMA waves need.
-template <int PRO>
-__device__ __forceinline__ uint32_t pro2(uint32_t u, float a0, float b0, float a1, float b1) {
-  uint32_t lo, hi, r;
-  if (PRO == FR_PRO_BN) {
-    asm("v_lshlrev_b32 %0, 16, %3\n\t"
-        "v_and_b32 %1, 0xffff0000, %3\n\t"
-        "v_fma_f32 %0, %0, %4, %5\n\t"
-        "v_fma_f32 %1, %1, %6, %7\n\t"
-        "v_cvt_pk_bf16_f32 %2, %0, %1"
-        : "=&v"(lo), "=&v"(hi), "=v"(r)
-        : "v"(u), "v"(a0), "v"(b0), "v"(a1), "v"(b1));
-    return r;
-  }
-  // PReLU: x > 0 ? x : a x.  Both halves scaled and packed; v_pk_ashrrev_i16 spreads the two sign bits into a mask and
-  // v_bfi_b32 takes the scaled half where the sign is set, the input half elsewhere.  Same values as the compare form:
-  // -0 and negative NaNs go through a x (x > 0 is false for them too), a x of a positive x is never selected.
-  uint32_t m;
-  asm("v_lshlrev_b32 %0, 16, %4\n\t"
-      "v_and_b32 %1, 0xffff0000, %4\n\t"
-      "v_mul_f32 %0, %0, %5\n\t"
-      "v_mul_f32 %1, %1, %6\n\t"
-      "v_cvt_pk_bf16_f32 %0, %0, %1\n\t"
-      "v_pk_ashrrev_i16 %2, 15, %4 op_sel_hi:[0,1]\n\t"
-      "v_bfi_b32 %3, %2, %0, %4"
-      : "=&v"(lo), "=&v"(hi), "=&v"(m), "=v"(r)
-      : "v"(u), "v"(a0), "v"(a1));
-  return r;
-}
+// pro2<PRO>: the BN / PReLU prologue on one dword (two bf16), written as instructions -- frhip_internal.h
 
 #define LDS_FENCE_BARRIER_RAW() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
