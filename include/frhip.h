@@ -312,6 +312,15 @@ typedef struct FrBnBwdArgs {
   int32_t add_kind;
   int32_t H, W, add_stride; /* geometry of gx for add_kind 2 */
   int32_t nblocks;
+  /* fr_bn_bwd_apply, round 6 (ABI v6), nx != NULL: the launch ALSO leaves the rows of fr_bn_bwd_reduce for the BatchNorm whose
+   * output gradient it has just formed -- part rows npart[nblocks][2][C] = (sum gx, sum gx * xhat_n) over this workgroup's rows,
+   * xhat_n = (nx - nmean) * ninvstd, gx as rounded and stored: on tensors that only stream through HBM (56x56 x 64 channels at
+   * batch 256: 103 MB) the separate reduce pass re-read gx right behind this one.  bf16, no gate; fr_reduce_parts(npart,
+   * nblocks, 2, C, ...) adds the rows. */
+  const void* nx;
+  const float* nmean;
+  const float* ninvstd;
+  float* npart;
 } FrBnBwdArgs;
 int fr_bn_bwd_reduce(const FrBnBwdArgs* args, int dtype, void* stream);
 int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream);

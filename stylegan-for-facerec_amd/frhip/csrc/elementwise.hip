@@ -586,8 +586,12 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_reduce_lean_kernel(const FrBnBwd
 // w/2, c] lands on the pixels with even h and w (MaxPool2d(1, 2) / the 1x1 stride-2 shortcut convolution, model_irse.py:52-56).
 // The four stage-entry units ran the general kernel for it: 387 us at 112x112 (1.2 GB of traffic, 200 us at HBM rate), 45-66
 // us at the other three.
-template <int ADD, bool SE = false>
-__global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdArgs p) {
+// NEXT (round 6): the rows of bn_bwd_reduce_lean_kernel<false> for the BatchNorm in front (input p.nx), from the rounded gx, in
+// the same pass.  Rounds 2-5 built this three times and dropped it: at 14x14 the separate kernels run two waves per SIMD where
+// this one (more registers) runs one, and they are latency-bound there.  On tensors that stream through HBM it is a pass less.
+template <int ADD, bool SE = false, bool NEXT = false>
+__global__ __launch_bounds__(NT, NEXT ? 4 : 6) void bn_bwd_apply_lean_kernel(const FrBnBwdArgs p) {
+  __shared__ float nred[NEXT ? NT * 2 * LV : 1];
   const int C = p.C, cpr = C / LV, tid = threadIdx.x;
   const int cc = tid % cpr, rt = tid / cpr, rtc = NT / cpr, c0 = cc * LV;
   const bf16_t* __restrict__ g = reinterpret_cast<const bf16_t*>(p.g) + c0;
@@ -603,6 +607,16 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdA
     a[j] = p.s0[c0 + j] * p.inv_count;
     bb[j] = p.s1[c0 + j] * p.inv_count;
   }
+  const bf16_t* __restrict__ nx = NEXT ? reinterpret_cast<const bf16_t*>(p.nx) + c0 : nullptr;
+  float nmu[NEXT ? LV : 1], nis[NEXT ? LV : 1], nacc[2][LV];
+  if (NEXT) {
+#pragma unroll
+    for (int j = 0; j < LV; ++j) {
+      nmu[j] = p.nmean[c0 + j];
+      nis[j] = p.ninvstd[c0 + j];
+      nacc[0][j] = nacc[1][j] = 0.f;
+    }
+  }
   // (Round 2-3 carried a NEXT variant here that also formed the backward sums of the BatchNorm in front from the rounded
   // gx -- bit-identical, one pass less, and 0.04-0.6 ms SLOWER per step beside the weight gradients of the side stream: 80
   // registers, one wave per SIMD where the two separate kernels run two.  Removed in round 4, ABI v4.  Round 5 rebuilt it once
@@ -612,7 +626,7 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdA
   const unsigned W = (unsigned)p.W, HW = (unsigned)p.rows_per_image, Wh = W >> 1, HWq = HW >> 2;  // ADD == 2
   const float invW = 1.0f / (float)p.W, invHW = 1.0f / (float)p.rows_per_image;
   for (int r0 = blockIdx.x * rtc * LUNRB + rt; r0 < nrows; r0 += rstep) {
-    uint2 gr[LUNRB], xr[LUNRB], er[LUNRB];
+    uint2 gr[LUNRB], xr[LUNRB], er[LUNRB], nr[NEXT ? LUNRB : 1];
     bool hit[LUNRB];
 #pragma unroll
     for (int u = 0; u < LUNRB; ++u) {
@@ -621,6 +635,7 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdA
       if (r < nrows) {
         gr[u] = ld8(g + (size_t)r * C);
         xr[u] = ld8(x + (size_t)r * C);
+        if (NEXT) nr[u] = ld8(nx + (size_t)r * C);
         if (ADD == 1) er[u] = ld8(add + (size_t)r * C);
         if (ADD == 2) {
           unsigned b, rem, h, w;
@@ -645,10 +660,22 @@ __global__ __launch_bounds__(NT, 6) void bn_bwd_apply_lean_kernel(const FrBnBwdA
           o[j] = coef[j] * (gv[j] - a[j] - (xv[j] - mu[j]) * is[j] * bb[j]);
           if (ADD == 1 || (ADD == 2 && hit[u])) o[j] += e[j];
         }
-        *reinterpret_cast<uint2*>(gx + (size_t)r * C) = pack4bf(o);
+        const uint2 packed = pack4bf(o);
+        *reinterpret_cast<uint2*>(gx + (size_t)r * C) = packed;
+        if (NEXT) {  // bn_bwd_reduce_lean_kernel<false> on what the tensor now holds
+          float gq[LV], xn[LV];
+          unpack4bf(packed, gq);
+          unpack4bf(nr[u], xn);
+#pragma unroll
+          for (int j = 0; j < LV; ++j) {
+            nacc[0][j] += gq[j];
+            nacc[1][j] = fmaf(gq[j], (xn[j] - nmu[j]) * nis[j], nacc[1][j]);
+          }
+        }
       }
     }
   }
+  if (NEXT) block_col_reduce<2, LV>(nacc, nred, p.npart + (size_t)blockIdx.x * 2 * C, C, cpr, tid);
 }
 
 // ------------------------------------------------------------------------------------------ SE
@@ -1628,6 +1655,11 @@ extern "C" int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream)
     if (args->se) {
       if (args->add_kind == 1) hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<1, true>), grid, blk, 0, st, *args);
       else hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<0, true>), grid, blk, 0, st, *args);
+    } else if (args->nx) {
+      if (!args->nmean || !args->ninvstd || !args->npart) FR_UNSUPPORTED("fr_bn_bwd_apply: nx needs nmean, ninvstd and npart");
+      if (args->add_kind == 1) hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<1, false, true>), grid, blk, 0, st, *args);
+      else if (args->add_kind == 2) hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<2, false, true>), grid, blk, 0, st, *args);
+      else hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<0, false, true>), grid, blk, 0, st, *args);
     } else {
       if (args->add_kind == 1) hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<1, false>), grid, blk, 0, st, *args);
       else if (args->add_kind == 2) hipLaunchKernelGGL((bn_bwd_apply_lean_kernel<2, false>), grid, blk, 0, st, *args);
@@ -1635,6 +1667,7 @@ extern "C" int fr_bn_bwd_apply(const FrBnBwdArgs* args, int dtype, void* stream)
     }
     FR_LAUNCH_CHECK();
   }
+  if (args->nx) FR_UNSUPPORTED("fr_bn_bwd_apply: nx (the sums of the BatchNorm in front) is served by the bf16 lean kernel only");
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(args->nblocks), dim3(NT), 0, st, *args),
              hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(args->nblocks), dim3(NT), 0, st, *args),
              "fr_bn_bwd_apply");

@@ -1080,6 +1080,7 @@ class BackbonePlan(object):
         B, st, fr = self.B, self.stream, self.fr
         # ---- residual units in reverse
         unit_done = {}  # unit index -> event recorded on the side stream after its weight gradients
+        sums_left = 0  # rows of BN2-backward sums the previous launch left in self.part (0: none)
         for i in range(len(self.units) - 1, -1, -1):
             u, d = self.units[i], self.ubuf[i]
             x = self.ubuf[i - 1]["out"] if i > 0 else self.z0
@@ -1153,6 +1154,8 @@ class BackbonePlan(object):
                           rows_per_image=HWo, nblocks=nb, **se_kw)
             if u.se is not None and se_sums:
                 self._reduce(L, B, 2, u.depth, db, dg)  # one row pair per image, left by fr_se_gscale_mlp_bwd_sums
+            elif sums_left:
+                self._reduce(L, sums_left, 2, u.depth, db, dg)  # left by the launch that formed g_out (nx below)
             else:
                 L.append(ops.bn_bwd_reduce(st, fr, part=self.part, **common))
                 self._reduce(L, nb, 3, u.depth, db, dg)
@@ -1273,6 +1276,16 @@ class BackbonePlan(object):
                 self._unit0_apply = ops._fill(_lib.FrBnBwdArgs(), **kw0)
                 self._unit0_apply_keep = kw0
             else:
+                # Round 6: where the unit in front has no gate and the tensor only streams through HBM, this launch also takes
+                # the sums BN2's backward of that unit needs (FrBnBwdArgs.nx) -- fr_bn_bwd_reduce, a pass over (g_x, y2) right
+                # behind this one, is gone there.  FRHIP_BN_NEXT_MB: smallest tensor (MB) it is done for, 0 = never
+                sums_left = 0
+                lim = _switch("FRHIP_BN_NEXT_MB", 20)
+                if (i > 0 and fr == FR_BF16 and lim > 0 and self.units[i - 1].se is None and
+                        rin * u.cin * 2 >= lim << 20):
+                    pb = self.ubuf[i - 1]
+                    kw.update(nx=pb["y2"], nmean=pb["bn2"].mean, ninvstd=pb["bn2"].invstd, npart=self.part)
+                    sums_left = kw["nblocks"]
                 L.append(ops.bn_bwd_apply(st, fr, **kw))
             done = None
             if self.dual:

@@ -1171,6 +1171,57 @@ def test_bn_backward_with_se_gate(K, name, dtype, tol, with_add):
     assert relerr(from_nhwc(gx), want) < tol * 2
 
 
+@pytest.mark.parametrize("add_kind", [0, 1, 2])
+@pytest.mark.parametrize("B,H,C", [(5, 8, 64), (3, 14, 128), (37, 6, 64)])
+def test_bn_backward_leaves_the_sums_of_the_batchnorm_in_front(K, B, H, C, add_kind):
+    """FrBnBwdArgs.nx (round 6): fr_bn_bwd_apply also leaves the partial rows fr_bn_bwd_reduce would find with a pass of its
+    own over (gx, nx) -- gx and the added rows BIT-IDENTICAL to the two launches (same rows per thread, same order)."""
+    from frhip import _lib
+    dtype = torch.bfloat16
+    rows, HW = B * H * H, H * H
+    x = q(synth.normal(89, "nx", (B, C, H, H)), dtype)
+    y2 = q(synth.normal(89, "ny", (B, C, H, H), std=1.5), dtype)
+    g = q(synth.normal(89, "ng", (B, C, H, H)), dtype)
+    gamma = synth.uniform(89, "nw", (C,), 0.8, 1.2).cuda()
+    s0 = synth.normal(89, "n0", (C,), std=3.0).cuda()
+    s1 = synth.normal(89, "n1", (C,), std=3.0).cuda()
+    mean, invstd = x.mean((0, 2, 3)).cuda(), (1.0 / torch.sqrt(x.var((0, 2, 3), unbiased=False) + 1e-5)).cuda()
+    nmean, ninvstd = y2.mean((0, 2, 3)).cuda(), (1.0 / torch.sqrt(y2.var((0, 2, 3), unbiased=False) + 1e-5)).cuda()
+    fr, st = K.fr_dtype(torch.empty(0, dtype=dtype)), K.current_stream_ptr()
+    nb = 7
+    kw = dict(g=nhwc(g, dtype), x=nhwc(x, dtype), mean=mean, invstd=invstd, gamma=gamma, s0=s0, s1=s1, rows=rows,
+              inv_count=1.0 / rows, C=C, rows_per_image=HW, nblocks=nb)
+    if add_kind == 1:
+        kw.update(add=nhwc(q(synth.normal(89, "na", (B, C, H, H)), dtype), dtype), add_kind=1)
+    elif add_kind == 2:
+        kw.update(add=nhwc(q(synth.normal(89, "na", (B, C, H // 2, H // 2)), dtype), dtype), add_kind=2, H=H, W=H, add_stride=2)
+    y2d = nhwc(y2, dtype)
+    gx0 = torch.zeros(B, H, H, C, device="cuda", dtype=dtype)
+    K.bn_bwd_apply(st, fr, gx=gx0, **kw)()
+    part0 = torch.zeros(nb, 3, C, device="cuda")
+    K.bn_bwd_reduce(st, fr, part=part0, g=gx0, x=y2d, mean=nmean, invstd=ninvstd, rows=rows, C=C, rows_per_image=HW,
+                    nblocks=nb)()
+    a0, a1 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    K.call("fr_reduce_parts", part0, nb, 3, C, a0, a1, None, st)()
+    gx1 = torch.full((B, H, H, C), 7.0, device="cuda", dtype=dtype)
+    part1 = torch.full((nb, 2, C), 7.0, device="cuda")
+    K.bn_bwd_apply(st, fr, gx=gx1, nx=y2d, nmean=nmean, ninvstd=ninvstd, npart=part1, **kw)()
+    b0, b1 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    K.call("fr_reduce_parts", part1, nb, 2, C, b0, b1, None, st)()
+    torch.cuda.synchronize()
+    assert torch.equal(gx0, gx1)
+    assert torch.equal(part0[:, :2], part1)
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    gq = from_nhwc(gx0).double()
+    xh = (y2.double() - nmean.cpu().double().view(1, C, 1, 1)) * ninvstd.cpu().double().view(1, C, 1, 1)
+    mag = gq.abs().sum((0, 2, 3)) + 1e-9
+    assert float(((b0.cpu().double() - gq.sum((0, 2, 3))).abs() / mag).max()) < 2e-6
+    assert float(((b1.cpu().double() - (gq * xh).sum((0, 2, 3))).abs() / (gq * xh).abs().sum((0, 2, 3))).max()) < 2e-6
+    with pytest.raises(_lib.FrhipError):  # fp32 has no such kernel: refused, never a silent second pass
+        K.bn_bwd_apply(st, K.FR_F32, gx=gx1.float(), nx=y2d, nmean=nmean, ninvstd=ninvstd, npart=part1,
+                       **dict(kw, g=kw["g"].float(), x=kw["x"].float()))()
+
+
 @pytest.mark.parametrize("name,dtype,tol", DT)
 @pytest.mark.parametrize("B,H,C", [(5, 7, 128), (3, 14, 256), (130, 4, 64)])
 def test_se_backward_leaves_the_sums_of_bn2(K, name, dtype, tol, B, H, C):
