@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 6
+#define FR_ABI_VERSION 7
 
 enum { FR_F32 = 0, FR_BF16 = 1 };
 
@@ -114,6 +114,12 @@ typedef struct FrConvArgs {
   void* pro_out;       /* NULL or [B*SH*SW][lda]: the residual sum of every source pixel */
   const float* pro_d;  /* [SC], FR_PRO_RESBN / FR_PRO_RESBN_SE only */
   const float* pro_g;  /* [B][SC] excite gates, FR_PRO_RESBN_SE only */
+  /* ABI v7: 1 = w is in MFMA-fragment order, [N / 16][taps][K / 32][64][8] with (n, tap, k) at
+   * (((n / 16 * taps + tap) * (K / 32) + k / 32) * 64 + (k % 32) / 8 * 16 + n % 16) * 8 + k % 8  (N = output columns, K = SC;
+   * FrPackTensor.frag writes it): the 64 lanes of a weight-fragment load then read 1024 contiguous bytes.  Taken by
+   * fr_conv3x3_strip on its LDS-strip instances (fr_conv3x3_strip_takes_frag) and by fr_conv3x3_s2_strip; refused elsewhere. */
+  int32_t w_frag;
+  int32_t reserved_;
 } FrConvArgs;
 
 /* Convolution forward / data gradient / dense GEMM on MFMA.
@@ -133,6 +139,9 @@ int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi);
 /* 1 when fr_conv3x3_strip serves the two-source prologues (FR_PRO_RESBN[_SE]) and FR_EPI_STATS_X for a C -> C layer of width W
  * at batch B (the LDS-strip instances; not the 64-channel rolling-window kernel) */
 int fr_conv3x3_strip_serves_resbn(int B, int C, int W);
+/* 1 when fr_conv3x3_strip reads fragment-order weights (FrConvArgs.w_frag) for a Cin -> Cout layer of width W at batch B: the
+ * shape is served and not by the 64-channel rolling-window kernel, which keeps its weights resident and takes the plain layout */
+int fr_conv3x3_strip_takes_frag(int B, int Cin, int Cout, int W);
 
 /* 1x1 convolution as a row-streaming GEMM (bf16; round 4): the weights stationary in registers, one row per output pixel,
  * stride 1 or 2 (SH = RH * stride), epilogue STORE or STATS (part[workgroup][2][N]; fr_conv1x1_stream_parts returns the number
@@ -464,7 +473,9 @@ typedef struct FrPackTensor {
   const float* w;
   void* wp; /* may be NULL */
   void* wt; /* may be NULL */
-  int32_t Cout, taps, Cin, pad_;
+  int32_t Cout, taps, Cin;
+  int32_t frag; /* ABI v7, bit 0: wp in MFMA-fragment order (FrConvArgs.w_frag; N = Cout, K = Cin), bit 1: wt (N = Cin, K = Cout);
+                   bf16, Cout % 64 == 0 and Cin % 64 == 0 (the 64 x 64 tile chunks) */
   const float* oscale; /* [Cout] or NULL: wp = w * oscale[co] (BatchNorm scale folded into the output channels) */
 } FrPackTensor;
 int fr_pack_weights_multi(const FrPackTensor* table_dev, const int32_t* chunks_dev, int nchunks, int dtype,

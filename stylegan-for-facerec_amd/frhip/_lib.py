@@ -114,7 +114,7 @@ lib = _load()
 
 
 def self_check():
-    assert lib.fr_abi_version() == 6
+    assert lib.fr_abi_version() == 7
     for i, s in enumerate((FrConvArgs, FrWgradArgs, FrApplyArgs, FrBnBwdArgs, FrSgdTensor, FrPackTensor, FrAdamTensor, FrBnEvalEntry,
                            FrBnFinArgs)):
         got = lib.fr_struct_size(i)

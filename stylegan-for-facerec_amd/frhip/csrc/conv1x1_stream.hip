@@ -176,6 +176,7 @@ extern "C" int fr_conv1x1_stream(const FrConvArgs* args, void* stream) {
   if (a.KH != 1 || a.KW != 1 || a.pad != 0 || a.mode != 0 || a.pro != FR_PRO_NONE || a.out_f32 || a.splitk > 1 || a.bias ||
       (a.epi != FR_EPI_STORE && a.epi != FR_EPI_STATS))
     FR_UNSUPPORTED("fr_conv1x1_stream: 1x1, no padding / prologue / bias, epilogue STORE or STATS");
+  if (a.w_frag) FR_UNSUPPORTED("fr_conv1x1_stream: fragment-order weights (w_frag) are read by the LDS-strip kernels only");
   if (!c1_shape(a.SC, a.N)) FR_UNSUPPORTED("fr_conv1x1_stream: shape not served (64->128, 128->256, 256->512 and their transposes)");
   if ((a.stride != 1 && a.stride != 2) || a.SH != a.RH * a.stride || a.SW != a.RW * a.stride)
     FR_UNSUPPORTED("fr_conv1x1_stream: stride 1 or 2 with SH = RH * stride, SW = RW * stride");

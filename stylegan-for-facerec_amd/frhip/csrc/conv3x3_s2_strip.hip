@@ -674,6 +674,7 @@ extern "C" int fr_conv3x3_s2_strip(const FrConvArgs* args, void* stream) {
     FR_UNSUPPORTED("fr_conv3x3_s2_strip: stride-2 3x3 pad-1 bf16 convolution (mode 0) or its data gradient (mode 2)");
   if (a.mode == 2 && (a.par_h >= 0 || a.par_w >= 0))
     FR_UNSUPPORTED("fr_conv3x3_s2_strip: the data gradient produces all four parity classes (par_h = par_w = -1)");
+  if (a.w_frag) FR_UNSUPPORTED("fr_conv3x3_s2_strip: fragment-order weights (w_frag) are not read here yet");
   if (a.lda % 8 || a.ldc % 8 || (a.aux && a.ldaux % 8)) FR_UNSUPPORTED("fr_conv3x3_s2_strip: strides must be 16-byte multiples");
   // low-res grid: forward output / gradient input
   const int WLo = a.mode == 0 ? a.RW : a.SW, HLo = a.mode == 0 ? a.RH : a.SH;

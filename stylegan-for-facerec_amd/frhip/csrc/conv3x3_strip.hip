@@ -242,6 +242,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
   {
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) wrow[j] = wgt + (size_t)(ncol0 + n0 + j * 16 + fr) * 9 * CIN + fq * 8;
+    // w_frag (round 6, ABI v7): the weights in MFMA-fragment order [N / 16][tap][K / 32][lane][8] -- the 64 lanes of a weight
+    // load read 1024 contiguous bytes (eight whole 128-byte lines) instead of 64 bytes of each of 16 rows 9 * CIN * 2 bytes
+    // apart (half of every line fetched, the other half wanted nine taps later and long evicted): 0.0609 -> 0.0560 ms at
+    // 256 -> 256 @14, 0.0701 -> 0.0641 at 128 @28, 0.0662 -> 0.0632 at 512 @7 (tools/kbench.py, B = 256)
+    const int wsh = p.w_frag ? 4 : 0;
+    if (wsh) {
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) wrow[j] = wgt + (size_t)((ncol0 + n0) / 16 + j) * 16 * 9 * CIN + lane * 8;
+    }
     const int epi = p.epi;
     const bool stats = epi == FR_EPI_STATS || epi == FR_EPI_PRELU_BWD || epi == FR_EPI_BNBWD || epi == FR_EPI_STATS_X;
     const int b = NIMG > 1 ? s * NIMG : s / C::NS;  // first image of the strip
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_strip_kernel(const FrConvA
     auto load_b = [&](int slot, int c0, int tap) {
       const int wt = flip ? 8 - tap : tap;
 #pragma unroll
-      for (int j = 0; j < C::TN; ++j) bq[slot][j] = *reinterpret_cast<const s16x8*>(wrow[j] + wt * CIN + kco() + c0);
+      for (int j = 0; j < C::TN; ++j) bq[slot][j] = *reinterpret_cast<const s16x8*>(wrow[j] + ((wt * CIN + kco() + c0) << wsh));
     };
     constexpr int NSTEP = 9 * C::TM;
     // ring depth must divide NSTEP (slots line up across the channel loop): 9 when registers allow, else 3
@@ -596,6 +605,11 @@ extern "C" int fr_conv3x3_strip_serves_resbn(int B, int C, int W) {
   return fr_conv3x3_strip_parts(B, C, C, W, FR_EPI_PRELU_BWD) > 0 ? 1 : 0;
 }
 
+extern "C" int fr_conv3x3_strip_takes_frag(int B, int Cin, int Cout, int W) {
+  if (Cin == 64 && Cout == 64 && (W == 112 || W == 56) && fr_roll64_enabled()) return 0;
+  return fr_conv3x3_strip_parts(B, Cin, Cout, W, FR_EPI_STORE) > 0 ? 1 : 0;
+}
+
 // Number of partial rows the kernel writes into `part` (= workgroups) for a supported shape, 0 if unsupported.
 extern "C" int fr_conv3x3_strip_parts(int B, int Cin, int Cout, int W, int epi) {
   if (Cin == 256 && Cout == 512 && W == 14 && epi != FR_EPI_STORE) return 0;
@@ -614,7 +628,10 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
       a.out_f32 || a.splitk > 1 || a.bias || a.epi == FR_EPI_MARGIN || a.epi == FR_EPI_ATOMIC)
     FR_UNSUPPORTED("fr_conv3x3_strip: only square stride-1 3x3 bf16 convolutions");
   if (a.lda % 8 || a.ldc % 8 || (a.aux && a.ldaux % 8)) FR_UNSUPPORTED("fr_conv3x3_strip: strides must be 16-byte multiples");
-  if (a.SC == 64 && a.N == 64 && (a.SW == 112 || a.SW == 56) && fr_roll64_enabled()) return fr_roll64_launch(a, st);
+  if (a.SC == 64 && a.N == 64 && (a.SW == 112 || a.SW == 56) && fr_roll64_enabled()) {
+    if (a.w_frag) FR_UNSUPPORTED("fr_conv3x3_strip: the 64-channel rolling-window kernel takes the plain weight layout (w_frag)");
+    return fr_roll64_launch(a, st);
+  }
 #define SHAPE(ci, co, w, rows, wn, nw) \
   if (a.SC == ci && a.N == co && a.SW == w) return by_pro<ci, co, w, rows, wn, nw>(a, st);
   // (round 3: 128 -> 128 @28 as 8 waves x (25 tiles x 1 column) on half images, one workgroup per CU, half the weight stream:

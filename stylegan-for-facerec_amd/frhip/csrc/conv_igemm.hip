@@ -501,6 +501,7 @@ int dispatch(const FrConvArgs& a, hipStream_t st) {
 extern "C" int fr_conv_igemm(const FrConvArgs* args, int dtype, void* stream) {
   FrConvArgs a = *args;
   if (a.SC % BK != 0) FR_UNSUPPORTED("fr_conv_igemm: source channels must be a multiple of 32");
+  if (a.w_frag) FR_UNSUPPORTED("fr_conv_igemm: fragment-order weights (w_frag) are read by the LDS-strip kernels only");
   if (a.stride != 1 && a.stride != 2) FR_UNSUPPORTED("fr_conv_igemm: stride must be 1 or 2");
   if (a.mode == 2 && (a.stride != 2 || a.KH != 3 || a.KW != 3 || a.pad != 1 || (a.RH & 1) || (a.RW & 1) || a.epi == FR_EPI_MARGIN))
     FR_UNSUPPORTED("fr_conv_igemm: mode 2 is the stride-2 3x3 pad-1 data gradient on even-sized outputs");

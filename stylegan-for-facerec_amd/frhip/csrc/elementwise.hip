@@ -1285,6 +1285,11 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 // (round 4: tensors whose channel counts are multiples of 64 -- every 3x3 and shortcut convolution of the IR nets -- are moved
 // by 64 x 64 tiles with 16-byte accesses on all three sides; chunk.y < 0 marks such a tile: -(index + 1).  The 32 x 32 tiles
 // with 4-byte loads and 2-byte stores ran the 350 MB of a step at 3 TB/s.)
+// element offset of the 8 values (n, tap, k .. k + 7), k % 8 == 0, in MFMA-fragment order (FrConvArgs.w_frag)
+__device__ __forceinline__ size_t frag_offset(int n, int tap, int k, int taps, int K) {
+  return ((((size_t)(n >> 4) * taps + tap) * (K >> 5) + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (n & 15)) * 8;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const FrPackTensor* __restrict__ table,
                                                                  const int2* __restrict__ chunks) {
@@ -1315,7 +1320,11 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const FrPackTen
         for (int k = 0; k < 16; ++k) f[k] *= sc;
       }
       const U128 lo = pack16<bf16_t>(f), hi = pack16<bf16_t>(f + 8);
-      if (t.wp) {
+      if (t.wp && (t.frag & 1)) {
+        bf16_t* dst = reinterpret_cast<bf16_t*>(t.wp);
+        st16(dst + frag_offset(co0 + r, tap, ci0 + q, t.taps, t.Cin), lo);
+        st16(dst + frag_offset(co0 + r, tap, ci0 + q + 8, t.taps, t.Cin), hi);
+      } else if (t.wp) {
         bf16_t* dst = reinterpret_cast<bf16_t*>(t.wp) + ((size_t)(co0 + r) * t.taps + tap) * t.Cin + ci0 + q;
         st16(dst, lo);
         st16(dst + 8, hi);
@@ -1331,12 +1340,18 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const FrPackTen
         uint32_t w32[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) w32[k] = (uint32_t)g[2 * k] | ((uint32_t)g[2 * k + 1] << 16);
-        bf16_t* dst = reinterpret_cast<bf16_t*>(t.wt) + ((size_t)(ci0 + r) * t.taps + tap) * t.Cout + co0 + q;
         U128 a, b;
         a.x = w32[0]; a.y = w32[1]; a.z = w32[2]; a.w = w32[3];
         b.x = w32[4]; b.y = w32[5]; b.z = w32[6]; b.w = w32[7];
-        st16(dst, a);
-        st16(dst + 8, b);
+        if (t.frag & 2) {
+          bf16_t* dst = reinterpret_cast<bf16_t*>(t.wt);
+          st16(dst + frag_offset(ci0 + r, tap, co0 + q, t.taps, t.Cout), a);
+          st16(dst + frag_offset(ci0 + r, tap, co0 + q + 8, t.taps, t.Cout), b);
+        } else {
+          bf16_t* dst = reinterpret_cast<bf16_t*>(t.wt) + ((size_t)(ci0 + r) * t.taps + tap) * t.Cout + co0 + q;
+          st16(dst, a);
+          st16(dst + 8, b);
+        }
       }
     }
     return;

@@ -299,9 +299,14 @@ class BackbonePlan(object):
         self._normalize_params()
         self._alloc()
         self._bind_params()
+        # weight layouts (round 6): the packed 3x3 copies the LDS-strip kernels read are kept in MFMA-fragment order
+        self.w_frag = self.fr == FR_BF16 and bool(_switch("FRHIP_W_FRAG", 1))
+        self._weight_layout = {}
+        self._pack_targets = set(id(d[k]) for d in self.ubuf for k in ("wp1", "wp2", "wt1", "wt2") if k in d)
         self._build_forward()
         if not self.infer:
             self._build_backward()
+        self._finish_pack()
 
     # ---- buffers -----------------------------------------------------------------------------------
     def _act(self, rows, C):
@@ -522,6 +527,11 @@ class BackbonePlan(object):
             # against 17.8 ms with 4-32 CUs held for the whole step.  What data-parallel runs do instead: frhip.parallel holds
             # the collectives back until the backward pass has left these layers, comm_gate below.)
             if n:
+                # Round 6: weights of the LDS-strip instances in MFMA-fragment order (FrConvArgs.w_frag): a weight load reads
+                # 1024 contiguous bytes instead of half of each of 16 lines (-5 ... -9 % per launch; FRHIP_W_FRAG=0: A/B)
+                if self._note_weight(kw["w"], self.w_frag and kw["SC"] % 64 == 0 and kw["N"] % 64 == 0 and bool(
+                        _lib.lib.fr_conv3x3_strip_takes_frag(kw["B"], kw["SC"], kw["N"], kw["SW"]))):
+                    kw = dict(kw, w_frag=1)
                 L.append(ops.conv_strip(self.stream, **kw))
                 self._last_conv_strips = n  # partial rows = strips, image-major
                 return n
@@ -530,14 +540,26 @@ class BackbonePlan(object):
             mode = kw.get("mode", 0)
             n = ops.s2_strip_parts(kw["B"], kw["SC"], kw["N"], kw["RW"] if mode == 0 else kw["SW"], mode)
             if n:
+                self._note_weight(kw["w"], False)
                 L.append(ops.conv_s2_strip(self.stream, **kw))
                 self._last_conv_strips = n if mode == 0 else 0
                 return n
         self._last_conv_strips = 0
+        self._note_weight(kw["w"], False)
         L.append(ops.conv(self.stream, self.fr, **kw))
         if kw.get("mode", 0) == 2:  # all four parity classes in one launch: [class][M tile] partial rows
             return 4 * ((kw["B"] * (kw["RH"] // 2) * (kw["RW"] // 2) + 127) // 128)
         return (kw["B"] * kw["RH"] * kw["RW"] + 127) // 128
+
+    def _note_weight(self, w, frag):
+        """Book-keeping of the weight layouts: a packed weight tensor has ONE layout, so every launch that reads it must agree.
+        Returns frag for tensors the plan packs itself (others -- a caller's fp32 master on the parity path -- stay plain)."""
+        if self._pack_targets is None or id(w) not in self._pack_targets:
+            return False
+        frag = bool(frag)
+        if self._weight_layout.setdefault(id(w), frag) != frag:
+            raise _lib.FrhipError("frhip: two launches want different layouts of one packed weight tensor")
+        return frag
 
     def _side_after_main(self, L):
         """Order the side stream behind everything enqueued on the main stream so far.  Round 6: the edge is the completion
@@ -944,10 +966,20 @@ class BackbonePlan(object):
             P.insert(0, self._eval_coeffs_launch())
         self.pack_list, self.fwd_list = P, L
 
+    def _finish_pack(self):
+        """Behind the forward AND backward lists: tell the packing launch which copies are read in fragment order."""
+        arr, dirty = self._pack_arr, False
+        for i, req in enumerate(self._pack_reqs):
+            bits = sum(b for b, t in ((1, req[1]), (2, req[2])) if t is not None and self._weight_layout.get(id(t), False))
+            if bits != arr[i].frag:
+                arr[i].frag, dirty = bits, True
+        if dirty:
+            self._pack_table.copy_(torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8))
+
     def _pack_launch(self):
         """One launch that writes the compute-dtype and transposed copies of every conv weight of the network."""
         n = len(self._pack_reqs)
-        arr = (_lib.FrPackTensor * n)()
+        arr = self._pack_arr = (_lib.FrPackTensor * n)()
         chunks = []
         for i, req in enumerate(self._pack_reqs):
             w, wp, wt, cout, taps, cin = req[:6]
@@ -1039,11 +1071,22 @@ class BackbonePlan(object):
         # Linear weight gradient (packed layout) -> torch layout
         glw = self.grad_of(ol.weight)
         g_a = self.g_xh[:B * self.feat_in].view(B, self.feat_in)
+        head_done = None
         if self.lin_cm:
             if glw is not None:  # straight into the master's layout (one workgroup per element: the add is onto the zeroed arena)
-                L.append(ops.wgrad(st, fr, g=gfT, src=self.a, dw=glw, B=B, GH=1, GW=1, Cout=512, SH=1, SW=1,
-                                   SC=self.feat_in, KH=1, KW=1, stride=1, pad=0, ldg=512, lda=self.feat_in, pro=0,
-                                   nsplit=1))
+                # Round 6: on the weight-gradient stream, which has nothing to do until the last unit's data gradients exist
+                # (70 us of a 51-MB write that feeds nothing downstream, off a main stream that is a chain of 5-us launches
+                # here; FRHIP_LINEAR_WGRAD_SIDE=0: A/B switch)
+                side = self.dual and bool(_switch("FRHIP_LINEAR_WGRAD_SIDE", 1))
+                if side:
+                    self._side_after_main(L)
+                lw = ops.wgrad(self.stream2 if side else st, fr, g=gfT, src=self.a, dw=glw, B=B, GH=1, GW=1, Cout=512, SH=1,
+                               SW=1, SC=self.feat_in, KH=1, KW=1, stride=1, pad=0, ldg=512, lda=self.feat_in, pro=0, nsplit=1)
+                L.append(lw)
+                if side:
+                    lw.tstream = self.stream2_t
+                    head_done = torch.cuda.Event()
+                    L.append(_EvRecord(head_done, self.stream2_t))
             # Linear data gradient (c-major) -> dropout backward + back to NHWC -> BN(out) backward
             L.append(ops.call("fr_linear_dgrad", gfT, ol.weight, self.g_cm, B, 512, self.feat_in, st))
             dropb = ops.call("fr_dropout_bwd_cm", self.g_cm, g_a, B, C, self.HWo, 0.0, 0, fr, st)
@@ -1073,7 +1116,7 @@ class BackbonePlan(object):
         cur = 0
         g_out = self.g_pp[cur][:rows_o * C]
         L.append(ops.bn_bwd_apply(st, fr, gx=g_out, gamma=ob.weight, s0=s0, s1=s1, inv_count=1.0 / rows_o, **common))
-        self.ready_marks.append((len(L), [ob1.weight, ob1.bias, ol.weight, ol.bias, ob.weight, ob.bias], None))
+        self.ready_marks.append((len(L), [ob1.weight, ob1.bias, ol.weight, ol.bias, ob.weight, ob.bias], head_done))
         self._build_backward_units(L, g_out, cur)
 
     def _build_backward_units(self, L, g_out, cur):

@@ -6,11 +6,20 @@ The head always computes in fp32 (FR_F32): it is <0.3 % of the step's FLOPs and 
 BASELINE.json is an fp32 bar (bf16 operands drift the logits by ~0.2).
 """
 import math
+import os
 
 import torch
 
 from . import ops
 from ._lib import FR_F32
+from .engine import _side_stream
+
+
+def _head_side_stream(dev):
+    """The device's weight-gradient stream (engine.py: one per device), or None: FRHIP_HEAD_SIDE=0 / FRHIP_SINGLE_STREAM=1."""
+    if os.environ.get("FRHIP_HEAD_SIDE", "1") == "0" or os.environ.get("FRHIP_SINGLE_STREAM", "0") != "0":
+        return None
+    return _side_stream(dev, 1)
 
 
 def _pad(n, m):
@@ -67,6 +76,22 @@ def margin_backward(saved, cfg, g, need_x, need_w, raw_x_grad=False):
     gcos = torch.empty(B, Np, device=dev)
     ops.call("fr_margin_bwd", g, label, cos_t, gcos, B, N, Np, kind, easy, cos_m, sin_m, th, s, FR_F32, st)()
     gx = gw = None
+    # Round 6: the two halves (three launches each, 55 us each at 7000 classes, neither fills the chip) run side by side: the
+    # weight's on the weight-gradient stream, which is idle until the backbone's backward pass starts.  Every buffer is
+    # allocated on the calling stream, which waits for the side stream before this function returns.
+    side = _head_side_stream(dev) if (need_x and need_w) else None
+    if side is not None:
+        main = torch.cuda.current_stream(dev)
+        N4 = _pad(N, 4)
+        GW = torch.empty(N4, D, device=dev)
+        gw = torch.empty(N, D, device=dev)
+        side.wait_stream(main)
+        sp = ops.stream_ptr(side)
+        ops.call("fr_fill_rows", GW, None, N4, D, sp)()
+        ops.wgrad(sp, FR_F32, g=gcos, src=xn, dw=GW, B=B, GH=1, GW=1, Cout=N4, SH=1, SW=1, SC=D, KH=1, KW=1,
+                  stride=1, pad=0, ldg=Np, lda=D, pro=0, nsplit=1)()
+        ops.call("fr_normalize_bwd", GW, w, inv_w, gw, N, D, sp)()
+        need_w = False
     if need_x:
         Gx = torch.empty(B, D, device=dev)
         nk = Np // 32
@@ -87,6 +112,8 @@ def margin_backward(saved, cfg, g, need_x, need_w, raw_x_grad=False):
                   stride=1, pad=0, ldg=Np, lda=D, pro=0, nsplit=1)()
         gw = torch.empty(N, D, device=dev)
         ops.call("fr_normalize_bwd", GW, w, inv_w, gw, N, D, st)()
+    if side is not None:
+        main.wait_stream(side)
     return gx, gw
 
 

@@ -40,6 +40,11 @@ def current_stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def stream_ptr(stream):
+    """hipStream_t of a torch.cuda.Stream as the void* the C ABI takes."""
+    return ctypes.c_void_p(stream.cuda_stream)
+
+
 class Launch(object):
     __slots__ = ("fn", "args", "name", "keep", "tstream", "stop_event", "stop_handle", "stop_stream")
 

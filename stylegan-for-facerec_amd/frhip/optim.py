@@ -26,9 +26,12 @@ class SGD(torch.optim.Optimizer):
         self._sig = None
         self._tables = []  # per group: (table_dev, chunks_dev, nchunks)
 
-    def zero_grad(self, set_to_none=False):
-        """Keeps gradient buffers alive (the engine writes into them).  Gradients that are views of an engine
-        gradient arena are cleared with ONE fill of the arena instead of one launch per parameter."""
+    def zero_grad(self, set_to_none=None):
+        """Keeps the engine's gradient buffers alive (it writes into them): gradients that are views of an engine gradient
+        arena are cleared with ONE fill of the arena instead of one launch per parameter.  Other gradients (the head's) are
+        dropped when ``set_to_none`` is left at its default, as torch.optim does since 2.0 -- autograd then installs the new
+        gradient instead of adding it onto a buffer of zeros (a fill and an add of N x 512 floats per step); ``False``
+        zero-fills them, ``True`` drops every .grad (the engine binds its views again in the next backward pass)."""
         arenas = {}
         for group in self.param_groups:
             for p in group["params"]:
@@ -39,6 +42,8 @@ class SGD(torch.optim.Optimizer):
                     p.grad = None
                 elif g._is_view() and getattr(g._base, "_frhip_grad_arena", False):
                     arenas[id(g._base)] = g._base
+                elif set_to_none is None:
+                    p.grad = None
                 else:
                     g.zero_()
         for a in arenas.values():

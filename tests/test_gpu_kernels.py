@@ -688,6 +688,68 @@ def test_conv3x3_strip(K, cin, cout, W, B):
 
 
 
+def to_frag(w):
+    """[N][taps][K] -> MFMA-fragment order [N / 16][taps][K / 32][64 lanes = (k % 32) / 8 * 16 + n % 16][8] (FrConvArgs.w_frag)."""
+    N, taps, Kc = w.shape
+    return w.view(N // 16, 16, taps, Kc // 32, 4, 8).permute(0, 2, 3, 4, 1, 5).contiguous()
+
+
+FRAG_CASES = [(256, 256, 14, 5), (256, 256, 14, 200), (128, 128, 28, 3), (64, 128, 56, 3), (128, 64, 56, 2), (128, 256, 28, 3),
+              (256, 128, 28, 3), (256, 512, 14, 3), (512, 256, 14, 3), (512, 512, 7, 3), (512, 512, 7, 6), (512, 512, 7, 8),
+              (512, 512, 7, 200)]
+
+
+@pytest.mark.parametrize("cin,cout,W,B", FRAG_CASES, ids=["%d_%d_%d_b%d" % s for s in FRAG_CASES])
+def test_conv3x3_strip_fragment_order_weights(K, cin, cout, W, B):
+    """FrConvArgs.w_frag (round 6): the same launch with the weights in MFMA-fragment order -- forward (BN prologue, statistics)
+    and mirrored-tap data gradient, every instance of the dispatch table incl. the channel-split / multi-image / channel-staged
+    ones -- is BIT-IDENTICAL to the plain layout: only the addresses of the weight loads differ.  The rolling-window kernel and
+    the generic GEMM refuse the flag."""
+    from frhip import _lib
+    dtype = torch.bfloat16
+    st = K.current_stream_ptr()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4100 + cin + cout + W + B)
+    x = torch.randn(B, W, W, cin, device="cuda", generator=gen).to(dtype)
+    w = (torch.randn(cout, 9, cin, device="cuda", generator=gen) * 0.05).to(dtype)
+    wt = w.permute(2, 1, 0).contiguous()
+    pa, pb = synth.uniform(41, "fa", (cin,), 0.5, 1.5).cuda(), synth.uniform(41, "fb", (cin,), -0.5, 0.5).cuda()
+    assert _lib.lib.fr_conv3x3_strip_takes_frag(B, cin, cout, W) == 1
+    common = dict(B=B, RH=W, RW=W, SH=W, SW=W, KH=3, KW=3, stride=1, pad=1)
+    store_only = (cin, cout, W) == (256, 512, 14)
+    res = []
+    for frag in (0, 1):
+        out = torch.full((B, W, W, cout), float("nan"), device="cuda", dtype=dtype)
+        nparts = K.strip_parts(B, cin, cout, W)
+        part = torch.zeros(nparts, 2, cout, device="cuda")
+        K.conv_strip(st, src=x, w=to_frag(w) if frag else w, out=out, SC=cin, N=cout, mode=0, lda=cin, ldc=cout, pro=K.PRO_BN,
+                     pro_a=pa, pro_b=pb, epi=K.EPI_STORE if store_only else K.EPI_STATS, part=part, w_frag=frag, **common)()
+        g = out  # the data gradient of a cout-channel tensor back to cin channels
+        gx = torch.full((B, W, W, cin), float("nan"), device="cuda", dtype=dtype)
+        nb = K.strip_parts(B, cout, cin, W, K.EPI_STORE)
+        if nb:
+            K.conv_strip(st, src=g, w=to_frag(wt) if frag else wt, out=gx, SC=cout, N=cin, mode=1, lda=cout, ldc=cin, pro=0,
+                         epi=K.EPI_STORE, w_frag=frag, **common)()
+        torch.cuda.synchronize()
+        res.append((out, part, gx))
+    assert torch.isfinite(res[0][0].float()).all()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][2].view(torch.int16), res[1][2].view(torch.int16))
+    with pytest.raises(_lib.FrhipError):
+        K.conv(st, _lib.FR_BF16, src=x, w=w, out=res[0][0], SC=cin, N=cout, mode=0, lda=cin, ldc=cout, pro=0, epi=K.EPI_STORE,
+               w_frag=1, **common)()
+
+
+def test_fragment_order_is_refused_by_the_rolling_window_kernel(K):
+    from frhip import _lib
+    assert _lib.lib.fr_conv3x3_strip_takes_frag(4, 64, 64, 56) == 0 and _lib.lib.fr_conv3x3_strip_takes_frag(4, 96, 96, 14) == 0
+    x = torch.zeros(2, 56, 56, 64, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(64, 9, 64, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(_lib.FrhipError):
+        K.conv_strip(K.current_stream_ptr(), src=x, w=w, out=torch.zeros_like(x), B=2, RH=56, RW=56, SH=56, SW=56, KH=3, KW=3,
+                     stride=1, pad=1, SC=64, N=64, mode=0, lda=64, ldc=64, pro=0, epi=K.EPI_STORE, w_frag=1)()
+
+
 @pytest.mark.parametrize("name,dtype,tol", DT)
 def test_fused_se_launches_are_bit_identical(K, name, dtype, tol):
     """fr_se_pool_parts_mlp_fwd == fr_se_pool_parts + fr_se_mlp_fwd and fr_se_gscale_mlp_bwd == fr_se_gscale + fr_se_mlp_bwd
@@ -1862,7 +1924,7 @@ def test_pack_weights_64_tiles_equal_32_tiles(K, fold):
     ws = [synth.normal(87, "w%d" % i, sh).cuda() for i, sh in enumerate(shapes)]
     osc = [synth.uniform(87, "o%d" % i, (sh[0],), 0.5, 1.5).cuda() if fold else None for i, sh in enumerate(shapes)]
 
-    def run(use64):
+    def run(use64, frag=False):
         arr = (_lib.FrPackTensor * len(shapes))()
         outs, chunks = [], []
         for i, (co, taps, ci) in enumerate(shapes):
@@ -1872,6 +1934,7 @@ def test_pack_weights_64_tiles_equal_32_tiles(K, fold):
             arr[i].w, arr[i].wp, arr[i].wt = ws[i].data_ptr(), wp.data_ptr(), wt.data_ptr()
             arr[i].oscale = osc[i].data_ptr() if fold else None
             arr[i].Cout, arr[i].taps, arr[i].Cin = co, taps, ci
+            arr[i].frag = 3 if (frag and co % 64 == 0 and ci % 64 == 0) else 0
             if use64 and co % 64 == 0 and ci % 64 == 0:
                 chunks.extend((i, -(t + 1)) for t in range(taps * (co // 64) * (ci // 64)))
             else:
@@ -1884,6 +1947,13 @@ def test_pack_weights_64_tiles_equal_32_tiles(K, fold):
         return outs
 
     a, b = run(False), run(True)
+    c = run(True, frag=True)  # round 6: both copies of the 64-tile tensors in MFMA-fragment order (FrPackTensor.frag)
+    for i, ((wp0, wt0), (wpf, wtf)) in enumerate(zip(a, c)):
+        co, taps, ci = shapes[i]
+        if co % 64 == 0 and ci % 64 == 0:
+            assert torch.equal(wpf.view(-1), to_frag(wp0).view(-1)) and torch.equal(wtf.view(-1), to_frag(wt0).view(-1)), shapes[i]
+        else:
+            assert torch.equal(wpf, wp0) and torch.equal(wtf, wt0)
     for i, ((wp0, wt0), (wp1, wt1)) in enumerate(zip(a, b)):
         assert not torch.isnan(wp1.float()).any() and not torch.isnan(wt1.float()).any(), shapes[i]
         assert torch.equal(wp0, wp1) and torch.equal(wt0, wt1), shapes[i]

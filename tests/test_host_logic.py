@@ -46,7 +46,7 @@ def test_run_time_switches_are_named_integers(monkeypatch):
     launcher of the library calls getenv."""
     from frhip import _lib, ops
     lib = _lib.lib
-    assert _lib.lib.fr_abi_version() == 6
+    assert _lib.lib.fr_abi_version() == 7
     monkeypatch.setenv("FRHIP_TEST_SWITCH_A", "7")
     assert lib.fr_get_option(b"FRHIP_TEST_SWITCH_A", 3) == 7          # from the environment
     assert lib.fr_get_option(b"FRHIP_TEST_SWITCH_B", 3) == 3          # unset: the first reader's default
