@@ -162,6 +162,9 @@ int fr_conv1x1_stream_parts(int B, int RH, int RW, int K, int N);
  * Replaces Conv2d(d, d, (3,3), stride 2, 1) of bottleneck_IR (backbone/model_irse.py:59) fwd + data gradient. */
 int fr_conv3x3_s2_strip(const FrConvArgs* args, void* stream);
 int fr_conv3x3_s2_strip_parts(int B, int Cin, int Cout, int WL, int mode);
+/* 1 when fr_conv3x3_s2_strip reads fragment-order weights (FrConvArgs.w_frag) for (B, C -> C, low-res width WL, mode): every
+ * served shape except the 64-channel layer (rolling-window kernel, weights resident, plain layout) */
+int fr_conv3x3_s2_strip_takes_frag(int B, int C, int WL, int mode);
 
 typedef struct FrWgradArgs {
   const void* g;   /* gradient of the conv output: [B*GH*GW][ldg], columns = Cout */

@@ -98,7 +98,7 @@ struct Taps {
 // acc += sum over the taps of (KIND, P) and all CIN channels, A from the LDS image, B from global/L2.
 template <class C, int CIN, int KIND, int P>
 __device__ __forceinline__ void mma_taps(const char* smem, const int (&abase0)[C::TM], f32x4 (&acc)[C::TM][C::TN],
-                                         const bf16_t* const (&wrow)[C::TN]) {
+                                         const bf16_t* const (&wrow)[C::TN], const int wsh) {
   using T = Taps<KIND, P>;
   constexpr int NT = T::NT;
   constexpr int UC = NT == 1 ? 2 : 1;  // 32-channel chunks per unrolled body (so that a body holds >= 2 tap-steps)
@@ -119,7 +119,7 @@ __device__ __forceinline__ void mma_taps(const char* smem, const int (&abase0)[C
     const int t = q % NT, u = q / NT;
 #pragma unroll
     for (int j = 0; j < C::TN; ++j)
-      bq[slot][j] = *reinterpret_cast<const s16x8*>(wrow[j] + T::ktap(t) * CIN + c0 + u * 32);
+      bq[slot][j] = *reinterpret_cast<const s16x8*>(wrow[j] + ((T::ktap(t) * CIN + c0 + u * 32) << wsh));
   };
   auto a_addr = [&](int step) -> const s16x8* {  // step in [0, 2*NSTEP): second half = next body
     const int wrap = step >= NSTEP ? 1 : 0;
@@ -303,6 +303,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
   const bf16_t* wrow[C::TN];
 #pragma unroll
   for (int j = 0; j < C::TN; ++j) wrow[j] = wgt + (size_t)(ncol0 + n0 + j * 16 + fr) * 9 * CIN + fq * 8;
+  const int wsh = p.w_frag ? 4 : 0;  // weights in MFMA-fragment order (FrConvArgs.w_frag; conv3x3_strip.hip): 1024 contiguous bytes per load
+  if (wsh) {
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) wrow[j] = wgt + (size_t)((ncol0 + n0) / 16 + j) * 16 * 9 * CIN + lane * 8;
+  }
   int abase[C::TM];
 #pragma unroll
   for (int i = 0; i < C::TM; ++i) {
@@ -505,20 +510,20 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
     S2_STAMP(1);
     __syncthreads();
     S2_STAMP(2);
-    mma_taps<C, CIN, 0, 0>(smem, abase, acc, wrow);
+    mma_taps<C, CIN, 0, 0>(smem, abase, acc, wrow, wsh);
     S2_STAMP(3);
     __syncthreads();  // every wave is done reading the plane
     S2_STAMP(4);
     load_image(0, 1);
     __syncthreads();
     S2_STAMP(5);
-    mma_taps<C, CIN, 0, 1>(smem, abase, acc, wrow);
+    mma_taps<C, CIN, 0, 1>(smem, abase, acc, wrow, wsh);
     __syncthreads();
     S2_STAMP(6);
     load_image(1, 0);
     __syncthreads();
     S2_STAMP(7);
-    mma_taps<C, CIN, 0, 2>(smem, abase, acc, wrow);
+    mma_taps<C, CIN, 0, 2>(smem, abase, acc, wrow, wsh);
     __syncthreads();
     S2_STAMP(8);
     load_image(1, 1);
@@ -526,7 +531,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
     __syncthreads();
     S2_STAMP(10);
     issue_aux(-1);
-    mma_taps<C, CIN, 0, 3>(smem, abase, acc, wrow);
+    mma_taps<C, CIN, 0, 3>(smem, abase, acc, wrow, wsh);
     S2_STAMP(11);
     __syncthreads();  // LDS is now the output tile
     S2_STAMP(12);
@@ -538,22 +543,22 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
     commit_plane();
     __syncthreads();
     issue_plane(0, 1);
-    mma_taps<C, CIN, 0, 0>(smem, abase, acc, wrow);
+    mma_taps<C, CIN, 0, 0>(smem, abase, acc, wrow, wsh);
     __syncthreads();  // every wave is done reading the plane
     commit_plane();
     __syncthreads();
     issue_plane(1, 0);
-    mma_taps<C, CIN, 0, 1>(smem, abase, acc, wrow);
+    mma_taps<C, CIN, 0, 1>(smem, abase, acc, wrow, wsh);
     __syncthreads();
     commit_plane();
     __syncthreads();
     issue_plane(1, 1);
-    mma_taps<C, CIN, 0, 2>(smem, abase, acc, wrow);
+    mma_taps<C, CIN, 0, 2>(smem, abase, acc, wrow, wsh);
     __syncthreads();
     commit_plane();
     __syncthreads();
     issue_aux(-1);
-    mma_taps<C, CIN, 0, 3>(smem, abase, acc, wrow);
+    mma_taps<C, CIN, 0, 3>(smem, abase, acc, wrow, wsh);
     __syncthreads();  // LDS is now the output tile
     epilogue(-1);
   } else {
@@ -570,30 +575,30 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_s2_kernel(const FrConvArgs
       if (half == 1) {  // half a class behind: wait for waves 0-3 to finish their first tap list
         while (*start < 4u) __builtin_amdgcn_s_sleep(2);
       }
-      mma_taps<C, CIN, 1, 0>(smem, abase, acc, wrow);
+      mma_taps<C, CIN, 1, 0>(smem, abase, acc, wrow, wsh);
       if (half == 0 && lane == 0)
         __hip_atomic_fetch_add(const_cast<unsigned*>(start), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
-      mma_taps<C, CIN, 1, 0>(smem, abase, acc, wrow);
+      mma_taps<C, CIN, 1, 0>(smem, abase, acc, wrow, wsh);
     }
     S2_STAMP(3);
     epilogue(0);
     S2_STAMP(4);
     zero_acc();
     issue_aux(1);
-    mma_taps<C, CIN, 1, 1>(smem, abase, acc, wrow);
+    mma_taps<C, CIN, 1, 1>(smem, abase, acc, wrow, wsh);
     S2_STAMP(5);
     epilogue(1);
     S2_STAMP(6);
     zero_acc();
     issue_aux(2);
-    mma_taps<C, CIN, 1, 2>(smem, abase, acc, wrow);
+    mma_taps<C, CIN, 1, 2>(smem, abase, acc, wrow, wsh);
     S2_STAMP(7);
     epilogue(2);
     S2_STAMP(8);
     zero_acc();
     issue_aux(3);
-    mma_taps<C, CIN, 1, 3>(smem, abase, acc, wrow);
+    mma_taps<C, CIN, 1, 3>(smem, abase, acc, wrow, wsh);
     S2_STAMP(9);
     epilogue(3);
     S2_STAMP(10);
@@ -666,6 +671,13 @@ extern "C" int fr_conv3x3_s2_strip_parts(int B, int Cin, int Cout, int WL, int m
   return mode == 2 ? 4 * strips : strips;
 }
 
+// 1 when the launch reads fragment-order weights (FrConvArgs.w_frag): every served shape but the 64-channel layer, whose
+// rolling-window kernel keeps its weights resident
+extern "C" int fr_conv3x3_s2_strip_takes_frag(int B, int C, int WL, int mode) {
+  if (C == 64) return 0;
+  return fr_conv3x3_s2_strip_parts(B, C, C, WL, mode) > 0 ? 1 : 0;
+}
+
 extern "C" int fr_conv3x3_s2_strip(const FrConvArgs* args, void* stream) {
   const FrConvArgs& a = *args;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -674,14 +686,16 @@ extern "C" int fr_conv3x3_s2_strip(const FrConvArgs* args, void* stream) {
     FR_UNSUPPORTED("fr_conv3x3_s2_strip: stride-2 3x3 pad-1 bf16 convolution (mode 0) or its data gradient (mode 2)");
   if (a.mode == 2 && (a.par_h >= 0 || a.par_w >= 0))
     FR_UNSUPPORTED("fr_conv3x3_s2_strip: the data gradient produces all four parity classes (par_h = par_w = -1)");
-  if (a.w_frag) FR_UNSUPPORTED("fr_conv3x3_s2_strip: fragment-order weights (w_frag) are not read here yet");
   if (a.lda % 8 || a.ldc % 8 || (a.aux && a.ldaux % 8)) FR_UNSUPPORTED("fr_conv3x3_s2_strip: strides must be 16-byte multiples");
   // low-res grid: forward output / gradient input
   const int WLo = a.mode == 0 ? a.RW : a.SW, HLo = a.mode == 0 ? a.RH : a.SH;
   const int WHi = a.mode == 0 ? a.SW : a.RW, HHi = a.mode == 0 ? a.SH : a.RH;
   if (WLo != HLo || WHi != 2 * WLo || HHi != 2 * HLo || a.SC != a.N)
     FR_UNSUPPORTED("fr_conv3x3_s2_strip: square images, high-res side = 2 x low-res side, Cin == Cout");
-  if (fr_s2roll_serves(a)) return fr_s2roll_launch(a, st);
+  if (fr_s2roll_serves(a)) {
+    if (a.w_frag) FR_UNSUPPORTED("fr_conv3x3_s2_strip: the 64-channel rolling-window kernel takes the plain weight layout (w_frag)");
+    return fr_s2roll_launch(a, st);
+  }
   if (fr_s2ws_serves(a)) return fr_s2ws_launch(a, st);  // forward, 128 / 256 / 512 channels (round 6)
   // fr_conv3x3_s2_strip_parts() has no epilogue argument: for the 64-channel layer it answers with the row count of the
   // rolling-window kernel.  A summing epilogue that kernel does not serve would make the strip kernel below write a

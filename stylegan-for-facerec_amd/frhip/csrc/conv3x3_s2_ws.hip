@@ -88,7 +88,7 @@ struct Taps {
 // acc += taps of plane P over the CK resident channels; A from the plane buffer, B (weights) from global / L2
 template <class C, int CIN, int P>
 __device__ __forceinline__ void mma_taps(const char* buf, const int (&abase0)[C::TM], f32x4 (&acc)[C::TM][C::TN],
-                                         const bf16_t* const (&wrow)[C::TN]) {
+                                         const bf16_t* const (&wrow)[C::TN], const int wsh) {
   using T = Taps<P>;
   constexpr int NT = T::NT;
 #ifndef FRHIP_S2WS_DB
@@ -113,7 +113,7 @@ __device__ __forceinline__ void mma_taps(const char* buf, const int (&abase0)[C:
     const int t = q % NT, u = q / NT;
 #pragma unroll
     for (int j = 0; j < C::TN; ++j)
-      bq[slot][j] = *reinterpret_cast<const s16x8*>(wrow[j] + T::ktap(t) * CIN + c0 + u * 32);
+      bq[slot][j] = *reinterpret_cast<const s16x8*>(wrow[j] + ((T::ktap(t) * CIN + c0 + u * 32) << wsh));
   };
   auto a_addr = [&](int step) -> const s16x8* {
     const int wrap = step >= NSTEP ? 1 : 0;
@@ -285,6 +285,11 @@ __global__ __launch_bounds__(512) void conv3x3_s2_ws_kernel(const FrConvArgs p, 
     const bf16_t* wrow[C::TN];
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) wrow[j] = wgt + (size_t)(ncol0 + n0 + j * 16 + fr) * 9 * CIN + fq * 8;
+  const int wsh = p.w_frag ? 4 : 0;  // weights in MFMA-fragment order (FrConvArgs.w_frag; conv3x3_strip.hip): 1024 contiguous bytes per load
+  if (wsh) {
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) wrow[j] = wgt + (size_t)((ncol0 + n0) / 16 + j) * 16 * 9 * CIN + lane * 8;
+  }
     int abase[C::TM];
 #pragma unroll
     for (int i = 0; i < C::TM; ++i) {
@@ -310,8 +315,8 @@ __global__ __launch_bounds__(512) void conv3x3_s2_ws_kernel(const FrConvArgs p, 
         const int ph = P * KSPL + kc;
         const bf16_t* wk[C::TN];
 #pragma unroll
-        for (int j = 0; j < C::TN; ++j) wk[j] = wrow[j] + kc * CK;
-        mma_taps<C, CIN, P>(smem + (ph & 1) * C::BUF, abase, acc, wk);
+        for (int j = 0; j < C::TN; ++j) wk[j] = wrow[j] + ((kc * CK) << wsh);
+        mma_taps<C, CIN, P>(smem + (ph & 1) * C::BUF, abase, acc, wk, wsh);
         WS_STAMP(tid == 0, 2 + ph);
         __syncthreads();
       }

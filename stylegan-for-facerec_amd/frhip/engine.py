@@ -540,7 +540,10 @@ class BackbonePlan(object):
             mode = kw.get("mode", 0)
             n = ops.s2_strip_parts(kw["B"], kw["SC"], kw["N"], kw["RW"] if mode == 0 else kw["SW"], mode)
             if n:
-                self._note_weight(kw["w"], False)
+                wl = kw["RW"] if mode == 0 else kw["SW"]
+                if self._note_weight(kw["w"], self.w_frag and bool(
+                        _lib.lib.fr_conv3x3_s2_strip_takes_frag(kw["B"], kw["SC"], wl, mode))):
+                    kw = dict(kw, w_frag=1)
                 L.append(ops.conv_s2_strip(self.stream, **kw))
                 self._last_conv_strips = n if mode == 0 else 0
                 return n

@@ -1053,6 +1053,50 @@ def test_conv3x3_s2_strip_dgrad(K, s2_walk, C, WL, B, walk):
                                    atol=tol * 10 * float((gx * aux).abs().sum() / C))
 
 
+S2_FRAG_CASES = [(128, 28, 3), (128, 28, 40), (256, 14, 3), (256, 14, 8), (512, 7, 3), (512, 7, 6), (512, 7, 8)]
+
+
+@pytest.mark.parametrize("C,WL,B", S2_FRAG_CASES, ids=["%d_%d_b%d" % s for s in S2_FRAG_CASES])
+def test_conv3x3_s2_strip_fragment_order_weights(K, C, WL, B):
+    """FrConvArgs.w_frag on the stride-2 kernels (the warp-specialised forward, the strip data gradient, and -- FRHIP_S2_WS = 0 --
+    the strip forward): bit-identical to the plain weight layout, outputs and partial rows."""
+    from frhip import _lib
+    dtype, st, H = torch.bfloat16, K.current_stream_ptr(), 2 * WL
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4300 + C + B)
+    x = torch.randn(B, H, H, C, device="cuda", generator=gen).to(dtype)
+    g = torch.randn(B, WL, WL, C, device="cuda", generator=gen).to(dtype)
+    w = (torch.randn(C, 9, C, device="cuda", generator=gen) * 0.05).to(dtype)
+    wt = w.permute(2, 1, 0).contiguous()
+    slope = synth.uniform(43, "fs", (C,), 0.1, 0.4).cuda()
+    assert _lib.lib.fr_conv3x3_s2_strip_takes_frag(B, C, WL, 0) == 1 and _lib.lib.fr_conv3x3_s2_strip_takes_frag(B, C, WL, 2) == 1
+    assert _lib.lib.fr_conv3x3_s2_strip_takes_frag(B, 64, 56, 0) == 0
+    for ws in (1, 0):
+        prev = K.set_option("FRHIP_S2_WS", ws)
+        try:
+            res = []
+            for frag in (0, 1):
+                n = K.s2_strip_parts(B, C, C, WL, 0)
+                out = torch.full((B, WL, WL, C), float("nan"), device="cuda", dtype=dtype)
+                part = torch.zeros(n, 2, C, device="cuda")
+                K.conv_s2_strip(st, src=x, w=to_frag(w) if frag else w, out=out, B=B, RH=WL, RW=WL, SH=H, SW=H, SC=C, N=C, KH=3,
+                                KW=3, stride=2, pad=1, mode=0, lda=C, ldc=C, pro=2, pro_a=slope, epi=K.EPI_STATS, part=part,
+                                w_frag=frag)()
+                n2 = K.s2_strip_parts(B, C, C, WL, 2)
+                gx = torch.full((B, H, H, C), float("nan"), device="cuda", dtype=dtype)
+                part2 = torch.zeros(n2, 2, C, device="cuda")
+                K.conv_s2_strip(st, src=g, w=to_frag(wt) if frag else wt, out=gx, B=B, RH=H, RW=H, SH=WL, SW=WL, SC=C, N=C, KH=3,
+                                KW=3, stride=2, pad=1, mode=2, par_h=-1, par_w=-1, lda=C, ldc=C, ldaux=C, pro=0,
+                                epi=K.EPI_PRELU_BWD, aux=x, epi_a=slope, part=part2, w_frag=frag)()
+                torch.cuda.synchronize()
+                res.append((out, part, gx, part2))
+        finally:
+            K.set_option("FRHIP_S2_WS", prev)
+        assert torch.isfinite(res[0][0].float()).all() and torch.isfinite(res[0][2].float()).all()
+        for a, b in zip(res[0], res[1]):
+            assert torch.equal(a, b), "FRHIP_S2_WS=%d" % ws
+
+
 @pytest.mark.parametrize("Cavg,ldk", [(0, 32), (3, 64)], ids=["ir", "psp"])
 @pytest.mark.parametrize("B,S", [(3, 9), (2, 112)])
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
