@@ -650,6 +650,12 @@ extern "C" int fr_conv3x3_strip(const FrConvArgs* args, void* stream) {
   // loaded and its prologue applied twice per image, 176-200 B of scratch; a 9-deep fragment ring here: 0.0623 vs 0.0596
   // (256 registers + scratch); a 6-deep one over two channel chunks per trip: 84 B of scratch; s_setprio 1 for the younger
   // half of the waves: no effect.  None instantiated.
+  // Round 6 (fragment-order weights; stamps: wave 0's K loop 24.5 us, then 14.4 us waiting for its SIMD partner -- 38.9 us for
+  // 27-31 us of MFMA work at the clock the loop holds): FOUR waves, one per SIMD, 13 x 4 tiles each (208 accumulator registers,
+  // A ring 13 deep, <256, 256, 14, 14, 4, 4> with __launch_bounds__(256, 1)): hipcc splits the 512 registers 256 + 256, moves
+  // 228 accumulator registers per 468 MFMAs through v_accvgpr_* and spills 136-604 B; K loop 41.8 us, load 6.2 (4.4), cells
+  // 4.7-26 (1.5-5.9): 0.0586 / 0.0713 / 0.0847 ms (forward BN / PReLU+stats / data gradient) against 0.0501 / 0.0538 / 0.0583.
+  // Not instantiated.
   // small batches (fewer whole-image workgroups than CUs): split the output channels over two workgroups per image
   // (measured at B = 128: 0.034 instead of 0.049 ms per launch -- IR-SE-101 trains at 128 images per GPU)
   if (a.SC == 256 && a.N == 256 && a.SW == 14 && small_batch(a.B)) return by_pro<256, 128, 14, 14, 8, 8, 2>(a, st);

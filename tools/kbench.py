@@ -16,7 +16,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "stylegan-for-facerec_amd"))
 import torch  # noqa: E402
 
-from frhip import ops  # noqa: E402
+from frhip import _lib, ops  # noqa: E402
 
 BF = torch.bfloat16
 
@@ -94,11 +94,18 @@ def conv_case(kind, cin, cout, W, B, stride=1, pro=1, epi=1, mode=0, iters=20):
     flops = 2.0 * B * Ho * Ho * N * 9 * SC  # stride 2: both directions do 9 taps per LOW-res pixel
     if pro == 4:  # FR_PRO_RESBN: the residual sum formed by its consumer (two sources, two coefficient pairs, stored once)
         kw.update(src2=rnd(*src.shape), pro_c=va, pro_d=vb, pro_out=torch.empty_like(src))
+    # the engine packs the weights of these kernels in MFMA-fragment order (FrConvArgs.w_frag; random data: same bytes).
+    # KBENCH_FRAG=0: the plain layout
+    frag = os.environ.get("KBENCH_FRAG", "1") != "0"
     if kind == "s2":  # stride-2 parity-plane kernel: mode 0 forward (W = input side), mode 2 all-class data gradient
         if mode == 2:
             kw.update(par_h=-1, par_w=-1)
+        if frag and _lib.lib.fr_conv3x3_s2_strip_takes_frag(B, SC, Ho, mode):
+            kw.update(w_frag=1)
         l = ops.conv_s2_strip(st, **kw)
     elif kind == "strip":
+        if frag and _lib.lib.fr_conv3x3_strip_takes_frag(B, SC, N, W):
+            kw.update(w_frag=1)
         l = ops.conv_strip(st, **kw)
     else:
         l = ops.conv(st, ops.FR_BF16, **kw)
