@@ -34,9 +34,14 @@ __device__ unsigned long long* fr_stamp_buf = nullptr;
 extern "C" int fr_debug_set_stamp_buffer(unsigned long long* dev_ptr) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(fr_stamp_buf), &dev_ptr, sizeof(dev_ptr));
 }
+// (the shader-clock counter s_memtime goes to a second plane of the buffer, 65536 x 8 entries behind the first: the clock the
+// loop holds is delta s_memtime / delta s_memrealtime x 100 MHz)
 #define FR_STAMP(k)                                                                                   \
   do {                                                                                                \
-    if (tid == 0 && fr_stamp_buf) fr_stamp_buf[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    if (tid == 0 && fr_stamp_buf) {                                                                   \
+      fr_stamp_buf[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();                  \
+      fr_stamp_buf[(size_t)(65536 + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime();            \
+    }                                                                                                 \
   } while (0)
 #else
 #define FR_STAMP(k)

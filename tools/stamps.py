@@ -26,7 +26,7 @@ def main():
     B = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 256
     fn = dict(kbench.suite_cases(B))[label]
     nblk = 1 << 16
-    buf = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(2 * nblk * 8, dtype=torch.int64, device="cuda")  # second plane: s_memtime (shader clock) of the strip kernel
     dbg = ctypes.CDLL(_lib.LIB_PATH)
     roll = "--roll" in sys.argv
     setter = dbg.fr_debug_set_stamp_buffer_roll if roll else dbg.fr_debug_set_stamp_buffer
@@ -37,7 +37,8 @@ def main():
     buf.zero_()
     fn(1)  # timeit runs 3 warm-up + 1 timed launch: the last one's stamps remain
     torch.cuda.synchronize()
-    s = buf.cpu().numpy().reshape(nblk, 8)
+    both = buf.cpu().numpy().reshape(2, nblk, 8)
+    s, clk = both[0], both[1]
     if roll:  # conv3x3_roll64: per workgroup, phase times summed over its nit iterations
         s = s[s[:, 7] != 0]
         nit = s[:, 7].astype(np.float64)
@@ -49,7 +50,12 @@ def main():
         life = s[:, 6] * 0.01
         print("  lifetime   median %7.1f us = %.2f us per iteration" % (np.median(life), np.median(life / nit)))
         return
+    clk = clk[s[:, 0] != 0]
     s = s[s[:, 0] != 0]
+    if not roll and clk[:, 2].any():  # the clock the K loop holds: shader cycles per 10-ns tick, wave 0 of every workgroup
+        ghz = (clk[:, 3] - clk[:, 2]).astype(np.float64) / np.maximum(1, (s[:, 3] - s[:, 2]).astype(np.float64)) * 0.1
+        print("  in-kernel clock over the K loop: median %.2f GHz  p10 %.2f  p90 %.2f" % (np.median(ghz), np.percentile(ghz, 10),
+                                                                                      np.percentile(ghz, 90)))
     t = s[:, :7].astype(np.float64) * 0.01  # us
     t0 = t[:, 0].min()
     names = ["load", "barrier1", "main", "barrier2", "cells", "store"]
