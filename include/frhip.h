@@ -31,7 +31,8 @@ enum {
   FR_PRO_NONE = 0,
   FR_PRO_BN = 1,     /* x*a[c]+b[c] */
   FR_PRO_PRELU = 2,  /* x>0?x:a[c]*x */
-  /* 3: FR_PRO_BNBWD2 of ABI v4 (BatchNorm backward inside the data gradient; measured +-0 on two streams, removed in v5) */
+  /* 3: FR_PRO_BNBWD2 of ABI v4 (BatchNorm backward inside the data gradient; measured +-0 on two streams, removed in v5; rebuilt
+   *    and measured again in round 6 on the fragment-order kernels: +0.1 ms per step, profiles/r06_ab_bn2_in_dgrad.txt) */
   FR_PRO_RESBN = 4   /* BN1 of a residual unit applied to the OUTPUT of the unit in front of it, formed on the way:
                         o = round(a[c]*x + b[c] + x2)  (x = conv2 output of the previous unit, a / b = its BN2 coefficients, x2 =
                         src2 = that unit's input: bottleneck_IR's `res + shortcut`, backbone/model_irse.py:64-66 with the
