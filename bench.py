@@ -162,7 +162,7 @@ def make_step(model, head, loss_fn, opt, dp):
 
     def sharded_step(x, y):
         loss, p1, p5 = head(model(x), y)  # global-batch loss / accuracy; the weight-shard gradient needs no exchange
-        opt.zero_grad()  # as the training loop calls it (train.py)
+        opt.zero_grad()
         loss.backward()
         if dp is not None:
             dp.synchronize()
@@ -177,7 +177,7 @@ def make_step(model, head, loss_fn, opt, dp):
         logits = head(feats, y)
         loss, _ = loss_fn(logits, y)
         prec = accuracy(logits.data, y, topk=(1, 5))
-        opt.zero_grad()  # as the training loop calls it (train.py)
+        opt.zero_grad()
         loss.backward()
         if dp is not None:
             dp.synchronize()

@@ -11,7 +11,8 @@ import bench  # noqa: E402
 
 
 def main():
-    a = argparse.Namespace(model="IR_50", head="ArcFace", classes=int(os.environ.get("CLASSES", 7000)), batch=256, dtype="bf16",
+    a = argparse.Namespace(model=os.environ.get("MODEL", "IR_50"), head=os.environ.get("HEAD", "ArcFace"),
+                           classes=int(os.environ.get("CLASSES", 7000)), batch=int(os.environ.get("BATCH", 256)), dtype="bf16",
                            sharded_head=False, resident_batches=4)
     dev = torch.device("cuda:0")
     model, head, loss_fn, opt, xs, ys = bench.build_job(a, dev, 0)
