@@ -793,6 +793,14 @@ class BackbonePlan(object):
                                       nblocks=nb))
                 self._bn_train_launches(L, first_bn, self.part, nb, self.M0)
         x = self.z0
+        # Round 6: the packing of the 3x3 weights (350 MB of traffic, 60 us) runs on the weight-gradient stream, idle in the
+        # forward pass, beside the stem (im2col rows + two GEMM passes, HBM-bound but below the HBM rate on their own); the main
+        # stream waits for it in front of the first residual unit.  Training plans with two streams; FRHIP_PACK_SIDE=0: A/B
+        self.pack_side = (self.dual and not fold and not self.infer and not self.body_only and
+                          bool(_switch("FRHIP_PACK_SIDE", 1)))
+        if self.pack_side:
+            self._pack_ev0, self._pack_ev1 = torch.cuda.Event(), torch.cuda.Event()
+            L.append(_EvWait(self.stream1_t, self._pack_ev1))
         for i, u in enumerate(self.units):
             d = self.ubuf[i]
             rin, rout = B * u.H * u.H, B * u.Ho * u.Ho
@@ -964,7 +972,12 @@ class BackbonePlan(object):
         self._bn_train_launches(L, self.bn1d, self.part, nbf, B)
         L.append(ops.bn_apply(st, FR_F32, x=self.f, out=self.feat, scale=self.bn1d.scale, shift=self.bn1d.shift, B=B,
                               H=1, W=1, C=512, res_kind=0, res_stride=1, nblocks=nbf))
-        P.append(self._pack_launch())
+        if self.pack_side:
+            pl = self._pack_launch(self.stream2)
+            pl.tstream = self.stream2_t
+            self.pack_side_list = [pl]
+        else:
+            P.append(self._pack_launch())
         if fold:  # the coefficients feed the weight folding: first launch of the step
             P.insert(0, self._eval_coeffs_launch())
         self.pack_list, self.fwd_list = P, L
@@ -979,7 +992,7 @@ class BackbonePlan(object):
         if dirty:
             self._pack_table.copy_(torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8))
 
-    def _pack_launch(self):
+    def _pack_launch(self, stream=None):
         """One launch that writes the compute-dtype and transposed copies of every conv weight of the network."""
         n = len(self._pack_reqs)
         arr = self._pack_arr = (_lib.FrPackTensor * n)()
@@ -1001,7 +1014,7 @@ class BackbonePlan(object):
         self._pack_chunks = torch.tensor(chunks, dtype=torch.int32).reshape(-1).to(self.device)
         table = ctypes.cast(ctypes.c_void_p(self._pack_table.data_ptr()), ctypes.POINTER(_lib.FrPackTensor))
         return ops.Launch("fr_pack_weights_multi", [table, ops.ptr(self._pack_chunks), len(chunks), self.fr,
-                                                    self.stream], keep=(self._pack_reqs,))
+                                                    stream if stream is not None else self.stream], keep=(self._pack_reqs,))
 
     def _eval_coeffs_launch(self):
         """One launch that turns the running statistics of every BatchNorm into (mean, invstd, scale, shift)."""
@@ -1484,6 +1497,11 @@ class BackbonePlan(object):
         B, S = self.B, self.S
         st = self.stream
         avg = avg_image
+        if self.pack_side:  # behind the previous step on the main stream (the optimizer's update, the last data gradient)
+            self._pack_ev0.record(self.stream1_t)
+            self.stream2_t.wait_event(self._pack_ev0)
+            ops.run(self.pack_side_list)
+            self._pack_ev1.record(self.stream2_t)
         ops.call("fr_stem_im2col", x, avg, self.X0, B, S, S, self.in_channels, self.avg_channels, self.K0, self.fr, st)()
         od = self.out[1]
         p = float(od.p) if od.training else 0.0
